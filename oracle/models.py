@@ -1,0 +1,211 @@
+"""torch-CPU restatement of the reference's belief-map CNNs.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Used as the parity checker for the HIP
+path and as the ``cpu_baseline`` leg of bench.py; never imported by ``dream_amd``.
+
+Restates (state_dict keys and shapes identical, so weights interchange):
+  * DreamHourglass   -- /root/reference/dream/models.py:557-827  (vgg_q / vgg_f and flags)
+  * ResnetSimple     -- /root/reference/dream/models.py:17-155   (resnet_h / resnet_f)
+  * SoftArgmaxPavlo  -- /root/reference/dream/spatial_softmax.py:15-95
+Pinned by tests/golden/cnn_*.npz (stub-imported reference, same weights, same inputs).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .topology import vgg19_features, ResNet101
+
+
+def _named_seq(items):
+    seq = nn.Sequential()
+    for name, mod in items:
+        seq.add_module(str(name), mod)
+    return seq
+
+
+class SoftArgmaxPavlo(nn.Module):
+    """spatial_softmax.py:15-95: 7x7 avg-pool (zero pad, /49) -> per-map max-subtract ->
+    exp(beta*.) -> / (sum + 1e-8) -> expectation of column / row index."""
+
+    def __init__(self, n_keypoints=5, learned_beta=False, initial_beta=25.0):
+        super().__init__()
+        beta = torch.ones(n_keypoints) * initial_beta
+        if learned_beta:
+            self.beta = nn.Parameter(beta)          # spatial_softmax.py:19-20
+        else:
+            self.beta = beta                        # plain tensor, not in state_dict (:22)
+
+    def forward(self, heatmaps, size_mult=1.0):
+        b, k, h, w = heatmaps.shape
+        pooled = F.avg_pool2d(heatmaps, 7, stride=1, padding=3)          # :18,:35
+        flat = pooled.contiguous().view(b, k, -1)
+        flat = flat - flat.max(dim=2, keepdim=True)[0]                   # :41-47
+        e = torch.exp(self.beta.view(1, k, 1) * flat)                    # :49-52
+        p = e.view(b, k, h, w) / (e.sum(dim=2, keepdim=True).view(b, k, 1, 1) + 1e-8)  # :55-59
+        cols = (torch.arange(0, w) * size_mult).float().view(1, 1, 1, w)
+        rows = (torch.arange(0, h) * size_mult).float().view(1, 1, h, 1)
+        x = (p * cols).view(b, k, -1).sum(dim=2)                         # :82-85
+        y = (p * rows).view(b, k, -1).sum(dim=2)                         # :87-90
+        return torch.stack((x, y), dim=2)                                # :92
+
+
+class DreamHourglass(nn.Module):
+    """models.py:557-827.  VGG19 encoder blocks (torchvision indices 0-3, 5-8, 10-17, 19-26,
+    28-35 with a fresh first conv), own MaxPool2d(2) between them, then either the
+    nearest-upsample decoder (Q) or the ConvTranspose decoder (F), then the 3-conv head."""
+
+    def __init__(self, n_keypoints, n_image_input_channels=3, internalize_spatial_softmax=True,
+                 learned_beta=True, initial_beta=1.0, skip_connections=False,
+                 deconv_decoder=False, full_output=False):
+        super().__init__()
+        self.n_keypoints = n_keypoints
+        self.internalize_spatial_softmax = internalize_spatial_softmax
+        self.skip_connections = skip_connections
+        self.deconv_decoder = deconv_decoder
+        self.full_output = full_output
+        vgg = vgg19_features()
+        self.down_sample = nn.MaxPool2d(2)                                             # :589
+
+        first = [(0, nn.Conv2d(n_image_input_channels, 64, 3, 1, 1))]                  # :592-597
+        self.layer_0_1_down = _named_seq(first + [(i, vgg[i]) for i in range(1, 4)])   # :598-599
+        self.layer_0_2_down = _named_seq([(i, vgg[i]) for i in range(5, 9)])           # :601-603
+        self.layer_0_3_down = _named_seq([(i, vgg[i]) for i in range(10, 18)])         # :605-607
+        self.layer_0_4_down = _named_seq([(i, vgg[i]) for i in range(19, 27)])         # :609-611
+        self.layer_0_5_down = _named_seq([(i, vgg[i]) for i in range(28, 36)])         # :613-615
+
+        def conv(ci, co):
+            return nn.Conv2d(ci, co, 3, 1, 1)
+
+        def deconv(ci, co):
+            return nn.ConvTranspose2d(ci, co, (3, 3), (2, 2), padding=1, output_padding=1)
+
+        relu = lambda: nn.ReLU(inplace=True)
+        if deconv_decoder:                                                             # :618-686
+            self.deconv_0_4 = _named_seq([(0, deconv(512, 256)), (1, relu()), (2, conv(256, 256)), (3, relu())])
+            self.deconv_0_3 = _named_seq([(0, deconv(256, 128)), (1, relu()), (2, conv(128, 128)), (3, relu())])
+            self.deconv_0_2 = _named_seq([(0, deconv(128, 64)), (1, relu()), (2, conv(64, 64)), (3, relu())])
+            self.deconv_0_1 = _named_seq([(0, deconv(64, 64)), (1, relu())])
+        else:                                                                          # :688-733
+            up = lambda: nn.Upsample(scale_factor=2)
+            # note: both blocks end WITHOUT a ReLU (:698-700, :708-710)
+            self.upsample_0_4 = _named_seq([(0, up()), (4, conv(512, 256)), (5, relu()), (6, conv(256, 256))])
+            self.upsample_0_3 = _named_seq([(0, up()), (4, conv(256, 128)), (5, relu()), (6, conv(128, 64))])
+            if full_output:
+                self.upsample_0_2 = _named_seq([(0, up()), (2, conv(64, 64)), (3, relu()), (4, conv(64, 64)), (5, relu())])
+                self.upsample_0_1 = _named_seq([("00", up()), (2, conv(64, 64)), (3, relu()), (4, conv(64, 64)), (5, relu())])
+        self.heads_0 = _named_seq([(0, conv(64, 64)), (1, relu()), (2, conv(64, 32)), (3, relu()),
+                                   (4, conv(32, n_keypoints))])                        # :736-747
+        if internalize_spatial_softmax:                                                # :750-759
+            self.softmax = _named_seq([(0, SoftArgmaxPavlo(n_keypoints, learned_beta, initial_beta))])
+
+    def forward(self, x):                                                              # :761-827
+        x1 = self.layer_0_1_down(x)
+        x1d = self.down_sample(x1)
+        x2 = self.layer_0_2_down(x1d)
+        x2d = self.down_sample(x2)
+        x3 = self.layer_0_3_down(x2d)
+        x3d = self.down_sample(x3)
+        x4 = self.layer_0_4_down(x3d)
+        x4d = self.down_sample(x4)
+        x5 = self.layer_0_5_down(x4d)
+        skip = self.skip_connections
+        d = x5 + x4d if skip else x5
+        if self.deconv_decoder:
+            y = self.deconv_0_4(d)
+            y = self.deconv_0_3(y + x3d if skip else y)
+            y = self.deconv_0_2(y + x2d if skip else y)
+            y = self.deconv_0_1(y + x1d if skip else y)
+            out = self.heads_0(y + x1 if skip else y)
+        else:
+            y = self.upsample_0_4(d)
+            y = self.upsample_0_3(y + x3d if skip else y)
+            if self.full_output:
+                y = self.upsample_0_1(self.upsample_0_2(y))
+            out = self.heads_0(y)
+        outs = [out]
+        if self.internalize_spatial_softmax:
+            outs.append(self.softmax(out))
+        return outs
+
+
+class ResnetSimple(nn.Module):
+    """models.py:17-155.  ResNet101 trunk, 4 (or 5) x [ConvT 4x4 s2 p1 -> BN -> ReLU], 1x1 -> K."""
+
+    def __init__(self, n_keypoints=7, full=False):
+        super().__init__()
+        net = ResNet101()
+        self.full = full
+        self.conv1, self.bn1, self.relu, self.maxpool = net.conv1, net.bn1, net.relu, net.maxpool
+        self.layer1, self.layer2, self.layer3, self.layer4 = net.layer1, net.layer2, net.layer3, net.layer4
+
+        def up_block(ci):
+            return [nn.ConvTranspose2d(ci, 256, 4, 2, 1, 0), nn.BatchNorm2d(256, momentum=0.1),
+                    nn.ReLU(inplace=True)]
+
+        ups = up_block(2048) + up_block(256) + up_block(256) + up_block(256)
+        if not full:
+            self.upsample = nn.Sequential(*(ups + [nn.Conv2d(256, n_keypoints, 1, 1)]))       # :37-79
+        else:
+            self.upsample = nn.Sequential(*ups)                                               # :81-122
+            self.upsample2 = nn.Sequential(*(up_block(256) + [nn.Conv2d(256, n_keypoints, 1, 1)]))  # :124-136
+
+    def forward(self, x):                                                                     # :138-155
+        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        x = self.upsample(x)
+        if self.full:
+            x = self.upsample2(x)
+        return [x]
+
+
+def build_model(arch, n_keypoints):
+    """arch in {vgg_q, vgg_f, resnet_h, resnet_f}: what DreamNetwork.__init__ builds for the four
+    shipped arch_configs (network.py:194-284), minus the DataParallel wrapper."""
+    if arch == "vgg_q":
+        return DreamHourglass(n_keypoints, internalize_spatial_softmax=False)
+    if arch == "vgg_f":
+        return DreamHourglass(n_keypoints, internalize_spatial_softmax=False, deconv_decoder=True)
+    if arch == "resnet_h":
+        return ResnetSimple(n_keypoints, full=False)
+    if arch == "resnet_f":
+        return ResnetSimple(n_keypoints, full=True)
+    raise ValueError(arch)
+
+
+def recipe_weights(state_dict, final_keys=(), final_scale=1.0):
+    """Construction-order-independent synthetic weights: every tensor is
+    drawn from RandomState(crc32(key)), fan-in scaled so activations neither die nor blow up.
+    Returns a new dict; BN running stats are made non-trivial so eval-mode BN is exercised."""
+    import zlib
+    import numpy as np
+    out = {}
+    for key, t in state_dict.items():
+        rs = np.random.RandomState(zlib.crc32(key.encode()) & 0x7FFFFFFF)
+        shape = tuple(t.shape)
+        if key.endswith("num_batches_tracked"):
+            v = np.zeros(shape, dtype=np.int64)
+        elif key.endswith("running_mean"):
+            v = rs.uniform(-0.1, 0.1, shape)
+        elif key.endswith("running_var"):
+            v = rs.uniform(0.8, 1.2, shape)
+        elif t.dim() == 4:
+            # He-uniform on fan-in keeps ReLU activations O(1) through 20+ layers
+            if "deconv" in key or ("upsample" in key and t.shape[-1] == 4):
+                # ConvTranspose2d weight is [Cin, Cout, kh, kw]; each output sees ~kh*kw/4 taps
+                fan_in = t.shape[0] * t.shape[2] * t.shape[3] / 4.0
+            else:
+                fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+            bound = (6.0 / fan_in) ** 0.5
+            v = rs.uniform(-bound, bound, shape)
+        elif key.endswith("weight"):        # BN gamma (last BN of a bottleneck kept small so the
+            v = rs.uniform(0.8, 1.2, shape)  # 33 residual adds do not blow the activations up)
+            if "bn3." in key or "downsample.1." in key:
+                v = v * 0.25
+        elif key.endswith("beta"):
+            v = np.asarray(t.detach().cpu().numpy(), dtype=np.float64)
+        else:                               # biases / BN beta
+            v = rs.uniform(-0.05, 0.05, shape)
+        if any(key.endswith(fk) for fk in final_keys):
+            v = v * final_scale
+        out[key] = torch.as_tensor(np.asarray(v), dtype=t.dtype)
+    return out

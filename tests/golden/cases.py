@@ -1,0 +1,113 @@
+"""Seeded synthetic inputs shared by make_golden.py (dev container, runs the real reference) and
+by the test-suite (dev container + GPU box, compares oracle / HIP path with the stored outputs).
+Pure NumPy: the same seeds give the same bytes everywhere."""
+import numpy as np
+
+
+def blob(res_wh, points, sigma=2):
+    """create_belief_map semantics (image_proc.py:866-910), vectorised; float64 [N,H,W]."""
+    width, height = res_wh
+    out = np.zeros((len(points), height, width))
+    w = int(sigma * 2)
+    dy, dx = np.mgrid[-w:w + 1, -w:w + 1]
+    g = np.exp(-((dx ** 2 + dy ** 2) / (2 * (sigma ** 2))))
+    for n, pt in enumerate(points):
+        u, v = int(pt[0]), int(pt[1])
+        if u - w >= 0 and u + w + 1 < width and v - w >= 0 and v + w + 1 < height:
+            out[n, v - w:v + w + 1, u - w:u + w + 1] = g
+    return out
+
+
+def peak_cases():
+    """name -> (maps float32 [K,H,W], offset).  Covers: the reference KAT, noisy blobs at every
+    output resolution of the four archs, border peaks, plateaus (ties), negative maps, two-blob
+    maps with score gaps on both sides of 0.25, all-zero maps, a map smaller than the filter."""
+    cases = {}
+    cases["ref_kat_80x60"] = (blob((80, 60), [(65.0, 20.0), (100.0, 80.0)]).astype(np.float32), 0.0)
+    for name, (h, w), off, seed in [("q100", (100, 100), 0.4395, 11), ("h208", (208, 208), 0.4395, 12),
+                                    ("f400", (400, 400), 0.0, 13), ("r416", (416, 416), 0.0, 14),
+                                    ("odd133x100", (100, 133), 0.4395, 15)]:
+        rs = np.random.RandomState(seed)
+        k = 7 if max(h, w) < 300 else 3
+        pts = np.stack([rs.uniform(0, w, k), rs.uniform(0, h, k)], 1)
+        m = blob((w, h), pts) * rs.uniform(0.3, 1.0, (k, 1, 1)) + rs.normal(0, 0.01, (k, h, w))
+        cases[name] = (m.astype(np.float32), off)
+    rs = np.random.RandomState(21)
+    # two blobs per map, score gap swept across the 0.25 rule
+    gaps = [0.0, 0.1, 0.2499, 0.25, 0.2501, 0.4, 0.9]
+    two = np.zeros((len(gaps), 100, 100))
+    for i, g in enumerate(gaps):
+        two[i] = blob((100, 100), [(30, 30)])[0] * 1.0 + blob((100, 100), [(70, 60)])[0] * (1.0 - g)
+    cases["two_blobs_gap"] = (two.astype(np.float32), 0.4395)
+    edge = np.zeros((6, 60, 80), np.float32)
+    edge[0, 0, 0] = 1.0                      # corner spike
+    edge[1, 59, 79] = 2.0                    # other corner
+    edge[2, 0, 40] = 1.0                     # top edge
+    edge[3, 30, 0] = 1.0                     # left edge
+    edge[4, 20:24, 30:34] = 0.5              # plateau -> ties in the smoothed map
+    edge[5, 10, 10] = 1.0
+    edge[5, 10, 69] = 1.0                    # symmetric twin peaks -> equal scores
+    cases["edges_plateau"] = (edge, 0.4395)
+    neg = (rs.normal(-0.2, 0.05, (3, 50, 50))).astype(np.float32)
+    neg[1, 25, 25] = 3.0                     # one strong positive in a negative map
+    neg[2] = 0.0                             # all-zero map
+    cases["negative_zero"] = (neg, 0.4395)
+    cases["tiny_5x7"] = ((rs.uniform(0, 1, (2, 5, 7))).astype(np.float32), 0.0)
+    cases["noise_100"] = ((rs.normal(0.05, 0.05, (4, 100, 100))).astype(np.float32), 0.4395)
+    # centroid window with exactly cancelling weights -> ZeroDivisionError branch
+    ring = np.zeros((40, 40), np.float32)
+    yy, xx = np.mgrid[0:40, 0:40]
+    r2 = (yy - 20) ** 2 + (xx - 20) ** 2
+    ring[(r2 >= 16) & (r2 <= 36)] = 1.0      # ring: smoothed max at the centre, 5x5 window ~empty
+    cases["ring_zero_window"] = (ring[None], 0.0)
+    return cases
+
+
+def softargmax_cases():
+    """name -> (maps float32 [B,K,H,W], beta)."""
+    kat = np.zeros((1, 3, 20, 30), np.float32)
+    kat[0, 0, 5, 7] = 10.0
+    kat[0, 1, 10, 15] = 10.0
+    kat[0, 2, 19, 29] = 10.0
+    rs = np.random.RandomState(31)
+    return {
+        "kat_b25": (kat, 25.0),
+        "rand_b1": (rs.normal(0, 1, (2, 7, 100, 100)).astype(np.float32), 1.0),
+        "rand_b25": (rs.normal(0, 0.2, (2, 7, 100, 100)).astype(np.float32), 25.0),
+        "odd_b5": (rs.normal(0, 0.5, (1, 17, 33, 21)).astype(np.float32), 5.0),
+    }
+
+
+def image_batch(b, h, w, seed=0):
+    """SURVEY.md 8d synthetic frames: uint8 RGB -> ToTensor -> Normalize(0.5, 0.5); NCHW float32."""
+    rs = np.random.RandomState(seed)
+    u8 = rs.randint(0, 256, (b, h, w, 3)).astype(np.uint8)
+    x = (u8.astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+
+
+def target_batch(b, k, out_wh, in_wh=(400, 400), seed=0):
+    """panda_synth_train_dr-shaped targets: K keypoints uniform in the input frame, scaled to the
+    output resolution, sigma-2 blobs; float32 [B,K,Ho,Wo]."""
+    rs = np.random.RandomState(seed + 1000)
+    wo, ho = out_wh
+    out = np.zeros((b, k, ho, wo), np.float32)
+    for i in range(b):
+        pts = np.stack([rs.uniform(0, in_wh[0], k) * wo / in_wh[0],
+                        rs.uniform(0, in_wh[1], k) * ho / in_wh[1]], 1)
+        out[i] = blob((wo, ho), pts).astype(np.float32)
+    return out
+
+
+# CNN parity cases: arch -> (n_keypoints, manipulator, [(B, H, W), ...])
+CNN_CASES = {
+    "vgg_q": (7, "panda", [(2, 64, 80), (1, 400, 400), (1, 50, 75)]),
+    "vgg_f": (7, "panda", [(2, 64, 80)]),
+    "resnet_h": (7, "panda", [(2, 64, 96)]),
+    "resnet_f": (17, "baxter", [(1, 64, 64)]),
+}
+
+# one-training-step golden (G5): learning rates and the recipe tweak that keep the loss finite
+TRAIN_LR = {"adam": 1e-5, "sgd": 1e-6}
+TRAIN_FINAL_KEYS = ("heads_0.4.weight", "heads_0.4.bias")
+TRAIN_FINAL_SCALE = 0.1

@@ -1,0 +1,124 @@
+"""Generate the committed golden fixtures by running the REAL reference (stub-imported, see
+ref_import.py) in the dev container.  Usage:  python tests/golden/make_golden.py
+
+Fixtures are data only (inputs are regenerated from seeds by cases.py; outputs are stored):
+  peaks_golden.npz      G1/G2  peaks_from_belief_maps + DreamNetwork.inference selection rule
+  softargmax_golden.npz G3     SoftArgmaxPavlo
+  cnn_<arch>.npz        G4     model(x)[0] for recipe weights (oracle.models.recipe_weights)
+  train_vgg_q.npz       G5     one DreamNetwork.train() step (loss, grad norms, post-Adam samples)
+  state_dict_manifest.json G6  key -> shape for the four archs (module.-prefixed, as saved)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import cases  # noqa: E402
+import ref_import  # noqa: E402
+from oracle import models as omodels  # noqa: E402
+
+
+def flatten_peaks(all_peaks):
+    """list[K] of list of (x, y, score, id) -> counts[K], xy float64 [N,2], score float32 [N], id [N]."""
+    counts = np.array([len(p) for p in all_peaks], np.int64)
+    flat = [q for p in all_peaks for q in p]
+    xy = np.array([[q[0], q[1]] for q in flat], np.float64).reshape(-1, 2)
+    sc = np.array([q[2] for q in flat], np.float32)
+    ids = np.array([q[3] for q in flat], np.int64)
+    return counts, xy, sc, ids
+
+
+def main():
+    dream = ref_import.import_reference()
+    torch.manual_seed(0)
+
+    # ---- G1 + G2 -------------------------------------------------------------------------
+    out = {}
+    net_q = dream.create_network_from_config_data(ref_import.network_config("vgg_q"))
+    for name, (maps, off) in cases.peak_cases().items():
+        pk = dream.image_proc.peaks_from_belief_maps(torch.from_numpy(maps), off)
+        c, xy, sc, ids = flatten_peaks(pk)
+        out[name + "/counts"], out[name + "/xy"], out[name + "/score"], out[name + "/id"] = c, xy, sc, ids
+        # selection rule through the reference's own DreamNetwork.inference: the model is replaced
+        # by a stand-in returning these maps; the trained output resolution decides the offset.
+        net_q.model = lambda x, _m=maps: [torch.from_numpy(_m)[None]]
+        net_q.network_config["training"]["config"]["net_output_resolution"] = (
+            [400, 400] if off == 0.0 else [100, 100])
+        _, kps = net_q.inference(torch.zeros(1, 3, 8, 8))
+        assert kps.dtype == torch.float32 and kps.device.type == "cpu"
+        out[name + "/keypoints"] = kps.numpy()
+    np.savez_compressed(os.path.join(HERE, "peaks_golden.npz"), **out)
+    print("peaks_golden:", {k: v.shape for k, v in out.items() if k.endswith("counts")})
+
+    # ---- G3 --------------------------------------------------------------------------------
+    out = {}
+    for name, (maps, beta) in cases.softargmax_cases().items():
+        sm = dream.spatial_softmax.SoftArgmaxPavlo(n_keypoints=maps.shape[1], learned_beta=False,
+                                                   initial_beta=beta)
+        out[name] = sm(torch.from_numpy(maps)).numpy()
+    np.savez_compressed(os.path.join(HERE, "softargmax_golden.npz"), **out)
+    print("softargmax kat:", out["kat_b25"])
+
+    # ---- G4 + G6 ---------------------------------------------------------------------------
+    manifest = {}
+    for arch, (k, manip, shapes) in cases.CNN_CASES.items():
+        net = dream.create_network_from_config_data(ref_import.network_config(arch, manip))
+        assert net.n_keypoints == k
+        sd = net.model.state_dict()
+        manifest[arch] = {key: list(v.shape) for key, v in sd.items()}
+        w = omodels.recipe_weights({key[len("module."):]: v for key, v in sd.items()})
+        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+        net.enable_evaluation()
+        out = {}
+        for (b, h, wd) in shapes:
+            x = torch.from_numpy(cases.image_batch(b, h, wd, seed=b * 1000 + h))
+            with torch.no_grad():
+                maps, kps = net.inference(x)
+            tag = "%dx%dx%d" % (b, h, wd)
+            y = maps.numpy()
+            if y.size <= 200000:
+                out[tag + "/maps"] = y
+            else:   # keep the file small: strided sample + checksums
+                out[tag + "/maps_sample"] = y[:, :, ::7, ::7].copy()
+                out[tag + "/maps_sum"] = np.array([y.astype(np.float64).sum(), np.abs(y).astype(np.float64).sum()])
+            out[tag + "/keypoints"] = kps.numpy()
+            print(arch, tag, "->", y.shape, "absmax %.3f" % np.abs(y).max(),
+                  "detections", int((kps.numpy()[..., 0] > -999).sum()), "/", kps.numpy().shape[0] * k)
+        np.savez_compressed(os.path.join(HERE, "cnn_%s.npz" % arch), **out)
+    with open(os.path.join(HERE, "state_dict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=False)
+
+    # ---- G5: one training step, vgg_q (config 3 at small resolution) ------------------------
+    for opt in ("adam", "sgd"):
+        cfg = ref_import.network_config("vgg_q", lr=cases.TRAIN_LR[opt], optimizer=opt)
+        cfg["training"]["config"]["net_input_resolution"] = [96, 64]
+        net = dream.create_network_from_config_data(cfg)
+        sd = net.model.state_dict()
+        w = omodels.recipe_weights({key[len("module."):]: v for key, v in sd.items()},
+                                   final_keys=cases.TRAIN_FINAL_KEYS, final_scale=cases.TRAIN_FINAL_SCALE)
+        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+        net.enable_training()
+        x = torch.from_numpy(cases.image_batch(2, 64, 96, seed=5))
+        tgt = torch.from_numpy(cases.target_batch(2, 7, (24, 16), in_wh=(96, 64), seed=5))
+        losses = []
+        for step in range(3):
+            loss = net.train([x], tgt)
+            losses.append(loss.item())
+            if step == 0:
+                gn = {key: float(p.grad.double().norm()) for key, p in net.model.named_parameters()}
+        out = {"losses": np.array(losses, np.float64)}
+        for key, v in gn.items():
+            out["gradnorm/" + key] = np.array(v)
+        for key, p in net.model.named_parameters():
+            out["param_sample/" + key] = p.detach().flatten()[:: max(1, p.numel() // 64)][:64].numpy().copy()
+        np.savez_compressed(os.path.join(HERE, "train_vgg_q_%s.npz" % opt), **out)
+        print("train", opt, "losses", losses)
+
+
+if __name__ == "__main__":
+    main()

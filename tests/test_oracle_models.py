@@ -1,0 +1,94 @@
+"""CPU: pin oracle.models against outputs of the stub-imported reference (tests/golden/cnn_*.npz,
+train_vgg_q_*.npz, state_dict_manifest.json) and the released-checkpoint sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import models as om
+from oracle import peaks as op
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("arch", ["vgg_q", "vgg_f", "resnet_h", "resnet_f"])
+def test_state_dict_manifest_and_checkpoint_size(arch):
+    k = cases.CNN_CASES[arch][0]
+    sd = om.build_model(arch, k).state_dict()
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))[arch]
+    assert ["module." + key for key in sd.keys()] == list(man.keys())
+    assert all(list(sd[key[len("module."):]].shape) == shp for key, shp in man.items())
+    nparam = sum(v.numel() for key, v in sd.items() if v.dtype.is_floating_point and "running" not in key)
+    # trained_models/DOWNLOAD.sh:12-38 : 85 / 86 / 207 / 211 MB checkpoints (K=7 for the shipped ones)
+    expect = {"vgg_q": 22220615, "vgg_f": 22442055, "resnet_h": 54039367, "resnet_f": 55091281}[arch]
+    assert nparam == expect
+
+
+@pytest.mark.parametrize("arch", ["vgg_q", "vgg_f", "resnet_h", "resnet_f"])
+def test_cnn_matches_reference_outputs(arch):
+    k, _, shapes = cases.CNN_CASES[arch]
+    g = np.load(os.path.join(GOLD, "cnn_%s.npz" % arch))
+    m = om.build_model(arch, k)
+    m.load_state_dict(om.recipe_weights(m.state_dict()))
+    m.eval()
+    for (b, h, w) in shapes:
+        if h * w > 100000 and os.environ.get("DREAM_FULL_ORACLE", "0") != "1" and arch != "vgg_q":
+            continue
+        x = torch.from_numpy(cases.image_batch(b, h, w, seed=b * 1000 + h))
+        with torch.no_grad():
+            y = m(x)[0].numpy()
+        tag = "%dx%dx%d" % (b, h, w)
+        if tag + "/maps" in g:
+            ref = g[tag + "/maps"]
+            err = np.abs(y - ref).max()
+        else:
+            ref = g[tag + "/maps_sample"]
+            err = np.abs(y[:, :, ::7, ::7] - ref).max()
+        # same torch CPU kernels; thread-count dependent summation order only
+        assert err <= 1e-5 * max(1.0, np.abs(ref).max()), (arch, tag, err)
+        off = op.upsampling_offset(*{"vgg_q": (100, 100), "vgg_f": (400, 400), "resnet_h": (208, 208),
+                                     "resnet_f": (416, 416)}[arch])
+        kps = op.keypoints_from_belief_maps(y, off)
+        ref_k = g[tag + "/keypoints"]
+        assert np.array_equal(kps == np.float32(-999.999), ref_k == np.float32(-999.999))
+        assert np.abs(kps - ref_k).max() < 1e-3
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_train_step_matches_reference(opt):
+    g = np.load(os.path.join(GOLD, "train_vgg_q_%s.npz" % opt))
+    m = om.build_model("vgg_q", 7)
+    m.load_state_dict(om.recipe_weights(m.state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE))
+    m.train()
+    lr = cases.TRAIN_LR[opt]
+    o = torch.optim.Adam(m.parameters(), lr=lr) if opt == "adam" else torch.optim.SGD(m.parameters(), lr=lr)
+    x = torch.from_numpy(cases.image_batch(2, 64, 96, seed=5))
+    t = torch.from_numpy(cases.target_batch(2, 7, (24, 16), in_wh=(96, 64), seed=5))
+    losses = []
+    for step in range(3):
+        o.zero_grad()
+        loss = torch.nn.functional.mse_loss(m(x)[0], t)
+        loss.backward()
+        o.step()
+        losses.append(loss.item())
+        if step == 0:
+            for key, p in m.named_parameters():
+                ref = float(g["gradnorm/module." + key])
+                assert abs(float(p.grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-6), key
+    assert np.allclose(losses, g["losses"], rtol=1e-4)
+    for key, p in m.named_parameters():
+        s = p.detach().flatten()[:: max(1, p.numel() // 64)][:64].numpy()
+        assert np.allclose(s, g["param_sample/module." + key], rtol=1e-4, atol=1e-6), key
+
+
+def test_softargmax_matches_reference_outputs():
+    g = np.load(os.path.join(GOLD, "softargmax_golden.npz"))
+    for name, (maps, beta) in cases.softargmax_cases().items():
+        sm = om.SoftArgmaxPavlo(maps.shape[1], learned_beta=False, initial_beta=beta)
+        y = sm(torch.from_numpy(maps)).numpy()
+        assert np.allclose(y, g[name], rtol=0, atol=1e-4), name
+    # SURVEY.md 8a6 KAT (border bias from the zero-padded avg-pool is expected behaviour)
+    assert np.allclose(g["kat_b25"][0], [[7.5230, 5.3138], [14.9651, 9.9651], [25.0729, 16.0064]], atol=1e-3)
