@@ -1,0 +1,132 @@
+"""ctypes binding of libdream_hip.so (the C ABI declared in include/dream_hip.h).
+
+This is the reference-side binding a DREAM maintainer would add: plain
+pointers and sizes, ``hipStream_t`` taken from ``torch.cuda.current_stream()``.  There is NO
+fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdream_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "dream_hip.h")
+
+CONV_RELU = 1
+CONV_UPSAMPLE2X = 2
+CONV_OUT_NCHW = 4
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_SZ = _c.c_size_t
+_F = _c.c_float
+_D = _c.c_double
+
+# name -> (restype, argtypes); must list every function of include/dream_hip.h (checked by
+# check_symbols(), which the CPU test-suite runs)
+_SIGNATURES = {
+    "dream_hip_abi_version": (_I, []),
+    "dream_hip_last_error": (_c.c_char_p, []),
+    "dream_hip_device_count": (_I, [_c.POINTER(_I)]),
+    "dream_hip_device_name": (_I, [_I, _c.c_char_p, _SZ]),
+    "dream_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dream_unpack_conv3x3_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_cout_pad": (_SZ, [_I]),
+    "dream_conv3x3_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_set_variant": (_I, [_I]),
+    "dream_conv3x3_num_variants": (_I, []),
+    "dream_conv3x3_variant_name": (_c.c_char_p, [_I]),
+    "dream_conv3x3_first_nchw_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_maxpool2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dream_nchw_to_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dream_nchw_to_nhwc_pad_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dream_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dream_keypoints_from_belief_maps_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _D, _P]),
+    "dream_peaks_from_belief_maps_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P]),
+    "dream_gaussian_sigma3_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "dream_softargmax_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "dream_mse_fwd_bwd_f32": (_I, [_P, _P, _P, _P, _SZ, _D, _P]),
+    "dream_relu_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
+    "dream_maxpool2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_upsample2_bwd_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "dream_conv3x3_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_first_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "dream_conv3x3_first_wgrad_f32": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),
+    "dream_adam_step_f32": (_I, [_P, _P, _P, _P, _SZ, _F, _F, _F, _F, _I, _P]),
+    "dream_sgd_step_f32": (_I, [_P, _P, _SZ, _F, _P]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def header_functions():
+    """Function names declared in include/dream_hip.h."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(dream_[a-z0-9_]+)\s*\(", text)))
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises HipLibraryError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryError(
+                "libdream_hip.so is not built (%s). Run `python __graft_entry__.py` (hipcc, gfx950). "
+                "There is no CPU fallback." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check_symbols():
+    """Every function the header declares must be exported and bound (no compute is run)."""
+    handle = lib()
+    declared = header_functions()
+    missing = [n for n in declared if not hasattr(handle, n)]
+    unbound = [n for n in declared if n not in _SIGNATURES]
+    if missing or unbound:
+        raise HipLibraryError("missing exports %s / unbound %s" % (missing, unbound))
+    if handle.dream_hip_abi_version() != 1:
+        raise HipLibraryError("ABI version mismatch")
+    return declared
+
+
+def call(name, *args):
+    """Invoke a status-returning entry point; non-zero -> RuntimeError with the library's message."""
+    handle = lib()
+    rc = getattr(handle, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, handle.dream_hip_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  The tensor must be contiguous fp32/int32/fp64
+    on a GPU: a CPU tensor here means the caller tried to run the HIP path without a device."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("dream_amd: tensor is on %s; the HIP path needs a GPU tensor (no CPU fallback)"
+                           % t.device)
+    if not t.is_contiguous():
+        raise RuntimeError("dream_amd: non-contiguous tensor passed to the HIP library")
+    return t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def cout_pad(cout):
+    return int(lib().dream_conv3x3_cout_pad(cout))

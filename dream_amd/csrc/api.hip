@@ -1,0 +1,24 @@
+// Library-level entry points of libdream_hip.so (version, error string, device probes).
+#include "common.h"
+#include "../../include/dream_hip.h"
+#include <string.h>
+
+char *dream_err_buf() {
+    static thread_local char buf[DREAM_ERR_LEN] = {0};
+    return buf;
+}
+
+extern "C" int dream_hip_abi_version(void) { return DREAM_HIP_ABI_VERSION; }
+extern "C" const char *dream_hip_last_error(void) { return dream_err_buf(); }
+extern "C" int dream_hip_device_count(int *count) {
+    DREAM_REQUIRE(count != nullptr, "null pointer");
+    DREAM_HIP_OK(hipGetDeviceCount(count));
+    return 0;
+}
+extern "C" int dream_hip_device_name(int dev, char *buf, size_t buflen) {
+    DREAM_REQUIRE(buf != nullptr && buflen > 0, "null buffer");
+    hipDeviceProp_t prop;
+    DREAM_HIP_OK(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}

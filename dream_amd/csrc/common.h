@@ -1,0 +1,32 @@
+// Host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stddef.h>
+
+char *dream_err_buf();            // thread-local, 512 bytes
+#define DREAM_ERR_LEN 512
+
+#define DREAM_REQUIRE(cond, ...)                                            \
+    do {                                                                    \
+        if (!(cond)) {                                                      \
+            snprintf(dream_err_buf(), DREAM_ERR_LEN, __VA_ARGS__);          \
+            return 1;                                                       \
+        }                                                                   \
+    } while (0)
+
+#define DREAM_HIP_OK(call)                                                  \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) {                                             \
+            snprintf(dream_err_buf(), DREAM_ERR_LEN, "%s failed: %s (%s:%d)", #call, \
+                     hipGetErrorString(e_), __FILE__, __LINE__);            \
+            return 2;                                                       \
+        }                                                                   \
+    } while (0)
+
+#define DREAM_LAUNCH_OK() DREAM_HIP_OK(hipGetLastError())
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,309 @@
+// HBM-bound helpers of the belief-map network: 2x2 max-pool (+backward), nearest-x2 upsample
+// backward, ReLU backward, NCHW<->NHWC layout changes, weight (un)packing, fused MSE loss +
+// gradient, Adam / SGD.  All are streaming kernels: 16-byte accesses per lane, consecutive lanes on
+// consecutive addresses, grid-stride loops capped at 256 CUs x 8 workgroups.
+//
+// Reference call sites: nn.MaxPool2d(2) dream/models.py:589,765-771; nn.Upsample dream/models.py:691,703;
+// nn.ReLU(inplace) throughout models.py; torch.nn.MSELoss dream/network.py:260-261,359;
+// torch.optim.Adam / SGD dream/network.py:666-685.
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 8;
+
+inline unsigned grid_for(size_t work_items, int block = 256) {
+    size_t g = ceil_div_sz(work_items, (size_t)block);
+    if (g > (size_t)kMaxBlocks) g = kMaxBlocks;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---- max-pool 2x2, NHWC, channels in float4 groups ------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool2_kernel(const f32x4 *x, f32x4 *y, int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const f32x4 *s = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C4 + c;
+        const f32x4 v00 = s[0], v01 = s[C4], v10 = s[(size_t)W * C4], v11 = s[(size_t)W * C4 + C4];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = fmaxf(fmaxf(v00[k], v01[k]), fmaxf(v10[k], v11[k]));
+        y[i] = o;
+    }
+}
+
+// backward: the gradient goes to the first maximal element in (row-major) window order, which is
+// what ATen's max_pool2d_with_indices records.  Rows/cols beyond 2*floor(H/2) get zero.
+__global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const f32x4 *dy, const f32x4 *x, f32x4 *dx,
+                                                           int B, int H, int W, int C4) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int oy = iy >> 1, ox = ix >> 1;
+        if (oy < Ho && ox < Wo) {
+            const f32x4 *s = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C4 + c;
+            const f32x4 v[4] = {s[0], s[C4], s[(size_t)W * C4], s[(size_t)W * C4 + C4]};
+            const f32x4 g = dy[(((size_t)b * Ho + oy) * Wo + ox) * C4 + c];
+            const int me = (iy & 1) * 2 + (ix & 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int arg = 0;
+                float best = v[0][k];
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+                    if (v[j][k] > best) { best = v[j][k]; arg = j; }
+                o[k] = (arg == me) ? g[k] : 0.0f;
+            }
+        }
+        dx[i] = o;
+    }
+}
+
+// nearest x2 upsample backward: dx[b,y,x,:] = sum of the 2x2 block of dy
+__global__ void __launch_bounds__(256) upsample2_bwd_kernel(const f32x4 *dy, f32x4 *dx, int B, int H, int W, int C4) {
+    const int Hs = H / 2, Ws = W / 2;
+    const size_t total = (size_t)B * Hs * Ws * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int sx = (int)(r % Ws);
+        r /= Ws;
+        const int sy = (int)(r % Hs);
+        const int b = (int)(r / Hs);
+        const f32x4 *s = dy + (((size_t)b * H + 2 * sy) * W + 2 * sx) * C4 + c;
+        const f32x4 a = s[0], bb = s[C4], cc = s[(size_t)W * C4], d = s[(size_t)W * C4 + C4];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (a[k] + bb[k]) + (cc[k] + d[k]);
+        dx[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) relu_bwd_kernel(const float *dy, const float *y, float *dx, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 g = ((const f32x4 *)dy)[i], v = ((const f32x4 *)y)[i];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = v[k] > 0.0f ? g[k] : 0.0f;
+        ((f32x4 *)dx)[i] = o;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        dx[i] = y[i] > 0.0f ? dy[i] : 0.0f;
+}
+
+// ---- layout: [B,C,H,W] <-> [B,H,W,C] through a 64x(C<=64) LDS tile ----------------------------------
+// One workgroup moves 64 consecutive pixels of one image x up to 64 channels; reads are coalesced
+// along pixels (NCHW side) and writes along channels (NHWC side), or the reverse.
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float *x, float *y, int C, int HW) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < C && p0 + tx < HW) tile[c][tx] = x[((size_t)b * C + c0 + c) * HW + p0 + tx];
+    __syncthreads();
+    for (int pp = ty; pp < 64; pp += 4)
+        if (c0 + tx < C && p0 + pp < HW) y[((size_t)b * HW + p0 + pp) * C + c0 + tx] = tile[tx][pp];
+}
+// [B,C,H,W] -> [B,H,W,Cpad] with zero fill for c >= C (C, Cpad small: one thread per (pixel, c))
+__global__ void __launch_bounds__(256) nchw_to_nhwc_pad_kernel(const float *x, float *y, int B, int C, int HW, int Cpad) {
+    const size_t total = (size_t)B * HW * Cpad;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Cpad);
+        const size_t r = i / Cpad;
+        const size_t pix = r % HW, b = r / HW;
+        y[i] = c < C ? x[(b * C + c) * HW + pix] : 0.0f;
+    }
+}
+__global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float *x, float *y, int C, int HW) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int pp = ty; pp < 64; pp += 4)
+        if (c0 + tx < C && p0 + pp < HW) tile[pp][tx] = x[((size_t)b * HW + p0 + pp) * C + c0 + tx];
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4)
+        if (c0 + c < C && p0 + tx < HW) y[((size_t)b * C + c0 + c) * HW + p0 + tx] = tile[tx][c];
+}
+
+// ---- weight packing ------------------------------------------------------------------------------
+// w is the OIHW tensor [Cout][Cin][3][3] as torch stores it; t = ky*3 + kx.
+// mode 0 (forward operator):        packed[t][r][c] = w[o=r][i=c][t]        r < Cout, c < Cin
+// mode 1 (data-gradient operator):  packed[t][r][c] = w[o=c][i=r][8 - t]   r < Cin,  c < Cout
+//   i.e. rows are the channels the conv kernel PRODUCES and columns the channels it CONSUMES;
+//   flipping the taps turns correlation with dL/dy into the transposed convolution.
+// packed is [9][RowsPad][ColsPad], zero padded.
+__global__ void __launch_bounds__(256) pack_w_kernel(const float *w, float *packed, int Cout, int Cin,
+                                                     int RowsPad, int ColsPad, int mode) {
+    const size_t total = (size_t)9 * RowsPad * ColsPad;
+    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % ColsPad);
+        size_t q = idx / ColsPad;
+        const int r = (int)(q % RowsPad);
+        const int t = (int)(q / RowsPad);
+        float v = 0.0f;
+        if (r < rows && c < cols)
+            v = (mode == 0) ? w[((size_t)r * Cin + c) * 9 + t] : w[((size_t)c * Cin + r) * 9 + (8 - t)];
+        packed[idx] = v;
+    }
+}
+__global__ void __launch_bounds__(256) unpack_w_kernel(const float *packed, float *w, int Cout, int Cin,
+                                                       int CoutPad, int CinPad) {
+    const size_t total = (size_t)Cout * Cin * 9;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int t = (int)(idx % 9);
+        size_t r = idx / 9;
+        const int i = (int)(r % Cin);
+        const int o = (int)(r / Cin);
+        w[idx] = packed[((size_t)t * CoutPad + o) * CinPad + i];
+    }
+}
+
+// ---- MSE loss (mean) forward + gradient -------------------------------------------------------------
+__global__ void __launch_bounds__(256) mse_kernel(const float *o, const float *t, float *g, float *loss_sum,
+                                                  size_t n, float scale) {
+    __shared__ double part[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = o[i] - t[i];
+        acc += (double)d * (double)d;
+        if (g) g[i] = d * scale;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += lane_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (float)(part[0] + part[1] + part[2] + part[3]));
+}
+
+// ---- optimizers ------------------------------------------------------------------------------------
+// torch.optim.Adam defaults (no weight decay, no amsgrad):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
+// p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void __launch_bounds__(256) adam_kernel(float *p, const float *g, float *m, float *v, size_t n,
+                                                   float step_size, float inv_sqrt_bc2, float b1, float b2, float eps) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);     // torch: lerp(m, g, 1-b1)
+        const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}
+__global__ void __launch_bounds__(256) sgd_kernel(float *p, const float *g, size_t n, float lr) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        p[i] = p[i] - lr * g[i];
+}
+
+}  // namespace
+
+extern "C" int dream_maxpool2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && H >= 2 && W >= 2 && C > 0 && C % 4 == 0, "maxpool2: bad arguments (C=%d must be a multiple of 4)", C);
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)x, (f32x4 *)y, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(dy && x && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0, "maxpool2_bwd: bad arguments");
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_upsample2_bwd_nhwc_f32(const float *dy, float *dx, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(dy && dx && B > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "upsample2_bwd: bad arguments");
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)dy, (f32x4 *)dx, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_relu_bwd_f32(const float *dy, const float *y, float *dx, size_t n, void *stream) {
+    DREAM_REQUIRE(dy && y && dx, "relu_bwd: null pointer");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad arguments");
+    const dim3 grid(ceil_div(H * W, 64), ceil_div(C, 64), B);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, H * W);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_nchw_to_nhwc_pad_f32(const float *x, float *y, int B, int C, int H, int W, int Cpad, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C, "nchw_to_nhwc_pad: bad arguments");
+    hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for((size_t)B * H * W * Cpad)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, C, H * W, Cpad);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad arguments");
+    const dim3 grid(ceil_div(H * W, 64), ceil_div(C, 64), B);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, y, C, H * W);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_pack_conv3x3_weight(const float *w_oihw, float *packed, int Cout, int Cin, int CoutPad,
+                                         int CinPad, int mode, void *stream) {
+    DREAM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "pack_conv3x3_weight: bad arguments");
+    // CoutPad / CinPad are the padded ROW / COLUMN counts of the packed tensor (see pack_w_kernel)
+    DREAM_REQUIRE(CoutPad >= (mode == 0 ? Cout : Cin) && CinPad >= (mode == 0 ? Cin : Cout), "pack_conv3x3_weight: padding smaller than the tensor");
+    hipLaunchKernelGGL(pack_w_kernel, dim3(grid_for((size_t)9 * CoutPad * CinPad)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, packed, Cout, Cin, CoutPad, CinPad, mode);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_unpack_conv3x3_weight(const float *packed, float *w_oihw, int Cout, int Cin, int CoutPad,
+                                           int CinPad, void *stream) {
+    DREAM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && CoutPad >= Cout && CinPad >= Cin, "unpack: bad arguments");
+    hipLaunchKernelGGL(unpack_w_kernel, dim3(grid_for((size_t)9 * Cout * Cin)), dim3(256), 0, (hipStream_t)stream,
+                       packed, w_oihw, Cout, Cin, CoutPad, CinPad);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+                                     size_t n, double n_total, void *stream) {
+    DREAM_REQUIRE(out && target && loss_sum && n > 0 && n_total > 0, "mse: bad arguments");
+    hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, target, grad, loss_sum,
+                       n, (float)(2.0 / n_total));
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, float lr, float beta1,
+                                   float beta2, float eps, int step, void *stream) {
+    DREAM_REQUIRE(p && g && m && v && step >= 1, "adam: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n,
+                       (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_sgd_step_f32(float *p, const float *g, size_t n, float lr, void *stream) {
+    DREAM_REQUIRE(p && g, "sgd: null pointer");
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, n, lr);
+    DREAM_LAUNCH_OK();
+    return 0;
+}

@@ -1,0 +1,36 @@
+// CDNA4 (gfx950) device intrinsics used by the DREAM kernels: thin named wrappers over the
+// compiler builtins so that the lane layouts are documented in one place.
+//
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 cycles/SIMD, 157 TFLOP/s chip peak):
+//   A operand: one float per lane, lane l holds A[row = l & 31][k = l >> 5]
+//   B operand: one float per lane, lane l holds B[k = l >> 5][col = l & 31]
+//   C/D      : 16 floats per lane, reg r of lane l is D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l & 31]
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DREAM_DEVICE __device__ __forceinline__
+// all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned (ds_read_b128)
+#define DREAM_DYNAMIC_LDS(type, var) extern __shared__ __attribute__((aligned(16))) type var[]
+
+DREAM_DEVICE f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// wave index within the workgroup as a provably wave-uniform (SGPR) value
+DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// cross-lane helpers (wave = 64 lanes)
+DREAM_DEVICE float  lane_xor(float v, int m)  { return __shfl_xor(v, m, 64); }
+DREAM_DEVICE double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+DREAM_DEVICE int    lane_xor(int v, int m)    { return __shfl_xor(v, m, 64); }
+DREAM_DEVICE int    lane_up(int v, int d)     { return __shfl_up(v, d, 64); }
+DREAM_DEVICE unsigned long long wave_ballot(int pred) { return __ballot(pred); }
+DREAM_DEVICE int    popcount64(unsigned long long v) { return __popcll(v); }
+
+// IEEE fp64 ops that the compiler must not contract into FMAs (bit-exactness with NumPy/SciPy)
+DREAM_DEVICE double dmul(double a, double b) { return __dmul_rn(a, b); }
+DREAM_DEVICE double dadd(double a, double b) { return __dadd_rn(a, b); }
+DREAM_DEVICE double ddiv(double a, double b) { return __ddiv_rn(a, b); }

@@ -1,0 +1,246 @@
+// Belief-map peak extraction: everything DreamNetwork.inference does after the CNN
+// (/root/reference/dream/network.py:529-581), i.e. dream.image_proc.peaks_from_belief_maps
+// (/root/reference/dream/image_proc.py:914-1018) and the per-keypoint selection rule.
+//
+// Bit-exactness contract (tests/test_peaks_gpu.py): the smoothed map equals
+// scipy.ndimage.gaussian_filter(m, sigma=3) bit-for-bit and the centroids equal NumPy's float64
+// np.average bit-for-bit.  That pins the arithmetic order:
+//   * Gaussian: two 1-D passes (axis 0 then axis 1), each pixel accumulated in fp64 as
+//       acc = x[l]*w[c];  for i = -12..-1: acc += (x[l+i] + x[l-i]) * w[c+i]
+//     (scipy's symmetric-kernel branch of NI_Correlate1D), 'reflect' (half-sample symmetric)
+//     boundary, result stored to fp32 after EACH pass.  The 13 distinct taps are the doubles scipy
+//     computes for sigma=3/radius=12, hard-coded as hex literals.
+//   * centroid: 25 products in fp64 laid out [col offset][row offset], summed with NumPy's
+//     8-lane pairwise scheme, divided, offset added, then rounded once to fp32.
+//   * no FMA contraction anywhere on these paths (dmul/dadd/ddiv = __dmul_rn/__dadd_rn/__ddiv_rn).
+// All three kernels are HBM/L2-bound streaming kernels (4 B/pixel compulsory read); fp64 rate is
+// irrelevant at 25 taps/pixel.
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+namespace {
+
+constexpr int R = 12;
+// scipy _gaussian_kernel1d(sigma=3, order=0, radius=12)[0..12]  (index 12 = centre tap)
+__constant__ double kTaps[13] = {
+    0x1.763a210dfb306p-15, 0x1.4fbe39149e277p-13, 0x1.0d8a5ad43c165p-11, 0x1.8345966f69518p-10,
+    0x1.f1e9915139406p-9,  0x1.1e6bccad344bap-7,  0x1.26defcaeb0202p-6,  0x1.0fa58939b528fp-5,
+    0x1.bfde9c12bec92p-5,  0x1.4a614d1afd337p-4,  0x1.b42a57d56c0bep-4,  0x1.01a25f86eb137p-3,
+    0x1.105a329f98197p-3};
+
+DREAM_DEVICE int reflect_index(int i, int n) {
+    // half-sample symmetric extension  (d c b a | a b c d | d c b a), any distance
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+
+// one 1-D pass; `stride` is the element stride along the filtered axis, `len` its length
+template <int AXIS>
+__global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float *out, int N, int H, int W) {
+    const size_t total = (size_t)N * H * W;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const size_t r = idx / W;
+        const int y = (int)(r % H);
+        const size_t n = r / H;
+        const float *base = in + n * (size_t)H * W;
+        const int l = AXIS == 0 ? y : x;
+        const int len = AXIS == 0 ? H : W;
+        auto at = [&](int pos) -> double {
+            const int q = (pos >= 0 && pos < len) ? pos : reflect_index(pos, len);
+            return (double)(AXIS == 0 ? base[(size_t)q * W + x] : base[(size_t)y * W + q]);
+        };
+        double acc = dmul(at(l), kTaps[R]);
+#pragma unroll
+        for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd(at(l + i), at(l - i)), kTaps[R + i]));
+        out[idx] = (float)acc;
+    }
+}
+
+DREAM_DEVICE double pairwise_sum25(const double *a) {
+    // NumPy pairwise summation for n = 25 (< 128): 8 strided partial sums, balanced combine, tail
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = dadd(dadd(a[j], a[8 + j]), a[16 + j]);
+    const double res = dadd(dadd(dadd(r[0], r[1]), dadd(r[2], r[3])), dadd(dadd(r[4], r[5]), dadd(r[6], r[7])));
+    return dadd(res, a[24]);
+}
+
+// image_proc.py:961-998
+DREAM_DEVICE void centroid_5x5(const float *ori, int H, int W, int x, int y, double offset, double *cx, double *cy) {
+    double wv[25], pj[25], pi[25];
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+#pragma unroll
+        for (int i = -2; i <= 2; ++i) {
+            const int t = (j + 2) * 5 + (i + 2);
+            const bool inb = (y + i >= 0) && (y + i < H) && (x + j >= 0) && (x + j < W);
+            const double w = inb ? (double)ori[(size_t)(y + i) * W + (x + j)] : 0.0;
+            wv[t] = w;
+            pj[t] = dmul(inb ? (double)(x + j) : 0.0, w);
+            pi[t] = dmul(inb ? (double)(y + i) : 0.0, w);
+        }
+    }
+    const double scl = pairwise_sum25(wv);
+    if (scl == 0.0) {            // np.average raises ZeroDivisionError -> integer peak (image_proc.py:995-998)
+        *cx = dadd((double)x, offset);
+        *cy = dadd((double)y, offset);
+    } else {
+        *cx = dadd(ddiv(pairwise_sum25(pj), scl), offset);
+        *cy = dadd(ddiv(pairwise_sum25(pi), scl), offset);
+    }
+}
+
+struct Top2 {
+    float s1, s2;
+    int i1;
+};
+DREAM_DEVICE Top2 top2_merge(Top2 a, Top2 b) {
+    Top2 o;
+    const bool a_first = (a.s1 > b.s1) || (a.s1 == b.s1 && (unsigned)a.i1 <= (unsigned)b.i1);
+    o.s1 = a_first ? a.s1 : b.s1;
+    o.i1 = a_first ? a.i1 : b.i1;
+    o.s2 = fmaxf(a_first ? b.s1 : a.s1, fmaxf(a.s2, b.s2));
+    return o;
+}
+
+// One workgroup per map.  LIST: also emit every peak (row-major order) up to `cap`.
+template <bool LIST>
+__global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const float *smooth, float *keypoints,
+                                                    int32_t *counts, double *xy, float *score, int H, int W,
+                                                    int cap, double offset) {
+    __shared__ int s_wave_cnt[4];
+    __shared__ float s_s1[4], s_s2[4];
+    __shared__ int s_i1[4];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float *ori = maps + (size_t)n * H * W;
+    const float *sm = smooth + (size_t)n * H * W;
+    const int total = H * W;
+    const float thresh = 0.01f;                       // image_proc.py:925 (compared in fp32)
+    const float NEG_INF = -__builtin_huge_valf();
+    Top2 best = {NEG_INF, NEG_INF, -1};
+    int running = 0;                                   // peaks found in earlier chunks (uniform)
+    for (int base = 0; base < total; base += 256) {
+        const int idx = base + tid;
+        bool is_peak = false;
+        int x = 0, y = 0;
+        if (idx < total) {
+            y = idx / W;
+            x = idx - y * W;
+            const float v = sm[idx];
+            const float up = y > 0 ? sm[idx - W] : 0.0f, down = y + 1 < H ? sm[idx + W] : 0.0f;
+            const float left = x > 0 ? sm[idx - 1] : 0.0f, right = x + 1 < W ? sm[idx + 1] : 0.0f;
+            is_peak = (v >= up) && (v >= down) && (v >= left) && (v >= right) && (v > thresh);
+        }
+        const unsigned long long mask = wave_ballot(is_peak);
+        const int rank_in_wave = popcount64(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave_cnt[wave] = popcount64(mask);
+        __syncthreads();
+        int wave_off = 0, chunk_total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) wave_off += s_wave_cnt[w];
+            chunk_total += s_wave_cnt[w];
+        }
+        if (is_peak) {
+            const float sc = ori[idx];
+            const Top2 mine = {sc, NEG_INF, idx};
+            best = top2_merge(best, mine);
+            if (LIST) {
+                const int rank = running + wave_off + rank_in_wave;
+                if (rank < cap) {
+                    double cx, cy;
+                    centroid_5x5(ori, H, W, x, y, offset, &cx, &cy);
+                    xy[((size_t)n * cap + rank) * 2 + 0] = cx;
+                    xy[((size_t)n * cap + rank) * 2 + 1] = cy;
+                    score[(size_t)n * cap + rank] = sc;
+                }
+            }
+        }
+        running += chunk_total;
+        __syncthreads();                                // s_wave_cnt is rewritten next chunk
+    }
+    // block-wide top-2 reduction
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Top2 other;
+        other.s1 = lane_xor(best.s1, m);
+        other.s2 = lane_xor(best.s2, m);
+        other.i1 = lane_xor(best.i1, m);
+        best = top2_merge(best, other);
+    }
+    if (lane == 0) { s_s1[wave] = best.s1; s_s2[wave] = best.s2; s_i1[wave] = best.i1; }
+    __syncthreads();
+    if (tid == 0) {
+        Top2 b = {s_s1[0], s_s2[0], s_i1[0]};
+#pragma unroll
+        for (int w = 1; w < 4; ++w) { const Top2 o = {s_s1[w], s_s2[w], s_i1[w]}; b = top2_merge(b, o); }
+        if (counts) counts[n] = running;
+        if (keypoints) {
+            // network.py:546-577 : one peak -> it; several -> best iff (best - second) >= 0.25 in fp32
+            float kx = -999.999f, ky = -999.999f;
+            const bool accept = (running == 1) || (running > 1 && (b.s1 - b.s2) >= 0.25f);
+            if (accept) {
+                const int y = b.i1 / W, x = b.i1 - y * W;
+                double cx, cy;
+                centroid_5x5(ori, H, W, x, y, offset, &cx, &cy);
+                kx = (float)cx;
+                ky = (float)cy;
+            }
+            keypoints[(size_t)n * 2 + 0] = kx;
+            keypoints[(size_t)n * 2 + 1] = ky;
+        }
+    }
+}
+
+inline unsigned stream_grid(size_t total) {
+    size_t g = (total + 255) / 256;
+    if (g > 256 * 8) g = 256 * 8;
+    return (unsigned)(g ? g : 1);
+}
+
+int smooth_maps(const float *maps, float *tmp, float *out, int N, int H, int W, hipStream_t s) {
+    const size_t total = (size_t)N * H * W;
+    hipLaunchKernelGGL(gauss_pass_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, maps, tmp, N, H, W);
+    DREAM_LAUNCH_OK();
+    hipLaunchKernelGGL(gauss_pass_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, (const float *)tmp, out, N, H, W);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dream_gaussian_sigma3_f32(const float *maps, float *tmp, float *out, int N, int H, int W, void *stream) {
+    DREAM_REQUIRE(maps && tmp && out && N > 0 && H > 0 && W > 0, "gaussian: bad arguments");
+    return smooth_maps(maps, tmp, out, N, H, W, (hipStream_t)stream);
+}
+
+extern "C" int dream_keypoints_from_belief_maps_f32(const float *maps, float *scratch, float *keypoints,
+                                                    int32_t *peak_counts, int N, int H, int W,
+                                                    double offset_due_to_upsampling, void *stream) {
+    DREAM_REQUIRE(maps && scratch && keypoints && N > 0 && H > 0 && W > 0, "keypoints_from_belief_maps: bad arguments");
+    const size_t total = (size_t)N * H * W;
+    if (int rc = smooth_maps(maps, scratch, scratch + total, N, H, W, (hipStream_t)stream)) return rc;
+    hipLaunchKernelGGL(peaks_kernel<false>, dim3(N), dim3(256), 0, (hipStream_t)stream, maps,
+                       (const float *)(scratch + total), keypoints, peak_counts, (double *)nullptr, (float *)nullptr,
+                       H, W, 0, offset_due_to_upsampling);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int dream_peaks_from_belief_maps_f32(const float *maps, float *scratch, double *xy, float *score,
+                                                int32_t *counts, int N, int H, int W, int cap,
+                                                double offset_due_to_upsampling, void *stream) {
+    DREAM_REQUIRE(maps && scratch && xy && score && counts && N > 0 && H > 0 && W > 0 && cap > 0,
+                  "peaks_from_belief_maps: bad arguments");
+    const size_t total = (size_t)N * H * W;
+    if (int rc = smooth_maps(maps, scratch, scratch + total, N, H, W, (hipStream_t)stream)) return rc;
+    hipLaunchKernelGGL(peaks_kernel<true>, dim3(N), dim3(256), 0, (hipStream_t)stream, maps,
+                       (const float *)(scratch + total), (float *)nullptr, counts, xy, score, H, W, cap,
+                       offset_due_to_upsampling);
+    DREAM_LAUNCH_OK();
+    return 0;
+}

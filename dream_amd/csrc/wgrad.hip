@@ -1,0 +1,342 @@
+// conv3x3 weight + bias gradient (replaces ATen's conv backward-weight reached from loss.backward(),
+// /root/reference/dream/network.py:335, for the Conv2d layers of dream/models.py:594-615,695-747).
+//
+//   dW[t][o][i] = sum over (b, pixel p) of  dy[b,p][o] * x[b, p + d(t)][i]        d(t) = (ky-1, kx-1)
+//   db[o]       = sum over (b, p) of dy[b,p][o]
+//
+// GEMM view per tap:  dW_t (Cout x Cin) = dY^T (Cout x P) * X_t (P x Cin): the reduction runs over
+// PIXELS (up to 20.5 M at 128x400x400), so the work is split over pixel tiles ("split-K") and every
+// workgroup keeps all NINE tap accumulators of its 64(cout) x 64(cin) tile in registers
+// (one 32x32 MFMA tile per wave per tap = 144 accumulator VGPRs): the dY tile and the X patch are
+// staged in LDS once per pixel tile and feed 9 MFMAs per k-step (k = 2 pixels for
+// v_mfma_f32_32x32x2_f32).  Partials go to a workspace and are summed in a FIXED order by a second
+// kernel, so the result is deterministic (no fp32 atomics).
+//
+// LDS: dY tile [128 px][64 cout] (32 KB) + X patch [<=192 px][64 cin] (48 KB): operand reads are
+// ds_read_b32 of 32 consecutive floats per half-wave (conflict-free for any row stride).
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+namespace {
+
+constexpr int WG_PIX = 128;       // pixels per tile (k extent 128, 64 MFMA k-steps)
+constexpr int WG_NPMAX = 192;     // patch pixels
+constexpr int WG_C = 64;          // channel tile (cout and cin)
+
+struct WgradParams {
+    const float *x;
+    const float *dy;
+    float *part;        // [splitk][9][CoutPad][Cin]
+    float *bias_part;   // [splitk][CoutPad]
+    int B, H, W, Hs, Ws, Cin, Cout, CoutPad;
+    int TH, TW, PW, tiles_x, tiles_y, rcpTW;
+    int tiles_total, splitk, flags;
+};
+
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
+    DREAM_DYNAMIC_LDS(float, smem);
+    float *sY = smem;                      // [128][64]
+    float *sX = smem + WG_PIX * WG_C;      // [NP][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
+    const int wo = wave >> 1, wi = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int co0 = blockIdx.x * WG_C, ci0 = blockIdx.y * WG_C, ks = blockIdx.z;
+    const int PW = p.PW, TW = p.TW, npix = p.TH * p.TW, NP = (p.TH + 2) * PW;
+    const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};          // this thread's share of the bias gradient
+
+    const int q = tid & 15, prow = tid >> 4;        // staging: 16 float4 per 64-channel row, 16 rows per pass
+    const bool y_chan_ok = (co0 + q * 4) < p.Cout;  // Cout % 4 == 0 is required by the host wrapper
+    const bool x_chan_ok = (ci0 + q * 4) < p.Cin;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int tile = ks; tile < p.tiles_total; tile += p.splitk) {
+        int t = tile;
+        const int tix = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int tiy = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int y0 = tiy * p.TH, x0 = tix * TW;
+        const float *xb = p.x + (size_t)b * p.Hs * p.Ws * p.Cin;
+        const float *dyb = p.dy + (size_t)b * p.H * p.W * p.Cout;
+
+        __syncthreads();                            // previous tile fully consumed
+        // ---- stage dY tile (rows m >= npix or outside the image are zero) ------------------------
+#pragma unroll
+        for (int it = 0; it < WG_PIX / 16; ++it) {
+            const int m = prow + it * 16;
+            const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+            const int oy = y0 + ty, ox = x0 + tx;
+            f32x4 v = zero4;
+            if (m < npix && oy < p.H && ox < p.W && y_chan_ok)
+                v = *(const f32x4 *)(dyb + ((size_t)oy * p.W + ox) * p.Cout + co0 + q * 4);
+            *(f32x4 *)(sY + m * WG_C + q * 4) = v;
+            bsum += v;
+        }
+        // ---- stage X patch ------------------------------------------------------------------------
+        for (int pp = prow; pp < NP; pp += 16) {
+            const int py = pp / PW, px = pp - py * PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            f32x4 v = zero4;
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && x_chan_ok) {
+                const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+                v = *(const f32x4 *)(xb + ((size_t)sy * p.Ws + sx) * p.Cin + ci0 + q * 4);
+            }
+            *(f32x4 *)(sX + pp * WG_C + q * 4) = v;
+        }
+        __syncthreads();
+
+        // ---- 64 k-steps x 9 taps ---------------------------------------------------------------------
+        const float *aY = sY + wo * 32 + li;
+        const float *bX = sX + wi * 32 + li;
+        const int nsteps = (npix + 1) >> 1;
+        for (int s = 0; s < nsteps; ++s) {
+            const int m = 2 * s + lh;
+            const int mc = m < npix ? m : 0;         // dY row m is zero there; keep the X address legal
+            const int ty = (mc * p.rcpTW) >> 16, tx = mc - ty * TW;
+            const float a = aY[m * WG_C];
+            const float *bp = bX + (ty * PW + tx) * WG_C;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    acc[ky * 3 + kx] = mfma_f32_32x32x2(a, bp[(ky * PW + kx) * WG_C], acc[ky * 3 + kx]);
+        }
+    }
+
+    // ---- write partials ----------------------------------------------------------------------------
+    float *part = p.part + (size_t)ks * 9 * p.CoutPad * p.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int i = ci0 + wi * 32 + li;
+            if (o < p.CoutPad && i < p.Cin) part[((size_t)t * p.CoutPad + o) * p.Cin + i] = acc[t][r];
+        }
+    }
+    if (blockIdx.y == 0) {
+        // threads sharing q (same 4 couts) differ in prow: reduce the 16 rows through LDS
+        __syncthreads();
+        *(f32x4 *)(smem + (prow * 16 + q) * 4) = bsum;
+        __syncthreads();
+        if (tid < WG_C) {
+            float s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += smem[(r * 16 + (tid >> 2)) * 4 + (tid & 3)];
+            if (co0 + tid < p.CoutPad) p.bias_part[(size_t)ks * p.CoutPad + co0 + tid] = s;
+        }
+    }
+}
+
+// fixed-order reduction over the split-K partials
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *part, float *out, size_t n, int splitk) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float s = 0.0f;
+        for (int k = 0; k < splitk; ++k) s += part[(size_t)k * n + i];
+        out[i] = s;
+    }
+}
+
+void choose_tile_w(int H, int W, int *th_out, int *tw_out) {
+    long best = -1;
+    int bnp = 0, bth = 1, btw = 1;
+    for (int tw = 1; tw <= WG_PIX; ++tw) {
+        int th = WG_PIX / tw;
+        if (th > H) th = H;
+        const int twc = tw > W ? W : tw;
+        const int np = (th + 2) * (twc + 2);
+        if (np > WG_NPMAX) continue;
+        const long tiles = (long)ceil_div(H, th) * ceil_div(W, twc);
+        if (best < 0 || tiles < best || (tiles == best && np < bnp)) { best = tiles; bnp = np; bth = th; btw = twc; }
+    }
+    *th_out = bth;
+    *tw_out = btw;
+}
+
+int pick_splitk(int B, int H, int W, int Cin, int CoutPad) {
+    int th, tw;
+    choose_tile_w(H, W, &th, &tw);
+    const long tiles = (long)B * ceil_div(H, th) * ceil_div(W, tw);
+    const long ctiles = (long)ceil_div(CoutPad, WG_C) * ceil_div(Cin, WG_C);
+    long sk = 1024 / ctiles;
+    if (sk < 1) sk = 1;
+    if (sk > tiles) sk = tiles;
+    if (sk > 1024) sk = 1024;
+    return (int)sk;
+}
+
+// ---- first layer (NCHW image, Cin <= 4): lane == cout, 9*Cin accumulators per lane ---------------------
+constexpr int FT = 16, FPW = FT + 4, FPH = FT + 2, FMAXC = 4;
+
+struct FirstWgradParams {
+    const float *x;
+    const float *dy;
+    float *part;          // [nblocks*4 waves][Cout][9*Cin + 1]  (last column = bias)
+    int B, H, W, Cin, Cout, tiles_x, tiles_y, tiles_total;
+};
+
+__global__ void __launch_bounds__(256) first_wgrad_kernel(const FirstWgradParams p) {
+    DREAM_DYNAMIC_LDS(float, smem);      // [Cin][FPH][FPW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
+    const int cout = blockIdx.y * 64 + lane;
+    float acc[FMAXC * 9];
+#pragma unroll
+    for (int i = 0; i < FMAXC * 9; ++i) acc[i] = 0.0f;
+    float bacc = 0.0f;
+    const int npatch = p.Cin * FPH * FPW;
+    for (int tile = blockIdx.x; tile < p.tiles_total; tile += gridDim.x) {
+        int t = tile;
+        const int tix = t % p.tiles_x;
+        t /= p.tiles_x;
+        const int tiy = t % p.tiles_y;
+        const int b = t / p.tiles_y;
+        const int y0 = tiy * FT, x0 = tix * FT;
+        __syncthreads();
+        for (int idx = tid; idx < npatch; idx += 256) {
+            const int c = idx / (FPH * FPW);
+            const int rem = idx - c * (FPH * FPW);
+            const int py = rem / FPW, px = rem - py * FPW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            float v = 0.0f;
+            if (px < FT + 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                v = p.x[(((size_t)b * p.Cin + c) * p.H + gy) * p.W + gx];
+            smem[idx] = v;
+        }
+        __syncthreads();
+        for (int g = 0; g < 16; ++g) {
+            const int row = wave * 4 + (g >> 2), xg = (g & 3) * 4;
+            const int oy = y0 + row, ox = x0 + xg;
+            float d[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[j] = (oy < p.H && ox + j < p.W) ? p.dy[(((size_t)b * p.H + oy) * p.W + ox + j) * p.Cout + cout] : 0.0f;
+            bacc += (d[0] + d[1]) + (d[2] + d[3]);
+#pragma unroll
+            for (int c = 0; c < FMAXC; ++c) {
+                if (c < p.Cin) {
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float *src = smem + (c * FPH + row + ky) * FPW + xg;
+                        const f32x4 v0 = *(const f32x4 *)src;
+                        const float v[6] = {v0[0], v0[1], v0[2], v0[3], src[4], src[5]};
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[c * 9 + ky * 3 + kx] = fmaf(d[j], v[j + kx], acc[c * 9 + ky * 3 + kx]);
+                    }
+                }
+            }
+        }
+    }
+    const int ncol = 9 * p.Cin + 1;
+    float *dst = p.part + (((size_t)blockIdx.x * 4 + wave) * p.Cout + cout) * ncol;
+#pragma unroll
+    for (int i = 0; i < FMAXC * 9; ++i)
+        if (i < 9 * p.Cin) dst[i] = acc[i];
+    dst[9 * p.Cin] = bacc;
+}
+
+__global__ void __launch_bounds__(256) first_wgrad_reduce_kernel(const float *part, float *dw, float *dbias,
+                                                                 int nparts, int Cout, int ncol) {
+    const int total = Cout * ncol;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float s = 0.0f;
+        for (int k = 0; k < nparts; ++k) s += part[(size_t)k * total + i];
+        const int o = i / ncol, c = i - o * ncol;
+        if (c == ncol - 1) dbias[o] = s;
+        else dw[(size_t)o * (ncol - 1) + c] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t dream_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad) {
+    const int sk = pick_splitk(B, H, W, Cin, CoutPad);
+    return ((size_t)sk * 9 * CoutPad * Cin + (size_t)(sk + 1) * CoutPad) * sizeof(float);
+}
+
+extern "C" int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias,
+                                            void *workspace, int B, int H, int W, int Cin, int Cout,
+                                            int CoutPad, int flags, void *stream) {
+    DREAM_REQUIRE(x && dy && dw_packed && workspace, "wgrad: null pointer");
+    DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout % 4 == 0 && CoutPad >= Cout,
+                  "wgrad: bad shape (Cin=%d, Cout=%d must be multiples of 4; CoutPad=%d)", Cin, Cout, CoutPad);
+    const bool ups = (flags & DREAM_CONV_UPSAMPLE2X) != 0;
+    DREAM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0), "wgrad: fused upsample needs even H, W");
+    WgradParams p;
+    p.x = x; p.dy = dy;
+    p.B = B; p.H = H; p.W = W; p.Hs = ups ? H / 2 : H; p.Ws = ups ? W / 2 : W;
+    p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad; p.flags = flags;
+    choose_tile_w(H, W, &p.TH, &p.TW);
+    p.PW = p.TW + 2;
+    p.tiles_x = ceil_div(W, p.TW); p.tiles_y = ceil_div(H, p.TH);
+    p.rcpTW = (65536 + p.TW - 1) / p.TW;
+    p.tiles_total = B * p.tiles_x * p.tiles_y;
+    p.splitk = pick_splitk(B, H, W, Cin, CoutPad);
+    p.part = (float *)workspace;
+    p.bias_part = p.part + (size_t)p.splitk * 9 * CoutPad * Cin;
+    const size_t lds = ((size_t)WG_PIX + (size_t)(p.TH + 2) * p.PW) * WG_C * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const dim3 grid(ceil_div(CoutPad, WG_C), ceil_div(Cin, WG_C), p.splitk);
+    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    const size_t n = (size_t)9 * CoutPad * Cin;
+    size_t g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)p.part, dw_packed, n, p.splitk);
+    DREAM_LAUNCH_OK();
+    if (dbias) {
+        // bias partials are [splitk][CoutPad]; only the first Cout entries are wanted
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)p.bias_part, p.bias_part + (size_t)p.splitk * CoutPad, (size_t)CoutPad, p.splitk);
+        DREAM_LAUNCH_OK();
+        DREAM_HIP_OK(hipMemcpyAsync(dbias, p.bias_part + (size_t)p.splitk * CoutPad, (size_t)Cout * sizeof(float),
+                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+static int first_wgrad_blocks(int B, int H, int W) {
+    const long tiles = (long)B * ceil_div(W, FT) * ceil_div(H, FT);
+    return (int)(tiles < 1024 ? tiles : 1024);
+}
+extern "C" size_t dream_conv3x3_first_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
+    return (size_t)first_wgrad_blocks(B, H, W) * 4 * Cout * (9 * Cin + 1) * sizeof(float);
+}
+
+extern "C" int dream_conv3x3_first_wgrad_f32(const float *x_nchw, const float *dy_nhwc, float *dw_oihw, float *dbias,
+                                             void *workspace, size_t workspace_bytes, int B, int H, int W, int Cin,
+                                             int Cout, void *stream) {
+    DREAM_REQUIRE(x_nchw && dy_nhwc && dw_oihw && dbias && workspace, "first_wgrad: null pointer");
+    DREAM_REQUIRE(Cin >= 1 && Cin <= FMAXC && Cout % 64 == 0, "first_wgrad: Cin <= %d and Cout %% 64 == 0 required", FMAXC);
+    FirstWgradParams p;
+    p.x = x_nchw; p.dy = dy_nhwc; p.part = (float *)workspace;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.tiles_x = ceil_div(W, FT); p.tiles_y = ceil_div(H, FT);
+    p.tiles_total = B * p.tiles_x * p.tiles_y;
+    const int nblocks = first_wgrad_blocks(B, H, W);
+    const int ncol = 9 * Cin + 1;
+    const size_t need = (size_t)nblocks * 4 * Cout * ncol * sizeof(float);
+    DREAM_REQUIRE(workspace_bytes >= need, "first_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    const size_t lds = (size_t)Cin * FPH * FPW * sizeof(float);
+    hipLaunchKernelGGL(first_wgrad_kernel, dim3(nblocks, Cout / 64), dim3(256), lds, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    hipLaunchKernelGGL(first_wgrad_reduce_kernel, dim3(ceil_div(Cout * ncol, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)p.part, dw_oihw, dbias, nblocks * 4, Cout, ncol);
+    DREAM_LAUNCH_OK();
+    return 0;
+}

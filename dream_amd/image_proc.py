@@ -1,0 +1,111 @@
+"""Host-side mirror of the parts of /root/reference/dream/image_proc.py that sit on the hot path or
+directly beside it: ``peaks_from_belief_maps`` (image_proc.py:914-1018, runs on the GPU here), the
+resolution arithmetic DreamNetwork needs (image_proc.py:94-133, 291-351) and the keypoint frame
+conversions used by ``keypoints_from_image`` (image_proc.py:135-260)."""
+import numpy as np
+import torch
+from PIL import Image as PILImage
+
+from . import ops
+
+KNOWN_IMAGE_PREPROC_TYPES = ["none", "resize", "shrink", "shrink-and-crop"]
+
+# scipy.ndimage._filters._gaussian_kernel1d(sigma=3, order=0, radius=12)[0:13] as float64 hex: the 13
+# distinct taps hard-coded in csrc/peaks.hip (index 12 = centre).  tests/test_oracle_peaks.py checks
+# that the installed scipy/numpy would compute exactly these.
+GAUSS_SIGMA3_HALF_TAPS_HEX = (
+    "0x1.763a210dfb306p-15", "0x1.4fbe39149e277p-13", "0x1.0d8a5ad43c165p-11", "0x1.8345966f69518p-10",
+    "0x1.f1e9915139406p-9", "0x1.1e6bccad344bap-7", "0x1.26defcaeb0202p-6", "0x1.0fa58939b528fp-5",
+    "0x1.bfde9c12bec92p-5", "0x1.4a614d1afd337p-4", "0x1.b42a57d56c0bep-4", "0x1.01a25f86eb137p-3",
+    "0x1.105a329f98197p-3")
+
+
+def peaks_from_belief_maps(belief_map_tensor, offset_due_to_upsampling):
+    """[N,H,W] tensor -> list (len N) of lists of (x, y, score, id), exactly the reference's return
+    value (float64 centroids, float32 scores, running ids), computed by the HIP peak kernels."""
+    assert (
+        len(belief_map_tensor.shape) == 3
+    ), "Expected belief_map_tensor to have shape [N x height x width], but it is {}.".format(belief_map_tensor.shape)
+    maps = belief_map_tensor.detach()
+    if not maps.is_cuda:
+        if not torch.cuda.is_available():
+            raise RuntimeError("dream_amd.peaks_from_belief_maps needs a GPU (no CPU fallback)")
+        maps = maps.cuda()
+    xy, score, counts = ops.peaks_list(maps.float(), offset_due_to_upsampling)
+    xy, score, counts = xy.cpu().numpy(), score.cpu().numpy(), counts.cpu().numpy()
+    all_peaks, counter = [], 0
+    for j in range(maps.shape[0]):
+        n = int(counts[j])
+        all_peaks.append([(xy[j, i, 0], xy[j, i, 1], score[j, i], counter + i) for i in range(n)])
+        counter += n
+    return all_peaks
+
+
+# ---- resolution arithmetic (image_proc.py:94-133, 300-351) ---------------------------------------------
+def shrink_resolution(image_input_resolution, image_ref_resolution):
+    factor = float(image_ref_resolution[1]) / float(image_input_resolution[1])
+    return (int(image_input_resolution[0] * factor), image_ref_resolution[1])
+
+
+def shrink_and_crop_resolution(image_input_resolution, image_ref_resolution):
+    """-> ((cropped width, cropped height), (crop x0, crop y0)) in input pixels: the largest centred
+    window of the input with the reference aspect ratio (same int() truncations as
+    image_proc.py:317-351, so (640,480) vs (400,400) gives ((480,480),(80,0)))."""
+    in_w, in_h = image_input_resolution
+    ref_w, ref_h = image_ref_resolution
+    h_from_w = int(float(in_w) / float(ref_w) * ref_h)
+    w_from_h = int(float(in_h) / float(ref_h) * ref_w)
+    if in_w >= w_from_h:
+        cropped = (w_from_h, in_h)
+    else:
+        assert in_h >= h_from_w
+        cropped = (in_w, h_from_w)
+    return cropped, ((in_w - cropped[0]) // 2, (in_h - cropped[1]) // 2)
+
+
+def resolution_after_preprocessing(image_input_resolution, image_ref_resolution, image_preprocessing):
+    assert (
+        image_preprocessing in KNOWN_IMAGE_PREPROC_TYPES
+    ), 'Image preprocessing type "{}" is not recognized.'.format(image_preprocessing)
+    if image_preprocessing == "none":
+        return image_input_resolution
+    if image_preprocessing == "shrink":
+        return shrink_resolution(image_input_resolution, image_ref_resolution)
+    return image_ref_resolution              # resize, shrink-and-crop
+
+
+def preprocess_image(input_image, image_ref_resolution, image_preprocessing):
+    assert isinstance(input_image, PILImage.Image), 'Expected "input_image" to be a PIL Image, but it is "{}".'.format(
+        type(input_image))
+    assert image_preprocessing in KNOWN_IMAGE_PREPROC_TYPES, 'Image preprocessing type "{}" is not recognized.'.format(
+        image_preprocessing)
+    if image_preprocessing == "none":
+        return input_image
+    if image_preprocessing == "resize":
+        return input_image.resize(image_ref_resolution, resample=PILImage.BILINEAR)
+    if image_preprocessing == "shrink":
+        return input_image.resize(shrink_resolution(input_image.size, image_ref_resolution), resample=PILImage.BILINEAR)
+    (cw, ch), (x0, y0) = shrink_and_crop_resolution(input_image.size, image_ref_resolution)
+    return input_image.crop((x0, y0, x0 + cw, y0 + ch)).resize(image_ref_resolution, resample=PILImage.BILINEAR)
+
+
+# ---- keypoint frame conversions (image_proc.py:135-147, 215-260) ----------------------------------------
+def convert_keypoints_to_netin_from_netout(keypoints_netout, net_output_resolution, net_input_resolution):
+    k = np.asarray(keypoints_netout, dtype=float).reshape(-1, 2)
+    return np.stack([k[:, 0] / net_output_resolution[0] * net_input_resolution[0],
+                     k[:, 1] / net_output_resolution[1] * net_input_resolution[1]], axis=1)
+
+
+def convert_keypoints_to_raw_from_netin(keypoints_netin, net_input_resolution, image_raw_resolution,
+                                        image_preprocessing):
+    assert image_preprocessing in KNOWN_IMAGE_PREPROC_TYPES, 'Image preprocessing type "{}" is not recognized.'.format(
+        image_preprocessing)
+    k = np.asarray(keypoints_netin, dtype=float).reshape(-1, 2)
+    if image_preprocessing == "none":
+        return k
+    if image_preprocessing in ("resize", "shrink"):
+        return np.stack([k[:, 0] / net_input_resolution[0] * image_raw_resolution[0],
+                         k[:, 1] / net_input_resolution[1] * image_raw_resolution[1]], axis=1)
+    (cw, ch), (x0, y0) = shrink_and_crop_resolution(image_raw_resolution, net_input_resolution)
+    return np.stack([k[:, 0] / net_input_resolution[0] * cw + x0,
+                     k[:, 1] / net_input_resolution[1] * ch + y0], axis=1)

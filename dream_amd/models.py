@@ -1,0 +1,341 @@
+"""MI355X-native belief-map networks behind the reference's model interface.
+
+Mirrors /root/reference/dream/models.py:
+  * ``DreamHourglass``  (models.py:557-827)  -- VGG19 encoder + upsample (Q) or ConvTranspose (F)
+    decoder + 3-conv head; ``state_dict()`` keys/shapes are the reference's, so released ``.pth``
+    files and ``dream_network.model.load_state_dict(torch.load(path))`` (dream/analysis.py:148) work.
+  * ``ResnetSimple``    (models.py:17-155)   -- parameter tree only in this round (see forward()).
+  * ``DreamDataParallel`` stands in for ``torch.nn.DataParallel`` (dream/network.py:244-256): it only
+    contributes the ``module.`` key prefix; data parallelism is one process per GPU with an RCCL
+    all-reduce of the flat gradient buffer (see ``_HourglassFunction.backward``).
+
+``nn.Conv2d`` objects are used purely as parameter containers (OIHW, as the reference stores them);
+their ATen forward is never called.  ``forward`` executes a static list of C-ABI calls on NHWC
+activations: first conv (NCHW image -> NHWC, VALU), MFMA 3x3 convs with fused bias/ReLU/upsample,
+2x2 max-pools, and an NCHW store in the last head conv.  If the HIP library or a GPU is missing the
+call raises -- there is no CPU path in this package.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, CONV_ZEROSTUFF2X
+from .spatial_softmax import SoftArgmaxPavlo
+
+# (container name, [(child index, cin, cout)]) -- child indices are torchvision's vgg19.features
+# indices the reference re-uses (models.py:598-615), which is what fixes the state_dict keys.
+_ENCODER = [
+    ("layer_0_1_down", [(0, 3, 64), (2, 64, 64)]),
+    ("layer_0_2_down", [(5, 64, 128), (7, 128, 128)]),
+    ("layer_0_3_down", [(10, 128, 256), (12, 256, 256), (14, 256, 256), (16, 256, 256)]),
+    ("layer_0_4_down", [(19, 256, 512), (21, 512, 512), (23, 512, 512), (25, 512, 512)]),
+    ("layer_0_5_down", [(28, 512, 512), (30, 512, 512), (32, 512, 512), (34, 512, 512)]),
+]
+
+
+class _Params(nn.Sequential):
+    """Sequential used only as a named parameter container (children are never called)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("dream_amd: parameter container, not callable; use the parent module")
+
+
+class _PackedCache:
+    """Packed copies of one conv weight for the MFMA kernels, refreshed when the parameter changes
+    (optimizer step / load_state_dict bump ``_version``)."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, weight, mode):
+        key = (id(weight), mode)
+        tag = (weight._version, weight.data_ptr(), weight.device)
+        hit = self._store.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                hit = (tag, ops.pack_weight(weight.detach(), mode))
+            self._store[key] = hit
+        return hit[1]
+
+
+class DreamHourglass(nn.Module):
+    def __init__(self, n_keypoints, n_image_input_channels=3, internalize_spatial_softmax=True,
+                 learned_beta=True, initial_beta=1.0, skip_connections=False, deconv_decoder=False,
+                 full_output=False):
+        super().__init__()
+        self.n_keypoints = n_keypoints
+        self.n_image_input_channels = n_image_input_channels
+        self.internalize_spatial_softmax = internalize_spatial_softmax
+        self.skip_connections = skip_connections
+        self.deconv_decoder = deconv_decoder
+        self.full_output = full_output
+        if internalize_spatial_softmax:
+            self.n_output_heads = 2
+            self.learned_beta = learned_beta
+            self.initial_beta = initial_beta
+        else:
+            self.n_output_heads = 1
+            self.learned_beta = False
+        if skip_connections:
+            raise NotImplementedError("dream_amd: skip_connections is not built yet (SURVEY.md 8f rank 3)")
+        if n_image_input_channels > 4:
+            raise NotImplementedError("dream_amd: first conv supports <= 4 input channels")
+
+        def conv(ci, co):
+            return nn.Conv2d(ci, co, kernel_size=3, stride=1, padding=1)
+
+        def deconv(ci, co):
+            return nn.ConvTranspose2d(ci, co, kernel_size=(3, 3), stride=(2, 2), padding=1, output_padding=1)
+
+        def container(items):
+            seq = _Params()
+            for name, mod in items:
+                seq.add_module(str(name), mod)
+            return seq
+
+        # plan entries: (kind, container name, child name, flags)
+        plan = []
+        for bi, (cname, convs) in enumerate(_ENCODER):
+            items = []
+            for (idx, ci, co) in convs:
+                if idx == 0:
+                    ci = n_image_input_channels
+                items.append((idx, conv(ci, co)))
+                plan.append(("first" if idx == 0 else "conv", cname, str(idx), CONV_RELU))
+            setattr(self, cname, container(items))
+            if bi + 1 < len(_ENCODER):
+                plan.append(("pool", None, None, 0))
+
+        if deconv_decoder:                                   # models.py:618-686
+            for cname, ci, co, has_conv in [("deconv_0_4", 512, 256, True), ("deconv_0_3", 256, 128, True),
+                                            ("deconv_0_2", 128, 64, True), ("deconv_0_1", 64, 64, False)]:
+                items = [(0, deconv(ci, co))]
+                plan.append(("deconv", cname, "0", CONV_RELU | CONV_ZEROSTUFF2X))
+                if has_conv:
+                    items.append((2, conv(co, co)))
+                    plan.append(("conv", cname, "2", CONV_RELU))
+                setattr(self, cname, container(items))
+        else:                                                # models.py:688-733
+            self.upsample_0_4 = container([(4, conv(512, 256)), (6, conv(256, 256))])
+            self.upsample_0_3 = container([(4, conv(256, 128)), (6, conv(128, 64))])
+            plan += [("conv", "upsample_0_4", "4", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_4", "6", 0),
+                     ("conv", "upsample_0_3", "4", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_3", "6", 0)]
+            if full_output:
+                self.upsample_0_2 = container([(2, conv(64, 64)), (4, conv(64, 64))])
+                self.upsample_0_1 = container([(2, conv(64, 64)), (4, conv(64, 64))])
+                plan += [("conv", "upsample_0_2", "2", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_2", "4", CONV_RELU),
+                         ("conv", "upsample_0_1", "2", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_1", "4", CONV_RELU)]
+        self.heads_0 = container([(0, conv(64, 64)), (2, conv(64, 32)), (4, conv(32, n_keypoints))])  # models.py:736-747
+        plan += [("conv", "heads_0", "0", CONV_RELU), ("conv", "heads_0", "2", CONV_RELU),
+                 ("conv", "heads_0", "4", CONV_OUT_NCHW)]
+        if internalize_spatial_softmax:                      # models.py:750-759
+            self.softmax = container([(0, SoftArgmaxPavlo(n_keypoints, learned_beta, initial_beta))])
+        self._plan = plan
+        self._packed = _PackedCache()
+
+    # ---- helpers -------------------------------------------------------------------------------------
+    def _layer(self, cname, child):
+        return getattr(getattr(self, cname), child)
+
+    def plan_layers(self):
+        """[(kind, module-or-None, flags)] in execution order."""
+        return [(kind, self._layer(c, ch) if c else None, flags) for kind, c, ch, flags in self._plan]
+
+    def plan_parameters(self):
+        out = []
+        for kind, mod, _ in self.plan_layers():
+            if mod is not None:
+                out += [mod.weight, mod.bias]
+        return out
+
+    def output_resolution(self, input_wh):
+        """(W,H) of the belief maps for a (W,H) input -- what the reference learns by pushing a zero
+        image through the model (dream/network.py:397-418), computed arithmetically here."""
+        w, h = int(input_wh[0]), int(input_wh[1])
+        for kind, _, flags in self.plan_layers():
+            if kind == "pool":
+                w, h = w // 2, h // 2
+            elif flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X):
+                w, h = w * 2, h * 2
+        return (w, h)
+
+    # ---- execution -------------------------------------------------------------------------------------
+    def run_forward(self, x, params, save):
+        """Executes the plan.  ``params`` is plan_parameters() (possibly autograd-detached).  With
+        ``save`` the per-layer inputs/outputs needed by run_backward are returned as well."""
+        if x.dim() != 4 or x.shape[1] != self.n_image_input_channels:
+            raise RuntimeError("expected [B,%d,H,W] input, got %s" % (self.n_image_input_channels, tuple(x.shape)))
+        saved = []
+        act = x
+        pi = 0
+        for kind, mod, flags in self.plan_layers():
+            inp = act
+            if kind == "pool":
+                act = ops.maxpool2(inp)
+            else:
+                w, bias = params[pi], params[pi + 1]
+                pi += 2
+                if kind == "first":
+                    act = ops.conv3x3_first(inp, w, bias, relu=bool(flags & CONV_RELU))
+                else:
+                    mode = 1 if kind == "deconv" else 0      # ConvTranspose weight is [Cin,Cout,3,3]
+                    packed, rows, _, _ = self._packed.get(mod.weight, mode)
+                    act = ops.conv3x3(inp, packed, bias, rows, flags)
+            if save:
+                saved.append((inp, act))
+        return act, saved
+
+    def run_backward(self, saved, grad_out_nchw):
+        """dL/d(belief maps) [B,K,Ho,Wo] -> list of parameter gradients in plan_parameters() order."""
+        layers = self.plan_layers()
+        grads = [None] * (2 * sum(1 for k, m, _ in layers if m is not None))
+        pi = len(grads)
+        g = None
+        for li in range(len(layers) - 1, -1, -1):
+            kind, mod, flags = layers[li]
+            inp, out = saved[li]
+            if kind == "pool":
+                g = ops.maxpool2_bwd(g, inp)
+                continue
+            if kind == "deconv":
+                raise NotImplementedError("dream_amd: ConvTranspose backward is not built yet (vgg_f training)")
+            pi -= 2
+            cout, cin = int(mod.weight.shape[0]), int(mod.weight.shape[1])
+            if flags & CONV_OUT_NCHW:
+                g = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))   # zero-padded K -> 16k channels
+            if flags & CONV_RELU:
+                g = ops.relu_bwd_(g, out)
+            if kind == "first":
+                grads[pi], grads[pi + 1] = ops.conv3x3_first_wgrad(inp, g)
+                g = None
+                continue
+            dw, db = ops.conv3x3_wgrad(inp, g, cout, cin, flags & CONV_UPSAMPLE2X)
+            grads[pi], grads[pi + 1] = dw, db
+            packed_t, rows, _, cols_pad = self._packed.get(mod.weight, 1)
+            if int(g.shape[3]) != cols_pad:
+                raise RuntimeError("internal: gradient has %d channels, packed weights expect %d" % (g.shape[3], cols_pad))
+            g = ops.conv3x3(g, packed_t, None, rows, 0)
+            if flags & CONV_UPSAMPLE2X:
+                g = ops.upsample2_bwd(g)
+        return grads
+
+    def forward(self, x):
+        params = self.plan_parameters()
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            out = _HourglassFunction.apply(self, x, *params)
+        else:
+            with torch.no_grad():
+                out, _ = self.run_forward(x, [p.detach() for p in params], save=False)
+        outputs = [out]
+        if self.internalize_spatial_softmax:
+            outputs.append(self.softmax[0](out))
+        return outputs
+
+
+class _HourglassFunction(torch.autograd.Function):
+    """Whole-network autograd node: forward keeps the NHWC activations, backward runs the HIP
+    backward plan and (when torch.distributed is initialised, one process per GPU) sums the flat
+    gradient buffer over ranks with ONE RCCL all-reduce before handing the views to autograd."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        out, saved = module.run_forward(x.detach(), [p.detach() for p in params], save=True)
+        ctx.module = module
+        ctx.saved_acts = saved
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        module = ctx.module
+        grads = module.run_backward(ctx.saved_acts, grad_out.contiguous())
+        ctx.saved_acts = None
+        grads = allreduce_gradients(grads)
+        return (None, None) + tuple(grads)
+
+
+def allreduce_gradients(grads):
+    """Data-parallel exchange step.  Every rank holds an equal chunk of the global
+    batch and has the gradient of its LOCAL mean loss; the gradient of the global mean loss is their
+    average, so: one all-reduce(sum) over a single flat fp32 buffer (RCCL over xGMI on GPUs, gloo in
+    the CPU tests), then a scale by 1/world_size.  No-op in single-process runs."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return grads
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    out, o = [], 0
+    for g in grads:
+        n = g.numel()
+        out.append(flat[o:o + n].view_as(g))
+        o += n
+    return out
+
+
+class ResnetSimple(nn.Module):
+    """Parameter tree of the reference's ResnetSimple (models.py:17-155) so that checkpoints load and
+    ``state_dict()`` matches; the HIP execution plan (7x7/1x1/strided convs, BatchNorm, 4x4
+    ConvTranspose) is not built in this round -- forward raises instead of falling back."""
+
+    def __init__(self, n_keypoints=7, freeze=False, pretrained=True, full=False):
+        super().__init__()
+        self.full = full
+        self.n_keypoints = n_keypoints
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        inplanes = 64
+        for li, (planes, blocks, stride) in enumerate([(64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2)], 1):
+            stage = nn.Sequential()
+            for bi in range(blocks):
+                blk = nn.Module()
+                s = stride if bi == 0 else 1
+                blk.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+                blk.bn1 = nn.BatchNorm2d(planes)
+                blk.conv2 = nn.Conv2d(planes, planes, 3, stride=s, padding=1, bias=False)
+                blk.bn2 = nn.BatchNorm2d(planes)
+                blk.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+                blk.bn3 = nn.BatchNorm2d(planes * 4)
+                if bi == 0 and (s != 1 or inplanes != planes * 4):
+                    blk.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=s, bias=False),
+                                                   nn.BatchNorm2d(planes * 4))
+                inplanes = planes * 4
+                stage.add_module(str(bi), blk)
+            setattr(self, "layer%d" % li, stage)
+
+        def up(ci):
+            return [nn.ConvTranspose2d(ci, 256, 4, 2, 1, 0), nn.BatchNorm2d(256, momentum=0.1), nn.ReLU(inplace=True)]
+
+        ups = up(2048) + up(256) + up(256) + up(256)
+        if not full:
+            self.upsample = nn.Sequential(*(ups + [nn.Conv2d(256, n_keypoints, 1, 1)]))
+        else:
+            self.upsample = nn.Sequential(*ups)
+            self.upsample2 = nn.Sequential(*(up(256) + [nn.Conv2d(256, n_keypoints, 1, 1)]))
+
+    def output_resolution(self, input_wh):
+        def trunk(v):
+            v = (v + 2 * 3 - 7) // 2 + 1          # conv1 7x7 s2 p3
+            v = (v + 2 * 1 - 3) // 2 + 1          # maxpool 3x3 s2 p1
+            for _ in range(3):                    # layer2..4: 3x3 s2 p1
+                v = (v + 2 * 1 - 3) // 2 + 1
+            return v
+        n_up = 5 if self.full else 4
+        return tuple(trunk(int(v)) * (2 ** n_up) for v in input_wh)
+
+    def forward(self, x):
+        raise NotImplementedError(
+            "dream_amd: the ResNet101 HIP execution plan (SURVEY.md 2.3 K5-K8) is not built yet; "
+            "refusing to fall back to another backend")
+
+
+class DreamDataParallel(nn.Module):
+    """Keeps the reference's ``module.``-prefixed state_dict (torch.nn.DataParallel wrapper at
+    dream/network.py:244-256,281-284) without DataParallel's per-call replicate/scatter/gather."""
+
+    def __init__(self, module, device_ids=None):
+        super().__init__()
+        self.module = module
+        self.device_ids = device_ids
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)

@@ -1,0 +1,349 @@
+"""``DreamNetwork`` on the MI355X HIP path: the drop-in boundary of this repo.
+
+Mirrors the public surface of /root/reference/dream/network.py (same names, argument meaning and
+AssertionError-based validation) so that ``scripts/train_network.py`` and
+``scripts/network_inference_dataset.py`` of the reference run unchanged on top of it:
+``create_network_from_config_file/_data`` (network.py:29-70), ``DreamNetwork`` with ``train``,
+``loss``, ``inference``, ``keypoints_from_image``, ``enable_training/evaluation``, resolution
+helpers and ``save_*`` (network.py:73-696).
+
+What is different underneath:
+  * ``self.model(x)`` runs hand-written gfx950 kernels through libdream_hip.so (dream_amd/models.py);
+  * ``inference`` runs the whole post-CNN stage (Gaussian smoothing, local maxima, float64 centroid,
+    best-peak rule; network.py:529-581 + image_proc.py:914-1018) in ONE pass on the GPU and copies
+    just the [B,K,2] float32 result to the host, instead of B*K device->host map copies;
+  * ``criterion`` / ``optimizer`` are HIP-kernel-backed drop-ins for MSELoss / Adam / SGD;
+  * multi-GPU is one process per GPU (torchrun) with an RCCL all-reduce of the flat gradient
+    buffer instead of single-process nn.DataParallel (network.py:244-256).
+"""
+import os
+
+import numpy as np
+import torch
+from PIL import Image as PILImage
+
+from . import image_proc, models, ops
+from .optim import HipAdam, HipSGD, HipMSELoss
+
+KNOWN_ARCHITECTURES = ["vgg", "resnet"]
+KNOWN_OPTIMIZERS = ["adam", "sgd"]
+
+
+def _load_yaml(path):
+    """The reference reads configs with ruamel.yaml YAML(typ="safe") (network.py:49-53); the files use
+    ``!!omap``.  ruamel is used when present, otherwise PyYAML with an omap constructor."""
+    try:
+        import ruamel.yaml
+        with open(path, "r") as f:
+            return ruamel.yaml.YAML(typ="safe").load(f)
+    except ImportError:
+        import yaml
+
+        class _Loader(yaml.SafeLoader):
+            pass
+
+        _Loader.add_constructor(
+            "tag:yaml.org,2002:omap",
+            lambda ld, node: dict(kv for d in ld.construct_sequence(node, deep=True) for kv in d.items()))
+        with open(path, "r") as f:
+            return yaml.load(f, Loader=_Loader)
+
+
+def _dump_yaml(data, path):
+    try:
+        import ruamel.yaml
+        saver = ruamel.yaml.YAML()
+        saver.default_flow_style = False
+        saver.explicit_start = False
+        with open(path, "w") as f:
+            saver.dump(data, f)
+    except ImportError:
+        import yaml
+
+        def plain(v):
+            if isinstance(v, dict):
+                return {k: plain(x) for k, x in v.items()}
+            if isinstance(v, (list, tuple)):
+                return [plain(x) for x in v]
+            if isinstance(v, np.generic):
+                return v.item()
+            return v
+        with open(path, "w") as f:
+            yaml.safe_dump(plain(data), f, default_flow_style=False, sort_keys=False)
+
+
+def create_network_from_config_file(config_file_path, network_params_path=None):
+    assert os.path.exists(config_file_path), 'Expected config_file_path "{}" to exist, but it does not.'.format(
+        config_file_path)
+    if network_params_path:
+        assert os.path.exists(
+            network_params_path
+        ), 'If provided, expected network_params_path "{}" to exist, but it does not.'.format(network_params_path)
+    print('Loading network config file "{}"'.format(config_file_path))
+    dream_network = create_network_from_config_data(_load_yaml(config_file_path))
+    if network_params_path:
+        print('Loading network weights file "{}"'.format(network_params_path))
+        dream_network.model.load_state_dict(torch.load(network_params_path, map_location="cpu"))
+    return dream_network
+
+
+def create_network_from_config_data(network_config_data):
+    return DreamNetwork(network_config_data)
+
+
+class DreamNetwork:
+    def __init__(self, network_config):
+        # ---- validation: same required keys and messages as network.py:77-183 ------------------------
+        assert "architecture" in network_config, 'Required key "architecture" is missing from network configuration.'
+        arch = network_config["architecture"]
+        assert "type" in arch, 'Required key "type" in dictionary "architecture" is missing from network configuration.'
+        assert "manipulator" in network_config, 'Required key "manipulator" is missing from network configuration.'
+        manip = network_config["manipulator"]
+        assert "name" in manip, 'Required key "name" in dictionary "manipulator" is missing from network configuration.'
+        assert "keypoints" in manip, 'Required key "keypoints" in dictionary "manipulator" is missing from network configuration.'
+
+        self.keypoint_names, self.friendly_keypoint_names, self.ros_keypoint_frames = [], [], []
+        for kp_def in manip["keypoints"]:
+            assert "name" in kp_def, 'Keypoint specification is missing key "name".'
+            name = kp_def["name"]
+            self.keypoint_names.append(name)
+            self.friendly_keypoint_names.append(kp_def["friendly_name"] if "friendly_name" in kp_def else name)
+            self.ros_keypoint_frames.append(kp_def["ros_frame"] if "ros_frame" in kp_def else name)
+
+        self.network_config = network_config
+        self.manipulator_name = manip["name"]
+        self.n_keypoints = len(self.keypoint_names)
+        self.architecture_type = arch["type"]
+
+        print("`network.py`.  `DreamNetwork:__init()` ----------")
+        print("  Manipulator: {}".format(self.manipulator_name))
+        print("  Keypoint names: {}".format(self.keypoint_names))
+        print("  Friendly keypoint names: {}".format(self.friendly_keypoint_names))
+        print("  Architecture type: {}".format(self.architecture_type))
+
+        assert "image_normalization" in arch, \
+            'Required key "image_normalization" in dictionary "architecture" is missing from network configuration.'
+        self.image_normalization = arch["image_normalization"]
+        assert "image_preprocessing" in arch, \
+            'Required key "image_preprocessing" in dictionary "architecture" is missing from network configuration.'
+        assert self.image_preprocessing() in image_proc.KNOWN_IMAGE_PREPROC_TYPES, \
+            'Image preprocessing type "{}" is not recognized.'.format(self.image_preprocessing())
+        assert "output_heads" in arch, \
+            'Required key "output_heads" in dictionary "architecture" is missing from network configuration.'
+        assert self.architecture_type in KNOWN_ARCHITECTURES, \
+            'Expected architecture type "{}" to be in the list of known network architectures, but it is not.'.format(
+                self.architecture_type)
+        assert "input_heads" in arch, \
+            'Required key "input_heads" in dictionary "architecture" is missing from network configuration.'
+        assert arch["input_heads"][0] == "image_rgb", 'First input head must be "image_rgb".'
+        assert "training" in network_config, 'Required key "training" is missing from network configuration.'
+        assert "config" in network_config["training"], \
+            'Required key "config" in dictionary "training" is missing from network configuration.'
+        tcfg = network_config["training"]["config"]
+        assert "net_input_resolution" in tcfg, 'Required key "net_input_resolution" is missing from training configuration.'
+        assert len(tcfg["net_input_resolution"]) == 2, \
+            "Expected trained net input resolution to have length 2, but it has length {}.".format(
+                len(tcfg["net_input_resolution"]))
+        assert "platform" in network_config["training"], \
+            'Required key "platform" in dictionary "training" is missing from network configuration.'
+        gpu_ids = network_config["training"]["platform"]["gpu_ids"]
+
+        self.use_belief_peak_scores = True            # network.py:189
+        self.belief_peak_next_best_score = 0.25       # network.py:191
+
+        # ---- model ------------------------------------------------------------------------------------
+        if self.architecture_type == "vgg":
+            vgg_kwargs = {}
+            if "spatial_softmax" in arch:
+                assert arch["output_heads"] == ["belief_maps", "keypoints"]
+                vgg_kwargs = {"internalize_spatial_softmax": True,
+                              "learned_beta": arch["spatial_softmax"]["learned_beta"],
+                              "initial_beta": arch["spatial_softmax"]["initial_beta"]}
+            else:
+                assert arch["output_heads"] == ["belief_maps"]
+                vgg_kwargs = {"internalize_spatial_softmax": False}
+            # network.py:217-230: "full_output" present => "deconv_decoder" must be present too (KeyError)
+            if "deconv_decoder" in arch and "full_output" not in arch:
+                vgg_kwargs["deconv_decoder"] = arch["deconv_decoder"]
+            elif "full_output" in arch:
+                vgg_kwargs["deconv_decoder"] = arch["deconv_decoder"]
+                vgg_kwargs["full_output"] = True
+            if "skip_connections" in arch:
+                vgg_kwargs["skip_connections"] = arch["skip_connections"]
+            if "n_stages" in arch:
+                raise NotImplementedError("dream_amd: DreamHourglassMultiStage (n_stages) is not built yet "
+                                          "(SURVEY.md 8f rank 3)")
+            net = models.DreamHourglass(self.n_keypoints, **vgg_kwargs)
+        elif self.architecture_type == "resnet":
+            assert arch["output_heads"] == ["belief_maps"]
+            resnet_kwargs = {}
+            if "full_decoder" in arch:
+                resnet_kwargs["full"] = arch["full_decoder"]
+            net = models.ResnetSimple(self.n_keypoints, **resnet_kwargs)
+        else:
+            assert False, 'Network architecture type "{}" not defined.'.format(self.architecture_type)
+
+        self.device = _pick_device(gpu_ids)
+        self.model = models.DreamDataParallel(net, device_ids=gpu_ids if gpu_ids else None).to(self.device)
+
+        loss_type = arch["loss"]["type"]
+        if loss_type == "mse":
+            self.criterion = HipMSELoss()
+        elif loss_type == "huber":
+            raise NotImplementedError("dream_amd: the Huber (SmoothL1) loss kernel is not built yet")
+        else:
+            assert False, "Loss not yet implemented."
+
+        self.optimizer = None
+
+        out_res = list(self.net_output_resolution_from_input_resolution(self.trained_net_input_resolution()))
+        if "net_output_resolution" in tcfg:
+            assert tcfg["net_output_resolution"] == out_res, \
+                "Network model and config file disagree for trained network output resolution."
+        else:
+            tcfg["net_output_resolution"] = out_res
+
+    # ---- small getters (network.py:319-326) ------------------------------------------------------------
+    def trained_net_input_resolution(self):
+        return tuple(self.network_config["training"]["config"]["net_input_resolution"])
+
+    def trained_net_output_resolution(self):
+        return tuple(self.network_config["training"]["config"]["net_output_resolution"])
+
+    def image_preprocessing(self):
+        return self.network_config["architecture"]["image_preprocessing"]
+
+    # ---- training (network.py:328-364) -------------------------------------------------------------------
+    def train(self, network_input_heads, target):
+        assert self.optimizer, "Optimizer must be defined. Use enable_training() first."
+        self.optimizer.zero_grad()
+        loss = self.loss(network_input_heads, target)
+        loss.backward()
+        self.optimizer.step()
+        return loss
+
+    def loss(self, network_input_heads, target):
+        network_output_heads = self.model(self._to_device(network_input_heads[0]))
+        if self.network_config["architecture"]["output_heads"] == ["belief_maps"]:
+            loss = self.criterion(network_output_heads[0], self._to_device(target))
+        else:
+            assert False, "Not yet implemented."
+        return loss
+
+    # ---- resolutions (network.py:366-418) ------------------------------------------------------------------
+    def net_resolutions_from_image_raw_resolution(self, image_raw_resolution, image_preprocessing_override=None):
+        assert len(image_raw_resolution) == 2, \
+            'Expected "image_raw_resolution" to have length 2, but it has length {}.'.format(len(image_raw_resolution))
+        preproc = image_preprocessing_override if image_preprocessing_override else self.image_preprocessing()
+        net_input_resolution = image_proc.resolution_after_preprocessing(
+            image_raw_resolution, self.trained_net_input_resolution(), preproc)
+        return net_input_resolution, self.net_output_resolution_from_input_resolution(net_input_resolution)
+
+    def net_output_resolution_from_input_resolution(self, net_input_resolution):
+        assert len(net_input_resolution) == 2, \
+            'Expected "net_input_resolution" to have length 2, but it has length {}.'.format(len(net_input_resolution))
+        # the reference pushes a zero image through the model (network.py:410-416); the layer list gives
+        # the same answer without a launch (and without needing a GPU to construct the network)
+        return tuple(self.model.module.output_resolution(net_input_resolution))
+
+    # ---- single image (network.py:423-499) -------------------------------------------------------------------
+    def keypoints_from_image(self, input_rgb_image_as_pil, image_preprocessing_override=None, debug=False):
+        assert isinstance(input_rgb_image_as_pil, PILImage.Image), \
+            'Expected "input_rgb_image_as_pil" to be a PIL Image, but it is {}.'.format(type(input_rgb_image_as_pil))
+        input_image_resolution = input_rgb_image_as_pil.size
+        preproc = image_preprocessing_override if image_preprocessing_override else self.image_preprocessing()
+        pre = image_proc.preprocess_image(input_rgb_image_as_pil, self.trained_net_input_resolution(), preproc)
+        netin_res_inf = pre.size
+        # ToTensor + Normalize(mean, stdev) (network.py:449-459)
+        arr = np.asarray(pre.convert("RGB"), dtype=np.float32) / np.float32(255.0)
+        mean = np.asarray(self.image_normalization["mean"], np.float32)
+        std = np.asarray(self.image_normalization["stdev"], np.float32)
+        x = torch.from_numpy(np.ascontiguousarray(((arr - mean) / std).transpose(2, 0, 1)))
+        with torch.no_grad():
+            maps_batch, kps_batch = self.inference(x.unsqueeze(0))
+        belief_maps_net_out = maps_batch[0]
+        kps_net_out = np.array(kps_batch[0], dtype=float)
+        netout_res_inf = (belief_maps_net_out[0].shape[1], belief_maps_net_out[0].shape[0])
+        kps_net_in = image_proc.convert_keypoints_to_netin_from_netout(kps_net_out, netout_res_inf, netin_res_inf)
+        kps_raw = image_proc.convert_keypoints_to_raw_from_netin(kps_net_in, netin_res_inf, input_image_resolution, preproc)
+        result = {"detected_keypoints": kps_raw}
+        if debug:
+            result["image_rgb_net_input"] = pre
+            result["belief_maps"] = belief_maps_net_out
+            result["detected_keypoints_net_output"] = kps_net_out
+            result["detected_keypoints_net_input"] = kps_net_in
+        return result
+
+    # ---- inference (network.py:503-590) --------------------------------------------------------------------------
+    def inference(self, network_input):
+        heads = self.network_config["architecture"]["output_heads"]
+        if heads == ["belief_maps", "keypoints"]:
+            return self.model(self._to_device(network_input))
+        if heads == ["belief_maps"]:
+            belief_maps_batch = self.model(self._to_device(network_input))[-1]
+            out_w, out_h = self.trained_net_output_resolution()
+            offset = 0.0 if (out_w >= 400 and out_h >= 400) else 0.4395           # network.py:534-538
+            with torch.no_grad():
+                kps, _ = ops.keypoints_from_belief_maps(belief_maps_batch.detach(), offset)
+            # the reference returns the keypoints as a CPU float32 tensor (network.py:581)
+            return [belief_maps_batch, kps.cpu()]
+        assert False, "Could not determine how to conduct inference on this network."
+
+    # ---- persistence (network.py:592-632) --------------------------------------------------------------------------
+    def save_network_config(self, config_file_path, overwrite=False):
+        if not overwrite:
+            assert not os.path.exists(config_file_path), 'Output file already exists in "{}".'.format(config_file_path)
+        _dump_yaml(self.network_config, config_file_path)
+
+    def save_network_params(self, network_params_path, overwrite=False):
+        if not overwrite:
+            assert not os.path.exists(network_params_path), 'Output file already exists in "{}".'.format(
+                network_params_path)
+        torch.save(self.model.state_dict(), network_params_path)
+
+    def save_network(self, output_dir, output_filename_without_extension, overwrite=False):
+        os.makedirs(output_dir, exist_ok=overwrite)
+        self.save_network_config(os.path.join(output_dir, output_filename_without_extension + ".yaml"), overwrite)
+        self.save_network_params(os.path.join(output_dir, output_filename_without_extension + ".pth"), overwrite)
+
+    # ---- modes (network.py:634-696) -----------------------------------------------------------------------------------
+    def enable_training(self):
+        if not self.optimizer:
+            tcfg = self.network_config["training"]["config"]
+            assert "optimizer" in tcfg, 'Required key "optimizer" in dictionary "config" is missing from network configuration.'
+            assert "type" in tcfg["optimizer"], \
+                'Required key "type" in dictionary "optimizer" is missing from network configuration.'
+            params = [p for p in self.model.parameters() if p.requires_grad]
+            optimizer_type = tcfg["optimizer"]["type"]
+            assert optimizer_type in KNOWN_OPTIMIZERS, \
+                'Expected optimizer_type "{}" to be in the list of known optimizers, but it is not.'.format(optimizer_type)
+            if optimizer_type == "adam":
+                assert "learning_rate" in tcfg["optimizer"], \
+                    'Required key "learning_rate" in dictionary "optimizer" is missing to use the Adam optimizer.'
+                self.optimizer = HipAdam(params, lr=tcfg["optimizer"]["learning_rate"])
+            else:
+                assert "learning_rate" in tcfg["optimizer"], \
+                    'Required key "learning_rate" in dictionary "optimizer" is missing to use the SGD optimizer.'
+                self.optimizer = HipSGD(params, lr=tcfg["optimizer"]["learning_rate"])
+        self.model.train()
+
+    def enable_evaluation(self):
+        self.model.eval()
+
+    def _to_device(self, t):
+        return t if t.device == self.device else t.to(self.device, non_blocking=True)
+
+
+def _pick_device(gpu_ids):
+    """One process drives one GPU: LOCAL_RANK under torchrun, else the first entry of gpu_ids, else 0.
+    On a GPU-less host the network can be constructed (config / state_dict work) but not run."""
+    if not torch.cuda.is_available():
+        return torch.device("cpu")
+    if "LOCAL_RANK" in os.environ:
+        idx = int(os.environ["LOCAL_RANK"])
+    elif gpu_ids:
+        idx = int(gpu_ids[0])
+    else:
+        idx = torch.cuda.current_device()
+    torch.cuda.set_device(idx)
+    return torch.device("cuda", idx)

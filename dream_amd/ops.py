@@ -1,0 +1,204 @@
+"""Thin functional layer over the C ABI: allocates outputs as torch tensors and forwards raw device
+pointers + the current HIP stream to libdream_hip.so.  No arithmetic happens in Python/ATen here."""
+import torch
+
+from . import _hip
+from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream
+
+CONV_ZEROSTUFF2X = 8
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("dream_amd: expected float32, got %s" % t.dtype)
+    return t.contiguous()
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def pack_weight(w_oihw, mode=0):
+    """OIHW [Cout,Cin,3,3] -> tap-major packed tensor (see dream_pack_conv3x3_weight).
+    Returns (packed, rows, rows_pad, cols_pad)."""
+    w = _f32(w_oihw)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    rows_pad, cols_pad = _hip.cout_pad(rows), round_up(cols, 16)
+    packed = torch.empty((9, rows_pad, cols_pad), dtype=torch.float32, device=w.device)
+    call("dream_pack_conv3x3_weight", ptr(w), ptr(packed), cout, cin, rows_pad, cols_pad, mode, stream())
+    return packed, rows, rows_pad, cols_pad
+
+
+def conv3x3(x_nhwc, packed, bias, cout, flags=0):
+    """x: [B,Hs,Ws,Cin] NHWC (Cin == packed.shape[2]); returns [B,H,W,cout] (or NCHW with OUT_NCHW)."""
+    x = _f32(x_nhwc)
+    b, hs, ws, cin = (int(v) for v in x.shape)
+    if cin != packed.shape[2]:
+        raise RuntimeError("conv3x3: input has %d channels, packed weights expect %d" % (cin, packed.shape[2]))
+    scale = 2 if flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X) else 1
+    h, w = hs * scale, ws * scale
+    shape = (b, cout, h, w) if flags & CONV_OUT_NCHW else (b, h, w, cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_nhwc_f32", ptr(x), ptr(packed), ptr(bias), ptr(y), b, h, w, cin, cout,
+         int(packed.shape[1]), flags, stream())
+    return y
+
+
+def conv3x3_first(x_nchw, w_oihw, bias, relu=True):
+    x, w = _f32(x_nchw), _f32(w_oihw)
+    b, cin, h, wd = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    y = torch.empty((b, h, wd, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_first_nchw_f32", ptr(x), ptr(w), ptr(bias), ptr(y), b, h, wd, cin, cout,
+         1 if relu else 0, stream())
+    return y
+
+
+def maxpool2(x_nhwc):
+    x = _f32(x_nhwc)
+    b, h, w, c = (int(v) for v in x.shape)
+    y = torch.empty((b, h // 2, w // 2, c), dtype=torch.float32, device=x.device)
+    call("dream_maxpool2_nhwc_f32", ptr(x), ptr(y), b, h, w, c, stream())
+    return y
+
+
+def nchw_to_nhwc(x, cpad=None):
+    x = _f32(x)
+    b, c, h, w = (int(v) for v in x.shape)
+    if cpad is None or cpad == c:
+        y = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+        call("dream_nchw_to_nhwc_f32", ptr(x), ptr(y), b, c, h, w, stream())
+    else:
+        y = torch.empty((b, h, w, cpad), dtype=torch.float32, device=x.device)
+        call("dream_nchw_to_nhwc_pad_f32", ptr(x), ptr(y), b, c, h, w, cpad, stream())
+    return y
+
+
+def nhwc_to_nchw(x):
+    x = _f32(x)
+    b, h, w, c = (int(v) for v in x.shape)
+    y = torch.empty((b, c, h, w), dtype=torch.float32, device=x.device)
+    call("dream_nhwc_to_nchw_f32", ptr(x), ptr(y), b, c, h, w, stream())
+    return y
+
+
+# ---- peak extraction --------------------------------------------------------------------------------
+def keypoints_from_belief_maps(maps_bkhw, offset):
+    """[B,K,H,W] device fp32 -> ([B,K,2] fp32 device tensor, [B,K] int32 peak counts)."""
+    m = _f32(maps_bkhw)
+    b, k, h, w = (int(v) for v in m.shape)
+    scratch = torch.empty((2, b * k, h, w), dtype=torch.float32, device=m.device)
+    kps = torch.empty((b, k, 2), dtype=torch.float32, device=m.device)
+    counts = torch.empty((b, k), dtype=torch.int32, device=m.device)
+    call("dream_keypoints_from_belief_maps_f32", ptr(m), ptr(scratch), ptr(kps), ptr(counts), b * k, h, w,
+         float(offset), stream())
+    return kps, counts
+
+
+def peaks_list(maps_khw, offset, cap=256):
+    """[K,H,W] -> (xy [K,cap,2] fp64, score [K,cap] fp32, counts [K] int32), all on the device."""
+    m = _f32(maps_khw)
+    k, h, w = (int(v) for v in m.shape)
+    while True:
+        scratch = torch.empty((2, k, h, w), dtype=torch.float32, device=m.device)
+        xy = torch.empty((k, cap, 2), dtype=torch.float64, device=m.device)
+        score = torch.empty((k, cap), dtype=torch.float32, device=m.device)
+        counts = torch.empty((k,), dtype=torch.int32, device=m.device)
+        call("dream_peaks_from_belief_maps_f32", ptr(m), ptr(scratch), ptr(xy), ptr(score), ptr(counts), k, h, w,
+             cap, float(offset), stream())
+        most = int(counts.max().item()) if k else 0
+        if most <= cap:
+            return xy, score, counts
+        cap = round_up(most, 256)
+
+
+def gaussian_sigma3(maps_nhw):
+    m = _f32(maps_nhw)
+    n, h, w = (int(v) for v in m.shape)
+    tmp, out = torch.empty_like(m), torch.empty_like(m)
+    call("dream_gaussian_sigma3_f32", ptr(m), ptr(tmp), ptr(out), n, h, w, stream())
+    return out
+
+
+def softargmax(maps_bkhw, beta, size_mult=1.0):
+    m = _f32(maps_bkhw)
+    b, k, h, w = (int(v) for v in m.shape)
+    scratch = torch.empty_like(m)
+    out = torch.empty((b, k, 2), dtype=torch.float32, device=m.device)
+    call("dream_softargmax_f32", ptr(m), ptr(_f32(beta)), ptr(scratch), ptr(out), b * k, k, h, w, float(size_mult),
+         stream())
+    return out
+
+
+# ---- training operators -------------------------------------------------------------------------------
+def mse_fwd_bwd(out, target, want_grad=True):
+    """Returns (loss 0-dim tensor, grad or None): mean((o-t)^2) and 2(o-t)/N."""
+    o, t = _f32(out), _f32(target)
+    if o.shape != t.shape:
+        raise RuntimeError("mse: shape mismatch %s vs %s" % (tuple(o.shape), tuple(t.shape)))
+    n = o.numel()
+    loss_sum = torch.zeros((1,), dtype=torch.float32, device=o.device)
+    grad = torch.empty_like(o) if want_grad else None
+    call("dream_mse_fwd_bwd_f32", ptr(o), ptr(t), ptr(grad), ptr(loss_sum), n, float(n), stream())
+    return loss_sum[0] / n, grad
+
+
+def relu_bwd_(dy, y):
+    """in place: dy *= (y > 0)"""
+    call("dream_relu_bwd_f32", ptr(dy), ptr(y), ptr(dy), dy.numel(), stream())
+    return dy
+
+
+def maxpool2_bwd(dy, x):
+    b, h, w, c = (int(v) for v in x.shape)
+    dx = torch.empty_like(x)
+    call("dream_maxpool2_bwd_nhwc_f32", ptr(_f32(dy)), ptr(x), ptr(dx), b, h, w, c, stream())
+    return dx
+
+
+def upsample2_bwd(dy):
+    b, h, w, c = (int(v) for v in dy.shape)
+    dx = torch.empty((b, h // 2, w // 2, c), dtype=torch.float32, device=dy.device)
+    call("dream_upsample2_bwd_nhwc_f32", ptr(_f32(dy)), ptr(dx), b, h, w, c, stream())
+    return dx
+
+
+def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
+    """-> (dW OIHW [cout,cin,3,3], dbias [cout]).  dy may carry padded channels (>= cout)."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    b, h, w, cdy = (int(v) for v in dy.shape)
+    if int(x.shape[3]) != cin:
+        raise RuntimeError("wgrad: x has %d channels, expected %d" % (x.shape[3], cin))
+    rows_pad = round_up(cdy, 64)
+    nbytes = int(_hip.lib().dream_conv3x3_wgrad_workspace(b, h, w, cin, rows_pad))
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    dwp = torch.empty((9, rows_pad, cin), dtype=torch.float32, device=x.device)
+    dbias = torch.empty((cdy,), dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dwp), ptr(dbias), ptr(ws), b, h, w, cin, cdy, rows_pad,
+         flags, stream())
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    call("dream_unpack_conv3x3_weight", ptr(dwp), ptr(dw), cout, cin, rows_pad, cin, stream())
+    return dw, dbias[:cout].contiguous()
+
+
+def conv3x3_first_wgrad(x_nchw, dy_nhwc):
+    x, dy = _f32(x_nchw), _f32(dy_nhwc)
+    b, cin, h, w = (int(v) for v in x.shape)
+    cout = int(dy.shape[3])
+    nbytes = int(_hip.lib().dream_conv3x3_first_wgrad_workspace(b, h, w, cin, cout))
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_first_wgrad_f32", ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), nbytes, b, h, w, cin, cout,
+         stream())
+    return dw, db
+
+
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+    call("dream_adam_step_f32", ptr(p), ptr(_f32(g)), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+         float(eps), int(step), stream())
+
+
+def sgd_step_(p, g, lr):
+    call("dream_sgd_step_f32", ptr(p), ptr(_f32(g)), p.numel(), float(lr), stream())

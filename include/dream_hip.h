@@ -1,0 +1,153 @@
+/* dream_hip.h -- C ABI of libdream_hip.so: the MI355X (gfx950) kernels behind DREAM's
+ * keypoint belief-map hot path.
+ *
+ * The reference (NVlabs/DREAM 1.3.0) is pure Python and has no FFI of its own; on this path it
+ * reaches native code only through torch ATen operators.  Every entry
+ * point below therefore cites the reference call site whose ATen operator (or NumPy/SciPy
+ * routine) it replaces.  The reference-side binding a maintainer would add is the ctypes stub in
+ * INTEGRATION.md (and, in this repo, dream_amd/_hip.py).
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on failure; dream_hip_last_error() then
+ *     returns a thread-local message.  No exceptions cross the boundary.
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors on the host side);
+ *     the library never allocates, frees or retains caller memory.
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream).  All work is enqueued
+ *     asynchronously on it; nothing synchronises.
+ *   - activations inside the network are NHWC fp32 ("pixel-major": one pixel's channels are
+ *     contiguous, so a wavefront's 64 lanes read/write whole 128-256 B lines); the boundary
+ *     tensors of the reference API (network input, belief maps, targets) stay NCHW fp32.
+ *   - all arithmetic is IEEE fp32 (MFMA v_mfma_f32_32x32x2_f32 == an fmaf chain); the peak
+ *     path accumulates in fp64 exactly like scipy/NumPy do.
+ */
+#ifndef DREAM_HIP_H
+#define DREAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DREAM_HIP_ABI_VERSION 1
+
+/* conv flags */
+#define DREAM_CONV_RELU        1   /* fuse ReLU into the epilogue (reference: nn.ReLU(inplace) after the conv) */
+#define DREAM_CONV_UPSAMPLE2X  2   /* input is [B,H/2,W/2,Cin]; nearest x2 upsample fused into the patch load
+                                      (reference: nn.Upsample(scale_factor=2), dream/models.py:691,703) */
+#define DREAM_CONV_OUT_NCHW    4   /* store the result as NCHW (the belief-map head) */
+#define DREAM_CONV_ZEROSTUFF2X 8   /* input is [B,H/2,W/2,Cin] placed at the even positions of a zero [B,H,W,Cin]
+                                      grid: with mode-1 packed weights this is ConvTranspose2d(k=3,s=2,p=1,
+                                      output_padding=1) (dream/models.py:621-686) */
+
+int         dream_hip_abi_version(void);
+const char *dream_hip_last_error(void);
+/* number of visible devices / name of device `dev` (into buf); used by smoke tests */
+int         dream_hip_device_count(int *count);
+int         dream_hip_device_name(int dev, char *buf, size_t buflen);
+
+/* ---- weight packing ------------------------------------------------------------------------
+ * OIHW [Cout,Cin,3,3] (torch.nn.Conv2d.weight, dream/models.py:594-615,695-747) ->
+ * tap-major [9][RowsPad][ColsPad] fp32, zero padded (rows = channels the conv kernel produces,
+ * columns = channels it consumes; the two Pad arguments are RowsPad, ColsPad in that order).
+ * mode 0: forward operator, packed[t][o][i] = w[o][i][t] (rows = Cout, cols = Cin).
+ * mode 1: data-gradient operator, packed[t][i][o] = w[o][i][8-t] (rows = Cin, cols = Cout): the
+ * same conv kernel applied to dL/dy then yields dL/dx (replaces ATen conv backward-input). */
+int dream_pack_conv3x3_weight(const float *w_oihw, float *packed, int Cout, int Cin,
+                              int CoutPad, int CinPad, int mode, void *stream);
+/* inverse of mode 0 for gradients: [9][CoutPad][CinPad] -> OIHW (only the unpadded part) */
+int dream_unpack_conv3x3_weight(const float *packed, float *w_oihw, int Cout, int Cin,
+                                int CoutPad, int CinPad, void *stream);
+size_t dream_conv3x3_cout_pad(int Cout);  /* padded row count the MFMA kernel wants (multiple of 128) */
+
+/* ---- forward operators -----------------------------------------------------------------------
+ * conv 3x3 stride 1 pad 1 + bias (+ReLU), NHWC, implicit GEMM on fp32 MFMA.
+ * Replaces torch.nn.Conv2d(k=3,s=1,p=1) at dream/models.py:594-615 (encoder), :695-710 (decoder),
+ * :736-747 (head).  x: [B,H,W,Cin] (or [B,H/2,W/2,Cin] with UPSAMPLE2X), Cin % 16 == 0;
+ * w: packed mode-0 weights [9][CoutPad][Cin]; bias: [Cout] or NULL; y: [B,H,W,Cout] NHWC, or
+ * [B,Cout,H,W] with OUT_NCHW. */
+int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y,
+                           int B, int H, int W, int Cin, int Cout, int CoutPad, int flags,
+                           void *stream);
+/* variant selection for benchmarking: -1 = heuristic; otherwise index into the variant table */
+int dream_conv3x3_set_variant(int variant);
+int dream_conv3x3_num_variants(void);
+const char *dream_conv3x3_variant_name(int variant);
+
+/* first encoder conv: NCHW fp32 image [B,Cin,H,W] (Cin <= 4, what DreamNetwork.inference receives,
+ * dream/network.py:503,519) -> NHWC [B,H,W,64*n]; w in OIHW as stored; fused bias (+ReLU).
+ * Replaces the fresh Conv2d(3,64,3,1,1) at dream/models.py:592-597. */
+int dream_conv3x3_first_nchw_f32(const float *x_nchw, const float *w_oihw, const float *bias,
+                                 float *y_nhwc, int B, int H, int W, int Cin, int Cout,
+                                 int relu, void *stream);
+
+/* nn.MaxPool2d(2) (dream/models.py:589,765-771): [B,H,W,C] -> [B,H/2,W/2,C] (floor). C % 4 == 0 */
+int dream_maxpool2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream);
+
+/* layout helpers (NCHW <-> NHWC, fp32).  nchw_to_nhwc_pad writes Cpad >= C channels per pixel,
+ * zero-filling the padding (used to hand the K-channel loss gradient to the MFMA kernels). */
+int dream_nchw_to_nhwc_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+int dream_nchw_to_nhwc_pad_f32(const float *x, float *y, int B, int C, int H, int W, int Cpad, void *stream);
+int dream_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W, void *stream);
+
+/* ---- peak extraction ---------------------------------------------------------------------------
+ * Everything after the CNN in DreamNetwork.inference (dream/network.py:529-581), i.e.
+ * dream.image_proc.peaks_from_belief_maps (dream/image_proc.py:914-1018: scipy gaussian_filter
+ * sigma 3 -> 4-neighbour local max > 0.01 -> 5x5 float64 centroid of the raw map) followed by the
+ * one-peak / best-by->=0.25 selection rule.  maps: [N,H,W] fp32 (N = B*K, i.e. NCHW belief maps);
+ * scratch: 2*N*H*W floats; keypoints: [N,2] fp32 (x,y) or -999.999; peak_counts: [N] int32 or NULL.
+ * Bit-exact with the reference (fp64 accumulation in scipy's/NumPy's order, no FMA contraction). */
+int dream_keypoints_from_belief_maps_f32(const float *maps, float *scratch, float *keypoints,
+                                         int32_t *peak_counts, int N, int H, int W,
+                                         double offset_due_to_upsampling, void *stream);
+/* the full peak list of peaks_from_belief_maps, row-major order per map, at most `cap` per map:
+ * xy: [N,cap,2] fp64, score: [N,cap] fp32, counts: [N] (true count, may exceed cap). */
+int dream_peaks_from_belief_maps_f32(const float *maps, float *scratch, double *xy, float *score,
+                                     int32_t *counts, int N, int H, int W, int cap,
+                                     double offset_due_to_upsampling, void *stream);
+/* scipy.ndimage.gaussian_filter(m, sigma=3) alone (mode reflect, truncate 4): [N,H,W] -> [N,H,W];
+ * tmp: N*H*W floats */
+int dream_gaussian_sigma3_f32(const float *maps, float *tmp, float *out, int N, int H, int W,
+                              void *stream);
+
+/* SoftArgmaxPavlo.forward (dream/spatial_softmax.py:24-95): maps [B*K,H,W], beta [K] (device),
+ * scratch N*H*W floats, out [B*K,2] (x,y). */
+int dream_softargmax_f32(const float *maps, const float *beta, float *scratch, float *out,
+                         int N, int K, int H, int W, float size_mult, void *stream);
+
+/* ---- training operators --------------------------------------------------------------------------
+ * MSELoss(mean) forward + gradient (dream/network.py:260-261,359; loss.backward() at :335):
+ * loss_sum[0] += sum((o-t)^2) (caller zeroes it and divides by n_total); grad = 2*(o-t)/n_total. */
+int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+                          size_t n, double n_total, void *stream);
+/* elementwise ReLU backward on NHWC tensors: dx = dy * (y > 0) (inplace allowed) */
+int dream_relu_bwd_f32(const float *dy, const float *y, float *dx, size_t n, void *stream);
+/* MaxPool2d(2) backward: dy [B,H/2,W/2,C], x [B,H,W,C] (forward input), dx [B,H,W,C];
+ * gradient goes to the first maximal element in window scan order (ATen semantics). */
+int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, float *dx,
+                                int B, int H, int W, int C, void *stream);
+/* nearest x2 upsample backward: dy [B,H,W,C] -> dx [B,H/2,W/2,C] = sum of the 2x2 block */
+int dream_upsample2_bwd_nhwc_f32(const float *dy, float *dx, int B, int H, int W, int C, void *stream);
+/* conv3x3 weight+bias gradient: x [B,H,W,Cin] (or half-res with UPSAMPLE2X), dy [B,H,W,Cout] NHWC
+ * -> dw_packed [9][CoutPad][Cin] (mode-0 layout, overwritten), dbias [Cout] (overwritten).
+ * workspace: dream_conv3x3_wgrad_workspace() bytes. Deterministic split-K reduction. */
+size_t dream_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad);
+int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias,
+                                 void *workspace, int B, int H, int W, int Cin, int Cout,
+                                 int CoutPad, int flags, void *stream);
+/* first-layer weight gradient: x NCHW [B,Cin,H,W], dy NHWC [B,H,W,Cout] -> dw OIHW, dbias */
+size_t dream_conv3x3_first_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
+int dream_conv3x3_first_wgrad_f32(const float *x_nchw, const float *dy_nhwc, float *dw_oihw,
+                                  float *dbias, void *workspace, size_t workspace_bytes,
+                                  int B, int H, int W, int Cin, int Cout, void *stream);
+/* torch.optim.Adam / SGD step with PyTorch defaults (dream/network.py:666-685) on one flat fp32
+ * buffer: p, g, m, v of n elements; step is the 1-based step count. */
+int dream_adam_step_f32(float *p, const float *g, float *m, float *v, size_t n, float lr,
+                        float beta1, float beta2, float eps, int step, void *stream);
+int dream_sgd_step_f32(float *p, const float *g, size_t n, float lr, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DREAM_HIP_H */

@@ -1,0 +1,38 @@
+// TEST INFRASTRUCTURE: emulator counterpart of dream_amd/csrc/include/dream_cdna4.h (same names, host
+// semantics).  The MFMA model follows the lane layout documented in the product header / the CDNA4
+// guide: A[row=l&31][k=l>>5], B[k=l>>5][col=l&31], D reg r -> row (r&3)+8*(r>>2)+4*(l>>5), col l&31,
+// computed as an fmaf chain over k = 0, 1.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define DREAM_DEVICE inline __attribute__((always_inline))
+#define DREAM_DYNAMIC_LDS(type, var) type *var = (type *)emu::tb->dyn_lds
+
+inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
+    emu::Block *blk = emu::tb;
+    const int w = emu::wave(), l = emu::lane();
+    const int par = (blk->wave_op[w][l]++) & 1;
+    blk->xchg_a[par][w][l] = a;
+    blk->xchg_b[par][w][l] = b;
+    emu::wave_barrier();
+    const float *A = blk->xchg_a[par][w], *B = blk->xchg_b[par][w];
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        c[r] = fmaf(A[row + 32], B[col + 32], fmaf(A[row], B[col], c[r]));
+    }
+    return c;
+}
+inline int wave_index() { return emu::wave(); }
+inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+inline int lane_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+inline int lane_up(int v, int d) { return __shfl_up(v, d, 64); }
+inline unsigned long long wave_ballot(int pred) { return __ballot(pred); }
+inline int popcount64(unsigned long long v) { return __popcll(v); }
+inline double dmul(double a, double b) { return a * b; }
+inline double dadd(double a, double b) { return a + b; }
+inline double ddiv(double a, double b) { return a / b; }
