@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the DREAM belief-map hot path on MI355X (driver contract: see the task brief).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]): DREAM-vgg-Q inference, batch 128 of synthetic 400x400 frames
+already resident in HBM, one "step" = DreamNetwork.inference(x) = CNN forward + peak extraction,
+result = [B,K,2] float32 keypoints on the host (the reference's return contract).  With N ranks each
+rank processes its own batch of 128 (embarrassingly parallel, no data-path collective): weak scaling.
+
+One JSON line on rank 0.  `roofline` is measured live: every launch of the dominant kernel
+(conv3x3_mfma_kernel, 22 launches per step) is bracketed by HIP events on the launch stream inside
+the timed region; achieved = algorithmic FLOPs of those launches / their summed duration.
+`cpu_baseline` times the CPU oracle (torch-CPU restatement of the reference + NumPy peak path) on a
+bounded sample of the same workload on this host's cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--res", type=int, default=400)
+    ap.add_argument("--mode", choices=["inference", "train"], default="inference")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(res, seconds):
+    """CPU oracle on a bounded sample of the same workload: batches of 4 frames, forward + peaks."""
+    import numpy as np
+    import torch
+    import cases
+    from oracle import models as omodels, peaks as opeaks
+    model = omodels.build_model("vgg_q", 7)
+    model.load_state_dict(omodels.recipe_weights(model.state_dict()))
+    model.eval()
+    bs = 4
+    x = torch.from_numpy(cases.image_batch(bs, res, res, seed=0))
+
+    def one():
+        with torch.no_grad():
+            maps = model(x)[0].numpy()
+        return opeaks.keypoints_from_belief_maps(maps, 0.4395)
+
+    one()                                   # warm-up
+    t0 = time.time()
+    n = 0
+    while True:
+        one()
+        n += bs
+        if time.time() - t0 >= seconds or n >= 64:
+            break
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d frames of %dx%d (batches of %d), oracle torch-CPU vgg_q forward + NumPy peak "
+                      "extraction, %.1f s" % (n, res, res, bs, dt)}
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import cases
+    import dream_amd
+    from dream_amd import ops
+    from oracle import models as omodels       # weights recipe only (bench leg); never on the timed path
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+    cfg = dream_amd.default_network_config("vgg_q", "panda", batch_size=args.batch)
+    cfg["training"]["config"]["net_input_resolution"] = [args.res, args.res]
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = dream_amd.create_network_from_config_data(cfg)
+    ref = omodels.build_model("vgg_q", 7)
+    net.model.load_state_dict({"module." + k: v for k, v in omodels.recipe_weights(ref.state_dict()).items()})
+    del ref
+
+    x = torch.from_numpy(cases.image_batch(args.batch, args.res, args.res, seed=rank)).cuda()
+    if args.mode == "train":
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        tgt = torch.from_numpy(cases.target_batch(args.batch, 7, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
+    else:
+        net.enable_evaluation()
+
+    # ---- per-launch timing of the dominant kernel (HIP events on the launch stream) ------------------
+    conv_events = []          # (start, end, flops)
+    recording = [False]
+    orig_conv = ops.conv3x3
+
+    def timed_conv(x_nhwc, packed, bias, cout, flags=0):
+        if not recording[0]:
+            return orig_conv(x_nhwc, packed, bias, cout, flags)
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        y = orig_conv(x_nhwc, packed, bias, cout, flags)
+        e.record()
+        b, hs, ws, cin = x_nhwc.shape
+        sc = 2 if flags & (ops.CONV_UPSAMPLE2X | ops.CONV_ZEROSTUFF2X) else 1
+        conv_events.append((s, e, 2.0 * b * hs * sc * ws * sc * cin * cout * 9))
+        return y
+
+    ops.conv3x3 = timed_conv
+
+    def step():
+        if args.mode == "train":
+            return net.train([x], tgt)
+        with torch.no_grad():
+            return net.inference(x)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    recording[0] = True
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    recording[0] = False
+
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    conv_ms = sum(s.elapsed_time(e) for s, e, _ in conv_events)
+    conv_flops = sum(f for _, _, f in conv_events)
+    n_launch = len(conv_events)
+
+    if rank == 0:
+        frames = args.batch * args.steps * world
+        line = {
+            "metric": "frames/s DREAM-vgg-Q %dx%d b=%d %s" % (args.res, args.res, args.batch, args.mode),
+            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DREAM-vgg-Q (panda, 7 keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames "
+                                   "resident in HBM; CNN forward + belief-map peak extraction (BASELINE.json configs[%d])"
+                                   % (args.mode, args.batch, args.res, args.res, 2 if args.mode == "train" else 1),
+                       "batch_per_gpu": args.batch, "resolution": [args.res, args.res], "parallelism": "dp%d" % world},
+            "roofline": {
+                "bound": "mfma", "kernel": "conv3x3_mfma_kernel",
+                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "traffic": None,
+                "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
+                "algorithmic_gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
+                "share_of_step_time": conv_ms * 1e-3 / dt,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline and args.mode == "inference":
+            line["cpu_baseline"] = cpu_baseline(args.res, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

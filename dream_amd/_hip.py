@@ -123,6 +123,16 @@ def ptr(t):
     return t.data_ptr()
 
 
+def device_tensor(t):
+    """The reference's functions accept host or device tensors; the HIP path needs device memory."""
+    import torch
+    if t.is_cuda:
+        return t
+    if not torch.cuda.is_available():
+        raise RuntimeError("dream_amd: this operation runs on the GPU only (no CPU fallback) and no GPU is visible")
+    return t.cuda()
+
+
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream

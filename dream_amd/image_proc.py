@@ -6,7 +6,7 @@ import numpy as np
 import torch
 from PIL import Image as PILImage
 
-from . import ops
+from . import _hip, ops
 
 KNOWN_IMAGE_PREPROC_TYPES = ["none", "resize", "shrink", "shrink-and-crop"]
 
@@ -26,11 +26,7 @@ def peaks_from_belief_maps(belief_map_tensor, offset_due_to_upsampling):
     assert (
         len(belief_map_tensor.shape) == 3
     ), "Expected belief_map_tensor to have shape [N x height x width], but it is {}.".format(belief_map_tensor.shape)
-    maps = belief_map_tensor.detach()
-    if not maps.is_cuda:
-        if not torch.cuda.is_available():
-            raise RuntimeError("dream_amd.peaks_from_belief_maps needs a GPU (no CPU fallback)")
-        maps = maps.cuda()
+    maps = _hip.device_tensor(belief_map_tensor.detach())
     xy, score, counts = ops.peaks_list(maps.float(), offset_due_to_upsampling)
     xy, score, counts = xy.cpu().numpy(), score.cpu().numpy(), counts.cpu().numpy()
     all_peaks, counter = [], 0

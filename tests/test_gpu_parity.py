@@ -1,0 +1,142 @@
+"""GPU suite (-m gpu): parity of the real libdream_hip.so (through the C ABI, on an MI355X) with the CPU
+oracle and with the committed golden outputs of the real reference.  Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import cases
+import parity_checks as pc
+from dream_amd import _hip, ops
+from oracle import models as om
+from oracle import peaks as op
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _require_gpu_and_native_library():
+    assert torch.cuda.is_available(), "-m gpu tests need a GPU"
+    _hip.check_symbols()
+    with open("/proc/self/maps") as f:
+        assert "libdream_hip.so" in f.read(), "the native HIP library is not loaded"
+    yield
+
+
+# ---- every distinct DREAM-vgg-Q conv layer shape, batch 1, at full resolution -----
+VGG_Q_LAYERS = [
+    (400, 64, 64, 1), (200, 64, 128, 1), (200, 128, 128, 1), (100, 128, 256, 1), (100, 256, 256, 1),
+    (50, 256, 512, 1), (50, 512, 512, 1), (25, 512, 512, 1),
+    (50, 512, 256, 3), (50, 256, 256, 0), (100, 256, 128, 3), (100, 128, 64, 0),
+    (100, 64, 64, 1), (100, 64, 32, 1), (100, 32, 7, 4), (100, 32, 17, 4),
+]
+
+
+@pytest.mark.parametrize("res,cin,cout,flags", VGG_Q_LAYERS)
+def test_conv_layer_shapes(res, cin, cout, flags):
+    pc.check_conv(DEV, 1, res, res, cin, cout, flags, seed=res + cin)
+
+
+@pytest.mark.parametrize("variant", range(9))
+def test_conv_variants(variant):
+    lib = _hip.lib()
+    lib.dream_conv3x3_set_variant(variant)
+    try:
+        pc.check_conv(DEV, 2, 33, 47, 64, 96, 1, seed=variant)
+        pc.check_conv(DEV, 2, 12, 20, 64, 7, 4, seed=variant)
+        pc.check_conv(DEV, 1, 26, 38, 32, 64, 3, seed=variant)
+    finally:
+        lib.dream_conv3x3_set_variant(-1)
+
+
+def test_conv_odd_shapes_and_transpose():
+    pc.check_conv(DEV, 3, 5, 3, 16, 16, 0)
+    pc.check_conv(DEV, 1, 13, 31, 48, 32, 1)
+    pc.check_conv(DEV, 2, 133, 100, 64, 64, 1)
+    pc.check_conv_transpose(DEV, 2, 25, 25, 64, 32)
+
+
+def test_first_conv_pool_layouts():
+    pc.check_first_conv(DEV, 1, 400, 400)
+    pc.check_first_conv(DEV, 2, 21, 37)
+    pc.check_pool_and_layouts(DEV)
+
+
+@pytest.mark.parametrize("name", sorted(cases.peak_cases().keys()))
+def test_peaks_bit_exact(name):
+    pc.check_peaks_case(DEV, name)
+
+
+def test_peaks_api_reference_kat():
+    pc.check_peaks_api(DEV)
+
+
+def test_softargmax():
+    pc.check_softargmax(DEV)
+
+
+def test_backward_ops():
+    pc.check_backward_ops(DEV)
+
+
+@pytest.mark.parametrize("shape", cases.CNN_CASES["vgg_q"][2])
+def test_vgg_q_inference_golden(shape):
+    pc.check_model_inference(DEV, "vgg_q", shape)
+
+
+def test_vgg_f_inference_golden():
+    pc.check_model_inference(DEV, "vgg_f", (2, 64, 80))
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_train_steps_golden(opt):
+    pc.check_train_steps(DEV, opt, steps=3)
+
+
+def test_resnet_refuses_instead_of_falling_back():
+    net = pc.build_network("resnet_h", DEV)
+    with pytest.raises(NotImplementedError):
+        net.inference(torch.zeros(1, 3, 64, 64, device=DEV))
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json configs[1] size (batch 128 of 400x400): size-independent properties.
+    (a) batch-position independence: the batch holds 4 distinct frames repeated 32x; every copy must give
+        bit-identical belief maps and keypoints (tiling/XCD placement must not leak into results);
+    (b) the first copy equals the CPU oracle within TOL and the peak stage is bit-exact on the HIP maps."""
+    net = pc.build_network("vgg_q", DEV)
+    net.enable_evaluation()
+    base = torch.from_numpy(cases.image_batch(4, 400, 400, seed=77))
+    x = base.repeat(32, 1, 1, 1).to(DEV)
+    with torch.no_grad():
+        maps, kps = net.inference(x)
+    maps = maps.cpu()
+    assert maps.shape == (128, 7, 100, 100) and kps.shape == (128, 7, 2)
+    for r in range(1, 32):
+        assert torch.equal(maps[4 * r:4 * r + 4], maps[:4])
+        assert torch.equal(kps[4 * r:4 * r + 4], kps[:4])
+    ref = om.build_model("vgg_q", 7)
+    ref.load_state_dict(om.recipe_weights(ref.state_dict()))
+    ref.eval()
+    with torch.no_grad():
+        ref_maps = ref(base[:2])[0].numpy()
+    assert np.abs(maps[:2].numpy() - ref_maps).max() <= pc.tol(ref_maps)
+    assert np.array_equal(kps[:4].numpy(), op.keypoints_from_belief_maps(maps[:4].numpy(), 0.4395))
+
+
+def test_full_size_peak_stage():
+    """896 maps of 100x100 (batch 128 x 7): gaussian linearity-free check -- compare a strided subset
+    with the oracle bit-for-bit and all counts with a NumPy recount on the device-smoothed maps."""
+    rs = np.random.RandomState(5)
+    maps = (rs.normal(0.05, 0.05, (896, 100, 100))).astype(np.float32)
+    maps[::3, 40:49, 50:59] += 0.8
+    m = torch.from_numpy(maps).to(DEV)
+    sm = ops.gaussian_sigma3(m).cpu().numpy()
+    kps, counts = ops.keypoints_from_belief_maps(m.view(128, 7, 100, 100), 0.4395)
+    kps, counts = kps.cpu().numpy().reshape(896, 2), counts.cpu().numpy().reshape(896)
+    for i in range(0, 896, 37):
+        assert np.array_equal(sm[i], op.gaussian_filter_sigma3(maps[i]))
+        assert np.array_equal(kps[i][None], op.keypoints_from_belief_maps(maps[i][None, None], 0.4395)[0])
+    for i in range(896):
+        assert counts[i] == int(op.peak_mask(sm[i]).sum())
