@@ -302,7 +302,10 @@ class DreamNetwork:
         torch.save(self.model.state_dict(), network_params_path)
 
     def save_network(self, output_dir, output_filename_without_extension, overwrite=False):
-        os.makedirs(output_dir, exist_ok=overwrite)
+        if os.path.exists(output_dir):         # dream.utilities.makedirs semantics (utilities.py:29-35)
+            assert overwrite, 'Specified directory "{}" already exists.'.format(output_dir)
+        else:
+            os.makedirs(output_dir)
         self.save_network_config(os.path.join(output_dir, output_filename_without_extension + ".yaml"), overwrite)
         self.save_network_params(os.path.join(output_dir, output_filename_without_extension + ".pth"), overwrite)
 

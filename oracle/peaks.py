@@ -154,3 +154,21 @@ def numpy_pairwise_sum25(a):
         r = [r[j] + a[i + j] for j in range(8)]
     res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
     return res + a[24]
+
+
+def c_keypoints_from_belief_maps(maps_bkhw, offset):
+    """Same result as keypoints_from_belief_maps through the plain-C restatement (oracle/peaks_c.c,
+    built by __graft_entry__.build_oracle()); ~100x faster, used as the single-core CPU baseline."""
+    import ctypes
+    import os
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpeaks_c.so"))
+    m = np.ascontiguousarray(maps_bkhw, dtype=np.float32)
+    b, k, h, w = m.shape
+    kps = np.empty((b * k, 2), np.float32)
+    counts = np.empty((b * k,), np.int32)
+    taps = np.ascontiguousarray(gaussian_weights())
+    P = ctypes.c_void_p
+    rc = lib.dream_oracle_keypoints(P(m.ctypes.data), b * k, h, w, ctypes.c_double(offset), P(taps.ctypes.data),
+                                    P(kps.ctypes.data), P(counts.ctypes.data))
+    assert rc == 0
+    return kps.reshape(b, k, 2), counts.reshape(b, k)

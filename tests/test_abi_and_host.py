@@ -1,0 +1,130 @@
+"""CPU: the C-ABI library loads and exports every symbol include/dream_hip.h declares (no compute), and the
+host-side mirror of the reference interface behaves like the reference (validation, resolutions,
+state_dict layout, refusal to run without a GPU)."""
+import json
+import os
+
+import pytest
+import torch
+
+import dream_amd
+from dream_amd import _hip, image_proc
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _hip.check_symbols()
+    assert len(declared) >= 30 and "dream_conv3x3_nhwc_f32" in declared
+    assert set(declared) == set(_hip._SIGNATURES.keys())
+    assert _hip.lib().dream_hip_abi_version() == 1
+    assert _hip.lib().dream_conv3x3_num_variants() == 9
+
+
+def test_argument_errors_are_reported_not_thrown():
+    lib = _hip.lib()
+    rc = lib.dream_conv3x3_nhwc_f32(None, None, None, None, 1, 8, 8, 32, 32, 128, 0, None)
+    assert rc != 0 and b"null" in lib.dream_hip_last_error()
+    rc = lib.dream_maxpool2_nhwc_f32(None, None, 1, 8, 8, 6, None)
+    assert rc != 0
+
+
+# ---- the reference's own resolution KATs (test/test_image_proc.py:20-91) -----------------------------
+def test_shrink_resolution():
+    assert image_proc.shrink_resolution((640, 480), (400, 400)) == (533, 400)
+    assert image_proc.shrink_resolution((640, 480), (640, 480)) == (640, 480)
+
+
+def test_shrink_and_crop_resolution():
+    assert image_proc.shrink_and_crop_resolution((640, 480), (400, 400)) == ((480, 480), (80, 0))
+    assert image_proc.shrink_and_crop_resolution((640, 480), (640, 480)) == ((640, 480), (0, 0))
+
+
+def test_resolution_after_preprocessing():
+    f = image_proc.resolution_after_preprocessing
+    assert f((640, 480), (400, 400), "none") == (640, 480)
+    assert f((640, 480), (400, 400), "resize") == (400, 400)
+    assert f((640, 480), (400, 400), "shrink") == (533, 400)
+    assert f((640, 480), (400, 400), "shrink-and-crop") == (400, 400)
+
+
+@pytest.mark.parametrize("arch,manip,out_res", [("vgg_q", "panda", (100, 100)), ("vgg_f", "panda", (400, 400)),
+                                                ("resnet_h", "panda", (208, 208)), ("resnet_f", "baxter", (416, 416))])
+def test_network_surface_and_state_dict(arch, manip, out_res, capsys):
+    net = dream_amd.create_network_from_config_data(dream_amd.default_network_config(arch, manip))
+    assert "DreamNetwork:__init()" in capsys.readouterr().out               # banner (network.py:118-122)
+    assert net.trained_net_output_resolution() == out_res
+    assert net.network_config["training"]["config"]["net_output_resolution"] == list(out_res)
+    assert net.trained_net_input_resolution() == (400, 400)
+    assert net.use_belief_peak_scores is True and net.belief_peak_next_best_score == 0.25
+    assert net.n_keypoints == len(net.keypoint_names) == len(net.friendly_keypoint_names) == len(net.ros_keypoint_frames)
+    man = json.load(open(os.path.join(GOLD, "state_dict_manifest.json")))[arch]
+    sd = net.model.state_dict()
+    assert list(sd.keys()) == list(man.keys())                               # module.-prefixed, reference order
+    assert all(list(sd[k].shape) == v for k, v in man.items())
+    for need in ("train", "loss", "inference", "keypoints_from_image", "enable_training", "enable_evaluation",
+                 "net_resolutions_from_image_raw_resolution", "net_output_resolution_from_input_resolution",
+                 "save_network_config", "save_network_params", "save_network", "image_preprocessing"):
+        assert callable(getattr(net, need))
+    assert net.net_resolutions_from_image_raw_resolution((640, 480)) == ((400, 400), out_res)
+    assert net.optimizer is None
+    with pytest.raises(AssertionError):
+        net.train([torch.zeros(1, 3, 8, 8)], torch.zeros(1))                 # "Use enable_training() first."
+    net.enable_training()
+    assert net.optimizer is not None and net.model.training
+    net.enable_evaluation()
+    assert not net.model.training
+
+
+def test_config_validation_uses_assertion_errors():
+    good = dream_amd.default_network_config("vgg_q")
+    for path in (["architecture"], ["manipulator"], ["training"], ["architecture", "type"],
+                 ["architecture", "image_normalization"], ["architecture", "output_heads"],
+                 ["training", "config", "net_input_resolution"], ["training", "platform"]):
+        cfg = json.loads(json.dumps(good))
+        d = cfg
+        for k in path[:-1]:
+            d = d[k]
+        del d[path[-1]]
+        with pytest.raises(AssertionError):
+            dream_amd.create_network_from_config_data(cfg)
+    cfg = json.loads(json.dumps(good))
+    cfg["architecture"]["type"] = "transformer"
+    with pytest.raises(AssertionError):
+        dream_amd.create_network_from_config_data(cfg)
+    cfg = json.loads(json.dumps(good))
+    cfg["training"]["config"]["net_output_resolution"] = [50, 50]           # disagrees with the model
+    with pytest.raises(AssertionError):
+        dream_amd.create_network_from_config_data(cfg)
+    assert dream_amd.KNOWN_OPTIMIZERS == ["adam", "sgd"] and dream_amd.KNOWN_ARCHITECTURES == ["vgg", "resnet"]
+
+
+def test_save_and_reload_roundtrip(tmp_path):
+    net = dream_amd.create_network_from_config_data(dream_amd.default_network_config("vgg_q"))
+    out = tmp_path / "run"
+    net.save_network(str(out), "epoch_1")
+    with pytest.raises(AssertionError):
+        net.save_network(str(out), "epoch_2")                                # directory exists, overwrite=False
+    with pytest.raises(AssertionError):
+        net.save_network_params(str(out / "epoch_1.pth"))                    # file exists, overwrite=False
+    net.save_network(str(out), "epoch_1", overwrite=True)
+    again = dream_amd.create_network_from_config_file(str(out / "epoch_1.yaml"), str(out / "epoch_1.pth"))
+    for (k1, v1), (k2, v2) in zip(net.model.state_dict().items(), again.model.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+
+
+def test_reads_reference_style_omap_yaml(tmp_path):
+    p = tmp_path / "c.yaml"
+    p.write_text("!!omap\n- architecture: !!omap\n  - type: vgg\n  - input_heads:\n    - image_rgb\n- n: 3\n")
+    from dream_amd.network import _load_yaml
+    assert _load_yaml(str(p)) == {"architecture": {"type": "vgg", "input_heads": ["image_rgb"]}, "n": 3}
+
+
+def test_no_cpu_fallback_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    net = dream_amd.create_network_from_config_data(dream_amd.default_network_config("vgg_q"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net.inference(torch.zeros(1, 3, 400, 400))
+    with pytest.raises(RuntimeError):
+        dream_amd.peaks_from_belief_maps(torch.zeros(1, 8, 8), 0.0)

@@ -74,3 +74,14 @@ def test_selection_rule_cases_present():
     assert (k[:3, 0] == np.float32(-999.999)).all()
     assert (k[4:6, 0] > 0).all()
     assert (g["negative_zero/keypoints"][0][2] == np.float32(-999.999)).all()
+
+
+@pytest.mark.parametrize("name", sorted(cases.peak_cases().keys()))
+def test_c_restatement_matches_reference_outputs(name):
+    import __graft_entry__
+    __graft_entry__.build_oracle(verbose=False)
+    g = _golden()
+    maps, off = cases.peak_cases()[name]
+    kps, counts = op.c_keypoints_from_belief_maps(maps[None], off)
+    assert np.array_equal(kps, g[name + "/keypoints"])
+    assert np.array_equal(counts[0], g[name + "/counts"])

@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 rocpd database (kernel trace [+ PMC]) into a small text/CSV report that can be
+committed under profiles/.  Usage: python tools/prof_summary.py gpurun_out/prof/r01_results.db out_prefix"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    out = sys.argv[2]
+    cur = db.cursor()
+    rows = list(cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) "
+                            "from kernels group by name order by sum(duration) desc"))
+    total = sum(r[2] for r in rows) or 1
+    with open(out + "_kernel_stats.csv", "w") as f:
+        f.write("kernel,calls,total_ms,avg_us,min_us,max_us,percent\n")
+        for name, n, tot, avg, mn, mx in rows:
+            f.write('"%s",%d,%.3f,%.1f,%.1f,%.1f,%.2f\n' % (name, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
+    print(open(out + "_kernel_stats.csv").read())
+    # per-dispatch list of the dominant kernel family, with launch geometry
+    with open(out + "_conv_dispatches.csv", "w") as f:
+        f.write("kernel,start_ms,duration_us,grid_x,grid_y,lds_bytes,vgprs\n")
+        t0 = None
+        for name, start, dur, gx, gy, lds, vg in cur.execute(
+                "select name, start, duration, grid_x, grid_y, lds_size, vgpr_count from kernels order by start"):
+            t0 = start if t0 is None else t0
+            if "conv3x3_mfma" in name or "wgrad" in name:
+                f.write('"%s",%.3f,%.1f,%d,%d,%d,%d\n' % (name.split("(")[0], (start - t0) / 1e6, dur / 1e3, gx, gy, lds, vg))
+    # PMC, if present
+    try:
+        cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)")]
+        pm = list(cur.execute("select * from counters_collection limit 1"))
+        if pm:
+            print("counters_collection columns:", cols)
+    except sqlite3.Error as e:
+        print("no PMC data:", e)
+
+
+if __name__ == "__main__":
+    main()
