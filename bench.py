@@ -41,6 +41,21 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE, separate runs of this same command, FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md and calibrated on the max-pool kernel).  Counters cannot be read from inside the
+    process, so the latest committed profile summary is reported; null for any other workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.mode != "inference" or args.batch != 128 or args.res != 400 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        d = json.load(f)["conv3x3_mfma_kernel"]
+    return {"bytes_per_launch": d["traffic_gb_per_launch"] * 1e9,
+            "algorithmic_bytes_per_launch": d["algorithmic_gb_per_launch"] * 1e9,
+            "source": "profiles/r01_pmc_traffic.json"}
+
+
 def cpu_baseline(res, seconds):
     """CPU oracle on a bounded sample of the same workload: batches of 4 frames, forward + peaks."""
     import numpy as np
@@ -178,7 +193,7 @@ def main():
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
-                "traffic": None,
+                "traffic": pmc_traffic(args),
                 "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
                 "algorithmic_gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
                 "share_of_step_time": conv_ms * 1e-3 / dt,
