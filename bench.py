@@ -10,7 +10,7 @@ result = [B,K,2] float32 keypoints on the host (the reference's return contract)
 rank processes its own batch of 128 (embarrassingly parallel, no data-path collective): weak scaling.
 
 One JSON line on rank 0.  `roofline` is measured live: every launch of the dominant kernel
-(conv3x3_mfma_kernel, 22 launches per step) is bracketed by HIP events on the launch stream inside
+(conv_mfma_kernel, 22 launches per step for vgg_q) is bracketed by HIP events on the launch stream inside
 the timed region; achieved = algorithmic FLOPs of those launches / their summed duration.
 `cpu_baseline` times the CPU oracle (torch-CPU restatement of the reference + NumPy peak path) on a
 bounded sample of the same workload on this host's cores (rank 0, N=1 only).
@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--mode", choices=["inference", "train"], default="inference")
+    ap.add_argument("--arch", choices=["vgg_q", "vgg_f", "resnet_h", "resnet_f"], default="vgg_q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -47,22 +48,23 @@ def pmc_traffic(args):
     MI355X_MICROARCH.md and calibrated on the max-pool kernel).  Counters cannot be read from inside the
     process, so the latest committed profile summary is reported; null for any other workload."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.mode != "inference" or args.batch != 128 or args.res != 400 or not os.path.exists(path):
+    if args.arch != "vgg_q" or args.mode != "inference" or args.batch != 128 or args.res != 400 or not os.path.exists(path):
         return None
     with open(path) as f:
-        d = json.load(f)["conv3x3_mfma_kernel"]
-    return {"bytes_per_launch": d["traffic_gb_per_launch"] * 1e9,
-            "algorithmic_bytes_per_launch": d["algorithmic_gb_per_launch"] * 1e9,
-            "source": "profiles/r01_pmc_traffic.json"}
+        d = json.load(f)["conv_mfma_kernel"]
+    return d["traffic_gb_per_launch"] * 1e9
 
 
-def cpu_baseline(res, seconds):
+ARCH_K = {"vgg_q": (7, "panda"), "vgg_f": (7, "panda"), "resnet_h": (7, "panda"), "resnet_f": (17, "baxter")}
+
+
+def cpu_baseline(arch, res, seconds):
     """CPU oracle on a bounded sample of the same workload: batches of 4 frames, forward + peaks."""
     import numpy as np
     import torch
     import cases
     from oracle import models as omodels, peaks as opeaks
-    model = omodels.build_model("vgg_q", 7)
+    model = omodels.build_model(arch, ARCH_K[arch][0])
     model.load_state_dict(omodels.recipe_weights(model.state_dict()))
     model.eval()
     bs = 4
@@ -71,7 +73,7 @@ def cpu_baseline(res, seconds):
     def one():
         with torch.no_grad():
             maps = model(x)[0].numpy()
-        return opeaks.keypoints_from_belief_maps(maps, 0.4395)
+        return opeaks.keypoints_from_belief_maps(maps, 0.0 if maps.shape[-1] >= 400 else 0.4395)
 
     one()                                   # warm-up
     t0 = time.time()
@@ -83,8 +85,8 @@ def cpu_baseline(res, seconds):
             break
     dt = time.time() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d frames of %dx%d (batches of %d), oracle torch-CPU vgg_q forward + NumPy peak "
-                      "extraction, %.1f s" % (n, res, res, bs, dt)}
+            "sample": "%d frames of %dx%d (batches of %d), oracle torch-CPU %s forward + NumPy peak "
+                      "extraction, %.1f s" % (n, res, res, bs, arch, dt)}
 
 
 def main():
@@ -106,13 +108,14 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
-    cfg = dream_amd.default_network_config("vgg_q", "panda", batch_size=args.batch)
+    n_kp, manip = ARCH_K[args.arch]
+    cfg = dream_amd.default_network_config(args.arch, manip, batch_size=args.batch)
     cfg["training"]["config"]["net_input_resolution"] = [args.res, args.res]
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         net = dream_amd.create_network_from_config_data(cfg)
-    ref = omodels.build_model("vgg_q", 7)
+    ref = omodels.build_model(args.arch, n_kp)
     net.model.load_state_dict({"module." + k: v for k, v in omodels.recipe_weights(ref.state_dict()).items()})
     del ref
 
@@ -120,29 +123,31 @@ def main():
     if args.mode == "train":
         net.enable_training()
         ow, oh = net.trained_net_output_resolution()
-        tgt = torch.from_numpy(cases.target_batch(args.batch, 7, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
+        tgt = torch.from_numpy(cases.target_batch(args.batch, n_kp, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
     else:
         net.enable_evaluation()
 
     # ---- per-launch timing of the dominant kernel (HIP events on the launch stream) ------------------
     conv_events = []          # (start, end, flops)
     recording = [False]
-    orig_conv = ops.conv3x3
 
-    def timed_conv(x_nhwc, packed, bias, cout, flags=0):
-        if not recording[0]:
-            return orig_conv(x_nhwc, packed, bias, cout, flags)
-        s = torch.cuda.Event(enable_timing=True)
-        e = torch.cuda.Event(enable_timing=True)
-        s.record()
-        y = orig_conv(x_nhwc, packed, bias, cout, flags)
-        e.record()
-        b, hs, ws, cin = x_nhwc.shape
-        sc = 2 if flags & (ops.CONV_UPSAMPLE2X | ops.CONV_ZEROSTUFF2X) else 1
-        conv_events.append((s, e, 2.0 * b * hs * sc * ws * sc * cin * cout * 9))
-        return y
+    def timed(orig, flops_of):
+        def wrapper(*a, **k):
+            if not recording[0]:
+                return orig(*a, **k)
+            s_ev = torch.cuda.Event(enable_timing=True)
+            e_ev = torch.cuda.Event(enable_timing=True)
+            s_ev.record()
+            y = orig(*a, **k)
+            e_ev.record()
+            conv_events.append((s_ev, e_ev, flops_of(y, *a, **k)))
+            return y
+        return wrapper
 
-    ops.conv3x3 = timed_conv
+    # algorithmic FLOPs of one launch = 2 * outputs * (input channels * taps); y is NHWC or NCHW [B,...]
+    ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0: 2.0 * y.numel() * x.shape[3] * 9)
+    ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y.numel() * x.shape[3] * ksize * ksize)
+    ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * 16)
 
     def step():
         if args.mode == "train":
@@ -180,27 +185,29 @@ def main():
     if rank == 0:
         frames = args.batch * args.steps * world
         line = {
-            "metric": "frames/s DREAM-vgg-Q %dx%d b=%d %s" % (args.res, args.res, args.batch, args.mode),
+            "metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DREAM-vgg-Q (panda, 7 keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames "
-                                   "resident in HBM; CNN forward + belief-map peak extraction (BASELINE.json configs[%d])"
-                                   % (args.mode, args.batch, args.res, args.res, 2 if args.mode == "train" else 1),
+            "config": {"workload": "DREAM-%s (%s, %d keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames "
+                                   "resident in HBM; CNN forward + belief-map peak extraction%s"
+                                   % (args.arch, manip, n_kp, args.mode, args.batch, args.res, args.res,
+                                      " (BASELINE.json configs[%d])" % (2 if args.mode == "train" else 1)
+                                      if args.arch == "vgg_q" else ""),
                        "batch_per_gpu": args.batch, "resolution": [args.res, args.res], "parallelism": "dp%d" % world},
             "roofline": {
-                "bound": "mfma", "kernel": "conv3x3_mfma_kernel",
+                "bound": "mfma", "kernel": "conv_mfma_kernel",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
-                "traffic": pmc_traffic(args),
+                "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
                 "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
                 "algorithmic_gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
                 "share_of_step_time": conv_ms * 1e-3 / dt,
             },
         }
         if world == 1 and not args.no_cpu_baseline and args.mode == "inference":
-            line["cpu_baseline"] = cpu_baseline(args.res, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.arch, args.res, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -32,7 +32,14 @@ _SIGNATURES = {
     "dream_hip_device_name": (_I, [_I, _c.c_char_p, _SZ]),
     "dream_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dream_unpack_conv3x3_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "dream_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_pack_convT4x4_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_conv3x3_cout_pad": (_SZ, [_I]),
+    "dream_conv2d_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv_transpose4x4s2_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_bn_fold_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "dream_im2col_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_maxpool3s2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_conv3x3_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_set_variant": (_I, [_I]),
     "dream_conv3x3_num_variants": (_I, []),
@@ -69,7 +76,7 @@ def header_functions():
     """Function names declared in include/dream_hip.h."""
     with open(HEADER_PATH) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
-    return sorted(set(re.findall(r"\b(dream_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(dream_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def lib():

@@ -1,0 +1,458 @@
+// conv 3x3 / stride 1 / pad 1 (+bias, +ReLU, optional fused nearest-x2 upsample of the input,
+// optional NCHW store) on NHWC fp32 tensors as an implicit GEMM on the CDNA4 fp32 matrix cores.
+//
+// Replaces torch.nn.Conv2d(k=3,s=1,p=1) at /root/reference/dream/models.py:594-615 (VGG19 encoder),
+// :695-710 (upsample decoder, with the nn.Upsample at :691,:703 fused into the patch load) and
+// :736-747 (belief-map head).  The same kernel run on mode-1 packed weights is the data-gradient
+// (conv backward-input) operator, and with DREAM_CONV_ZEROSTUFF2X it is ConvTranspose2d(k=3,s=2,p=1,
+// output_padding=1) (dream/models.py:621-686): a transposed conv == a stride-1 conv of the
+// zero-stuffed input with the flipped kernel; the stuffing is done in the patch loader.
+//
+// GEMM view:  D[m][n] = sum_k A[m][k] * B[k][n]
+//   m = output pixel of a TH x TW patch of one image (BM = 32*MR*WM rows per workgroup)
+//   n = output channel                                (BN = 32*NR*WN columns per workgroup)
+//   k = (tap, cin): 9 taps x Cin, walked as  for cin-chunk(KC) { for tap(9) { KC } }
+// One workgroup = 4 wavefronts (WM x WN); each wavefront owns MR x NR accumulators of
+// v_mfma_f32_32x32x2_f32 (exact fp32: an fmaf chain, so results are independent of tiling).
+//
+// LDS: the input patch for the current cin-chunk -- (TH+2) x (TW+2) pixels x KC floats, loaded ONCE
+// and re-read by all 9 taps (per-lane ds_read addresses make the tap shift free) -- plus a
+// double-buffered [BN][KC] weight tile per tap.  Pixel / cout rows are padded to KC+4 floats so a
+// ds_read_b128 lane group lands on distinct 16-B slots.  A lane's ds_read_b128 delivers 4
+// consecutive k's; lanes 0-31 take k..k+3 and lanes 32-63 k+4..k+7 of the same row, which feeds 4
+// MFMAs (the k order inside the sum is a permutation shared by A and B).
+//
+// Global traffic: activations are read as 64/128-B pieces of NHWC pixels (whole lines per 4/8
+// lanes), weights as 64/128-B rows of the tap-major packed tensor; both are prefetched into
+// registers one stage ahead (issued before the MFMA block, written to LDS after it).
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+struct ConvParams {
+    const float *x;
+    const float *w;          // [ntaps][CoutPad][Cin]
+    const float *scale;      // per-channel multiplier (eval-mode BatchNorm fold) or null
+    const float *shift;      // per-channel addend (bias / BN shift) or null
+    const float *residual;   // tensor of the output's shape added before the ReLU, or null
+    float *y;
+    int B, H, W;             // grid of output positions per image that the tiles cover
+    int Hin, Win;            // logical input extent (after fused upsample / zero-stuffing)
+    int Hs, Ws;              // extent of the tensor actually read
+    int Ho, Wo;              // extent of the tensor written
+    int Cin, Cout, CoutPad;
+    int TH, TW, PH, PW;      // pixel tile and staged patch
+    int tiles_x, tiles_y;
+    int rcpTW;               // ceil(65536 / TW): m / TW == (m * rcpTW) >> 16 for m < 256
+    int in_scale;            // input row of patch row 0 = y0 * in_scale - pad_y
+    int in_step;             // input pixels between consecutive patch pixels (2 for a strided 1x1)
+    int lane_stride;         // patch pixels between consecutive output positions (2 for a strided 3x3)
+    int pad_y, pad_x;
+    int ntaps;
+    int tap_off[16];         // LDS float offset of each tap inside the patch: (dy * PW + dx) * (KC + 4)
+    int out_scale, out_oy, out_ox;   // output pixel = position * out_scale + (out_oy, out_ox)
+    int flags;
+};
+
+template <int MR, int NR, int WM, int WN, int KC, int NPM>
+struct ConvCfg {
+    static constexpr int BM = 32 * MR * WM;
+    static constexpr int BN = 32 * NR * WN;
+    static constexpr int S = KC + 4;                 // padded row stride in floats
+    static constexpr int Q = KC / 4;                 // float4 pieces per row
+    static constexpr int NP_MAX = NPM;               // patch pixels the tile chooser may use
+    static constexpr int NA_IT = (NP_MAX * Q + 255) / 256;
+    static constexpr int NB_IT = (BN * Q + 255) / 256;
+    static constexpr int NB_FULL = (BN * Q) % 256 == 0;
+};
+
+template <int MR, int NR, int WM, int WN, int KC, int NPM>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
+    using C = ConvCfg<MR, NR, WM, WN, KC, NPM>;
+    constexpr int S = C::S, Q = C::Q, BN = C::BN;
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+
+    DREAM_DYNAMIC_LDS(float, smem);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_index();
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int PW = p.PW, TW = p.TW;
+    const int NP = p.PH * PW;
+    float *sA = smem;
+    float *sB0 = smem + NP * S;
+    float *sB1 = sB0 + BN * S;
+
+    // ---- which tile -------------------------------------------------------------------------
+    int t = blockIdx.x;
+    const int tix = t % p.tiles_x;
+    t /= p.tiles_x;
+    const int tiy = t % p.tiles_y;
+    const int b = t / p.tiles_y;
+    const int y0 = tiy * p.TH, x0 = tix * TW;
+    const int n0 = blockIdx.y * BN;
+    const bool zst = (p.flags & DREAM_CONV_ZEROSTUFF2X) != 0;
+    const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0 || zst;
+    const float *xb = p.x + (size_t)b * p.Hs * p.Ws * p.Cin;
+
+    // ---- staging plan (fixed for the whole kernel) ---------------------------------------------
+    int a_goff[C::NA_IT];     // element offset of this thread's float4 inside image b, or -1 (zero pad)
+    int a_soff[C::NA_IT];     // LDS float offset, or -1 when this slot does not exist
+#pragma unroll
+    for (int it = 0; it < C::NA_IT; ++it) {
+        const int idx = tid + it * 256;
+        const int pp = idx / Q, q = idx % Q;
+        a_soff[it] = (pp < NP) ? pp * S + q * 4 : -1;
+        const int py = pp / PW, px = pp - py * PW;
+        const int gy = y0 * p.in_scale - p.pad_y + py * p.in_step, gx = x0 * p.in_scale - p.pad_x + px * p.in_step;
+        const bool inb = (pp < NP) && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win &&
+                         !(zst && ((gy | gx) & 1));      // zero-stuffed input: odd rows/cols are zeros
+        const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+        a_goff[it] = inb ? (sy * p.Ws + sx) * p.Cin + q * 4 : -1;
+    }
+    int b_goff[C::NB_IT], b_soff[C::NB_IT];
+#pragma unroll
+    for (int it = 0; it < C::NB_IT; ++it) {
+        const int idx = tid + it * 256;
+        const int n = idx / Q, q = idx % Q;
+        const bool ok = C::NB_FULL || (n < BN);
+        b_soff[it] = ok ? n * S + q * 4 : -1;
+        b_goff[it] = (n0 + n) * p.Cin + q * 4;
+    }
+    const size_t w_tap_stride = (size_t)p.CoutPad * p.Cin;
+
+    // ---- fragment addresses -----------------------------------------------------------------------
+    int a_frag[MR], b_frag[NR];
+#pragma unroll
+    for (int ms = 0; ms < MR; ++ms) {
+        int m = (wm * MR + ms) * 32 + li;
+        if (m >= p.TH * TW) m = 0;                       // idle rows compute garbage that is never stored
+        const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+        a_frag[ms] = (ty * PW + tx) * p.lane_stride * S + lh * 4;
+    }
+#pragma unroll
+    for (int ns = 0; ns < NR; ++ns) b_frag[ns] = ((wn * NR + ns) * 32 + li) * S + lh * 4;
+
+    f32x16 acc[MR][NR];
+#pragma unroll
+    for (int ms = 0; ms < MR; ++ms)
+#pragma unroll
+        for (int ns = 0; ns < NR; ++ns)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
+
+    f32x4 a_reg[C::NA_IT], b_reg[C::NB_IT];
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    auto load_a = [&](int c0) {
+#pragma unroll
+        for (int it = 0; it < C::NA_IT; ++it)
+            a_reg[it] = (a_goff[it] >= 0) ? *(const f32x4 *)(xb + a_goff[it] + c0) : zero4;
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int it = 0; it < C::NA_IT; ++it)
+            if (a_soff[it] >= 0) *(f32x4 *)(sA + a_soff[it]) = a_reg[it];
+    };
+    auto load_b = [&](int tap, int c0) {
+        const float *wt = p.w + (size_t)tap * w_tap_stride + c0;
+#pragma unroll
+        for (int it = 0; it < C::NB_IT; ++it)
+            if (C::NB_FULL || b_soff[it] >= 0) b_reg[it] = *(const f32x4 *)(wt + b_goff[it]);
+    };
+    auto store_b = [&](float *sB) {
+#pragma unroll
+        for (int it = 0; it < C::NB_IT; ++it)
+            if (C::NB_FULL || b_soff[it] >= 0) *(f32x4 *)(sB + b_soff[it]) = b_reg[it];
+    };
+
+    const int nchunks = p.Cin / KC;
+
+    // ---- prologue: stage (chunk 0, tap 0) --------------------------------------------------------
+    load_a(0);
+    load_b(0, 0);
+    store_a();
+    store_b(sB0);
+    __syncthreads();
+
+    int buf = 0, tap = 0, chunk = 0;
+    const int ntaps = p.ntaps, nstages = nchunks * ntaps;
+    for (int st = 0; st < nstages; ++st) {
+        const bool last_tap = (tap == ntaps - 1);
+        const bool more_chunks = (chunk + 1 < nchunks);
+        const bool have_next = (st + 1 < nstages);
+        // prefetch the next stage's operands into registers (in flight during the MFMAs)
+        if (have_next) load_b(last_tap ? 0 : tap + 1, last_tap ? (chunk + 1) * KC : chunk * KC);
+        if (last_tap && more_chunks) load_a((chunk + 1) * KC);
+
+        // ---- MFMA block: KC k's of this tap --------------------------------------------------------
+        const float *sAt = sA + p.tap_off[tap];
+        const float *sBt = buf ? sB1 : sB0;
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 8) {
+            f32x4 af[MR], bf[NR];
+#pragma unroll
+            for (int ms = 0; ms < MR; ++ms) af[ms] = *(const f32x4 *)(sAt + a_frag[ms] + kk);
+#pragma unroll
+            for (int ns = 0; ns < NR; ++ns) bf[ns] = *(const f32x4 *)(sBt + b_frag[ns] + kk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int ms = 0; ms < MR; ++ms)
+#pragma unroll
+                    for (int ns = 0; ns < NR; ++ns)
+                        acc[ms][ns] = mfma_f32_32x32x2(af[ms][r], bf[ns][r], acc[ms][ns]);
+        }
+
+        // ---- publish the next stage -----------------------------------------------------------------
+        if (have_next) store_b(buf ? sB0 : sB1);          // other buffer: last read one stage ago
+        if (last_tap && more_chunks) {
+            __syncthreads();                               // every wave is done with this chunk's patch
+            store_a();
+        }
+        __syncthreads();
+        buf ^= 1;
+        if (last_tap) { tap = 0; ++chunk; } else ++tap;
+    }
+
+    // ---- epilogue: (BN scale), bias/shift, residual, ReLU, store ---------------------------------------
+    const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
+    const bool nchw = (p.flags & DREAM_CONV_OUT_NCHW) != 0;
+    float scale_v[NR], shift_v[NR];
+    int ncol[NR];
+#pragma unroll
+    for (int ns = 0; ns < NR; ++ns) {
+        ncol[ns] = n0 + (wn * NR + ns) * 32 + li;
+        const bool cok = ncol[ns] < p.Cout;
+        scale_v[ns] = (p.scale != nullptr && cok) ? p.scale[ncol[ns]] : 1.0f;
+        shift_v[ns] = (p.shift != nullptr && cok) ? p.shift[ncol[ns]] : 0.0f;
+    }
+    const int npix = p.TH * TW;
+#pragma unroll
+    for (int ms = 0; ms < MR; ++ms) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+            const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
+            const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
+#pragma unroll
+            for (int ns = 0; ns < NR; ++ns) {
+                if (ok && ncol[ns] < p.Cout) {
+                    const size_t o = nchw
+                        ? (((size_t)b * p.Cout + ncol[ns]) * p.Ho + oy) * p.Wo + ox
+                        : (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns];
+                    float v = acc[ms][ns][r];
+                    if (p.scale != nullptr) v = v * scale_v[ns];
+                    v = v + shift_v[ns];
+                    if (p.residual != nullptr) v = v + p.residual[o];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    p.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct Variant {
+    const char *name;
+    int BM, BN, KC, NP_MAX;
+    void (*kernel)(const ConvParams);
+};
+
+#define DREAM_VARIANT(MR, NR, WM, WN, KC, NPM)                                                   \
+    {                                                                                            \
+        "m" #MR "n" #NR "w" #WM "x" #WN "k" #KC, 32 * MR * WM, 32 * NR * WN, KC, NPM,           \
+            conv_mfma_kernel<MR, NR, WM, WN, KC, NPM>                                            \
+    }
+
+const Variant kVariants[] = {
+    DREAM_VARIANT(2, 2, 2, 2, 32, 192),   // 0: 128 px x 128 cout
+    DREAM_VARIANT(2, 2, 4, 1, 32, 352),   // 1: 256 px x  64 cout
+    DREAM_VARIANT(2, 1, 4, 1, 32, 352),   // 2: 256 px x  32 cout
+    DREAM_VARIANT(2, 2, 2, 2, 16, 192),   // 3
+    DREAM_VARIANT(2, 2, 4, 1, 16, 352),   // 4
+    DREAM_VARIANT(2, 1, 4, 1, 16, 352),   // 5
+    DREAM_VARIANT(1, 2, 4, 1, 32, 192),   // 6: 128 px x  64 cout
+    DREAM_VARIANT(1, 1, 4, 1, 32, 192),   // 7: 128 px x  32 cout
+    DREAM_VARIANT(1, 2, 2, 2, 32, 128),   // 8:  64 px x 128 cout (small feature maps, small batch)
+    DREAM_VARIANT(2, 2, 2, 2, 16, 608),   // 9: 128 px x 128 cout, big patch (stride-2 3x3 convs)
+};
+constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+constexpr int kNumSelectable = 9;          // variants a caller may force (9 is picked automatically)
+int g_forced_variant = -1;
+bool g_attr_set[kNumVariants] = {};
+
+// pixel tile: maximise useful rows per workgroup, then minimise the staged patch
+void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, int *th_out, int *tw_out) {
+    long best_tiles = -1;
+    int best_np = 0, bth = 1, btw = 1;
+    for (int tw = 1; tw <= BM && tw <= 255; ++tw) {
+        int th = BM / tw;
+        if (th < 1) break;
+        if (th > H) th = H;
+        const int twc = tw > W ? W : tw;
+        const int np = ((th - 1) * lane_stride + kext) * ((twc - 1) * lane_stride + kext);
+        if (np > np_max) continue;
+        const long tiles = (long)ceil_div(H, th) * ceil_div(W, twc);
+        if (best_tiles < 0 || tiles < best_tiles || (tiles == best_tiles && np < best_np)) {
+            best_tiles = tiles;
+            best_np = np;
+            bth = th;
+            btw = twc;
+        }
+    }
+    *th_out = bth;
+    *tw_out = btw;
+}
+
+int pick_variant(long pixels, int Cin, int Cout, bool big_patch) {
+    if (big_patch) return 9;
+    const bool k32 = (Cin % 32 == 0);
+    if (Cout > 64) {
+        // enough 128x128 tiles to fill 256 CUs x 2 workgroups?  otherwise the 64-px variant
+        const long tiles128 = ((pixels + 127) / 128) * (long)ceil_div(Cout, 128);
+        if (k32 && tiles128 < 512) return 8;
+        return k32 ? 0 : 3;
+    }
+    const long tiles256 = (pixels + 255) / 256;
+    if (Cout > 32) {
+        if (k32 && tiles256 < 512) return 6;
+        return k32 ? 1 : 4;
+    }
+    if (k32 && tiles256 < 512) return 7;
+    return k32 ? 2 : 5;
+}
+
+struct ConvGeom {
+    int H, W;                 // grid of output positions
+    int Hin, Win, Hs, Ws;     // logical input extent, stored input extent
+    int Ho, Wo;               // output tensor extent
+    int in_scale, in_step, lane_stride, pad;
+    int ntaps;
+    int tap_dy[16], tap_dx[16];
+    int kext;                 // patch rows needed beyond (TH-1)*lane_stride
+    int out_scale, out_oy, out_ox;
+};
+
+int launch_conv(const float *x, const float *w, const float *scale, const float *shift, const float *residual,
+                float *y, int B, int Cin, int Cout, int CoutPad, const ConvGeom &g, int flags, void *stream) {
+    DREAM_REQUIRE(x && w && y, "null pointer");
+    DREAM_REQUIRE(B > 0 && g.H > 0 && g.W > 0 && Cin > 0 && Cout > 0, "bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, g.H, g.W, Cin, Cout);
+    DREAM_REQUIRE(Cin % 16 == 0, "Cin=%d must be a multiple of 16 (pad the channels)", Cin);
+    DREAM_REQUIRE((size_t)g.Hs * g.Ws * (size_t)Cin < ((size_t)1 << 31) && (size_t)g.Ho * g.Wo * (size_t)Cout < ((size_t)1 << 31),
+                  "image too large for 32-bit offsets");
+    const bool big_patch = g.lane_stride > 1;
+    int v = (g_forced_variant >= 0 && !big_patch) ? g_forced_variant : pick_variant((long)B * g.H * g.W, Cin, Cout, big_patch);
+    if (Cin % kVariants[v].KC != 0) v = (kVariants[v].BN >= 128) ? 3 : (kVariants[v].BN == 64 ? 4 : 5);
+    const Variant &var = kVariants[v];
+    DREAM_REQUIRE(CoutPad % var.BN == 0 && CoutPad >= Cout, "CoutPad=%d must be a multiple of %d (variant %s)", CoutPad, var.BN, var.name);
+
+    ConvParams p;
+    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.B = B; p.H = g.H; p.W = g.W; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws; p.Ho = g.Ho; p.Wo = g.Wo;
+    p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
+    choose_tile(g.H, g.W, var.BM, var.NP_MAX, g.lane_stride, g.kext, &p.TH, &p.TW);
+    p.PH = (p.TH - 1) * g.lane_stride + g.kext;
+    p.PW = (p.TW - 1) * g.lane_stride + g.kext;
+    DREAM_REQUIRE(p.PH * p.PW <= var.NP_MAX, "internal: patch %dx%d exceeds variant %s", p.PH, p.PW, var.name);
+    p.tiles_x = ceil_div(g.W, p.TW);
+    p.tiles_y = ceil_div(g.H, p.TH);
+    p.rcpTW = (65536 + p.TW - 1) / p.TW;
+    p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride; p.pad_y = g.pad; p.pad_x = g.pad;
+    p.ntaps = g.ntaps;
+    const int S = var.KC + 4;
+    for (int t = 0; t < 16; ++t) p.tap_off[t] = t < g.ntaps ? (g.tap_dy[t] * p.PW + g.tap_dx[t]) * S : 0;
+    p.out_scale = g.out_scale; p.out_oy = g.out_oy; p.out_ox = g.out_ox;
+    p.flags = flags;
+
+    const size_t lds = ((size_t)p.PH * p.PW + 2 * (size_t)var.BN) * S * sizeof(float);
+    DREAM_REQUIRE(lds <= 160 * 1024, "LDS request %zu too large", lds);
+    if (!g_attr_set[v]) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_attr_set[v] = true;
+    }
+    const dim3 grid((unsigned)((size_t)B * p.tiles_x * p.tiles_y), (unsigned)ceil_div(Cout, var.BN));
+    hipLaunchKernelGGL(var.kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dream_conv3x3_set_variant(int variant) {
+    DREAM_REQUIRE(variant >= -1 && variant < kNumSelectable, "variant %d out of range", variant);
+    g_forced_variant = variant;
+    return 0;
+}
+extern "C" int dream_conv3x3_num_variants(void) { return kNumSelectable; }
+extern "C" const char *dream_conv3x3_variant_name(int variant) {
+    return (variant >= 0 && variant < kNumVariants) ? kVariants[variant].name : "heuristic";
+}
+extern "C" size_t dream_conv3x3_cout_pad(int Cout) {
+    // a multiple of every BN in the variant table, so any variant can run any layer
+    return (size_t)ceil_div(Cout, 128) * 128;
+}
+
+// k x k convolution (k in {1,3}), stride in {1,2}, pad = k/2; H, W are the INPUT extent (after the fused
+// x2 upsample / zero-stuffing when those flags are set).
+extern "C" int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                                     int CoutPad, int ksize, int stride, int flags, void *stream) {
+    DREAM_REQUIRE(ksize == 1 || ksize == 3, "conv2d: kernel size %d not supported (1 or 3)", ksize);
+    DREAM_REQUIRE(stride == 1 || stride == 2, "conv2d: stride %d not supported (1 or 2)", stride);
+    const bool ups = (flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X)) != 0;
+    DREAM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample / zero-stuffing needs even H, W (got %dx%d)", H, W);
+    DREAM_REQUIRE(!ups || stride == 1, "fused upsample with a strided conv is not supported");
+    ConvGeom g;
+    const int pad = ksize / 2;
+    g.Hin = H; g.Win = W;
+    g.Hs = ups ? H / 2 : H; g.Ws = ups ? W / 2 : W;
+    g.Ho = (H + 2 * pad - ksize) / stride + 1;
+    g.Wo = (W + 2 * pad - ksize) / stride + 1;
+    g.H = g.Ho; g.W = g.Wo;
+    g.in_scale = stride;
+    g.in_step = (ksize == 1) ? stride : 1;          // a strided 1x1 only stages the pixels it uses
+    g.lane_stride = (ksize == 1) ? 1 : stride;
+    g.pad = pad;
+    g.ntaps = ksize * ksize;
+    for (int t = 0; t < g.ntaps; ++t) { g.tap_dy[t] = t / ksize; g.tap_dx[t] = t % ksize; }
+    g.kext = ksize;
+    g.out_scale = 1; g.out_oy = 0; g.out_ox = 0;
+    return launch_conv(x, w_packed, scale, shift, residual, y, B, Cin, Cout, CoutPad, g, flags, stream);
+}
+
+extern "C" int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
+                                      int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream) {
+    return dream_conv2d_nhwc_f32(x, w_packed, nullptr, bias, nullptr, y, B, H, W, Cin, Cout, CoutPad, 3, 1, flags, stream);
+}
+
+// ConvTranspose2d(k=4, s=2, p=1) by sub-pixel decomposition: output pixel (2m+a, 2n+b) is a 2x2 convolution of
+// the input around (m, n) with the taps ky = 3 - 2*ty - a, kx = 3 - 2*tx - b (ty, tx in {0,1}); four launches,
+// one per phase (a, b), each writing its quarter of the [B,2H,2W,Cout] output.  No multiplications by zero.
+// w_packed: [4 phases][4 taps][CoutPad][Cin] from dream_pack_convT4x4_weight.
+extern "C" int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w_packed, const float *scale,
+                                                  const float *shift, float *y, int B, int H, int W, int Cin,
+                                                  int Cout, int CoutPad, int flags, void *stream) {
+    DREAM_REQUIRE((flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X | DREAM_CONV_OUT_NCHW)) == 0, "convT4x4: unsupported flags");
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        ConvGeom g;
+        g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W; g.Ho = 2 * H; g.Wo = 2 * W;
+        g.in_scale = 1; g.in_step = 1; g.lane_stride = 1; g.pad = 1;
+        g.ntaps = 4;
+        for (int t = 0; t < 4; ++t) { g.tap_dy[t] = (t >> 1) + a; g.tap_dx[t] = (t & 1) + b; }
+        g.kext = 3;
+        g.out_scale = 2; g.out_oy = a; g.out_ox = b;
+        const float *wp = w_packed + (size_t)ph * 4 * CoutPad * Cin;
+        if (int rc = launch_conv(x, wp, scale, shift, nullptr, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
+    }
+    return 0;
+}

@@ -150,8 +150,8 @@ __global__ void __launch_bounds__(256) nhwc_to_nchw_kernel(const float *x, float
 //   flipping the taps turns correlation with dL/dy into the transposed convolution.
 // packed is [9][RowsPad][ColsPad], zero padded.
 __global__ void __launch_bounds__(256) pack_w_kernel(const float *w, float *packed, int Cout, int Cin,
-                                                     int RowsPad, int ColsPad, int mode) {
-    const size_t total = (size_t)9 * RowsPad * ColsPad;
+                                                     int RowsPad, int ColsPad, int mode, int ntaps) {
+    const size_t total = (size_t)ntaps * RowsPad * ColsPad;
     const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int c = (int)(idx % ColsPad);
@@ -160,16 +160,16 @@ __global__ void __launch_bounds__(256) pack_w_kernel(const float *w, float *pack
         const int t = (int)(q / RowsPad);
         float v = 0.0f;
         if (r < rows && c < cols)
-            v = (mode == 0) ? w[((size_t)r * Cin + c) * 9 + t] : w[((size_t)c * Cin + r) * 9 + (8 - t)];
+            v = (mode == 0) ? w[((size_t)r * Cin + c) * ntaps + t] : w[((size_t)c * Cin + r) * ntaps + (ntaps - 1 - t)];
         packed[idx] = v;
     }
 }
 __global__ void __launch_bounds__(256) unpack_w_kernel(const float *packed, float *w, int Cout, int Cin,
-                                                       int CoutPad, int CinPad) {
-    const size_t total = (size_t)Cout * Cin * 9;
+                                                       int CoutPad, int CinPad, int ntaps) {
+    const size_t total = (size_t)Cout * Cin * ntaps;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int t = (int)(idx % 9);
-        size_t r = idx / 9;
+        const int t = (int)(idx % ntaps);
+        size_t r = idx / ntaps;
         const int i = (int)(r % Cin);
         const int o = (int)(r / Cin);
         w[idx] = packed[((size_t)t * CoutPad + o) * CinPad + i];
@@ -211,6 +211,88 @@ __global__ void __launch_bounds__(256) adam_kernel(float *p, const float *g, flo
 __global__ void __launch_bounds__(256) sgd_kernel(float *p, const float *g, size_t n, float lr) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         p[i] = p[i] - lr * g[i];
+}
+
+
+// ConvTranspose2d(k4,s2,p1) weight [Cin][Cout][4][4] -> [phase a*2+b][tap ty*2+tx][RowsPad][ColsPad] with
+// ky = 3 - 2*ty - a, kx = 3 - 2*tx - b (see dream_conv_transpose4x4s2_nhwc_f32); rows = Cout, cols = Cin.
+__global__ void __launch_bounds__(256) pack_wT4_kernel(const float *wT, float *packed, int Cin, int Cout,
+                                                       int RowsPad, int ColsPad) {
+    const size_t total = (size_t)16 * RowsPad * ColsPad;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % ColsPad);
+        size_t q = idx / ColsPad;
+        const int r = (int)(q % RowsPad);
+        const int pt = (int)(q / RowsPad);
+        const int ph = pt >> 2, t = pt & 3;
+        const int ky = 3 - 2 * (t >> 1) - (ph >> 1), kx = 3 - 2 * (t & 1) - (ph & 1);
+        packed[idx] = (r < Cout && c < Cin) ? wT[(((size_t)c * Cout + r) * 4 + ky) * 4 + kx] : 0.0f;
+    }
+}
+
+// eval-mode BatchNorm (+ optional preceding conv bias) folded to y = conv * scale + shift
+__global__ void __launch_bounds__(256) bn_fold_kernel(const float *gamma, const float *beta, const float *mean,
+                                                      const float *var, const float *conv_bias, float eps,
+                                                      float *scale, float *shift, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        const float s = gamma[c] / sqrtf(var[c] + eps);
+        scale[c] = s;
+        shift[c] = beta[c] - mean[c] * s + (conv_bias ? conv_bias[c] * s : 0.0f);
+    }
+}
+
+// im2col for the ResNet stem: NCHW image -> NHWC [B,Ho,Wo,Kpad], k = (c*KH + ky)*KW + kx (the OIHW
+// flattening of the weight), zero for out-of-image taps and for k >= C*KH*KW.  One thread per output float;
+// writes are fully coalesced, reads hit L1/L2 (the image is 1.9 MB per frame).
+__global__ void __launch_bounds__(256) im2col_nchw_kernel(const float *x, float *y, int B, int C, int H, int W,
+                                                          int KH, int KW, int stride, int pad, int Ho, int Wo, int Kpad) {
+    const size_t total = (size_t)B * Ho * Wo * Kpad;
+    const int K = C * KH * KW;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % Kpad);
+        size_t r = idx / Kpad;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float v = 0.0f;
+        if (k < K) {
+            const int kx = k % KW, ky = (k / KW) % KH, c = k / (KW * KH);
+            const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * C + c) * H + iy) * W + ix];
+        }
+        y[idx] = v;
+    }
+}
+
+// nn.MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (ResNet stem); padding never wins (-inf)
+__global__ void __launch_bounds__(256) maxpool3s2_kernel(const f32x4 *x, f32x4 *y, int B, int H, int W, int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float ninf = -__builtin_huge_valf();
+        f32x4 o = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy - 1 + dy;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - 1 + dx;
+                if (ix < 0 || ix >= W) continue;
+                const f32x4 v = x[(((size_t)b * H + iy) * W + ix) * C4 + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], v[k]);
+            }
+        }
+        y[i] = o;
+    }
 }
 
 }  // namespace
@@ -272,7 +354,50 @@ extern "C" int dream_pack_conv3x3_weight(const float *w_oihw, float *packed, int
     // CoutPad / CinPad are the padded ROW / COLUMN counts of the packed tensor (see pack_w_kernel)
     DREAM_REQUIRE(CoutPad >= (mode == 0 ? Cout : Cin) && CinPad >= (mode == 0 ? Cin : Cout), "pack_conv3x3_weight: padding smaller than the tensor");
     hipLaunchKernelGGL(pack_w_kernel, dim3(grid_for((size_t)9 * CoutPad * CinPad)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, packed, Cout, Cin, CoutPad, CinPad, mode);
+                       w_oihw, packed, Cout, Cin, CoutPad, CinPad, mode, 9);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_pack_conv_weight(const float *w_oihw, float *packed, int Cout, int Cin, int ntaps, int RowsPad,
+                                      int ColsPad, int mode, void *stream) {
+    DREAM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && ntaps >= 1 && (mode == 0 || mode == 1), "pack_conv_weight: bad arguments");
+    DREAM_REQUIRE(RowsPad >= (mode == 0 ? Cout : Cin) && ColsPad >= (mode == 0 ? Cin : Cout), "pack_conv_weight: padding smaller than the tensor");
+    hipLaunchKernelGGL(pack_w_kernel, dim3(grid_for((size_t)ntaps * RowsPad * ColsPad)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, packed, Cout, Cin, RowsPad, ColsPad, mode, ntaps);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_pack_convT4x4_weight(const float *wT, float *packed, int Cin, int Cout, int RowsPad, int ColsPad,
+                                          void *stream) {
+    DREAM_REQUIRE(wT && packed && Cin > 0 && Cout > 0 && RowsPad >= Cout && ColsPad >= Cin, "pack_convT4x4_weight: bad arguments");
+    hipLaunchKernelGGL(pack_wT4_kernel, dim3(grid_for((size_t)16 * RowsPad * ColsPad)), dim3(256), 0, (hipStream_t)stream,
+                       wT, packed, Cin, Cout, RowsPad, ColsPad);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_bn_fold_f32(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                                 const float *conv_bias, float eps, float *scale, float *shift, int C, void *stream) {
+    DREAM_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_fold: bad arguments");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, conv_bias, eps, scale, shift, C);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_im2col_nchw_f32(const float *x, float *y, int B, int C, int H, int W, int KH, int KW, int stride,
+                                     int pad, int Kpad, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && Kpad >= C * KH * KW, "im2col: bad arguments");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    DREAM_REQUIRE(Ho > 0 && Wo > 0, "im2col: empty output");
+    hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for((size_t)B * Ho * Wo * Kpad)), dim3(256), 0, (hipStream_t)stream,
+                       x, y, B, C, H, W, KH, KW, stride, pad, Ho, Wo, Kpad);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_maxpool3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool3s2: bad arguments");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)x, (f32x4 *)y, B, H, W, C / 4, Ho, Wo);
     DREAM_LAUNCH_OK();
     return 0;
 }
@@ -280,7 +405,7 @@ extern "C" int dream_unpack_conv3x3_weight(const float *packed, float *w_oihw, i
                                            int CinPad, void *stream) {
     DREAM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && CoutPad >= Cout && CinPad >= Cin, "unpack: bad arguments");
     hipLaunchKernelGGL(unpack_w_kernel, dim3(grid_for((size_t)9 * Cout * Cin)), dim3(256), 0, (hipStream_t)stream,
-                       packed, w_oihw, Cout, Cin, CoutPad, CinPad);
+                       packed, w_oihw, Cout, Cin, CoutPad, CinPad, 9);
     DREAM_LAUNCH_OK();
     return 0;
 }

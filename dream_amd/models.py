@@ -273,14 +273,18 @@ def allreduce_gradients(grads):
 
 
 class ResnetSimple(nn.Module):
-    """Parameter tree of the reference's ResnetSimple (models.py:17-155) so that checkpoints load and
-    ``state_dict()`` matches; the HIP execution plan (7x7/1x1/strided convs, BatchNorm, 4x4
-    ConvTranspose) is not built in this round -- forward raises instead of falling back."""
+    """The reference's ResnetSimple (models.py:17-155): torchvision ResNet101 trunk + 4 (or 5) x
+    [ConvTranspose2d(4,2,1) -> BatchNorm -> ReLU] + 1x1 conv to K maps; identical ``state_dict()``.
+    Evaluation mode runs entirely on the MFMA conv kernel: 1x1 / 3x3 / strided convs with the eval-mode
+    BatchNorm folded into the epilogue (y = conv*scale + shift), the Bottleneck residual add + ReLU fused
+    into the third conv, the 7x7 stem as im2col + 1-tap conv, the 4x4 transposed convs by sub-pixel
+    decomposition.  Train-mode BatchNorm / backward are not built yet and raise."""
 
     def __init__(self, n_keypoints=7, freeze=False, pretrained=True, full=False):
         super().__init__()
         self.full = full
         self.n_keypoints = n_keypoints
+        self._cache = {}
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
@@ -322,10 +326,76 @@ class ResnetSimple(nn.Module):
         n_up = 5 if self.full else 4
         return tuple(trunk(int(v)) * (2 ** n_up) for v in input_wh)
 
+    # ---- execution (eval-mode BatchNorm folded into the conv epilogues) ----------------------------------
+    def _cached(self, key, tensors, build):
+        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                hit = (tag, build())
+            self._cache[key] = hit
+        return hit[1]
+
+    def _fold(self, name, bn, conv_bias=None):
+        tensors = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv_bias] if conv_bias is not None else [])
+        return self._cached(("bn", name), tensors, lambda: ops.bn_fold(
+            bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var, bn.eps,
+            conv_bias.detach() if conv_bias is not None else None))
+
+    def _conv_bn(self, name, x, conv, bn, relu, residual=None):
+        k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
+        packed, rows, _ = self._cached(("w", name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), 0))
+        scale, shift = self._fold(name, bn, conv.bias)
+        return ops.conv2d(x, packed, rows, k, stride, scale, shift, residual, CONV_RELU if relu else 0)
+
+    def run_forward(self, x):
+        if self.training:
+            raise NotImplementedError("dream_amd: train-mode BatchNorm (batch statistics) for the ResNet path is "
+                                      "not built yet; call enable_evaluation() -- refusing to fall back")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("expected [B,3,H,W] input, got %s" % (tuple(x.shape),))
+        # stem: 7x7 s2 conv as im2col (K = 147 -> 160) + 1-tap MFMA conv, BN+ReLU fused; then MaxPool(3,2,1)
+        col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
+        w1 = self._cached(("w", "conv1"), [self.conv1.weight],
+                          lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
+        s1, t1 = self._fold("bn1", self.bn1)
+        y = ops.conv2d(col, w1[0], 64, 1, 1, s1, t1, None, CONV_RELU)
+        del col
+        y = ops.maxpool3s2(y)
+        for li in (1, 2, 3, 4):
+            stage = getattr(self, "layer%d" % li)
+            for bi, blk in enumerate(stage):
+                name = "layer%d.%d" % (li, bi)
+                idt = y
+                if hasattr(blk, "downsample"):
+                    idt = self._conv_bn(name + ".ds", y, blk.downsample[0], blk.downsample[1], relu=False)
+                o = self._conv_bn(name + ".1", y, blk.conv1, blk.bn1, relu=True)
+                o = self._conv_bn(name + ".2", o, blk.conv2, blk.bn2, relu=True)
+                y = self._conv_bn(name + ".3", o, blk.conv3, blk.bn3, relu=True, residual=idt)
+        seqs = [("upsample", self.upsample)] + ([("upsample2", self.upsample2)] if self.full else [])
+        for sname, seq in seqs:
+            mods = list(seq)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                name = "%s.%d" % (sname, i)
+                if isinstance(m, nn.ConvTranspose2d):
+                    bn = mods[i + 1]
+                    packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
+                    scale, shift = self._fold(name, bn, m.bias)
+                    y = ops.conv_transpose4x4s2(y, packed, cout, scale, shift, CONV_RELU)
+                    i += 3                                  # ConvTranspose2d, BatchNorm2d, ReLU
+                else:                                       # final 1x1 conv -> K belief maps, NCHW
+                    packed, rows, _ = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_conv_weight(m.weight.detach(), 0))
+                    y = ops.conv2d(y, packed, rows, 1, 1, None, m.bias.detach(), None, CONV_OUT_NCHW)
+                    i += 1
+        return y
+
     def forward(self, x):
-        raise NotImplementedError(
-            "dream_amd: the ResNet101 HIP execution plan (SURVEY.md 2.3 K5-K8) is not built yet; "
-            "refusing to fall back to another backend")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise NotImplementedError("dream_amd: ResNet backward is not built yet -- refusing to fall back")
+        with torch.no_grad():
+            return [self.run_forward(x)]
 
 
 class DreamDataParallel(nn.Module):

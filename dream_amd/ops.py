@@ -202,3 +202,89 @@ def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
 
 def sgd_step_(p, g, lr):
     call("dream_sgd_step_f32", ptr(p), ptr(_f32(g)), p.numel(), float(lr), stream())
+
+
+# ---- generic conv path (ResNet) ---------------------------------------------------------------------
+def pack_conv_weight(w_oihw, mode=0):
+    """OIHW [Cout,Cin,kh,kw] (kh*kw taps) -> [ntaps][rows_pad][cols_pad]; returns (packed, rows, ntaps)."""
+    w = _f32(w_oihw)
+    cout, cin, kh, kw = (int(v) for v in w.shape)
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    rows_pad, cols_pad = _hip.cout_pad(rows), round_up(cols, 16)
+    packed = torch.empty((kh * kw, rows_pad, cols_pad), dtype=torch.float32, device=w.device)
+    call("dream_pack_conv_weight", ptr(w), ptr(packed), cout, cin, kh * kw, rows_pad, cols_pad, mode, stream())
+    return packed, rows, kh * kw
+
+
+def pack_matrix_weight(w2d, cols_pad):
+    """[Cout, K] matrix (e.g. the 7x7 stem weight flattened to K = 147) -> 1-tap packed [1][rows_pad][cols_pad]."""
+    w = _f32(w2d)
+    cout, k = (int(v) for v in w.shape)
+    rows_pad = _hip.cout_pad(cout)
+    packed = torch.empty((1, rows_pad, cols_pad), dtype=torch.float32, device=w.device)
+    call("dream_pack_conv_weight", ptr(w), ptr(packed), cout, k, 1, rows_pad, cols_pad, 0, stream())
+    return packed, cout, 1
+
+
+def pack_convT4x4_weight(wT):
+    """ConvTranspose2d weight [Cin,Cout,4,4] -> [4][4][rows_pad][cols_pad]; returns (packed, cout)."""
+    w = _f32(wT)
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    rows_pad, cols_pad = _hip.cout_pad(cout), round_up(cin, 16)
+    packed = torch.empty((4, 4, rows_pad, cols_pad), dtype=torch.float32, device=w.device)
+    call("dream_pack_convT4x4_weight", ptr(w), ptr(packed), cin, cout, rows_pad, cols_pad, stream())
+    return packed, cout
+
+
+def conv2d(x_nhwc, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0):
+    """k x k (1 or 3) conv, stride 1/2, pad k/2, fused y = conv*scale + shift (+residual) (ReLU)."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    if cin != packed.shape[-1]:
+        raise RuntimeError("conv2d: input has %d channels, packed weights expect %d" % (cin, packed.shape[-1]))
+    if flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X):
+        h, w = 2 * h, 2 * w
+    pad = ksize // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    shape = (b, cout, ho, wo) if flags & CONV_OUT_NCHW else (b, ho, wo, cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != shape:
+        raise RuntimeError("conv2d: residual shape %s != output shape %s" % (tuple(residual.shape), shape))
+    call("dream_conv2d_nhwc_f32", ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(residual), ptr(y), b, h, w, cin,
+         cout, int(packed.shape[-2]), ksize, stride, flags, stream())
+    return y
+
+
+def conv_transpose4x4s2(x_nhwc, packed, cout, scale=None, shift=None, flags=0):
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv_transpose4x4s2_nhwc_f32", ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(y), b, h, w, cin, cout,
+         int(packed.shape[-2]), flags, stream())
+    return y
+
+
+def bn_fold(bn_weight, bn_bias, running_mean, running_var, eps, conv_bias=None):
+    c = int(bn_weight.numel())
+    scale = torch.empty((c,), dtype=torch.float32, device=bn_weight.device)
+    shift = torch.empty_like(scale)
+    call("dream_bn_fold_f32", ptr(_f32(bn_weight)), ptr(_f32(bn_bias)), ptr(_f32(running_mean)), ptr(_f32(running_var)),
+         ptr(conv_bias), float(eps), ptr(scale), ptr(shift), c, stream())
+    return scale, shift
+
+
+def im2col_nchw(x_nchw, kh, kw, stride, pad, kpad):
+    x = _f32(x_nchw)
+    b, c, h, w = (int(v) for v in x.shape)
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+    y = torch.empty((b, ho, wo, kpad), dtype=torch.float32, device=x.device)
+    call("dream_im2col_nchw_f32", ptr(x), ptr(y), b, c, h, w, kh, kw, stride, pad, kpad, stream())
+    return y
+
+
+def maxpool3s2(x_nhwc):
+    x = _f32(x_nhwc)
+    b, h, w, c = (int(v) for v in x.shape)
+    y = torch.empty((b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    call("dream_maxpool3s2_nhwc_f32", ptr(x), ptr(y), b, h, w, c, stream())
+    return y

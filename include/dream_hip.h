@@ -59,6 +59,13 @@ int dream_pack_conv3x3_weight(const float *w_oihw, float *packed, int Cout, int 
 /* inverse of mode 0 for gradients: [9][CoutPad][CinPad] -> OIHW (only the unpadded part) */
 int dream_unpack_conv3x3_weight(const float *packed, float *w_oihw, int Cout, int Cin,
                                 int CoutPad, int CinPad, void *stream);
+/* generic forms: OIHW [Cout,Cin,kh,kw] with ntaps = kh*kw -> [ntaps][RowsPad][ColsPad] (modes as above), and the
+ * ConvTranspose2d(k4,s2,p1) weight [Cin,Cout,4,4] (dream/models.py:37-136) -> [4 phases][4 taps][RowsPad][ColsPad]
+ * for the sub-pixel decomposition used by dream_conv_transpose4x4s2_nhwc_f32. */
+int dream_pack_conv_weight(const float *w_oihw, float *packed, int Cout, int Cin, int ntaps, int RowsPad,
+                           int ColsPad, int mode, void *stream);
+int dream_pack_convT4x4_weight(const float *wT, float *packed, int Cin, int Cout, int RowsPad, int ColsPad,
+                               void *stream);
 size_t dream_conv3x3_cout_pad(int Cout);  /* padded row count the MFMA kernel wants (multiple of 128) */
 
 /* ---- forward operators -----------------------------------------------------------------------
@@ -70,6 +77,27 @@ size_t dream_conv3x3_cout_pad(int Cout);  /* padded row count the MFMA kernel wa
 int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y,
                            int B, int H, int W, int Cin, int Cout, int CoutPad, int flags,
                            void *stream);
+/* general form used by the ResNet path (torchvision Bottleneck convs, dream/models.py:22-32,138-148): k x k
+ * (k = 1 or 3), stride 1 or 2, pad k/2, NHWC.  H, W = INPUT extent.  Epilogue: y = conv * scale[c] + shift[c]
+ * (+ residual) (ReLU): scale/shift carry an eval-mode BatchNorm (dream_bn_fold_f32) or a bias; residual is the
+ * Bottleneck identity branch.  Any of scale / shift / residual may be NULL. */
+int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                          const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int CoutPad,
+                          int ksize, int stride, int flags, void *stream);
+/* nn.ConvTranspose2d(k=4,s=2,p=1) (+BN+ReLU) of the ResNet decoder (dream/models.py:37-136): [B,H,W,Cin] ->
+ * [B,2H,2W,Cout], sub-pixel decomposition (four 2x2 convolutions, no zero multiplications). */
+int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w_packed, const float *scale,
+                                       const float *shift, float *y, int B, int H, int W, int Cin, int Cout,
+                                       int CoutPad, int flags, void *stream);
+/* eval-mode nn.BatchNorm2d folded into the conv epilogue: scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale (+ conv_bias*scale when the conv has a bias; conv_bias may be NULL). */
+int dream_bn_fold_f32(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                      const float *conv_bias, float eps, float *scale, float *shift, int C, void *stream);
+/* ResNet stem helpers: im2col of the NCHW image for the 7x7 stride-2 conv (-> [B,Ho,Wo,Kpad] NHWC, k ordered as
+ * the OIHW weight flattening, zero padded) so that conv1 runs as a 1x1 MFMA conv; MaxPool2d(3,2,1) on NHWC. */
+int dream_im2col_nchw_f32(const float *x, float *y, int B, int C, int H, int W, int KH, int KW, int stride,
+                          int pad, int Kpad, void *stream);
+int dream_maxpool3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream);
 /* variant selection for benchmarking: -1 = heuristic; otherwise index into the variant table */
 int dream_conv3x3_set_variant(int variant);
 int dream_conv3x3_num_variants(void);

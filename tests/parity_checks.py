@@ -70,6 +70,55 @@ def check_conv_transpose(dev, B, H, W, Cin, Cout, seed=0):
     return err
 
 
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def check_conv2d_general(dev, B, H, W, Cin, Cout, k, stride, seed=0):
+    """k x k / stride conv with the fused BN-scale, shift, residual and ReLU epilogue (ResNet Bottleneck)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, None, stride=stride, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g)
+    ref = (ref + res).relu()
+    packed, rows, _ = ops.pack_conv_weight(to(dev, w), 0)
+    y = ops.conv2d(to(dev, _nhwc(x)), packed, Cout, k, stride, to(dev, scale), to(dev, shift), to(dev, _nhwc(res)),
+                   ops.CONV_RELU).cpu()
+    err = float((y.permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= tol(ref.numpy()), (B, H, W, Cin, Cout, k, stride, err)
+
+
+def check_conv_transpose4x4(dev, B, H, W, Cin, Cout, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wT = torch.randn(Cin, Cout, 4, 4, generator=g) * (2.0 / (4 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x, wT, bias, stride=2, padding=1).relu()
+    packed, cout = ops.pack_convT4x4_weight(to(dev, wT))
+    y = ops.conv_transpose4x4s2(to(dev, _nhwc(x)), packed, cout, None, to(dev, bias), ops.CONV_RELU).cpu()
+    err = float((y.permute(0, 3, 1, 2) - ref).abs().max())
+    assert err <= tol(ref.numpy()), err
+
+
+def check_resnet_stem(dev, B, H, W):
+    x = torch.randn(B, 3, H, W)
+    w = torch.randn(64, 3, 7, 7) * 0.1
+    ref = F.conv2d(x, w, None, stride=2, padding=3)
+    col = ops.im2col_nchw(to(dev, x), 7, 7, 2, 3, 160)
+    packed, rows, _ = ops.pack_matrix_weight(to(dev, w.reshape(64, 147)), 160)
+    y = ops.conv2d(col, packed, 64, 1, 1)
+    assert float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= tol(ref.numpy())
+    mp = ops.maxpool3s2(y).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(mp, F.max_pool2d(y.cpu().permute(0, 3, 1, 2), 3, 2, 1))
+    gam, bet, mean, var = torch.rand(64) + 0.5, torch.randn(64), torch.randn(64), torch.rand(64) + 0.5
+    sc, sh = ops.bn_fold(to(dev, gam), to(dev, bet), to(dev, mean), to(dev, var), 1e-5)
+    bn = F.batch_norm(ref, mean, var, gam, bet, False, 0.1, 1e-5)
+    assert float((ref * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1) - bn).abs().max()) <= tol(bn.numpy())
+
+
 def check_first_conv(dev, B, H, W, seed=0):
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, 3, H, W, generator=g)

@@ -34,6 +34,20 @@ def test_conv_heuristic_and_odd_shapes(emu):
     pc.check_conv_transpose("cpu", 1, 5, 7, 32, 48)
 
 
+def test_general_conv_resnet_ops(emu):
+    pc.check_conv2d_general("cpu", 2, 9, 11, 64, 48, 1, 1)
+    pc.check_conv2d_general("cpu", 1, 13, 13, 32, 128, 1, 2)      # strided 1x1 (Bottleneck downsample)
+    pc.check_conv2d_general("cpu", 2, 12, 10, 32, 64, 3, 2)       # strided 3x3 (big-patch variant)
+    pc.check_conv2d_general("cpu", 1, 13, 25, 64, 32, 3, 2)
+    pc.check_conv_transpose4x4("cpu", 1, 5, 6, 32, 48)
+    pc.check_conv_transpose4x4("cpu", 2, 13, 13, 64, 32)
+    pc.check_resnet_stem("cpu", 2, 30, 37)
+
+
+def test_resnet_h_inference_golden(emu):
+    pc.check_model_inference("cpu", "resnet_h", (2, 64, 96))
+
+
 def test_first_conv_pool_layouts(emu):
     pc.check_first_conv("cpu", 1, 16, 16)
     pc.check_first_conv("cpu", 2, 21, 37)

@@ -94,10 +94,54 @@ def test_train_steps_golden(opt):
     pc.check_train_steps(DEV, opt, steps=3)
 
 
-def test_resnet_refuses_instead_of_falling_back():
+RESNET_LAYERS = [   # (H, Cin, Cout, k, stride): one of each kind in ResNet101 @400x400
+    (100, 64, 64, 1, 1), (100, 64, 256, 1, 1), (100, 256, 128, 1, 1), (100, 128, 128, 3, 2), (100, 256, 512, 1, 2),
+    (50, 512, 256, 1, 1), (50, 256, 256, 3, 2), (25, 256, 1024, 1, 1), (25, 1024, 512, 1, 1), (25, 512, 512, 3, 2),
+    (13, 512, 2048, 1, 1), (13, 2048, 512, 1, 1), (13, 512, 512, 3, 1),
+]
+
+
+@pytest.mark.parametrize("res,cin,cout,k,stride", RESNET_LAYERS)
+def test_resnet_layer_shapes(res, cin, cout, k, stride):
+    pc.check_conv2d_general(DEV, 2, res, res, cin, cout, k, stride, seed=res + cin + k)
+
+
+def test_resnet_decoder_and_stem_ops():
+    pc.check_conv_transpose4x4(DEV, 2, 13, 13, 2048, 256)
+    pc.check_conv_transpose4x4(DEV, 1, 52, 52, 256, 256)
+    pc.check_resnet_stem(DEV, 2, 400, 400)
+
+
+def test_resnet_h_inference_golden():
+    pc.check_model_inference(DEV, "resnet_h", (2, 64, 96))
+
+
+def test_resnet_f_inference_golden():
+    pc.check_model_inference(DEV, "resnet_f", (1, 64, 64))
+
+
+def test_resnet_f_full_resolution_matches_oracle():
+    """configs[4] shape (400x400 -> 416x416 maps, 17 keypoints), 2 frames: HIP vs the CPU oracle."""
+    net = pc.build_network("resnet_f", DEV)
+    net.enable_evaluation()
+    ref = om.build_model("resnet_f", 17)
+    ref.load_state_dict(om.recipe_weights(ref.state_dict()))
+    ref.eval()
+    x = torch.from_numpy(cases.image_batch(2, 400, 400, seed=41))
+    with torch.no_grad():
+        maps, kps = net.inference(x.to(DEV))
+        ref_maps = ref(x)[0].numpy()
+    assert maps.shape == (2, 17, 416, 416)
+    y = maps.cpu().numpy()
+    assert np.abs(y - ref_maps).max() <= pc.tol(ref_maps)
+    assert np.array_equal(kps.numpy(), op.keypoints_from_belief_maps(y, 0.0))
+
+
+def test_resnet_training_refuses_instead_of_falling_back():
     net = pc.build_network("resnet_h", DEV)
+    net.enable_training()
     with pytest.raises(NotImplementedError):
-        net.inference(torch.zeros(1, 3, 64, 64, device=DEV))
+        net.train([torch.zeros(2, 3, 64, 64, device=DEV)], torch.zeros(2, 7, 32, 32, device=DEV))
 
 
 def test_full_size_batch_properties():
