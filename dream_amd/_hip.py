@@ -37,6 +37,18 @@ _SIGNATURES = {
     "dream_conv3x3_cout_pad": (_SZ, [_I]),
     "dream_conv2d_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv_transpose4x4s2_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv4x4s2_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv2d_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I, _I, _I]),
+    "dream_conv2d_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_convT4x4_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "dream_convT4x4_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_unpack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "dream_bn_workspace": (_SZ, [_I]),
+    "dream_bn_train_fwd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _F, _F, _I, _P]),
+    "dream_bn_train_bwd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),
+    "dream_channel_sum_nhwc_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
+    "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
     "dream_bn_fold_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "dream_im2col_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_maxpool3s2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

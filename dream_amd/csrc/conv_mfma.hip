@@ -49,7 +49,8 @@ struct ConvParams {
     int lane_stride;         // patch pixels between consecutive output positions (2 for a strided 3x3)
     int pad_y, pad_x;
     int ntaps;
-    int tap_off[16];         // LDS float offset of each tap inside the patch: (dy * PW + dx) * (KC + 4)
+    unsigned long long tap_dy, tap_dx;   // 16 x 4-bit patch offsets of the taps (decoded with scalar ALU ops:
+                                         // no kernarg load on the per-stage critical path)
     int out_scale, out_oy, out_ox;   // output pixel = position * out_scale + (out_oy, out_ox)
     int flags;
 };
@@ -188,7 +189,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         if (last_tap && more_chunks) load_a((chunk + 1) * KC);
 
         // ---- MFMA block: KC k's of this tap --------------------------------------------------------
-        const float *sAt = sA + p.tap_off[tap];
+        const int tdy = (int)((p.tap_dy >> (4 * tap)) & 15), tdx = (int)((p.tap_dx >> (4 * tap)) & 15);
+        const float *sAt = sA + (tdy * PW + tdx) * S;
         const float *sBt = buf ? sB1 : sB0;
 #pragma unroll
         for (int kk = 0; kk < KC; kk += 8) {
@@ -369,7 +371,11 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
     p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride; p.pad_y = g.pad; p.pad_x = g.pad;
     p.ntaps = g.ntaps;
     const int S = var.KC + 4;
-    for (int t = 0; t < 16; ++t) p.tap_off[t] = t < g.ntaps ? (g.tap_dy[t] * p.PW + g.tap_dx[t]) * S : 0;
+    p.tap_dy = 0; p.tap_dx = 0;
+    for (int t = 0; t < g.ntaps; ++t) {
+        p.tap_dy |= (unsigned long long)g.tap_dy[t] << (4 * t);
+        p.tap_dx |= (unsigned long long)g.tap_dx[t] << (4 * t);
+    }
     p.out_scale = g.out_scale; p.out_oy = g.out_oy; p.out_ox = g.out_ox;
     p.flags = flags;
 
@@ -409,12 +415,13 @@ extern "C" int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, cons
     DREAM_REQUIRE(ksize == 1 || ksize == 3, "conv2d: kernel size %d not supported (1 or 3)", ksize);
     DREAM_REQUIRE(stride == 1 || stride == 2, "conv2d: stride %d not supported (1 or 2)", stride);
     const bool ups = (flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X)) != 0;
-    DREAM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample / zero-stuffing needs even H, W (got %dx%d)", H, W);
+    // zero-stuffing also accepts an odd extent 2*Hs-1 (data gradient of a stride-2 conv with an odd input)
+    DREAM_REQUIRE(!(flags & DREAM_CONV_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample needs even H, W (got %dx%d)", H, W);
     DREAM_REQUIRE(!ups || stride == 1, "fused upsample with a strided conv is not supported");
     ConvGeom g;
     const int pad = ksize / 2;
     g.Hin = H; g.Win = W;
-    g.Hs = ups ? H / 2 : H; g.Ws = ups ? W / 2 : W;
+    g.Hs = ups ? (H + 1) / 2 : H; g.Ws = ups ? (W + 1) / 2 : W;
     g.Ho = (H + 2 * pad - ksize) / stride + 1;
     g.Wo = (W + 2 * pad - ksize) / stride + 1;
     g.H = g.Ho; g.W = g.Wo;
@@ -455,4 +462,21 @@ extern "C" int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w
         if (int rc = launch_conv(x, wp, scale, shift, nullptr, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
     }
     return 0;
+}
+
+// Data gradient of ConvTranspose2d(k4,s2,p1): dx[m] = sum_k dy[2m - 1 + k] * wT[.][.][k] -- a 4x4 stride-2 pad-1
+// convolution of dy [B,2H,2W,Cout_T] producing [B,H,W,Cin_T].  w_packed: [16][RowsPad >= Cin_T][Cout_T] from
+// dream_pack_conv_weight(wT viewed as OIHW with O = Cin_T, I = Cout_T, ntaps 16, mode 0).
+extern "C" int dream_conv4x4s2_nhwc_f32(const float *x, const float *w_packed, const float *residual, float *y, int B,
+                                        int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream) {
+    DREAM_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv4x4s2: even input extent expected (got %dx%d)", H, W);
+    ConvGeom g;
+    g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W;
+    g.Ho = H / 2; g.Wo = W / 2; g.H = g.Ho; g.W = g.Wo;
+    g.in_scale = 2; g.in_step = 1; g.lane_stride = 2; g.pad = 1;
+    g.ntaps = 16;
+    for (int t = 0; t < 16; ++t) { g.tap_dy[t] = t / 4; g.tap_dx[t] = t % 4; }
+    g.kext = 4;
+    g.out_scale = 1; g.out_oy = 0; g.out_ox = 0;
+    return launch_conv(x, w_packed, nullptr, nullptr, residual, y, B, Cin, Cout, CoutPad, g, flags, stream);
 }

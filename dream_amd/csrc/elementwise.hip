@@ -295,6 +295,64 @@ __global__ void __launch_bounds__(256) maxpool3s2_kernel(const f32x4 *x, f32x4 *
     }
 }
 
+
+// MaxPool2d(3,2,1) backward.  One thread per input float4: visit the (<= 4) windows that contain this pixel,
+// recompute each window's first maximum in scan order (ATen max_pool2d_with_indices semantics: strict > while
+// scanning rows then columns, so the first maximal element wins) and take that window's gradient if it is us.
+__global__ void __launch_bounds__(256) maxpool3s2_bwd_kernel(const f32x4 *dy, const f32x4 *x, f32x4 *dx, int B, int H, int W,
+                                                             int C4, int Ho, int Wo) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        // windows oy with 2*oy-1 <= iy <= 2*oy+1
+        const int oy_lo = iy / 2, oy_hi = (iy + 1) / 2, ox_lo = ix / 2, ox_hi = (ix + 1) / 2;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const f32x4 g = dy[(((size_t)b * Ho + oy) * Wo + ox) * C4 + c];
+                const float ninf = -__builtin_huge_valf();
+                f32x4 best = {ninf, ninf, ninf, ninf};
+                int arg[4] = {-1, -1, -1, -1};
+                for (int dyy = 0; dyy < 3; ++dyy) {
+                    const int yy = 2 * oy - 1 + dyy;
+                    if (yy < 0 || yy >= H) continue;
+                    for (int dxx = 0; dxx < 3; ++dxx) {
+                        const int xx = 2 * ox - 1 + dxx;
+                        if (xx < 0 || xx >= W) continue;
+                        const f32x4 v = x[(((size_t)b * H + yy) * W + xx) * C4 + c];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (v[k] > best[k] || arg[k] < 0) { best[k] = v[k]; arg[k] = yy * W + xx; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (arg[k] == iy * W + ix) o[k] += g[k];
+            }
+        }
+        dx[i] = o;
+    }
+}
+
+__global__ void __launch_bounds__(256) add_inplace_kernel(float *dst, const float *src, size_t n) {
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = ((f32x4 *)dst)[i];
+        const f32x4 b = ((const f32x4 *)src)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += b[k];
+        ((f32x4 *)dst)[i] = a;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
+}
+
 }  // namespace
 
 extern "C" int dream_maxpool2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream) {
@@ -406,6 +464,28 @@ extern "C" int dream_unpack_conv3x3_weight(const float *packed, float *w_oihw, i
     DREAM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && CoutPad >= Cout && CinPad >= Cin, "unpack: bad arguments");
     hipLaunchKernelGGL(unpack_w_kernel, dim3(grid_for((size_t)9 * Cout * Cin)), dim3(256), 0, (hipStream_t)stream,
                        packed, w_oihw, Cout, Cin, CoutPad, CinPad, 9);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_unpack_conv_weight(const float *packed, float *w, int Rows, int Cols, int ntaps, int RowsPad,
+                                        int ColsPad, void *stream) {
+    DREAM_REQUIRE(w && packed && Rows > 0 && Cols > 0 && ntaps > 0 && RowsPad >= Rows && ColsPad >= Cols, "unpack_conv_weight: bad arguments");
+    hipLaunchKernelGGL(unpack_w_kernel, dim3(grid_for((size_t)ntaps * Rows * Cols)), dim3(256), 0, (hipStream_t)stream,
+                       packed, w, Rows, Cols, RowsPad, ColsPad, ntaps);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(dy && x && dx && B > 0 && H > 0 && W > 0 && C % 4 == 0, "maxpool3s2_bwd: bad arguments");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3(grid_for((size_t)B * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4, Ho, Wo);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream) {
+    DREAM_REQUIRE(dst && src, "add_inplace: null pointer");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -21,16 +21,22 @@
 namespace {
 
 constexpr int WG_PIX = 128;       // pixels per tile (k extent 128, 64 MFMA k-steps)
-constexpr int WG_NPMAX = 192;     // patch pixels
+constexpr int WG_NPMAX = 192;     // patch pixels (stride-1 taps)
+constexpr int WG_NPMAX_STRIDED = 352;   // stride-2 taps need ~4x the tile; 1 workgroup per CU then
 constexpr int WG_C = 64;          // channel tile (cout and cin)
 
 struct WgradParams {
-    const float *x;
-    const float *dy;
-    float *part;        // [splitk][9][CoutPad][Cin]
-    float *bias_part;   // [splitk][CoutPad]
-    int B, H, W, Hs, Ws, Cin, Cout, CoutPad;
-    int TH, TW, PW, tiles_x, tiles_y, rcpTW;
+    const float *tile_t;     // tensor whose channels become the ROWS of dW, sampled at the tile positions
+    const float *patch_t;    // tensor whose channels become the COLUMNS of dW, sampled through the taps
+    float *part;             // [splitk][ntaps_total][RowsPad][Cp]
+    float *bias_part;        // [splitk][RowsPad] (column sums of tile_t) or null
+    int B, Ht, Wt;           // tile tensor extent == grid of positions
+    int Hin, Win, Hs, Ws;    // logical / stored extent of the patch tensor
+    int Ct, Cp, RowsPad;     // channels of tile / patch tensor
+    int TH, TW, PH, PW, tiles_x, tiles_y, rcpTW;
+    int in_scale, in_step, lane_stride, pad;
+    int ntaps_total, tap_base, ntaps;          // this launch handles taps [tap_base, tap_base + ntaps), ntaps <= 9
+    unsigned long long tap_dy, tap_dx;         // 16 x 4-bit patch offsets
     int tiles_total, splitk, flags;
 };
 
@@ -42,19 +48,27 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     const int wo = wave >> 1, wi = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int co0 = blockIdx.x * WG_C, ci0 = blockIdx.y * WG_C, ks = blockIdx.z;
-    const int PW = p.PW, TW = p.TW, npix = p.TH * p.TW, NP = (p.TH + 2) * PW;
-    const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0;
+    const int PW = p.PW, TW = p.TW, npix = p.TH * p.TW, NP = p.PH * PW;
+    const bool zst = (p.flags & DREAM_CONV_ZEROSTUFF2X) != 0;
+    const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0 || zst;
 
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-    f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};          // this thread's share of the bias gradient
+    f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};          // this thread's share of the column sums of tile_t
+
+    int toff[9];                                    // LDS offsets of this launch's taps (wave-uniform)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int tt = p.tap_base + t;
+        toff[t] = ((int)((p.tap_dy >> (4 * tt)) & 15) * PW + (int)((p.tap_dx >> (4 * tt)) & 15)) * WG_C;
+    }
 
     const int q = tid & 15, prow = tid >> 4;        // staging: 16 float4 per 64-channel row, 16 rows per pass
-    const bool y_chan_ok = (co0 + q * 4) < p.Cout;  // Cout % 4 == 0 is required by the host wrapper
-    const bool x_chan_ok = (ci0 + q * 4) < p.Cin;
+    const bool y_chan_ok = (co0 + q * 4) < p.Ct;    // channel counts are multiples of 4 (host wrapper)
+    const bool x_chan_ok = (ci0 + q * 4) < p.Cp;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int tile = ks; tile < p.tiles_total; tile += p.splitk) {
@@ -64,66 +78,66 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         const int tiy = t % p.tiles_y;
         const int b = t / p.tiles_y;
         const int y0 = tiy * p.TH, x0 = tix * TW;
-        const float *xb = p.x + (size_t)b * p.Hs * p.Ws * p.Cin;
-        const float *dyb = p.dy + (size_t)b * p.H * p.W * p.Cout;
+        const float *xb = p.patch_t + (size_t)b * p.Hs * p.Ws * p.Cp;
+        const float *dyb = p.tile_t + (size_t)b * p.Ht * p.Wt * p.Ct;
 
         __syncthreads();                            // previous tile fully consumed
-        // ---- stage dY tile (rows m >= npix or outside the image are zero) ------------------------
+        // ---- stage the tile tensor (rows m >= npix or outside the image are zero) ------------------
 #pragma unroll
         for (int it = 0; it < WG_PIX / 16; ++it) {
             const int m = prow + it * 16;
             const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
             const int oy = y0 + ty, ox = x0 + tx;
             f32x4 v = zero4;
-            if (m < npix && oy < p.H && ox < p.W && y_chan_ok)
-                v = *(const f32x4 *)(dyb + ((size_t)oy * p.W + ox) * p.Cout + co0 + q * 4);
+            if (m < npix && oy < p.Ht && ox < p.Wt && y_chan_ok)
+                v = *(const f32x4 *)(dyb + ((size_t)oy * p.Wt + ox) * p.Ct + co0 + q * 4);
             *(f32x4 *)(sY + m * WG_C + q * 4) = v;
             bsum += v;
         }
-        // ---- stage X patch ------------------------------------------------------------------------
+        // ---- stage the patch --------------------------------------------------------------------------
         for (int pp = prow; pp < NP; pp += 16) {
             const int py = pp / PW, px = pp - py * PW;
-            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const int gy = y0 * p.in_scale - p.pad + py * p.in_step, gx = x0 * p.in_scale - p.pad + px * p.in_step;
             f32x4 v = zero4;
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && x_chan_ok) {
+            if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && x_chan_ok && !(zst && ((gy | gx) & 1))) {
                 const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
-                v = *(const f32x4 *)(xb + ((size_t)sy * p.Ws + sx) * p.Cin + ci0 + q * 4);
+                v = *(const f32x4 *)(xb + ((size_t)sy * p.Ws + sx) * p.Cp + ci0 + q * 4);
             }
             *(f32x4 *)(sX + pp * WG_C + q * 4) = v;
         }
         __syncthreads();
 
-        // ---- 64 k-steps x 9 taps ---------------------------------------------------------------------
+        // ---- k-steps (2 positions each) x taps --------------------------------------------------------
         const float *aY = sY + wo * 32 + li;
         const float *bX = sX + wi * 32 + li;
         const int nsteps = (npix + 1) >> 1;
         for (int s = 0; s < nsteps; ++s) {
             const int m = 2 * s + lh;
-            const int mc = m < npix ? m : 0;         // dY row m is zero there; keep the X address legal
+            const int mc = m < npix ? m : 0;         // tile row m is zero there; keep the patch address legal
             const int ty = (mc * p.rcpTW) >> 16, tx = mc - ty * TW;
             const float a = aY[m * WG_C];
-            const float *bp = bX + (ty * PW + tx) * WG_C;
+            const float *bp = bX + (ty * PW + tx) * p.lane_stride * WG_C;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-                    acc[ky * 3 + kx] = mfma_f32_32x32x2(a, bp[(ky * PW + kx) * WG_C], acc[ky * 3 + kx]);
+            for (int tp = 0; tp < 9; ++tp)
+                if (tp < p.ntaps) acc[tp] = mfma_f32_32x32x2(a, bp[toff[tp]], acc[tp]);
         }
     }
 
     // ---- write partials ----------------------------------------------------------------------------
-    float *part = p.part + (size_t)ks * 9 * p.CoutPad * p.Cin;
+    float *part = p.part + ((size_t)ks * p.ntaps_total + p.tap_base) * p.RowsPad * p.Cp;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+        if (t < p.ntaps) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int i = ci0 + wi * 32 + li;
-            if (o < p.CoutPad && i < p.Cin) part[((size_t)t * p.CoutPad + o) * p.Cin + i] = acc[t][r];
+            for (int r = 0; r < 16; ++r) {
+                const int o = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int i = ci0 + wi * 32 + li;
+                if (o < p.RowsPad && i < p.Cp) part[((size_t)t * p.RowsPad + o) * p.Cp + i] = acc[t][r];
+            }
         }
     }
-    if (blockIdx.y == 0) {
-        // threads sharing q (same 4 couts) differ in prow: reduce the 16 rows through LDS
+    if (blockIdx.y == 0 && p.bias_part != nullptr) {
+        // threads sharing q (same 4 channels) differ in prow: reduce the 16 rows through LDS
         __syncthreads();
         *(f32x4 *)(smem + (prow * 16 + q) * 4) = bsum;
         __syncthreads();
@@ -131,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
             float s = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += smem[(r * 16 + (tid >> 2)) * 4 + (tid & 3)];
-            if (co0 + tid < p.CoutPad) p.bias_part[(size_t)ks * p.CoutPad + co0 + tid] = s;
+            if (co0 + tid < p.RowsPad) p.bias_part[(size_t)ks * p.RowsPad + co0 + tid] = s;
         }
     }
 }
@@ -145,32 +159,132 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *part, fl
     }
 }
 
-void choose_tile_w(int H, int W, int *th_out, int *tw_out) {
+struct WgradGeom {
+    int Ht, Wt, Hin, Win, Hs, Ws;
+    int in_scale, in_step, lane_stride, pad, kext;
+    int ntaps;
+    int tap_dy[16], tap_dx[16];
+};
+
+void choose_tile_w(const WgradGeom &g, int *th_out, int *tw_out) {
+    const int np_max = g.lane_stride > 1 ? WG_NPMAX_STRIDED : WG_NPMAX;
     long best = -1;
     int bnp = 0, bth = 1, btw = 1;
     for (int tw = 1; tw <= WG_PIX; ++tw) {
-        int th = WG_PIX / tw;
-        if (th > H) th = H;
-        const int twc = tw > W ? W : tw;
-        const int np = (th + 2) * (twc + 2);
-        if (np > WG_NPMAX) continue;
-        const long tiles = (long)ceil_div(H, th) * ceil_div(W, twc);
-        if (best < 0 || tiles < best || (tiles == best && np < bnp)) { best = tiles; bnp = np; bth = th; btw = twc; }
+        for (int th = WG_PIX / tw; th >= 1; th = (g.lane_stride > 1 ? th - 1 : 0)) {
+            int thc = th > g.Ht ? g.Ht : th;
+            const int twc = tw > g.Wt ? g.Wt : tw;
+            const int np = ((thc - 1) * g.lane_stride + g.kext) * ((twc - 1) * g.lane_stride + g.kext);
+            if (np > np_max) continue;
+            const long tiles = (long)ceil_div(g.Ht, thc) * ceil_div(g.Wt, twc);
+            if (best < 0 || tiles < best || (tiles == best && np < bnp)) { best = tiles; bnp = np; bth = thc; btw = twc; }
+            break;
+        }
     }
     *th_out = bth;
     *tw_out = btw;
 }
 
-int pick_splitk(int B, int H, int W, int Cin, int CoutPad) {
+int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
     int th, tw;
-    choose_tile_w(H, W, &th, &tw);
-    const long tiles = (long)B * ceil_div(H, th) * ceil_div(W, tw);
-    const long ctiles = (long)ceil_div(CoutPad, WG_C) * ceil_div(Cin, WG_C);
+    choose_tile_w(g, &th, &tw);
+    const long tiles = (long)B * ceil_div(g.Ht, th) * ceil_div(g.Wt, tw);
+    const long ctiles = (long)ceil_div(RowsPad, WG_C) * ceil_div(Cp, WG_C);
     long sk = 1024 / ctiles;
     if (sk < 1) sk = 1;
     if (sk > tiles) sk = tiles;
     if (sk > 1024) sk = 1024;
     return (int)sk;
+}
+
+size_t wgrad_workspace_bytes(int B, const WgradGeom &g, int Cp, int RowsPad) {
+    const int sk = pick_splitk_g(B, g, Cp, RowsPad);
+    return ((size_t)sk * g.ntaps * RowsPad * Cp + (size_t)(sk + 1) * RowsPad) * sizeof(float);
+}
+
+int launch_wgrad(const float *tile_t, const float *patch_t, float *dw_packed, float *dbias, int nbias, void *workspace,
+                 int B, int Ct, int RowsPad, int Cp, const WgradGeom &g, int flags, void *stream) {
+    DREAM_REQUIRE(tile_t && patch_t && dw_packed && workspace, "wgrad: null pointer");
+    DREAM_REQUIRE(B > 0 && Ct % 4 == 0 && Cp % 4 == 0 && RowsPad >= Ct, "wgrad: bad channels (%d, %d, pad %d)", Ct, Cp, RowsPad);
+    WgradParams p;
+    p.tile_t = tile_t; p.patch_t = patch_t;
+    p.B = B; p.Ht = g.Ht; p.Wt = g.Wt; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws;
+    p.Ct = Ct; p.Cp = Cp; p.RowsPad = RowsPad; p.flags = flags;
+    choose_tile_w(g, &p.TH, &p.TW);
+    p.PH = (p.TH - 1) * g.lane_stride + g.kext;
+    p.PW = (p.TW - 1) * g.lane_stride + g.kext;
+    p.tiles_x = ceil_div(g.Wt, p.TW); p.tiles_y = ceil_div(g.Ht, p.TH);
+    p.rcpTW = (65536 + p.TW - 1) / p.TW;
+    p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride; p.pad = g.pad;
+    p.ntaps_total = g.ntaps;
+    p.tap_dy = 0; p.tap_dx = 0;
+    for (int t = 0; t < g.ntaps; ++t) {
+        p.tap_dy |= (unsigned long long)g.tap_dy[t] << (4 * t);
+        p.tap_dx |= (unsigned long long)g.tap_dx[t] << (4 * t);
+    }
+    p.tiles_total = B * p.tiles_x * p.tiles_y;
+    p.splitk = pick_splitk_g(B, g, Cp, RowsPad);
+    p.part = (float *)workspace;
+    float *bias_part = p.part + (size_t)p.splitk * g.ntaps * RowsPad * Cp;
+    const size_t lds = ((size_t)WG_PIX + (size_t)p.PH * p.PW) * WG_C * sizeof(float);
+    DREAM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const dim3 grid(ceil_div(RowsPad, WG_C), ceil_div(Cp, WG_C), p.splitk);
+    for (int base = 0; base < g.ntaps; base += 8) {        // <= 9 tap accumulators per launch
+        p.tap_base = base;
+        p.ntaps = (g.ntaps - base > 9) ? 8 : (g.ntaps - base);
+        p.bias_part = (dbias != nullptr && base == 0) ? bias_part : nullptr;
+        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+        DREAM_LAUNCH_OK();
+        if (p.ntaps == g.ntaps - base) break;
+    }
+    const size_t n = (size_t)g.ntaps * RowsPad * Cp;
+    size_t gr = (n + 255) / 256;
+    if (gr > 2048) gr = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gr), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)p.part, dw_packed, n, p.splitk);
+    DREAM_LAUNCH_OK();
+    if (dbias) {
+        // bias partials are [splitk][RowsPad]; only the first nbias entries are wanted
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)bias_part, bias_part + (size_t)p.splitk * RowsPad, (size_t)RowsPad, p.splitk);
+        DREAM_LAUNCH_OK();
+        DREAM_HIP_OK(hipMemcpyAsync(dbias, bias_part + (size_t)p.splitk * RowsPad, (size_t)nbias * sizeof(float),
+                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
+    return 0;
+}
+
+WgradGeom conv_geom(int H, int W, int ksize, int stride, int flags) {
+    const bool ups = (flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X)) != 0;
+    WgradGeom g;
+    const int pad = ksize / 2;
+    g.Hin = H; g.Win = W;
+    g.Hs = ups ? (H + 1) / 2 : H; g.Ws = ups ? (W + 1) / 2 : W;
+    g.Ht = (H + 2 * pad - ksize) / stride + 1;
+    g.Wt = (W + 2 * pad - ksize) / stride + 1;
+    g.in_scale = stride;
+    g.in_step = (ksize == 1) ? stride : 1;
+    g.lane_stride = (ksize == 1) ? 1 : stride;
+    g.pad = pad;
+    g.kext = ksize;
+    g.ntaps = ksize * ksize;
+    for (int t = 0; t < g.ntaps; ++t) { g.tap_dy[t] = t / ksize; g.tap_dx[t] = t % ksize; }
+    return g;
+}
+
+WgradGeom convT4_geom(int H, int W) {
+    // dW_T[i][o][ky][kx] = sum_m x[m][i] * dy[2m - 1 + k][o]: tile = x (H x W), patch = dy (2H x 2W), stride-2 taps
+    WgradGeom g;
+    g.Ht = H; g.Wt = W; g.Hin = 2 * H; g.Win = 2 * W; g.Hs = 2 * H; g.Ws = 2 * W;
+    g.in_scale = 2; g.in_step = 1; g.lane_stride = 2; g.pad = 1; g.kext = 4;
+    g.ntaps = 16;
+    for (int t = 0; t < 16; ++t) { g.tap_dy[t] = t / 4; g.tap_dx[t] = t % 4; }
+    return g;
 }
 
 // ---- first layer (NCHW image, Cin <= 4): lane == cout, 9*Cin accumulators per lane ---------------------
@@ -259,55 +373,34 @@ __global__ void __launch_bounds__(256) first_wgrad_reduce_kernel(const float *pa
 
 }  // namespace
 
-extern "C" size_t dream_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad) {
-    const int sk = pick_splitk(B, H, W, Cin, CoutPad);
-    return ((size_t)sk * 9 * CoutPad * Cin + (size_t)(sk + 1) * CoutPad) * sizeof(float);
+extern "C" size_t dream_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad, int ksize, int stride) {
+    return wgrad_workspace_bytes(B, conv_geom(H, W, ksize, stride, 0), Cin, CoutPad);
 }
-
+// k x k conv (k = 1 | 3, stride 1 | 2, pad k/2) weight + bias gradient.  x [B,H,W,Cin] (half-res with the fused
+// upsample / zero-stuff flags), dy [B,Ho,Wo,Cout] -> dw_packed [k*k][CoutPad][Cin] (mode-0 layout), dbias [Cout] or null
+extern "C" int dream_conv2d_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias, void *workspace,
+                                           int B, int H, int W, int Cin, int Cout, int CoutPad, int ksize, int stride,
+                                           int flags, void *stream) {
+    DREAM_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "conv2d_wgrad: unsupported k=%d s=%d", ksize, stride);
+    return launch_wgrad(dy, x, dw_packed, dbias, Cout, workspace, B, Cout, CoutPad, Cin, conv_geom(H, W, ksize, stride, flags),
+                        flags, stream);
+}
+extern "C" size_t dream_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad) {
+    return dream_conv2d_wgrad_workspace(B, H, W, Cin, CoutPad, 3, 1);
+}
 extern "C" int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias,
                                             void *workspace, int B, int H, int W, int Cin, int Cout,
                                             int CoutPad, int flags, void *stream) {
-    DREAM_REQUIRE(x && dy && dw_packed && workspace, "wgrad: null pointer");
-    DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin % 4 == 0 && Cout % 4 == 0 && CoutPad >= Cout,
-                  "wgrad: bad shape (Cin=%d, Cout=%d must be multiples of 4; CoutPad=%d)", Cin, Cout, CoutPad);
-    const bool ups = (flags & DREAM_CONV_UPSAMPLE2X) != 0;
-    DREAM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0), "wgrad: fused upsample needs even H, W");
-    WgradParams p;
-    p.x = x; p.dy = dy;
-    p.B = B; p.H = H; p.W = W; p.Hs = ups ? H / 2 : H; p.Ws = ups ? W / 2 : W;
-    p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad; p.flags = flags;
-    choose_tile_w(H, W, &p.TH, &p.TW);
-    p.PW = p.TW + 2;
-    p.tiles_x = ceil_div(W, p.TW); p.tiles_y = ceil_div(H, p.TH);
-    p.rcpTW = (65536 + p.TW - 1) / p.TW;
-    p.tiles_total = B * p.tiles_x * p.tiles_y;
-    p.splitk = pick_splitk(B, H, W, Cin, CoutPad);
-    p.part = (float *)workspace;
-    p.bias_part = p.part + (size_t)p.splitk * 9 * CoutPad * Cin;
-    const size_t lds = ((size_t)WG_PIX + (size_t)(p.TH + 2) * p.PW) * WG_C * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    const dim3 grid(ceil_div(CoutPad, WG_C), ceil_div(Cin, WG_C), p.splitk);
-    hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
-    DREAM_LAUNCH_OK();
-    const size_t n = (size_t)9 * CoutPad * Cin;
-    size_t g = (n + 255) / 256;
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
-                       (const float *)p.part, dw_packed, n, p.splitk);
-    DREAM_LAUNCH_OK();
-    if (dbias) {
-        // bias partials are [splitk][CoutPad]; only the first Cout entries are wanted
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                           (const float *)p.bias_part, p.bias_part + (size_t)p.splitk * CoutPad, (size_t)CoutPad, p.splitk);
-        DREAM_LAUNCH_OK();
-        DREAM_HIP_OK(hipMemcpyAsync(dbias, p.bias_part + (size_t)p.splitk * CoutPad, (size_t)Cout * sizeof(float),
-                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    }
-    return 0;
+    return dream_conv2d_wgrad_nhwc_f32(x, dy, dw_packed, dbias, workspace, B, H, W, Cin, Cout, CoutPad, 3, 1, flags, stream);
+}
+extern "C" size_t dream_convT4x4_wgrad_workspace(int B, int H, int W, int CinPad, int Cout) {
+    return wgrad_workspace_bytes(B, convT4_geom(H, W), Cout, CinPad);
+}
+// ConvTranspose2d(k4,s2,p1) weight gradient: x [B,H,W,Cin], dy [B,2H,2W,Cout] -> dw_packed [16][CinPad][Cout]
+// (tap t = ky*4+kx; unpack with dream_unpack_conv_weight(rows = Cin, cols = Cout, ntaps = 16) gives [Cin,Cout,4,4])
+extern "C" int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
+                                             int H, int W, int Cin, int CinPad, int Cout, void *stream) {
+    return launch_wgrad(x, dy, dw_packed, nullptr, 0, workspace, B, Cin, CinPad, Cout, convT4_geom(H, W), 0, stream);
 }
 
 static int first_wgrad_blocks(int B, int H, int W) {

@@ -278,7 +278,8 @@ class ResnetSimple(nn.Module):
     Evaluation mode runs entirely on the MFMA conv kernel: 1x1 / 3x3 / strided convs with the eval-mode
     BatchNorm folded into the epilogue (y = conv*scale + shift), the Bottleneck residual add + ReLU fused
     into the third conv, the 7x7 stem as im2col + 1-tap conv, the 4x4 transposed convs by sub-pixel
-    decomposition.  Train-mode BatchNorm / backward are not built yet and raise."""
+    decomposition.  Training mode uses batch-statistics BatchNorm kernels (csrc/bn.hip) between the convs and
+    a tape-driven backward plan (data gradients, weight gradients, BN gradients) built from the same kernels."""
 
     def __init__(self, n_keypoints=7, freeze=False, pretrained=True, full=False):
         super().__init__()
@@ -349,9 +350,6 @@ class ResnetSimple(nn.Module):
         return ops.conv2d(x, packed, rows, k, stride, scale, shift, residual, CONV_RELU if relu else 0)
 
     def run_forward(self, x):
-        if self.training:
-            raise NotImplementedError("dream_amd: train-mode BatchNorm (batch statistics) for the ResNet path is "
-                                      "not built yet; call enable_evaluation() -- refusing to fall back")
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("expected [B,3,H,W] input, got %s" % (tuple(x.shape),))
         # stem: 7x7 s2 conv as im2col (K = 147 -> 160) + 1-tap MFMA conv, BN+ReLU fused; then MaxPool(3,2,1)
@@ -391,11 +389,155 @@ class ResnetSimple(nn.Module):
                     i += 1
         return y
 
+    # ---- training: train-mode BatchNorm (batch statistics), activations kept for the backward plan --------
+    def _packed_w(self, name, conv, mode):
+        return self._cached(("w%d" % mode, name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), mode))
+
+    def _unit_fwd(self, tape, name, x, conv, bn, relu, residual=None):
+        """conv -> BN(batch stats) (+residual) (ReLU); records what the backward needs."""
+        k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
+        packed, rows, _ = self._packed_w(name, conv, 0)
+        z = ops.conv2d(x, packed, rows, k, stride, None, conv.bias.detach() if conv.bias is not None else None, None, 0)
+        y, mean, invstd = ops.bn_train_fwd(z, bn, residual, relu)
+        tape.append(dict(kind="conv", name=name, conv=conv, bn=bn, relu=relu, x=x, z=z, y=y, mean=mean, invstd=invstd,
+                         k=k, stride=stride, has_res=residual is not None))
+        return y
+
+    def run_forward_train(self, x):
+        tape = []
+        col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
+        w1 = self._cached(("w", "conv1"), [self.conv1.weight],
+                          lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
+        z = ops.conv2d(col, w1[0], 64, 1, 1)
+        y, mean, invstd = ops.bn_train_fwd(z, self.bn1, None, True)
+        tape.append(dict(kind="stem", conv=self.conv1, bn=self.bn1, relu=True, x=col, z=z, y=y, mean=mean, invstd=invstd))
+        yp = ops.maxpool3s2(y)
+        tape.append(dict(kind="pool", x=y))
+        y = yp
+        for li in (1, 2, 3, 4):
+            for bi, blk in enumerate(getattr(self, "layer%d" % li)):
+                name = "layer%d.%d" % (li, bi)
+                tape.append(dict(kind="block_begin", name=name, ds=hasattr(blk, "downsample")))
+                idt = y
+                if hasattr(blk, "downsample"):
+                    idt = self._unit_fwd(tape, name + ".ds", y, blk.downsample[0], blk.downsample[1], relu=False)
+                o = self._unit_fwd(tape, name + ".1", y, blk.conv1, blk.bn1, relu=True)
+                o = self._unit_fwd(tape, name + ".2", o, blk.conv2, blk.bn2, relu=True)
+                y = self._unit_fwd(tape, name + ".3", o, blk.conv3, blk.bn3, relu=True, residual=idt)
+                tape.append(dict(kind="block_end", name=name))
+        seqs = [("upsample", self.upsample)] + ([("upsample2", self.upsample2)] if self.full else [])
+        for sname, seq in seqs:
+            mods = list(seq)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                name = "%s.%d" % (sname, i)
+                if isinstance(m, nn.ConvTranspose2d):
+                    bn = mods[i + 1]
+                    packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
+                    z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)
+                    y2, mean, invstd = ops.bn_train_fwd(z, bn, None, True)
+                    tape.append(dict(kind="convT", name=name, conv=m, bn=bn, relu=True, x=y, z=z, y=y2, mean=mean, invstd=invstd))
+                    y = y2
+                    i += 3
+                else:
+                    packed, rows, _ = self._packed_w(name, m, 0)
+                    out = ops.conv2d(y, packed, rows, 1, 1, None, m.bias.detach(), None, CONV_OUT_NCHW)
+                    tape.append(dict(kind="final", name=name, conv=m, x=y))
+                    y = out
+                    i += 1
+        return y, tape
+
+    def run_backward(self, tape, grad_out_nchw):
+        """-> {parameter: gradient}.  Walks the tape backwards; gradients that meet at a Bottleneck input are summed
+        by the residual input of the data-gradient conv (no separate add kernel)."""
+        grads = {}
+        g = None                 # gradient w.r.t. the output of the unit being processed
+        block = None             # state of the Bottleneck being unwound
+        for rec in reversed(tape):
+            kind = rec["kind"]
+            if kind == "final":
+                m = rec["conv"]
+                cout, cin = int(m.weight.shape[0]), int(m.weight.shape[1])
+                gy = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))
+                dw, db = ops.conv2d_wgrad(rec["x"], gy, cout, cin, 1, 1, 0, want_bias=True)
+                grads[m.weight], grads[m.bias] = dw, db
+                packed_t, rows, _ = self._packed_w(rec["name"], m, 1)
+                g = ops.conv2d(gy, packed_t, rows, 1, 1)
+            elif kind == "convT":
+                m, bn = rec["conv"], rec["bn"]
+                dz, _, dgam, dbet = ops.bn_train_bwd(rec["z"], g, rec["y"], bn.weight, rec["mean"], rec["invstd"], True)
+                grads[bn.weight], grads[bn.bias] = dgam, dbet
+                grads[m.weight] = ops.convT4x4_wgrad(rec["x"], dz)
+                grads[m.bias] = ops.channel_sum(dz)
+                pk, rows = self._cached(("wTb", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_bwd_weight(m.weight.detach()))
+                g = ops.conv4x4s2(dz, pk, rows)
+            elif kind == "block_end":
+                block = dict(g_out=g, g_idt=None, g_ds=None)
+            elif kind == "conv":
+                conv, bn, name = rec["conv"], rec["bn"], rec["name"]
+                cout, cin = int(conv.weight.shape[0]), int(conv.weight.shape[1])
+                is_ds = name.endswith(".ds")
+                dy = block["g_idt"] if is_ds else g
+                dz, gm, dgam, dbet = ops.bn_train_bwd(rec["z"], dy, rec["y"], bn.weight, rec["mean"], rec["invstd"],
+                                                      rec["relu"], want_g=rec["has_res"])
+                grads[bn.weight], grads[bn.bias] = dgam, dbet
+                if rec["has_res"]:
+                    block["g_idt"] = gm          # masked block-output gradient == gradient of the identity branch
+                dw, _ = ops.conv2d_wgrad(rec["x"], dz, cout, cin, rec["k"], rec["stride"])
+                grads[conv.weight] = dw
+                packed_t, rows, _ = self._packed_w(name, conv, 1)
+                in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
+                if is_ds:
+                    block["g_ds"] = ops.conv2d_bwd_data(dz, packed_t, cin, rec["k"], rec["stride"], in_hw)
+                elif name.endswith(".1"):
+                    # block input: main-path gradient + identity / downsample gradient
+                    block["dz1"] = (dz, packed_t, cin, rec["k"], rec["stride"], in_hw)
+                else:
+                    g = ops.conv2d_bwd_data(dz, packed_t, cin, rec["k"], rec["stride"], in_hw)
+            elif kind == "block_begin":
+                dz, packed_t, cin, k, stride, in_hw = block["dz1"]
+                other = block["g_ds"] if rec["ds"] else block["g_idt"]
+                g = ops.conv2d_bwd_data(dz, packed_t, cin, k, stride, in_hw, residual=other)
+                block = None
+            elif kind == "pool":
+                g = ops.maxpool3s2_bwd(g, rec["x"])
+            elif kind == "stem":
+                bn = rec["bn"]
+                dz, _, dgam, dbet = ops.bn_train_bwd(rec["z"], g, rec["y"], bn.weight, rec["mean"], rec["invstd"], True)
+                grads[bn.weight], grads[bn.bias] = dgam, dbet
+                dw, _ = ops.conv2d_wgrad(rec["x"], dz, 64, 160, 1, 1)
+                grads[rec["conv"].weight] = dw.reshape(64, 160)[:, :147].reshape(64, 3, 7, 7).contiguous()
+                g = None
+        return grads
+
     def forward(self, x):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("dream_amd: ResNet backward is not built yet -- refusing to fall back")
+        params = list(self.parameters())
+        if self.training:
+            if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+                return [_ResnetFunction.apply(self, x, *params)]
+            with torch.no_grad():
+                return [self.run_forward_train(x)[0]]
         with torch.no_grad():
             return [self.run_forward(x)]
+
+
+class _ResnetFunction(torch.autograd.Function):
+    """Whole-network autograd node for ResnetSimple in training mode (see _HourglassFunction)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        out, tape = module.run_forward_train(x.detach())
+        ctx.module, ctx.tape, ctx.params = module, tape, params
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gdict = ctx.module.run_backward(ctx.tape, grad_out.contiguous())
+        ctx.tape = None
+        grads = [gdict[p] for p in ctx.params]
+        grads = allreduce_gradients(grads)
+        return (None, None) + tuple(grads)
 
 
 class DreamDataParallel(nn.Module):

@@ -288,3 +288,130 @@ def maxpool3s2(x_nhwc):
     y = torch.empty((b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
     call("dream_maxpool3s2_nhwc_f32", ptr(x), ptr(y), b, h, w, c, stream())
     return y
+
+
+# ---- ResNet training operators -------------------------------------------------------------------------
+def _workspace(nbytes, device):
+    return torch.empty(((int(nbytes) + 7) // 8,), dtype=torch.float64, device=device)
+
+
+def bn_train_fwd(x_nhwc, bn, residual=None, relu=True):
+    """Train-mode BatchNorm2d on NHWC: returns (y, save_mean, save_invstd); updates bn's running stats."""
+    x = _f32(x_nhwc)
+    c = int(x.shape[-1])
+    npix = x.numel() // c
+    y = torch.empty_like(x)
+    mean = torch.empty((c,), dtype=torch.float32, device=x.device)
+    invstd = torch.empty_like(mean)
+    ws = _workspace(_hip.lib().dream_bn_workspace(c), x.device)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    call("dream_bn_train_fwd_nhwc_f32", ptr(x), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(residual), ptr(y),
+         ptr(mean), ptr(invstd), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(ws), npix, c,
+         float(bn.eps), float(momentum), 1 if relu else 0, stream())
+    return y, mean, invstd
+
+
+def bn_train_bwd(x_nhwc, dy, y_act, gamma, mean, invstd, relu=True, want_g=False):
+    """-> (dx, g or None, dgamma, dbeta)."""
+    x = _f32(x_nhwc)
+    c = int(x.shape[-1])
+    npix = x.numel() // c
+    dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    dgamma = torch.empty((c,), dtype=torch.float32, device=x.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace(_hip.lib().dream_bn_workspace(c), x.device)
+    call("dream_bn_train_bwd_nhwc_f32", ptr(x), ptr(_f32(dy)), ptr(y_act), ptr(gamma.detach()), ptr(mean), ptr(invstd), ptr(dx),
+         ptr(g), ptr(dgamma), ptr(dbeta), ptr(ws), npix, c, 1 if relu else 0, stream())
+    return dx, g, dgamma, dbeta
+
+
+def channel_sum(x_nhwc):
+    x = _f32(x_nhwc)
+    c = int(x.shape[-1])
+    out = torch.empty((c,), dtype=torch.float32, device=x.device)
+    ws = _workspace(_hip.lib().dream_bn_workspace(c), x.device)
+    call("dream_channel_sum_nhwc_f32", ptr(x), ptr(out), ptr(ws), x.numel() // c, c, stream())
+    return out
+
+
+def conv2d_wgrad(x_nhwc, dy_nhwc, cout, cin, ksize, stride=1, flags=0, want_bias=False):
+    """-> (dW [cout,cin,k,k], dbias [cout] or None).  x: [B,H,W,cin] (half-res with fused upsample), dy: [B,Ho,Wo,C>=cout]."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    b, hs, ws_, _ = (int(v) for v in x.shape)
+    scale = 2 if flags & CONV_UPSAMPLE2X else 1
+    h, w = hs * scale, ws_ * scale
+    cdy = int(dy.shape[3])
+    if int(x.shape[3]) != cin:
+        raise RuntimeError("wgrad: x has %d channels, expected %d" % (x.shape[3], cin))
+    rows_pad = round_up(cdy, 64)
+    nbytes = int(_hip.lib().dream_conv2d_wgrad_workspace(b, h, w, cin, rows_pad, ksize, stride))
+    ws = _workspace(nbytes, x.device)
+    nt = ksize * ksize
+    dwp = torch.empty((nt, rows_pad, cin), dtype=torch.float32, device=x.device)
+    dbias = torch.empty((cdy,), dtype=torch.float32, device=x.device) if want_bias else None
+    call("dream_conv2d_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dwp), ptr(dbias), ptr(ws), b, h, w, cin, cdy, rows_pad, ksize,
+         stride, flags, stream())
+    dw = torch.empty((cout, cin, ksize, ksize), dtype=torch.float32, device=x.device)
+    call("dream_unpack_conv_weight", ptr(dwp), ptr(dw), cout, cin, nt, rows_pad, cin, stream())
+    return dw, (dbias[:cout].contiguous() if want_bias else None)
+
+
+def convT4x4_wgrad(x_nhwc, dy_nhwc):
+    """ConvTranspose2d(4,2,1) weight gradient -> [Cin,Cout,4,4]."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    cout = int(dy.shape[3])
+    rows_pad = round_up(cin, 64)
+    ws = _workspace(_hip.lib().dream_convT4x4_wgrad_workspace(b, h, w, rows_pad, cout), x.device)
+    dwp = torch.empty((16, rows_pad, cout), dtype=torch.float32, device=x.device)
+    call("dream_convT4x4_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dwp), ptr(ws), b, h, w, cin, rows_pad, cout, stream())
+    dw = torch.empty((cin, cout, 4, 4), dtype=torch.float32, device=x.device)
+    call("dream_unpack_conv_weight", ptr(dwp), ptr(dw), cin, cout, 16, rows_pad, cout, stream())
+    return dw
+
+
+def conv4x4s2(x_nhwc, packed16, cout, residual=None):
+    """4x4 stride-2 pad-1 conv (data gradient of the 4x4 transposed conv)."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, h // 2, w // 2, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv4x4s2_nhwc_f32", ptr(x), ptr(packed16), ptr(residual), ptr(y), b, h, w, cin, cout,
+         int(packed16.shape[-2]), 0, stream())
+    return y
+
+
+def pack_convT4x4_bwd_weight(wT):
+    """[Cin_T,Cout_T,4,4] -> 16-tap packed [16][rows_pad >= Cin_T][Cout_T] for conv4x4s2."""
+    w = _f32(wT)
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    rows_pad, cols_pad = _hip.cout_pad(cin), round_up(cout, 16)
+    packed = torch.empty((16, rows_pad, cols_pad), dtype=torch.float32, device=w.device)
+    call("dream_pack_conv_weight", ptr(w), ptr(packed), cin, cout, 16, rows_pad, cols_pad, 0, stream())
+    return packed, cin
+
+
+def conv2d_bwd_data(dy_nhwc, packed_t, cin, ksize, stride, in_hw, residual=None):
+    """Data gradient of a k x k / stride conv: stride 1 -> same-size conv with mode-1 weights; stride 2 -> the same on
+    the zero-stuffed gradient (extent in_hw, which may be odd)."""
+    dy = _f32(dy_nhwc)
+    if stride == 1:
+        return conv2d(dy, packed_t, cin, ksize, 1, None, None, residual, 0)
+    b, ho, wo, c = (int(v) for v in dy.shape)
+    h, w = in_hw
+    y = torch.empty((b, h, w, cin), dtype=torch.float32, device=dy.device)
+    call("dream_conv2d_nhwc_f32", ptr(dy), ptr(packed_t), None, None, ptr(residual), ptr(y), b, h, w, c, cin,
+         int(packed_t.shape[-2]), ksize, 1, CONV_ZEROSTUFF2X, stream())
+    return y
+
+
+def maxpool3s2_bwd(dy, x):
+    b, h, w, c = (int(v) for v in x.shape)
+    dx = torch.empty_like(x)
+    call("dream_maxpool3s2_bwd_nhwc_f32", ptr(_f32(dy)), ptr(x), ptr(dx), b, h, w, c, stream())
+    return dx
+
+
+def add_(dst, src):
+    call("dream_add_inplace_f32", ptr(dst), ptr(_f32(src)), dst.numel(), stream())
+    return dst

@@ -89,6 +89,10 @@ int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *sc
 int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w_packed, const float *scale,
                                        const float *shift, float *y, int B, int H, int W, int Cin, int Cout,
                                        int CoutPad, int flags, void *stream);
+/* 4x4 stride-2 pad-1 conv: the data gradient of the ConvTranspose2d(4,2,1) above (x = dL/dy of the transposed
+ * conv [B,2H,2W,Cout_T], output [B,H,W,Cin_T]; weights packed as 16 taps, see the kernel comment). */
+int dream_conv4x4s2_nhwc_f32(const float *x, const float *w_packed, const float *residual, float *y, int B,
+                             int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream);
 /* eval-mode nn.BatchNorm2d folded into the conv epilogue: scale = gamma/sqrt(var+eps),
  * shift = beta - mean*scale (+ conv_bias*scale when the conv has a bias; conv_bias may be NULL). */
 int dream_bn_fold_f32(const float *gamma, const float *beta, const float *running_mean, const float *running_var,
@@ -164,6 +168,35 @@ size_t dream_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad);
 int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias,
                                  void *workspace, int B, int H, int W, int Cin, int Cout,
                                  int CoutPad, int flags, void *stream);
+/* general forms for the ResNet path (1x1 / 3x3, stride 1 / 2) and the 4x4 transposed conv */
+size_t dream_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad, int ksize, int stride);
+int dream_conv2d_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias, void *workspace,
+                                int B, int H, int W, int Cin, int Cout, int CoutPad, int ksize, int stride,
+                                int flags, void *stream);
+size_t dream_convT4x4_wgrad_workspace(int B, int H, int W, int CinPad, int Cout);
+int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
+                                  int H, int W, int Cin, int CinPad, int Cout, void *stream);
+/* [ntaps][RowsPad][ColsPad] -> [Rows][Cols][ntaps] (OIHW / ConvTranspose [Cin,Cout,kh,kw]) */
+int dream_unpack_conv_weight(const float *packed, float *w, int Rows, int Cols, int ntaps, int RowsPad, int ColsPad,
+                             void *stream);
+/* train-mode nn.BatchNorm2d (torchvision ResNet + decoder BNs, dream/models.py:22-32,37-136), NHWC, npix = B*H*W.
+ * forward: batch statistics -> save_mean/save_invstd, running stats update (momentum, unbiased var),
+ * y = bn(x) (+residual) (ReLU).  backward: g = dy*(y_act>0 if relu); dgamma, dbeta; dx; optional g_out = g
+ * (gradient of the Bottleneck identity branch).  workspace: dream_bn_workspace(C) bytes. */
+size_t dream_bn_workspace(int C);
+int dream_bn_train_fwd_nhwc_f32(const float *x, const float *gamma, const float *beta, const float *residual,
+                                float *y, float *save_mean, float *save_invstd, float *running_mean,
+                                float *running_var, long long *num_batches_tracked, void *workspace,
+                                size_t npix, int C, float eps, float momentum, int relu, void *stream);
+int dream_bn_train_bwd_nhwc_f32(const float *x, const float *dy, const float *y_act, const float *gamma,
+                                const float *save_mean, const float *save_invstd, float *dx, float *g_out,
+                                float *dgamma, float *dbeta, void *workspace, size_t npix, int C, int relu,
+                                void *stream);
+int dream_channel_sum_nhwc_f32(const float *x, float *out, void *workspace, size_t npix, int C, void *stream);
+/* MaxPool2d(3,2,1) backward (ATen first-max semantics; overlapping windows accumulate) */
+int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
+/* dst += src (gradient accumulation where two branches meet) */
+int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream);
 /* first-layer weight gradient: x NCHW [B,Cin,H,W], dy NHWC [B,H,W,Cout] -> dw OIHW, dbias */
 size_t dream_conv3x3_first_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
 int dream_conv3x3_first_wgrad_f32(const float *x_nchw, const float *dy_nhwc, float *dw_oihw,

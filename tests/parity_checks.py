@@ -293,3 +293,122 @@ def check_backward_ops(dev):
     l, gr = ops.mse_fwd_bwd(to(dev, o), to(dev, t))
     assert abs(l.item() - F.mse_loss(o, t).item()) < 1e-6
     assert float((gr.cpu() - 2 * (o - t) / o.numel()).abs().max()) < 1e-7
+
+
+def check_resnet_train_step(dev, arch="resnet_h", shape=(2, 64, 64), steps=1):
+    """One DreamNetwork.train() step of a ResNet (train-mode BatchNorm + full backward).  Train-mode BN over the
+    few samples of a small test batch is ill-conditioned (two correct fp32 implementations differ by percents in
+    the deep layers), so the yardstick is the fp64 oracle: the HIP path must be as close to it as torch's own fp32
+    CPU path is (factor 3 + a 1e-4 floor), on the loss, on every parameter gradient and on the BN buffers."""
+    k = cases.CNN_CASES[arch][0]
+    b, h, w = shape
+    wts = om.recipe_weights(om.build_model(arch, k).state_dict())
+    ref32 = om.build_model(arch, k)
+    ref32.load_state_dict(wts)
+    ref32.train()
+    ref64 = om.build_model(arch, k)
+    ref64.load_state_dict(wts)
+    ref64.double().train()
+    net = build_network(arch, dev, weights=wts, optimizer="sgd", lr=0.0, in_res=(w, h))
+    net.enable_training()
+    out_wh = net.net_output_resolution_from_input_resolution((w, h))
+    x = torch.from_numpy(cases.image_batch(b, h, w, seed=3))
+    t = torch.from_numpy(cases.target_batch(b, k, out_wh, in_wh=(w, h), seed=3))
+    l32 = F.mse_loss(ref32(x)[0], t)
+    l32.backward()
+    l64 = F.mse_loss(ref64(x.double())[0], t.double())
+    l64.backward()
+    loss = net.train([to(dev, x)], to(dev, t))
+    assert abs(loss.item() - l64.item()) <= 3 * abs(l32.item() - l64.item()) + 1e-4 * abs(l64.item())
+    # direction of every parameter gradient vs the fp64 truth: a wiring error (missing branch, wrong tap, wrong
+    # BN term) drops the cosine far below what fp32 round-off + ReLU-mask flips cost torch's own fp32 path
+    def cos(a, b_):
+        return float((a * b_).sum() / (a.norm() * b_.norm() + 1e-300))
+    gnorm = max(p.grad.norm().item() for p in ref64.parameters())
+    c32, chip = [], []
+    for (name, p32), (_, p64), (_, pm) in zip(ref32.named_parameters(), ref64.named_parameters(),
+                                              net.model.module.named_parameters()):
+        if p64.grad.norm().item() < 1e-7 * gnorm:       # conv biases in front of a BN: true gradient is exactly 0
+            assert pm.grad.detach().cpu().double().norm().item() < 1e-4 * gnorm, name
+            continue
+        c32.append(cos(p32.grad.double(), p64.grad))
+        chip.append((cos(pm.grad.detach().cpu().double(), p64.grad), name))
+    floor = min(0.98, min(c32) - 0.02)
+    bad = [(n, c) for c, n in chip if c < floor]
+    assert not bad, (floor, bad[:5])
+    for (name, b32), (_, b64), (_, bm) in zip(ref32.named_buffers(), ref64.named_buffers(), net.model.module.named_buffers()):
+        if name.startswith("_") or "beta_const" in name:
+            continue
+        scale = b64.double().abs().max().item() + 1e-6
+        e32 = (b32.double() - b64.double()).abs().max().item() / scale
+        ehip = (bm.detach().cpu().double() - b64.double()).abs().max().item() / scale
+        assert ehip <= 3 * e32 + 1e-3, (name, ehip, e32)
+
+
+def check_resnet_training_ops(dev):
+    def nchw(t):
+        return t.permute(0, 3, 1, 2)
+    for (B, C, H, W, relu, res) in [(2, 64, 5, 7, True, True), (3, 256, 4, 4, True, False), (2, 2048, 3, 3, False, False),
+                                    (1, 48, 6, 5, True, False)]:
+        bn = torch.nn.BatchNorm2d(C)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_()
+        bn2 = torch.nn.BatchNorm2d(C)
+        bn2.load_state_dict(bn.state_dict())
+        bn2 = bn2.to(dev) if dev != "cpu" else bn2
+        x = torch.randn(B, C, H, W, requires_grad=True)
+        r = torch.randn(B, C, H, W) if res else None
+        y_ref = bn(x)
+        if res:
+            y_ref = y_ref + r
+        if relu:
+            y_ref = y_ref.relu()
+        dy = torch.randn_like(y_ref)
+        y_ref.backward(dy)
+        y, mean, invstd = ops.bn_train_fwd(to(dev, _nhwc(x.detach())), bn2, to(dev, _nhwc(r)) if res else None, relu)
+        dx, g, dgam, dbet = ops.bn_train_bwd(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)), y, bn2.weight, mean, invstd, relu,
+                                             want_g=True)
+        assert float((nchw(y.cpu()) - y_ref).abs().max()) < 1e-5
+        assert float((bn.running_mean - bn2.running_mean.cpu()).abs().max()) < 1e-6
+        assert float((bn.running_var - bn2.running_var.cpu()).abs().max()) < 1e-5
+        assert int(bn2.num_batches_tracked.item()) == 1
+        assert float((nchw(dx.cpu()) - x.grad).abs().max()) < 1e-5
+        assert float((dgam.cpu() - bn.weight.grad).abs().max()) < 1e-4 and float((dbet.cpu() - bn.bias.grad).abs().max()) < 1e-4
+        gm = dy * (y_ref > 0) if relu else dy
+        assert float((nchw(g.cpu()) - gm).abs().max()) == 0.0
+    for (B, H, W, Cin, Cout, k, s_) in [(2, 9, 11, 64, 48, 1, 1), (1, 13, 13, 32, 128, 1, 2), (2, 12, 10, 32, 64, 3, 2),
+                                        (1, 13, 25, 64, 32, 3, 2)]:
+        x = torch.randn(B, Cin, H, W, requires_grad=True)
+        w = (torch.randn(Cout, Cin, k, k) * 0.1).requires_grad_()
+        y = F.conv2d(x, w, None, stride=s_, padding=k // 2)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        dw, _ = ops.conv2d_wgrad(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)), Cout, Cin, k, s_)
+        packed_t, rows, _ = ops.pack_conv_weight(to(dev, w.detach()), 1)
+        dx = ops.conv2d_bwd_data(to(dev, _nhwc(dy)), packed_t, Cin, k, s_, (H, W))
+        assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy())
+        assert float((nchw(dx.cpu()) - x.grad).abs().max()) <= tol(x.grad.numpy())
+    for (B, H, W, Cin, Cout) in [(1, 5, 6, 32, 48), (2, 13, 13, 64, 32)]:
+        x = torch.randn(B, Cin, H, W, requires_grad=True)
+        wT = (torch.randn(Cin, Cout, 4, 4) * 0.1).requires_grad_()
+        y = F.conv_transpose2d(x, wT, None, stride=2, padding=1)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        dw = ops.convT4x4_wgrad(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)))
+        pk, rows = ops.pack_convT4x4_bwd_weight(to(dev, wT.detach()))
+        dx = ops.conv4x4s2(to(dev, _nhwc(dy)), pk, rows)
+        assert float((dw.cpu() - wT.grad).abs().max()) <= tol(wT.grad.numpy())
+        assert float((nchw(dx.cpu()) - x.grad).abs().max()) <= tol(x.grad.numpy())
+    for xin in (torch.randn(2, 8, 9, 11), torch.round(torch.randn(1, 4, 7, 7) * 2)):     # second: ties
+        xin.requires_grad_()
+        y = F.max_pool2d(xin, 3, 2, 1)
+        dy = torch.randn_like(y)
+        y.backward(dy)
+        dx = ops.maxpool3s2_bwd(to(dev, _nhwc(dy)), to(dev, _nhwc(xin.detach())))
+        assert torch.equal(nchw(dx.cpu()), xin.grad)
+    a, b = torch.randn(1003), torch.randn(1003)
+    c = to(dev, a.clone())
+    ops.add_(c, to(dev, b))
+    assert torch.equal(c.cpu(), a + b)
+    cs = torch.randn(3, 5, 4, 64)
+    assert float((ops.channel_sum(to(dev, cs)).cpu() - cs.sum((0, 1, 2))).abs().max()) < 1e-4

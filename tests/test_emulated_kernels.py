@@ -81,3 +81,11 @@ def test_vgg_f_inference_golden(emu):
 
 def test_train_step_golden(emu):
     pc.check_train_steps("cpu", "adam", steps=1)
+
+
+def test_resnet_training_ops(emu):
+    pc.check_resnet_training_ops("cpu")
+
+
+def test_resnet_h_train_step(emu):
+    pc.check_resnet_train_step("cpu", "resnet_h", (2, 64, 64))

@@ -137,11 +137,23 @@ def test_resnet_f_full_resolution_matches_oracle():
     assert np.array_equal(kps.numpy(), op.keypoints_from_belief_maps(y, 0.0))
 
 
-def test_resnet_training_refuses_instead_of_falling_back():
-    net = pc.build_network("resnet_h", DEV)
+def test_resnet_training_ops():
+    pc.check_resnet_training_ops(DEV)
+
+
+def test_resnet_h_train_step():
+    pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
+
+
+def test_resnet_f_train_step():
+    pc.check_resnet_train_step(DEV, "resnet_f", (2, 64, 64))
+
+
+def test_unbuilt_paths_refuse_instead_of_falling_back():
+    net = pc.build_network("vgg_f", DEV)                  # ConvTranspose 3x3 backward is not built yet
     net.enable_training()
     with pytest.raises(NotImplementedError):
-        net.train([torch.zeros(2, 3, 64, 64, device=DEV)], torch.zeros(2, 7, 32, 32, device=DEV))
+        net.train([torch.zeros(2, 3, 64, 64, device=DEV)], torch.zeros(2, 7, 64, 64, device=DEV))
 
 
 def test_full_size_batch_properties():
