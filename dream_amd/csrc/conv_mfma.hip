@@ -318,16 +318,19 @@ void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, in
 int pick_variant(long pixels, int Cin, int Cout, bool big_patch) {
     if (big_patch) return 9;
     const bool k32 = (Cin % 32 == 0);
+    // measured on MI355X (profiles/r01_microbench_conv_variants.txt): the KC=16 variants (half the LDS, 3-4
+    // workgroups per CU) win by 3-13 % up to Cin = 256; deeper reductions prefer KC=32 (fewer barriers)
+    const bool prefer16 = Cin <= 256;
     if (Cout > 64) {
         // enough 128x128 tiles to fill 256 CUs x 2 workgroups?  otherwise the 64-px variant
         const long tiles128 = ((pixels + 127) / 128) * (long)ceil_div(Cout, 128);
         if (k32 && tiles128 < 512) return 8;
-        return k32 ? 0 : 3;
+        return (k32 && !prefer16) ? 0 : 3;
     }
     const long tiles256 = (pixels + 255) / 256;
     if (Cout > 32) {
         if (k32 && tiles256 < 512) return 6;
-        return k32 ? 1 : 4;
+        return (k32 && !prefer16) ? 1 : 4;
     }
     if (k32 && tiles256 < 512) return 7;
     return k32 ? 2 : 5;
