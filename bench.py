@@ -26,6 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense fp16/bf16 MFMA peak (not the 2:1-sparse figure)
 
 
 def parse():
@@ -36,6 +37,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--mode", choices=["inference", "train"], default="inference")
+    ap.add_argument("--precision", choices=["fp32", "fp16x3"], default="fp32",
+                    help="conv kernel for inference: exact fp32 MFMA, or split-precision fp16x3 (fp32 in/out, fp32-class error)")
     ap.add_argument("--arch", choices=["vgg_q", "vgg_f", "resnet_h", "resnet_f"], default="vgg_q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -126,6 +129,8 @@ def main():
         tgt = torch.from_numpy(cases.target_batch(args.batch, n_kp, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
     else:
         net.enable_evaluation()
+        if args.precision != "fp32":
+            net.model.module.precision = args.precision
 
     # ---- per-launch timing of the dominant kernel (HIP events on the launch stream) ------------------
     conv_events = []          # (start, end, flops)
@@ -148,6 +153,7 @@ def main():
     ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0: 2.0 * y.numel() * x.shape[3] * 9)
     ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y.numel() * x.shape[3] * ksize * ksize)
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * 16)
+    ops.conv2d_f16x3 = timed(ops.conv2d_f16x3, lambda y, x, amax, p16, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
 
     def step():
         if args.mode == "train":
@@ -182,13 +188,17 @@ def main():
     conv_flops = sum(f for _, _, f in conv_events)
     n_launch = len(conv_events)
 
+    # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
+    # fp16 MFMA MACs, so its ceiling in ALGORITHMIC flops is the dense fp16 MFMA peak / 3
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" or args.mode == "train" else PEAK_F16_MFMA_TFLOPS / 3.0
     if rank == 0:
         frames = args.batch * args.steps * world
         line = {
             "metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
             "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16x3 split MFMA, f32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": "DREAM-%s (%s, %d keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames "
                                    "resident in HBM; CNN forward + belief-map peak extraction%s"
                                    % (args.arch, manip, n_kp, args.mode, args.batch, args.res, args.res,
@@ -196,10 +206,10 @@ def main():
                                       if args.arch == "vgg_q" else ""),
                        "batch_per_gpu": args.batch, "resolution": [args.res, args.res], "parallelism": "dp%d" % world},
             "roofline": {
-                "bound": "mfma", "kernel": "conv_mfma_kernel",
+                "bound": "mfma", "kernel": "conv_mfma_kernel" if args.precision == "fp32" else "conv_f16x3_kernel",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if conv_ms > 0 else None,
+                "peak": peak, "unit": "TFLOP/s",
+                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
                 "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
                 "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
                 "algorithmic_gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,

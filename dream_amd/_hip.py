@@ -49,6 +49,12 @@ _SIGNATURES = {
     "dream_channel_sum_nhwc_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
     "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
+    "dream_conv2d_amax_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_first_nchw_amax_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_absmax_f32": (_I, [_P, _SZ, _P, _P]),
+    "dream_pack_conv_weight_f16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv2d_f16x3_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv_f16x3_set_variant": (_I, [_I]),
     "dream_bn_fold_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "dream_im2col_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_maxpool3s2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

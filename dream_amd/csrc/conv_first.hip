@@ -22,6 +22,7 @@ struct FirstParams {
     const float *w;
     const float *bias;
     float *y;
+    unsigned *amax_out;
     int B, H, W, Cin, Cout;
     int tiles_x, tiles_y;
     int relu;
@@ -58,6 +59,7 @@ __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p)
     __syncthreads();
 
     // wave w owns rows 4w..4w+3; 4 groups of 4 pixels per row
+    float amax = 0.0f;
     for (int g = 0; g < 16; ++g) {
         const int row = wave * 4 + (g >> 2), xg = (g & 3) * 4;
         float acc0 = bv, acc1 = bv, acc2 = bv, acc3 = bv;
@@ -83,24 +85,28 @@ __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p)
         const int oy = y0 + row, ox = x0 + xg;
         if (oy < p.H) {
             float *dst = p.y + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cout;
-            if (ox + 0 < p.W) dst[0] = acc0;
-            if (ox + 1 < p.W) dst[(size_t)p.Cout] = acc1;
-            if (ox + 2 < p.W) dst[(size_t)2 * p.Cout] = acc2;
-            if (ox + 3 < p.W) dst[(size_t)3 * p.Cout] = acc3;
+            if (ox + 0 < p.W) { dst[0] = acc0; amax = fmaxf(amax, fabsf(acc0)); }
+            if (ox + 1 < p.W) { dst[(size_t)p.Cout] = acc1; amax = fmaxf(amax, fabsf(acc1)); }
+            if (ox + 2 < p.W) { dst[(size_t)2 * p.Cout] = acc2; amax = fmaxf(amax, fabsf(acc2)); }
+            if (ox + 3 < p.W) { dst[(size_t)3 * p.Cout] = acc3; amax = fmaxf(amax, fabsf(acc3)); }
         }
+    }
+    if (p.amax_out != nullptr) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, lane_xor(amax, m));
+        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(amax));
     }
 }
 }  // namespace
 
-extern "C" int dream_conv3x3_first_nchw_f32(const float *x_nchw, const float *w_oihw, const float *bias,
-                                            float *y_nhwc, int B, int H, int W, int Cin, int Cout,
-                                            int relu, void *stream) {
+static int first_impl(const float *x_nchw, const float *w_oihw, const float *bias, float *y_nhwc, int B, int H, int W,
+                      int Cin, int Cout, int relu, void *stream, unsigned *amax_out) {
     DREAM_REQUIRE(x_nchw && w_oihw && y_nhwc, "null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0, "bad shape");
     DREAM_REQUIRE(Cin >= 1 && Cin <= FMAXC, "first conv supports Cin <= %d (got %d)", FMAXC, Cin);
     DREAM_REQUIRE(Cout % 64 == 0, "first conv needs Cout %% 64 == 0 (got %d)", Cout);
     FirstParams p;
-    p.x = x_nchw; p.w = w_oihw; p.bias = bias; p.y = y_nhwc;
+    p.x = x_nchw; p.w = w_oihw; p.bias = bias; p.y = y_nhwc; p.amax_out = amax_out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.tiles_x = ceil_div(W, FT); p.tiles_y = ceil_div(H, FT);
     const size_t lds = (size_t)Cin * FPH * FPW * sizeof(float);
@@ -108,4 +114,15 @@ extern "C" int dream_conv3x3_first_nchw_f32(const float *x_nchw, const float *w_
     hipLaunchKernelGGL(conv3x3_first_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int dream_conv3x3_first_nchw_f32(const float *x_nchw, const float *w_oihw, const float *bias,
+                                            float *y_nhwc, int B, int H, int W, int Cin, int Cout,
+                                            int relu, void *stream) {
+    return first_impl(x_nchw, w_oihw, bias, y_nhwc, B, H, W, Cin, Cout, relu, stream, nullptr);
+}
+extern "C" int dream_conv3x3_first_nchw_amax_f32(const float *x_nchw, const float *w_oihw, const float *bias,
+                                                 float *y_nhwc, unsigned *amax_out, int B, int H, int W, int Cin,
+                                                 int Cout, int relu, void *stream) {
+    return first_impl(x_nchw, w_oihw, bias, y_nhwc, B, H, W, Cin, Cout, relu, stream, amax_out);
 }

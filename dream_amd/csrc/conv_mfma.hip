@@ -36,6 +36,7 @@ struct ConvParams {
     const float *shift;      // per-channel addend (bias / BN shift) or null
     const float *residual;   // tensor of the output's shape added before the ReLU, or null
     float *y;
+    unsigned *amax_out;      // optional: atomicMax of the bit pattern of max|y| (y >= 0 bit patterns are ordered)
     int B, H, W;             // grid of output positions per image that the tiles cover
     int Hin, Win;            // logical input extent (after fused upsample / zero-stuffing)
     int Hs, Ws;              // extent of the tensor actually read
@@ -54,6 +55,13 @@ struct ConvParams {
     int out_scale, out_oy, out_ox;   // output pixel = position * out_scale + (out_oy, out_ox)
     int flags;
 };
+
+// one atomicMax per wave on the bit pattern (non-negative floats order like unsigned integers)
+DREAM_DEVICE void publish_amax(unsigned *dst, float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, lane_xor(v, m));
+    if ((threadIdx.x & 63) == 0) atomicMax(dst, __float_as_uint(v));
+}
 
 template <int MR, int NR, int WM, int WN, int KC, int NPM>
 struct ConvCfg {
@@ -232,6 +240,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
         shift_v[ns] = (p.shift != nullptr && cok) ? p.shift[ncol[ns]] : 0.0f;
     }
     const int npix = p.TH * TW;
+    float amax = 0.0f;
 #pragma unroll
     for (int ms = 0; ms < MR; ++ms) {
 #pragma unroll
@@ -252,10 +261,12 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                     if (p.residual != nullptr) v = v + p.residual[o];
                     if (relu) v = fmaxf(v, 0.0f);
                     p.y[o] = v;
+                    amax = fmaxf(amax, fabsf(v));
                 }
             }
         }
     }
+    if (p.amax_out != nullptr) publish_amax(p.amax_out, amax);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -348,7 +359,8 @@ struct ConvGeom {
 };
 
 int launch_conv(const float *x, const float *w, const float *scale, const float *shift, const float *residual,
-                float *y, int B, int Cin, int Cout, int CoutPad, const ConvGeom &g, int flags, void *stream) {
+                float *y, int B, int Cin, int Cout, int CoutPad, const ConvGeom &g, int flags, void *stream,
+                unsigned *amax_out = nullptr) {
     DREAM_REQUIRE(x && w && y, "null pointer");
     DREAM_REQUIRE(B > 0 && g.H > 0 && g.W > 0 && Cin > 0 && Cout > 0, "bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, g.H, g.W, Cin, Cout);
     DREAM_REQUIRE(Cin % 16 == 0, "Cin=%d must be a multiple of 16 (pad the channels)", Cin);
@@ -361,7 +373,7 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
     DREAM_REQUIRE(CoutPad % var.BN == 0 && CoutPad >= Cout, "CoutPad=%d must be a multiple of %d (variant %s)", CoutPad, var.BN, var.name);
 
     ConvParams p;
-    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y; p.amax_out = amax_out;
     p.B = B; p.H = g.H; p.W = g.W; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws; p.Ho = g.Ho; p.Wo = g.Wo;
     p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
     choose_tile(g.H, g.W, var.BM, var.NP_MAX, g.lane_stride, g.kext, &p.TH, &p.TW);
@@ -412,9 +424,9 @@ extern "C" size_t dream_conv3x3_cout_pad(int Cout) {
 
 // k x k convolution (k in {1,3}), stride in {1,2}, pad = k/2; H, W are the INPUT extent (after the fused
 // x2 upsample / zero-stuffing when those flags are set).
-extern "C" int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
-                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
-                                     int CoutPad, int ksize, int stride, int flags, void *stream) {
+static int conv2d_impl(const float *x, const float *w_packed, const float *scale, const float *shift,
+                       const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                       int CoutPad, int ksize, int stride, int flags, void *stream, unsigned *amax_out) {
     DREAM_REQUIRE(ksize == 1 || ksize == 3, "conv2d: kernel size %d not supported (1 or 3)", ksize);
     DREAM_REQUIRE(stride == 1 || stride == 2, "conv2d: stride %d not supported (1 or 2)", stride);
     const bool ups = (flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X)) != 0;
@@ -436,7 +448,19 @@ extern "C" int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, cons
     for (int t = 0; t < g.ntaps; ++t) { g.tap_dy[t] = t / ksize; g.tap_dx[t] = t % ksize; }
     g.kext = ksize;
     g.out_scale = 1; g.out_oy = 0; g.out_ox = 0;
-    return launch_conv(x, w_packed, scale, shift, residual, y, B, Cin, Cout, CoutPad, g, flags, stream);
+    return launch_conv(x, w_packed, scale, shift, residual, y, B, Cin, Cout, CoutPad, g, flags, stream, amax_out);
+}
+extern "C" int dream_conv2d_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                                     int CoutPad, int ksize, int stride, int flags, void *stream) {
+    return conv2d_impl(x, w_packed, scale, shift, residual, y, B, H, W, Cin, Cout, CoutPad, ksize, stride, flags, stream, nullptr);
+}
+// same, and additionally atomicMax(max|y|) into *amax_out (caller zeroes it): the dynamic range the split-precision
+// kernel needs for the NEXT layer's input scaling
+extern "C" int dream_conv2d_amax_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                          const float *residual, float *y, unsigned *amax_out, int B, int H, int W, int Cin,
+                                          int Cout, int CoutPad, int ksize, int stride, int flags, void *stream) {
+    return conv2d_impl(x, w_packed, scale, shift, residual, y, B, H, W, Cin, Cout, CoutPad, ksize, stride, flags, stream, amax_out);
 }
 
 extern "C" int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,

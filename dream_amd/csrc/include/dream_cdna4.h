@@ -19,6 +19,15 @@ DREAM_DEVICE f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s dense, 32 cycles/SIMD issue):
+//   A operand: 8 halfs per lane, lane l holds A[row = l & 31][k = 8*(l>>5) .. 8*(l>>5)+7]
+//   B operand: 8 halfs per lane, lane l holds B[k = 8*(l>>5) .. +7][col = l & 31];  C/D as above
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+DREAM_DEVICE f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
 // wave index within the workgroup as a provably wave-uniform (SGPR) value
 DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -47,13 +47,14 @@ class _PackedCache:
     def __init__(self):
         self._store = {}
 
-    def get(self, weight, mode):
-        key = (id(weight), mode)
+    def get(self, weight, mode, f16x3=False):
+        key = (id(weight), mode, f16x3)
         tag = (weight._version, weight.data_ptr(), weight.device)
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
-                hit = (tag, ops.pack_weight(weight.detach(), mode))
+                packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
+                hit = (tag, packed)
             self._store[key] = hit
         return hit[1]
 
@@ -132,6 +133,9 @@ class DreamHourglass(nn.Module):
             self.softmax = container([(0, SoftArgmaxPavlo(n_keypoints, learned_beta, initial_beta))])
         self._plan = plan
         self._packed = _PackedCache()
+        # "fp32": exact fp32 MFMA kernel everywhere.  "fp16x3": inference runs the split-precision kernel
+        # (fp32 in/out, 3 fp16 MFMAs per product, fp32-class error); training always uses the fp32 kernels.
+        self.precision = "fp32"
 
     # ---- helpers -------------------------------------------------------------------------------------
     def _layer(self, cname, child):
@@ -160,11 +164,34 @@ class DreamHourglass(nn.Module):
         return (w, h)
 
     # ---- execution -------------------------------------------------------------------------------------
+    def run_forward_f16x3(self, x, params):
+        """Inference plan on the split-precision conv kernel.  Each kernel publishes max|y| of its output (amax side
+        channel) so the next conv can scale its input into fp16 range; pooling cannot raise the maximum."""
+        act, amax = x, None
+        pi = 0
+        for kind, mod, flags in self.plan_layers():
+            if kind == "pool":
+                act = ops.maxpool2(act)
+                continue
+            w, bias = params[pi], params[pi + 1]
+            pi += 2
+            if kind == "first":
+                act, amax = ops.conv3x3_first_amax(act, w, bias, relu=bool(flags & CONV_RELU))
+            else:
+                p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
+                act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
+                                             want_amax=not (flags & CONV_OUT_NCHW))
+        return act
+
     def run_forward(self, x, params, save):
         """Executes the plan.  ``params`` is plan_parameters() (possibly autograd-detached).  With
         ``save`` the per-layer inputs/outputs needed by run_backward are returned as well."""
         if x.dim() != 4 or x.shape[1] != self.n_image_input_channels:
             raise RuntimeError("expected [B,%d,H,W] input, got %s" % (self.n_image_input_channels, tuple(x.shape)))
+        if self.precision == "fp16x3" and not save:
+            return self.run_forward_f16x3(x, params), []
+        if self.precision not in ("fp32", "fp16x3"):
+            raise ValueError("unknown precision %r" % (self.precision,))
         saved = []
         act = x
         pi = 0

@@ -415,3 +415,58 @@ def maxpool3s2_bwd(dy, x):
 def add_(dst, src):
     call("dream_add_inplace_f32", ptr(dst), ptr(_f32(src)), dst.numel(), stream())
     return dst
+
+
+# ---- split-precision (fp16x3) path ----------------------------------------------------------------------
+def new_amax(device):
+    """Device scalar (uint32 bit pattern of a non-negative float) that kernels atomicMax their max|y| into."""
+    return torch.zeros((1,), dtype=torch.int32, device=device)
+
+
+def absmax(x):
+    a = new_amax(x.device)
+    call("dream_absmax_f32", ptr(_f32(x)), x.numel(), ptr(a), stream())
+    return a
+
+
+def pack_conv_weight_f16x3(w_oihw, mode=0):
+    """-> (hi, lo, exp, rows): two fp16 planes [ntaps][rows_pad][cols_pad] of w*2^exp and the device int exp."""
+    w = _f32(w_oihw)
+    cout, cin, kh, kw = (int(v) for v in w.shape)
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    rows_pad, cols_pad = _hip.cout_pad(rows), round_up(cols, 32)
+    hi = torch.empty((kh * kw, rows_pad, cols_pad), dtype=torch.float16, device=w.device)
+    lo = torch.empty_like(hi)
+    exp = torch.zeros((1,), dtype=torch.int32, device=w.device)
+    scratch = torch.zeros((1,), dtype=torch.int32, device=w.device)
+    call("dream_pack_conv_weight_f16x3", ptr(w), ptr(hi), ptr(lo), ptr(exp), ptr(scratch), cout, cin, kh * kw, rows_pad,
+         cols_pad, mode, stream())
+    return hi, lo, exp, rows
+
+
+def conv2d_f16x3(x_nhwc, amax_in, packed16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True):
+    """Split-precision conv (stride 1): returns (y, amax_out)."""
+    hi, lo, exp, _ = packed16
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    if cin != hi.shape[-1]:
+        raise RuntimeError("conv2d_f16x3: input has %d channels, packed weights expect %d" % (cin, hi.shape[-1]))
+    if flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X):
+        h, w = 2 * h, 2 * w
+    shape = (b, cout, h, w) if flags & CONV_OUT_NCHW else (b, h, w, cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    amax_out = new_amax(x.device) if want_amax else None
+    call("dream_conv2d_f16x3_nhwc_f32", ptr(x), ptr(amax_in), ptr(hi), ptr(lo), ptr(exp), ptr(scale), ptr(shift),
+         ptr(residual), ptr(y), ptr(amax_out), b, h, w, cin, cout, int(hi.shape[-2]), ksize, 1, flags, stream())
+    return y, amax_out
+
+
+def conv3x3_first_amax(x_nchw, w_oihw, bias, relu=True):
+    x, w = _f32(x_nchw), _f32(w_oihw)
+    b, cin, h, wd = (int(v) for v in x.shape)
+    cout = int(w.shape[0])
+    y = torch.empty((b, h, wd, cout), dtype=torch.float32, device=x.device)
+    amax = new_amax(x.device)
+    call("dream_conv3x3_first_nchw_amax_f32", ptr(x), ptr(w), ptr(bias), ptr(y), ptr(amax), b, h, wd, cin, cout,
+         1 if relu else 0, stream())
+    return y, amax

@@ -102,6 +102,26 @@ int dream_bn_fold_f32(const float *gamma, const float *beta, const float *runnin
 int dream_im2col_nchw_f32(const float *x, float *y, int B, int C, int H, int W, int KH, int KW, int stride,
                           int pad, int Kpad, void *stream);
 int dream_maxpool3s2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream);
+/* ---- split-precision ("fp16x3") path: fp32 in/out, fp32-class accuracy on the fp16 matrix cores ------------------
+ * Each operand v*2^e = hi + lo (two fp16), product = hi*hi + hi*lo + lo*hi (3 x v_mfma_f32_32x32x16_f16, fp32
+ * accumulate).  Activations are split on the fly using the per-tensor max|x| published by the producing kernel
+ * (amax side channel: a device uint32 holding the float's bit pattern, zeroed by the caller, atomicMax'ed by the
+ * *_amax entry points); weights are pre-split by dream_pack_conv_weight_f16x3.  Same reference call sites as
+ * dream_conv2d_nhwc_f32. */
+int dream_conv2d_amax_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                               const float *residual, float *y, unsigned *amax_out, int B, int H, int W, int Cin,
+                               int Cout, int CoutPad, int ksize, int stride, int flags, void *stream);
+int dream_conv3x3_first_nchw_amax_f32(const float *x_nchw, const float *w_oihw, const float *bias,
+                                      float *y_nhwc, unsigned *amax_out, int B, int H, int W, int Cin,
+                                      int Cout, int relu, void *stream);
+int dream_absmax_f32(const float *x, size_t n, unsigned *amax_out, void *stream);
+int dream_pack_conv_weight_f16x3(const float *w_oihw, void *hi, void *lo, int *exp_out, unsigned *scratch,
+                                 int Cout, int Cin, int ntaps, int RowsPad, int ColsPad, int mode, void *stream);
+int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi, const void *w_lo,
+                                const int *w_exp, const float *scale, const float *shift, const float *residual,
+                                float *y, unsigned *amax_out, int B, int H, int W, int Cin, int Cout, int CoutPad,
+                                int ksize, int stride, int flags, void *stream);
+int dream_conv_f16x3_set_variant(int variant);
 /* variant selection for benchmarking: -1 = heuristic; otherwise index into the variant table */
 int dream_conv3x3_set_variant(int variant);
 int dream_conv3x3_num_variants(void);

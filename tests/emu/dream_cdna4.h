@@ -26,6 +26,29 @@ inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     }
     return c;
 }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_32x32x16_f16 model: lane l holds A[row = l&31][k = 8*(l>>5) .. +7], B[k = 8*(l>>5) .. +7][col = l&31];
+// products are exact in fp32, accumulated sequentially in fp32 (the hardware's internal order is not documented;
+// differences are at fp32 round-off level)
+inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
+    emu::Block *blk = emu::tb;
+    const int w = emu::wave(), l = emu::lane();
+    const int par = (blk->wave_op[w][l]++) & 1;
+    static thread_local _Float16 xa[2][16][64][8], xb[2][16][64][8];
+    for (int k = 0; k < 8; ++k) { xa[par][w][l][k] = a[k]; xb[par][w][l][k] = b[k]; }
+    emu::wave_barrier();
+    const int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int h = 0; h < 2; ++h)
+            for (int k = 0; k < 8; ++k)
+                acc += (float)xa[par][w][row + 32 * h][k] * (float)xb[par][w][col + 32 * h][k];
+        c[r] = acc;
+    }
+    return c;
+}
 inline int wave_index() { return emu::wave(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }

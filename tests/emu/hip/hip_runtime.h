@@ -91,6 +91,7 @@ inline hipError_t hipGetDeviceCount(int *c) { *c = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     strcpy(p->name, "SIMT emulator"); strcpy(p->gcnArchName, "host"); p->multiProcessorCount = 0; return hipSuccess;
 }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, int, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 
 // ---- wave-level primitives --------------------------------------------------------------------------
@@ -122,6 +123,13 @@ inline unsigned long long __ballot(int pred) {
     const int n = (int)(b->bdim.x - w * 64 < 64 ? b->bdim.x - w * 64 : 64);
     for (int i = 0; i < n; ++i) if (b->xchg_d[par][w][i] != 0.0) m |= 1ull << i;
     return m;
+}
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline unsigned atomicMax(unsigned *p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
 }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline double __dmul_rn(double a, double b) { return a * b; }

@@ -201,13 +201,41 @@ def build_network(arch, dev, weights=None, optimizer="adam", lr=1e-4, in_res=Non
     return net
 
 
-def check_model_inference(dev, arch, shape):
+def check_conv_f16x3(dev, B, H, W, Cin, Cout, k, flags, x_scale=1.0, w_scale=0.1, seed=0):
+    """Split-precision conv vs an fp64 reference: error relative to the output maximum must stay in the fp32 class
+    (<= 5e-6; torch's own fp32 conv is ~5e-7 on these shapes), including with an outlier that sets the tensor scale
+    and with extreme tensor magnitudes; the published amax must equal max|y|."""
+    g = torch.Generator().manual_seed(seed)
+    ups = bool(flags & ops.CONV_UPSAMPLE2X)
+    x = torch.randn(B, Cin, H // 2 if ups else H, W // 2 if ups else W, generator=g) * x_scale
+    x[0, 0, 0, 0] = 40 * x_scale
+    w = torch.randn(Cout, Cin, k, k, generator=g) * w_scale
+    bias = torch.randn(Cout, generator=g) * x_scale * w_scale
+    xr = F.interpolate(x, scale_factor=2) if ups else x
+    ref = F.conv2d(xr.double(), w.double(), bias.double(), padding=k // 2)
+    if flags & ops.CONV_RELU:
+        ref = ref.relu()
+    p16 = ops.pack_conv_weight_f16x3(to(dev, w), 0)
+    amax_in = ops.absmax(to(dev, x))
+    y, amax_out = ops.conv2d_f16x3(to(dev, _nhwc(x)), amax_in, p16, Cout, k, None, to(dev, bias), None, flags)
+    got = y.cpu() if flags & ops.CONV_OUT_NCHW else y.cpu().permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    err = float((got.double() - ref).abs().max()) / scale
+    assert err <= 5e-6, (B, H, W, Cin, Cout, k, flags, err)
+    am = float(np.frombuffer(amax_out.cpu().numpy().tobytes(), dtype=np.float32)[0])
+    assert abs(am - float(got.abs().max())) <= 1e-6 * scale
+    return err
+
+
+def check_model_inference(dev, arch, shape, precision="fp32"):
     """belief maps within TOL of the reference's golden output; detections agree; coordinates within
     1e-3 px (they are bit-exact functions of maps that differ in the last bits)."""
     b, h, w = shape
     g = np.load(os.path.join(GOLD, "cnn_%s.npz" % arch))
     net = build_network(arch, dev)
     net.enable_evaluation()
+    if precision != "fp32":
+        net.model.module.precision = precision
     x = torch.from_numpy(cases.image_batch(b, h, w, seed=b * 1000 + h))
     with torch.no_grad():
         maps, kps = net.inference(to(dev, x))

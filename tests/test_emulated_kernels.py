@@ -89,3 +89,19 @@ def test_resnet_training_ops(emu):
 
 def test_resnet_h_train_step(emu):
     pc.check_resnet_train_step("cpu", "resnet_h", (2, 64, 64))
+
+
+def test_split_precision_conv(emu):
+    for v in range(4):
+        emu.dream_conv_f16x3_set_variant(v)
+        try:
+            pc.check_conv_f16x3("cpu", 1, 7, 9, 32, 40, 3, 1, seed=v)
+            pc.check_conv_f16x3("cpu", 2, 12, 20, 64, 7, 3, 4, x_scale=300.0, w_scale=1e-3, seed=v)
+            pc.check_conv_f16x3("cpu", 1, 6, 8, 32, 64, 3, 3, x_scale=1e-3, w_scale=5.0, seed=v)
+            pc.check_conv_f16x3("cpu", 2, 9, 11, 64, 48, 1, 0, seed=v)
+        finally:
+            emu.dream_conv_f16x3_set_variant(-1)
+
+
+def test_vgg_q_inference_golden_split_precision(emu):
+    pc.check_model_inference("cpu", "vgg_q", (1, 50, 75), precision="fp16x3")

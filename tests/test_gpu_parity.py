@@ -196,3 +196,48 @@ def test_full_size_peak_stage():
         assert np.array_equal(kps[i][None], op.keypoints_from_belief_maps(maps[i][None, None], 0.4395)[0])
     for i in range(896):
         assert counts[i] == int(op.peak_mask(sm[i]).sum())
+
+
+# ---- split-precision (fp16x3) path ------------------------------------------------------------------------------
+@pytest.mark.parametrize("res,cin,cout,flags", [l for l in VGG_Q_LAYERS if l[1] % 32 == 0])
+def test_split_precision_layer_shapes(res, cin, cout, flags):
+    pc.check_conv_f16x3(DEV, 1, res, res, cin, cout, 3, flags, seed=res + cin)
+
+
+def test_split_precision_variants_and_scales():
+    lib = _hip.lib()
+    for v in range(4):
+        lib.dream_conv_f16x3_set_variant(v)
+        try:
+            pc.check_conv_f16x3(DEV, 2, 33, 47, 64, 96, 3, 1, seed=v)
+            pc.check_conv_f16x3(DEV, 2, 12, 20, 64, 7, 3, 4, x_scale=300.0, w_scale=1e-3, seed=v)
+            pc.check_conv_f16x3(DEV, 1, 26, 38, 32, 64, 3, 3, x_scale=1e-3, w_scale=5.0, seed=v)
+            pc.check_conv_f16x3(DEV, 2, 25, 25, 512, 128, 1, 0, seed=v)
+        finally:
+            lib.dream_conv_f16x3_set_variant(-1)
+
+
+@pytest.mark.parametrize("shape", cases.CNN_CASES["vgg_q"][2])
+def test_vgg_q_inference_golden_split_precision(shape):
+    pc.check_model_inference(DEV, "vgg_q", shape, precision="fp16x3")
+
+
+def test_vgg_f_inference_golden_split_precision():
+    pc.check_model_inference(DEV, "vgg_f", (2, 64, 80), precision="fp16x3")
+
+
+def test_split_precision_vs_fp32_path_full_size():
+    """B=16 of 400x400: the two conv paths must agree far inside the 1e-4 tolerance and give the same detections."""
+    net = pc.build_network("vgg_q", DEV)
+    net.enable_evaluation()
+    x = torch.from_numpy(cases.image_batch(16, 400, 400, seed=5)).to(DEV)
+    with torch.no_grad():
+        m32, k32 = net.inference(x)
+        net.model.module.precision = "fp16x3"
+        m16, k16 = net.inference(x)
+    scale = max(1.0, float(m32.abs().max()))
+    assert float((m32 - m16).abs().max()) <= 0.25 * pc.TOL * scale
+    same = (k32 == -999.999) == (k16 == -999.999)
+    assert same.float().mean() >= 0.97
+    both = (k32 != -999.999) & (k16 != -999.999)
+    assert float((k32 - k16).abs()[both].max()) < 0.05

@@ -56,18 +56,45 @@ def main():
                 row["variants"][name] = {"error": str(err)[:120]}
             finally:
                 lib.dream_conv3x3_set_variant(-1)
+        if cin % 32 == 0 and not (flags & 4 and False):
+            p16 = ops.pack_conv_weight_f16x3(w, 0)
+            amax = ops.absmax(x)
+            for v16 in (-1, 0, 1, 2, 3):
+                lib.dream_conv_f16x3_set_variant(v16)
+                try:
+                    ops.conv2d_f16x3(x, amax, p16, cout, 3, None, bias, None, flags)
+                    torch.cuda.synchronize()
+                    best = 1e9
+                    for _ in range(args.reps):
+                        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        s.record()
+                        ops.conv2d_f16x3(x, amax, p16, cout, 3, None, bias, None, flags)
+                        e.record()
+                        torch.cuda.synchronize()
+                        best = min(best, s.elapsed_time(e))
+                    row["variants"]["f16x3_v%d" % v16] = {"ms": best, "tflops": flops / best / 1e9}
+                except RuntimeError as err:
+                    row["variants"]["f16x3_v%d" % v16] = {"error": str(err)[:120]}
+                finally:
+                    lib.dream_conv_f16x3_set_variant(-1)
         results.append(row)
         line = "%4d %3d->%3d f%d | " % (res, cin, cout, flags) + " ".join(
-            "%s:%5.1f" % (k[:11], v.get("tflops", -1)) for k, v in row["variants"].items())
+            "%s:%5.1f" % (k[-11:], v.get("tflops", -1)) for k, v in row["variants"].items())
         print(line, flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "microbench.json"), "w") as f:
         json.dump({"batch": args.batch, "results": results}, f, indent=1)
     # weighted whole-network estimate with the best variant per layer vs the heuristic
+    t16 = 0.0
+    for r in results:
+        ok16 = [v["ms"] for k, v in r["variants"].items() if k.startswith("f16x3") and "ms" in v]
+        ok32 = [v["ms"] for k, v in r["variants"].items() if not k.startswith("f16x3") and "ms" in v]
+        t16 += (min(ok16) if ok16 else min(ok32)) * r["count"]
+    print("best with f16x3: conv time for %d frames = %.1f ms -> %.0f frames/s (convs only)" % (args.batch, t16, args.batch / t16 * 1e3))
     for pick in ("heuristic", "best"):
         t = 0.0
         for r in results:
-            ok = {k: v for k, v in r["variants"].items() if "ms" in v}
+            ok = {k: v for k, v in r["variants"].items() if "ms" in v and not k.startswith("f16x3")}
             ms = ok["heuristic"]["ms"] if pick == "heuristic" else min(v["ms"] for v in ok.values())
             t += ms * r["count"]
         print("%s: conv time for %d frames = %.1f ms -> %.0f frames/s (convs only)" % (pick, args.batch, t, args.batch / t * 1e3))
@@ -75,3 +102,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+
