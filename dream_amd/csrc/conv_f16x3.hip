@@ -47,13 +47,14 @@ constexpr int S16 = KC + 8;         // LDS row stride in halfs (80 B: odd number
 DREAM_DEVICE float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
 template <int MR, int NR, int WM, int WN, int NPM>
-__global__ void __launch_bounds__(256, 2) conv_f16x3_kernel(const Conv16Params p) {
+__global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv16Params p) {
+    constexpr int NT = 64 * WM * WN;                // 4 or 8 wavefronts per workgroup
     constexpr int BN = 32 * NR * WN;
     constexpr int Q = KC / 4;                       // float4 pieces per patch row
-    constexpr int NA_IT = (NPM * Q + 255) / 256;
+    constexpr int NA_IT = (NPM * Q + NT - 1) / NT;
     constexpr int NB_PIECES = BN * (KC / 8);        // 16-B pieces per weight plane per stage
-    constexpr int NB_IT = (NB_PIECES + 255) / 256;
-    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int NB_IT = (NB_PIECES + NT - 1) / NT;
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 wavefronts per workgroup");
 
     DREAM_DYNAMIC_LDS(_Float16, smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
@@ -86,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3_kernel(const Conv16Params p
     int a_goff[NA_IT], a_soff[NA_IT];
 #pragma unroll
     for (int it = 0; it < NA_IT; ++it) {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NT;
         const int pp = idx / Q, q = idx % Q;
         a_soff[it] = (pp < NP) ? pp * S16 + q * 4 : -1;
         const int py = pp / PW, px = pp - py * PW;
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3_kernel(const Conv16Params p
     int b_goff[NB_IT], b_soff[NB_IT];
 #pragma unroll
     for (int it = 0; it < NB_IT; ++it) {
-        const int idx = tid + it * 256;
+        const int idx = tid + it * NT;
         const int n = idx / (KC / 8), q = idx % (KC / 8);
         b_soff[it] = (idx < NB_PIECES) ? n * S16 + q * 8 : -1;
         b_goff[it] = (n0 + n) * p.Cin + q * 8;
@@ -257,11 +258,7 @@ __global__ void __launch_bounds__(256, 2) conv_f16x3_kernel(const Conv16Params p
             }
         }
     }
-    if (p.amax_out != nullptr) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, lane_xor(amax, m));
-        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(amax));
-    }
+    if (p.amax_out != nullptr) publish_amax(p.amax_out, amax);
 }
 
 // ---- weight packing: amax -> exponent -> two fp16 planes ----------------------------------------------------
@@ -299,22 +296,25 @@ __global__ void __launch_bounds__(256) pack_w16_kernel(const float *w, _Float16 
 
 struct Variant16 {
     const char *name;
-    int BM, BN, NP_MAX;
+    int BM, BN, NP_MAX, threads;
     void (*kernel)(const Conv16Params);
 };
 const Variant16 kVariants16[] = {
-    {"f16x3 m2n2w2x2", 128, 128, 192, conv_f16x3_kernel<2, 2, 2, 2, 192>},
-    {"f16x3 m2n2w4x1", 256, 64, 352, conv_f16x3_kernel<2, 2, 4, 1, 352>},
-    {"f16x3 m2n1w4x1", 256, 32, 352, conv_f16x3_kernel<2, 1, 4, 1, 352>},
-    {"f16x3 m1n2w2x2", 64, 128, 128, conv_f16x3_kernel<1, 2, 2, 2, 128>},
+    {"f16x3 m2n2w2x2", 128, 128, 192, 256, conv_f16x3_kernel<2, 2, 2, 2, 192>},
+    {"f16x3 m2n2w4x1", 256, 64, 352, 256, conv_f16x3_kernel<2, 2, 4, 1, 352>},
+    {"f16x3 m2n1w4x1", 256, 32, 352, 256, conv_f16x3_kernel<2, 1, 4, 1, 352>},
+    {"f16x3 m1n2w2x2", 64, 128, 128, 256, conv_f16x3_kernel<1, 2, 2, 2, 128>},
+    {"f16x3 m2n2w4x2", 256, 128, 352, 512, conv_f16x3_kernel<2, 2, 4, 2, 352>},   // 8 waves, 1 workgroup per CU
+    {"f16x3 m2n2w8x1", 512, 64, 640, 512, conv_f16x3_kernel<2, 2, 8, 1, 640>},    // 512 px x 64 cout
 };
-bool g_attr16[4] = {};
+constexpr int kNum16 = 6;
+bool g_attr16[kNum16] = {};
 int g_forced16 = -1;
 
 void choose_tile16(int H, int W, int BM, int np_max, int lane_stride, int kext, int *th_out, int *tw_out) {
     long best_tiles = -1;
     int best_np = 0, bth = 1, btw = 1;
-    for (int tw = 1; tw <= BM && tw <= 255; ++tw) {
+    for (int tw = 1; tw <= BM && tw <= 127; ++tw) {     // tw < 128 keeps the (m * rcpTW) >> 16 division exact for m < 512
         int th = BM / tw;
         if (th < 1) break;
         if (th > H) th = H;
@@ -333,7 +333,7 @@ void choose_tile16(int H, int W, int BM, int np_max, int lane_stride, int kext, 
 }  // namespace
 
 extern "C" int dream_conv_f16x3_set_variant(int v) {
-    DREAM_REQUIRE(v >= -1 && v < 4, "variant out of range");
+    DREAM_REQUIRE(v >= -1 && v < kNum16, "variant out of range");
     g_forced16 = v;
     return 0;
 }
@@ -389,7 +389,11 @@ extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_
     p.Ho = H; p.Wo = W; p.H = H; p.W = W;
     p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
     const long pixels = (long)B * H * W;
-    int v = g_forced16 >= 0 ? g_forced16 : (Cout > 64 ? (((pixels + 127) / 128) * ceil_div(Cout, 128) < 512 ? 3 : 0) : (Cout > 32 ? 1 : 2));
+    // measured (profiles/r01_microbench_f16x3.txt): the 256-px x 64-cout tile beats 128 x 128 on every layer (the
+    // weight tile is the dominant LDS fill at this MFMA rate and is amortised over twice the pixels)
+    int v = Cout > 32 ? 1 : 2;
+    if (Cout > 64 && ((pixels + 255) / 256) * ceil_div(Cout, 64) < 512) v = 3;       // tiny grids: 64-px tiles
+    if (g_forced16 >= 0) v = g_forced16;
     const Variant16 &var = kVariants16[v];
     DREAM_REQUIRE(CoutPad % var.BN == 0 && CoutPad >= Cout, "CoutPad=%d must be a multiple of %d", CoutPad, var.BN);
     choose_tile16(H, W, var.BM, var.NP_MAX, 1, ksize, &p.TH, &p.TW);
@@ -412,7 +416,7 @@ extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_
         g_attr16[v] = true;
     }
     const dim3 grid((unsigned)((size_t)B * p.tiles_x * p.tiles_y), (unsigned)ceil_div(Cout, var.BN));
-    hipLaunchKernelGGL(var.kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(var.kernel, grid, dim3(var.threads), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -91,11 +91,7 @@ __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p)
             if (ox + 3 < p.W) { dst[(size_t)3 * p.Cout] = acc3; amax = fmaxf(amax, fabsf(acc3)); }
         }
     }
-    if (p.amax_out != nullptr) {
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, lane_xor(amax, m));
-        if (lane == 0) atomicMax(p.amax_out, __float_as_uint(amax));
-    }
+    if (p.amax_out != nullptr) publish_amax(p.amax_out, amax);
 }
 }  // namespace
 

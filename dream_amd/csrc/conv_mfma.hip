@@ -56,13 +56,6 @@ struct ConvParams {
     int flags;
 };
 
-// one atomicMax per wave on the bit pattern (non-negative floats order like unsigned integers)
-DREAM_DEVICE void publish_amax(unsigned *dst, float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, lane_xor(v, m));
-    if ((threadIdx.x & 63) == 0) atomicMax(dst, __float_as_uint(v));
-}
-
 template <int MR, int NR, int WM, int WN, int KC, int NPM>
 struct ConvCfg {
     static constexpr int BM = 32 * MR * WM;

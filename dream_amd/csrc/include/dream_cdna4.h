@@ -43,3 +43,16 @@ DREAM_DEVICE int    popcount64(unsigned long long v) { return __popcll(v); }
 DREAM_DEVICE double dmul(double a, double b) { return __dmul_rn(a, b); }
 DREAM_DEVICE double dadd(double a, double b) { return __dadd_rn(a, b); }
 DREAM_DEVICE double ddiv(double a, double b) { return __ddiv_rn(a, b); }
+
+// amax side channel: wave-reduce max|v| and atomicMax its bit pattern (non-negative floats order like unsigned
+// integers) into one device word.  Same-address atomics serialise in L2 (~12 ns each), so a wave first LOOKS at the
+// current value (relaxed, L2-served) and only issues the atomic when it would raise it: after the first few waves
+// almost nobody does.
+DREAM_DEVICE void publish_amax(unsigned *dst, float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, lane_xor(v, m));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(v);
+        if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+    }
+}

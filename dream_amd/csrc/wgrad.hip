@@ -277,13 +277,14 @@ WgradGeom conv_geom(int H, int W, int ksize, int stride, int flags) {
     return g;
 }
 
-WgradGeom convT4_geom(int H, int W) {
+WgradGeom convT_geom(int H, int W, int k) {
+    // ConvTranspose2d(k, stride 2, pad 1, output 2H x 2W; k = 4, or k = 3 with output_padding 1):
     // dW_T[i][o][ky][kx] = sum_m x[m][i] * dy[2m - 1 + k][o]: tile = x (H x W), patch = dy (2H x 2W), stride-2 taps
     WgradGeom g;
     g.Ht = H; g.Wt = W; g.Hin = 2 * H; g.Win = 2 * W; g.Hs = 2 * H; g.Ws = 2 * W;
-    g.in_scale = 2; g.in_step = 1; g.lane_stride = 2; g.pad = 1; g.kext = 4;
-    g.ntaps = 16;
-    for (int t = 0; t < 16; ++t) { g.tap_dy[t] = t / 4; g.tap_dx[t] = t % 4; }
+    g.in_scale = 2; g.in_step = 1; g.lane_stride = 2; g.pad = 1; g.kext = k;
+    g.ntaps = k * k;
+    for (int t = 0; t < k * k; ++t) { g.tap_dy[t] = t / k; g.tap_dx[t] = t % k; }
     return g;
 }
 
@@ -394,13 +395,22 @@ extern "C" int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, flo
     return dream_conv2d_wgrad_nhwc_f32(x, dy, dw_packed, dbias, workspace, B, H, W, Cin, Cout, CoutPad, 3, 1, flags, stream);
 }
 extern "C" size_t dream_convT4x4_wgrad_workspace(int B, int H, int W, int CinPad, int Cout) {
-    return wgrad_workspace_bytes(B, convT4_geom(H, W), Cout, CinPad);
+    return wgrad_workspace_bytes(B, convT_geom(H, W, 4), Cout, CinPad);
+}
+extern "C" size_t dream_convT_wgrad_workspace(int B, int H, int W, int CinPad, int Cout, int ksize) {
+    return wgrad_workspace_bytes(B, convT_geom(H, W, ksize), Cout, CinPad);
+}
+// ConvTranspose2d(k = 3 (output_padding 1) | 4, stride 2, pad 1) weight gradient -> dw_packed [k*k][CinPad][Cout]
+extern "C" int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
+                                          int H, int W, int Cin, int CinPad, int Cout, int ksize, void *stream) {
+    DREAM_REQUIRE(ksize == 3 || ksize == 4, "convT_wgrad: kernel size %d not supported", ksize);
+    return launch_wgrad(x, dy, dw_packed, nullptr, 0, workspace, B, Cin, CinPad, Cout, convT_geom(H, W, ksize), 0, stream);
 }
 // ConvTranspose2d(k4,s2,p1) weight gradient: x [B,H,W,Cin], dy [B,2H,2W,Cout] -> dw_packed [16][CinPad][Cout]
 // (tap t = ky*4+kx; unpack with dream_unpack_conv_weight(rows = Cin, cols = Cout, ntaps = 16) gives [Cin,Cout,4,4])
 extern "C" int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                              int H, int W, int Cin, int CinPad, int Cout, void *stream) {
-    return launch_wgrad(x, dy, dw_packed, nullptr, 0, workspace, B, Cin, CinPad, Cout, convT4_geom(H, W), 0, stream);
+    return launch_wgrad(x, dy, dw_packed, nullptr, 0, workspace, B, Cin, CinPad, Cout, convT_geom(H, W, 4), 0, stream);
 }
 
 static int first_wgrad_blocks(int B, int H, int W) {

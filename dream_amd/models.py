@@ -136,6 +136,7 @@ class DreamHourglass(nn.Module):
         # "fp32": exact fp32 MFMA kernel everywhere.  "fp16x3": inference runs the split-precision kernel
         # (fp32 in/out, 3 fp16 MFMAs per product, fp32-class error); training always uses the fp32 kernels.
         self.precision = "fp32"
+        self._aux = {}
 
     # ---- helpers -------------------------------------------------------------------------------------
     def _layer(self, cname, child):
@@ -144,6 +145,17 @@ class DreamHourglass(nn.Module):
     def plan_layers(self):
         """[(kind, module-or-None, flags)] in execution order."""
         return [(kind, self._layer(c, ch) if c else None, flags) for kind, c, ch, flags in self._plan]
+
+    def _packed_aux(self, mod):
+        """[Cin_T,Cout_T,3,3] ConvTranspose weight packed as the stride-2 conv that is its data gradient."""
+        key = ("s2", id(mod.weight))
+        tag = (mod.weight._version, mod.weight.data_ptr())
+        hit = self._aux.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad():
+                hit = (tag, ops.pack_conv_weight(mod.weight.detach(), 0))
+            self._aux[key] = hit
+        return hit[1]
 
     def plan_parameters(self):
         out = []
@@ -224,9 +236,16 @@ class DreamHourglass(nn.Module):
             if kind == "pool":
                 g = ops.maxpool2_bwd(g, inp)
                 continue
-            if kind == "deconv":
-                raise NotImplementedError("dream_amd: ConvTranspose backward is not built yet (vgg_f training)")
             pi -= 2
+            if kind == "deconv":
+                # ConvTranspose2d(3,2,1,op 1) + ReLU (models.py:621-686): bias grad = column sums, weight grad over the
+                # stride-2 taps of dy, data grad = the 3x3 stride-2 conv of dy with the (un-flipped) weight
+                g = ops.relu_bwd_(g, out)
+                grads[pi] = ops.convT_wgrad(inp, g, 3)
+                grads[pi + 1] = ops.channel_sum(g)
+                packed_s2, rows_s2, _ = self._packed_aux(mod)
+                g = ops.conv2d(g, packed_s2, rows_s2, 3, 2)
+                continue
             cout, cin = int(mod.weight.shape[0]), int(mod.weight.shape[1])
             if flags & CONV_OUT_NCHW:
                 g = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))   # zero-padded K -> 16k channels

@@ -470,3 +470,18 @@ def conv3x3_first_amax(x_nchw, w_oihw, bias, relu=True):
     call("dream_conv3x3_first_nchw_amax_f32", ptr(x), ptr(w), ptr(bias), ptr(y), ptr(amax), b, h, wd, cin, cout,
          1 if relu else 0, stream())
     return y, amax
+
+
+def convT_wgrad(x_nhwc, dy_nhwc, ksize):
+    """ConvTranspose2d(k=3 (output_padding 1) or 4, stride 2, pad 1) weight gradient -> [Cin,Cout,k,k]."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    cout = int(dy.shape[3])
+    rows_pad = round_up(cin, 64)
+    ws = _workspace(_hip.lib().dream_convT_wgrad_workspace(b, h, w, rows_pad, cout, ksize), x.device)
+    nt = ksize * ksize
+    dwp = torch.empty((nt, rows_pad, cout), dtype=torch.float32, device=x.device)
+    call("dream_convT_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dwp), ptr(ws), b, h, w, cin, rows_pad, cout, ksize, stream())
+    dw = torch.empty((cin, cout, ksize, ksize), dtype=torch.float32, device=x.device)
+    call("dream_unpack_conv_weight", ptr(dwp), ptr(dw), cin, cout, nt, rows_pad, cout, stream())
+    return dw

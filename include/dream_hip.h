@@ -196,6 +196,9 @@ int dream_conv2d_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packe
 size_t dream_convT4x4_wgrad_workspace(int B, int H, int W, int CinPad, int Cout);
 int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                   int H, int W, int Cin, int CinPad, int Cout, void *stream);
+size_t dream_convT_wgrad_workspace(int B, int H, int W, int CinPad, int Cout, int ksize);
+int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
+                               int H, int W, int Cin, int CinPad, int Cout, int ksize, void *stream);
 /* [ntaps][RowsPad][ColsPad] -> [Rows][Cols][ntaps] (OIHW / ConvTranspose [Cin,Cout,kh,kw]) */
 int dream_unpack_conv_weight(const float *packed, float *w, int Rows, int Cols, int ntaps, int RowsPad, int ColsPad,
                              void *stream);

@@ -59,3 +59,11 @@ inline int popcount64(unsigned long long v) { return __popcll(v); }
 inline double dmul(double a, double b) { return a * b; }
 inline double dadd(double a, double b) { return a + b; }
 inline double ddiv(double a, double b) { return a / b; }
+
+inline void publish_amax(unsigned *dst, float v) {
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, lane_xor(v, m));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned bits = __float_as_uint(v);
+        if (bits > __atomic_load_n(dst, __ATOMIC_RELAXED)) atomicMax(dst, bits);
+    }
+}

@@ -440,3 +440,25 @@ def check_resnet_training_ops(dev):
     assert torch.equal(c.cpu(), a + b)
     cs = torch.randn(3, 5, 4, 64)
     assert float((ops.channel_sum(to(dev, cs)).cpu() - cs.sum((0, 1, 2))).abs().max()) < 1e-4
+
+
+def check_vgg_train_grads(dev, arch="vgg_f", shape=(2, 32, 48)):
+    """One training step of a VGG-type network against torch autograd on the CPU oracle (well-conditioned: no BN)."""
+    k = cases.CNN_CASES[arch][0]
+    b, h, w = shape
+    wts = om.recipe_weights(om.build_model(arch, k).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    ref = om.build_model(arch, k)
+    ref.load_state_dict(wts)
+    ref.train()
+    net = build_network(arch, dev, weights=wts, optimizer="sgd", lr=0.0, in_res=(w, h))
+    net.enable_training()
+    out_wh = net.net_output_resolution_from_input_resolution((w, h))
+    x = torch.from_numpy(cases.image_batch(b, h, w, seed=3))
+    t = torch.from_numpy(cases.target_batch(b, k, out_wh, in_wh=(w, h), seed=3))
+    lref = F.mse_loss(ref(x)[0], t)
+    lref.backward()
+    loss = net.train([to(dev, x)], to(dev, t))
+    assert abs(loss.item() - lref.item()) <= 1e-5 * abs(lref.item()) + 1e-9
+    for (name, p1), (_, p2) in zip(ref.named_parameters(), net.model.module.named_parameters()):
+        scale = p1.grad.abs().max().item() + 1e-12
+        assert (p1.grad - p2.grad.cpu()).abs().max().item() <= 1e-3 * scale, name

@@ -92,7 +92,7 @@ def test_resnet_h_train_step(emu):
 
 
 def test_split_precision_conv(emu):
-    for v in range(4):
+    for v in range(6):
         emu.dream_conv_f16x3_set_variant(v)
         try:
             pc.check_conv_f16x3("cpu", 1, 7, 9, 32, 40, 3, 1, seed=v)
@@ -105,3 +105,7 @@ def test_split_precision_conv(emu):
 
 def test_vgg_q_inference_golden_split_precision(emu):
     pc.check_model_inference("cpu", "vgg_q", (1, 50, 75), precision="fp16x3")
+
+
+def test_vgg_f_train_step(emu):
+    pc.check_vgg_train_grads("cpu", "vgg_f", (2, 32, 48))

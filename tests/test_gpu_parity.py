@@ -149,11 +149,21 @@ def test_resnet_f_train_step():
     pc.check_resnet_train_step(DEV, "resnet_f", (2, 64, 64))
 
 
+def test_vgg_f_train_step():
+    pc.check_vgg_train_grads(DEV, "vgg_f", (2, 64, 96))
+
+
 def test_unbuilt_paths_refuse_instead_of_falling_back():
-    net = pc.build_network("vgg_f", DEV)                  # ConvTranspose 3x3 backward is not built yet
-    net.enable_training()
+    import dream_amd
+    for patch in ({"n_stages": 2, "deconv_decoder": False, "full_output": True}, {"skip_connections": True}):
+        cfg = dream_amd.default_network_config("vgg_q")
+        cfg["architecture"].update(patch)
+        with pytest.raises(NotImplementedError):
+            dream_amd.create_network_from_config_data(cfg)
+    cfg = dream_amd.default_network_config("vgg_q")
+    cfg["architecture"]["loss"]["type"] = "huber"
     with pytest.raises(NotImplementedError):
-        net.train([torch.zeros(2, 3, 64, 64, device=DEV)], torch.zeros(2, 7, 64, 64, device=DEV))
+        dream_amd.create_network_from_config_data(cfg)
 
 
 def test_full_size_batch_properties():
@@ -206,7 +216,7 @@ def test_split_precision_layer_shapes(res, cin, cout, flags):
 
 def test_split_precision_variants_and_scales():
     lib = _hip.lib()
-    for v in range(4):
+    for v in range(6):
         lib.dream_conv_f16x3_set_variant(v)
         try:
             pc.check_conv_f16x3(DEV, 2, 33, 47, 64, 96, 3, 1, seed=v)
