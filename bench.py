@@ -191,6 +191,9 @@ def main():
         return dt, ms, fl, len(conv_events), out
 
     dt, conv_ms, conv_flops, n_launch, out_main = timed_region()
+    # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
+    # fp16 MFMA MACs, so its ceiling in ALGORITHMIC flops is the dense fp16 MFMA peak / 3
+    peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" or args.mode == "train" else PEAK_F16_MFMA_TFLOPS / 3.0
 
     # second, informational leg: the same workload on the split-precision conv kernel (fp32 in/out, 3 fp16 MFMAs per
     # product).  The headline `value` stays the exact-fp32 path unless --precision fp16x3 is given explicitly.
