@@ -74,6 +74,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
     const int n0 = blockIdx.y * BN;
     const bool zst = (p.flags & DREAM_CONV_ZEROSTUFF2X) != 0;
     const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0 || zst;
+    const bool pool = (p.flags & DREAM_CONV_POOL2) != 0;
     const float *xb = p.x + (size_t)b * p.Hs * p.Ws * p.Cin;
 
     // input scale: max|x| * 2^ea in [2^13, 2^14)
@@ -111,7 +112,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
     for (int ms = 0; ms < MR; ++ms) {
         int m = (wm * MR + ms) * 32 + li;
         if (m >= p.TH * TW) m = 0;
-        const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+        int ty, tx;
+        tile_xy(m, TW, p.rcpTW, pool, &ty, &tx);
         a_frag[ms] = (ty * PW + tx) * p.lane_stride * S16 + lh * 8;
     }
 #pragma unroll
@@ -237,23 +239,49 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
     float amax = 0.0f;
 #pragma unroll
     for (int ms = 0; ms < MR; ++ms) {
+        if (!pool) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
-            const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
-            const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+                const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
+                const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
 #pragma unroll
-            for (int ns = 0; ns < NR; ++ns) {
-                if (ok && ncol[ns] < p.Cout) {
-                    const size_t o = nchw
-                        ? (((size_t)b * p.Cout + ncol[ns]) * p.Ho + oy) * p.Wo + ox
-                        : (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns];
-                    float v = acc[ms][ns][r] * scale_v[ns] + shift_v[ns];
-                    if (p.residual != nullptr) v = v + p.residual[o];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    p.y[o] = v;
-                    amax = fmaxf(amax, fabsf(v));
+                for (int ns = 0; ns < NR; ++ns) {
+                    if (ok && ncol[ns] < p.Cout) {
+                        const size_t o = nchw
+                            ? (((size_t)b * p.Cout + ncol[ns]) * p.Ho + oy) * p.Wo + ox
+                            : (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns];
+                        float v = acc[ms][ns][r] * scale_v[ns] + shift_v[ns];
+                        if (p.residual != nullptr) v = v + p.residual[o];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        p.y[o] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                }
+            }
+        } else {
+            // fused MaxPool2d(2): registers 4g..4g+3 of a lane are one 2x2 window (window-major tile order)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int m0 = (wm * MR + ms) * 32 + 8 * g4 + 4 * lh;
+                const int q = m0 >> 2, hw = TW >> 1;
+                const int wy = (q * p.rcpTW) >> 16, wx = q - wy * hw;
+                const bool ok = (m0 < npix) && (y0 + 2 * wy + 1 < p.H) && (x0 + 2 * wx + 1 < p.W);
+                const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+#pragma unroll
+                for (int ns = 0; ns < NR; ++ns) {
+                    if (ok && ncol[ns] < p.Cout) {
+                        float best = -__builtin_huge_valf();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[ms][ns][4 * g4 + j] * scale_v[ns] + shift_v[ns];
+                            if (relu) v = fmaxf(v, 0.0f);
+                            best = fmaxf(best, v);
+                        }
+                        p.y[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns]] = best;
+                        amax = fmaxf(amax, fabsf(best));
+                    }
                 }
             }
         }
@@ -311,14 +339,17 @@ constexpr int kNum16 = 6;
 bool g_attr16[kNum16] = {};
 int g_forced16 = -1;
 
-void choose_tile16(int H, int W, int BM, int np_max, int lane_stride, int kext, int *th_out, int *tw_out) {
+void choose_tile16(int H, int W, int BM, int np_max, int lane_stride, int kext, bool even, int *th_out, int *tw_out) {
     long best_tiles = -1;
-    int best_np = 0, bth = 1, btw = 1;
-    for (int tw = 1; tw <= BM && tw <= 127; ++tw) {     // tw < 128 keeps the (m * rcpTW) >> 16 division exact for m < 512
+    int best_np = 0, bth = even ? 2 : 1, btw = even ? 2 : 1;
+    const int He = even ? (H + 1) / 2 * 2 : H, We = even ? (W + 1) / 2 * 2 : W;
+    // divisor (tw, or tw/2 with the fused pool) < 128 keeps the (m * rcpTW) >> 16 division exact for m < 512
+    for (int tw = even ? 2 : 1; tw <= BM && tw <= (even ? 254 : 127); tw += even ? 2 : 1) {
         int th = BM / tw;
+        if (even) th &= ~1;
         if (th < 1) break;
-        if (th > H) th = H;
-        const int twc = tw > W ? W : tw;
+        if (th > He) th = He;
+        const int twc = tw > We ? We : tw;
         const int np = ((th - 1) * lane_stride + kext) * ((twc - 1) * lane_stride + kext);
         if (np > np_max) continue;
         const long tiles = (long)ceil_div(H, th) * ceil_div(W, twc);
@@ -396,10 +427,13 @@ extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_
     if (g_forced16 >= 0) v = g_forced16;
     const Variant16 &var = kVariants16[v];
     DREAM_REQUIRE(CoutPad % var.BN == 0 && CoutPad >= Cout, "CoutPad=%d must be a multiple of %d", CoutPad, var.BN);
-    choose_tile16(H, W, var.BM, var.NP_MAX, 1, ksize, &p.TH, &p.TW);
+    const bool pool = (flags & DREAM_CONV_POOL2) != 0;
+    DREAM_REQUIRE(!pool || (!(flags & DREAM_CONV_OUT_NCHW) && residual == nullptr && H >= 2 && W >= 2), "fused max-pool: NHWC output, no residual");
+    choose_tile16(H, W, var.BM, var.NP_MAX, 1, ksize, pool, &p.TH, &p.TW);
     p.PH = p.TH - 1 + ksize; p.PW = p.TW - 1 + ksize;
     p.tiles_x = ceil_div(W, p.TW); p.tiles_y = ceil_div(H, p.TH);
-    p.rcpTW = (65536 + p.TW - 1) / p.TW;
+    p.rcpTW = pool ? (65536 + p.TW / 2 - 1) / (p.TW / 2) : (65536 + p.TW - 1) / p.TW;
+    if (pool) { p.Ho = H / 2; p.Wo = W / 2; }
     p.in_scale = 1; p.in_step = 1; p.lane_stride = 1; p.pad_y = pad; p.pad_x = pad;
     p.ntaps = ksize * ksize;
     p.tap_dy = 0; p.tap_dx = 0;

@@ -97,6 +97,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     const int n0 = blockIdx.y * BN;
     const bool zst = (p.flags & DREAM_CONV_ZEROSTUFF2X) != 0;
     const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0 || zst;
+    const bool pool = (p.flags & DREAM_CONV_POOL2) != 0;
     const float *xb = p.x + (size_t)b * p.Hs * p.Ws * p.Cin;
 
     // ---- staging plan (fixed for the whole kernel) ---------------------------------------------
@@ -131,7 +132,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     for (int ms = 0; ms < MR; ++ms) {
         int m = (wm * MR + ms) * 32 + li;
         if (m >= p.TH * TW) m = 0;                       // idle rows compute garbage that is never stored
-        const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+        int ty, tx;
+        tile_xy(m, TW, p.rcpTW, pool, &ty, &tx);
         a_frag[ms] = (ty * PW + tx) * p.lane_stride * S + lh * 4;
     }
 #pragma unroll
@@ -236,25 +238,53 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     float amax = 0.0f;
 #pragma unroll
     for (int ms = 0; ms < MR; ++ms) {
+        if (!pool) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
-            const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
-            const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
+            for (int r = 0; r < 16; ++r) {
+                const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+                const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
+                const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
 #pragma unroll
-            for (int ns = 0; ns < NR; ++ns) {
-                if (ok && ncol[ns] < p.Cout) {
-                    const size_t o = nchw
-                        ? (((size_t)b * p.Cout + ncol[ns]) * p.Ho + oy) * p.Wo + ox
-                        : (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns];
-                    float v = acc[ms][ns][r];
-                    if (p.scale != nullptr) v = v * scale_v[ns];
-                    v = v + shift_v[ns];
-                    if (p.residual != nullptr) v = v + p.residual[o];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    p.y[o] = v;
-                    amax = fmaxf(amax, fabsf(v));
+                for (int ns = 0; ns < NR; ++ns) {
+                    if (ok && ncol[ns] < p.Cout) {
+                        const size_t o = nchw
+                            ? (((size_t)b * p.Cout + ncol[ns]) * p.Ho + oy) * p.Wo + ox
+                            : (((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns];
+                        float v = acc[ms][ns][r];
+                        if (p.scale != nullptr) v = v * scale_v[ns];
+                        v = v + shift_v[ns];
+                        if (p.residual != nullptr) v = v + p.residual[o];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        p.y[o] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                }
+            }
+        } else {
+            // fused MaxPool2d(2): registers 4g..4g+3 of a lane are one 2x2 window (window-major tile order)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int m0 = (wm * MR + ms) * 32 + 8 * g4 + 4 * lh;
+                const int q = m0 >> 2, hw = TW >> 1;
+                const int wy = (q * p.rcpTW) >> 16, wx = q - wy * hw;
+                const bool ok = (m0 < npix) && (y0 + 2 * wy + 1 < p.H) && (x0 + 2 * wx + 1 < p.W);
+                const int oy = (y0 >> 1) + wy, ox = (x0 >> 1) + wx;
+#pragma unroll
+                for (int ns = 0; ns < NR; ++ns) {
+                    if (ok && ncol[ns] < p.Cout) {
+                        float best = -__builtin_huge_valf();
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = acc[ms][ns][4 * g4 + j];
+                            if (p.scale != nullptr) v = v * scale_v[ns];
+                            v = v + shift_v[ns];
+                            if (relu) v = fmaxf(v, 0.0f);
+                            best = fmaxf(best, v);
+                        }
+                        p.y[(((size_t)b * p.Ho + oy) * p.Wo + ox) * p.Cout + ncol[ns]] = best;
+                        amax = fmaxf(amax, fabsf(best));
+                    }
                 }
             }
         }
@@ -297,14 +327,16 @@ int g_forced_variant = -1;
 bool g_attr_set[kNumVariants] = {};
 
 // pixel tile: maximise useful rows per workgroup, then minimise the staged patch
-void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, int *th_out, int *tw_out) {
+void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, bool even, int *th_out, int *tw_out) {
     long best_tiles = -1;
-    int best_np = 0, bth = 1, btw = 1;
-    for (int tw = 1; tw <= BM && tw <= 255; ++tw) {
+    int best_np = 0, bth = even ? 2 : 1, btw = even ? 2 : 1;
+    const int He = even ? (H + 1) / 2 * 2 : H, We = even ? (W + 1) / 2 * 2 : W;
+    for (int tw = even ? 2 : 1; tw <= BM && tw <= 127 * (even ? 2 : 1) && tw <= 254; tw += even ? 2 : 1) {
         int th = BM / tw;
+        if (even) th &= ~1;
         if (th < 1) break;
-        if (th > H) th = H;
-        const int twc = tw > W ? W : tw;
+        if (th > He) th = He;
+        const int twc = tw > We ? We : tw;
         const int np = ((th - 1) * lane_stride + kext) * ((twc - 1) * lane_stride + kext);
         if (np > np_max) continue;
         const long tiles = (long)ceil_div(H, th) * ceil_div(W, twc);
@@ -369,13 +401,15 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y; p.amax_out = amax_out;
     p.B = B; p.H = g.H; p.W = g.W; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws; p.Ho = g.Ho; p.Wo = g.Wo;
     p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
-    choose_tile(g.H, g.W, var.BM, var.NP_MAX, g.lane_stride, g.kext, &p.TH, &p.TW);
+    const bool pool = (flags & DREAM_CONV_POOL2) != 0;
+    choose_tile(g.H, g.W, var.BM, var.NP_MAX, g.lane_stride, g.kext, pool, &p.TH, &p.TW);
     p.PH = (p.TH - 1) * g.lane_stride + g.kext;
     p.PW = (p.TW - 1) * g.lane_stride + g.kext;
     DREAM_REQUIRE(p.PH * p.PW <= var.NP_MAX, "internal: patch %dx%d exceeds variant %s", p.PH, p.PW, var.name);
     p.tiles_x = ceil_div(g.W, p.TW);
     p.tiles_y = ceil_div(g.H, p.TH);
-    p.rcpTW = (65536 + p.TW - 1) / p.TW;
+    p.rcpTW = pool ? (65536 + p.TW / 2 - 1) / (p.TW / 2) : (65536 + p.TW - 1) / p.TW;
+    if (pool) { p.Ho = g.H / 2; p.Wo = g.W / 2; }
     p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride; p.pad_y = g.pad; p.pad_x = g.pad;
     p.ntaps = g.ntaps;
     const int S = var.KC + 4;
@@ -426,6 +460,8 @@ static int conv2d_impl(const float *x, const float *w_packed, const float *scale
     // zero-stuffing also accepts an odd extent 2*Hs-1 (data gradient of a stride-2 conv with an odd input)
     DREAM_REQUIRE(!(flags & DREAM_CONV_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample needs even H, W (got %dx%d)", H, W);
     DREAM_REQUIRE(!ups || stride == 1, "fused upsample with a strided conv is not supported");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (stride == 1 && !(flags & DREAM_CONV_OUT_NCHW) && residual == nullptr && H >= 2 && W >= 2),
+                  "fused max-pool: stride 1, NHWC output, no residual");
     ConvGeom g;
     const int pad = ksize / 2;
     g.Hin = H; g.Win = W;

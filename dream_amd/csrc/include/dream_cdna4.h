@@ -56,3 +56,19 @@ DREAM_DEVICE void publish_amax(unsigned *dst, float v) {
         if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
     }
 }
+
+// Position (ty, tx) of tile row m.  Row-major over the TH x TW tile, or -- when the 2x2 max-pool is fused -- window-
+// major: m = 4*window + (dy*2 + dx), so the four accumulator registers (r & 3) of a lane hold exactly one pooling
+// window.  rcp = ceil(65536 / d) with d = TW (row-major) or TW/2 (pool); exact for m < 512, d < 128.
+DREAM_DEVICE void tile_xy(int m, int TW, int rcp, bool pool, int *ty, int *tx) {
+    if (!pool) {
+        const int y = (m * rcp) >> 16;
+        *ty = y;
+        *tx = m - y * TW;
+    } else {
+        const int q = m >> 2, j = m & 3, hw = TW >> 1;
+        const int wy = (q * rcp) >> 16, wx = q - wy * hw;
+        *ty = 2 * wy + (j >> 1);
+        *tx = 2 * wx + (j & 1);
+    }
+}

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, CONV_ZEROSTUFF2X
+from .ops import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, CONV_ZEROSTUFF2X, CONV_POOL2
 from .spatial_softmax import SoftArgmaxPavlo
 
 # (container name, [(child index, cin, cout)]) -- child indices are torchvision's vgg19.features
@@ -181,8 +181,11 @@ class DreamHourglass(nn.Module):
         channel) so the next conv can scale its input into fp16 range; pooling cannot raise the maximum."""
         act, amax = x, None
         pi = 0
-        for kind, mod, flags in self.plan_layers():
+        layers = self.plan_layers()
+        for li, (kind, mod, flags) in enumerate(layers):
             if kind == "pool":
+                if li > 0 and layers[li - 1][0] in ("conv", "deconv"):
+                    continue                         # fused into the previous conv's epilogue
                 act = ops.maxpool2(act)
                 continue
             w, bias = params[pi], params[pi + 1]
@@ -190,6 +193,8 @@ class DreamHourglass(nn.Module):
             if kind == "first":
                 act, amax = ops.conv3x3_first_amax(act, w, bias, relu=bool(flags & CONV_RELU))
             else:
+                if li + 1 < len(layers) and layers[li + 1][0] == "pool":
+                    flags = flags | CONV_POOL2
                 p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
                 act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
                                              want_amax=not (flags & CONV_OUT_NCHW))
@@ -207,11 +212,16 @@ class DreamHourglass(nn.Module):
         saved = []
         act = x
         pi = 0
-        for kind, mod, flags in self.plan_layers():
+        layers = self.plan_layers()
+        for li, (kind, mod, flags) in enumerate(layers):
             inp = act
             if kind == "pool":
+                if not save and li > 0 and layers[li - 1][0] in ("conv", "deconv"):
+                    continue                         # inference: fused into the previous conv's epilogue
                 act = ops.maxpool2(inp)
             else:
+                if not save and kind != "first" and li + 1 < len(layers) and layers[li + 1][0] == "pool":
+                    flags = flags | CONV_POOL2
                 w, bias = params[pi], params[pi + 1]
                 pi += 2
                 if kind == "first":

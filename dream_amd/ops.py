@@ -6,6 +6,7 @@ from . import _hip
 from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream
 
 CONV_ZEROSTUFF2X = 8
+CONV_POOL2 = 16
 
 
 def _f32(t):
@@ -39,6 +40,8 @@ def conv3x3(x_nhwc, packed, bias, cout, flags=0):
     scale = 2 if flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X) else 1
     h, w = hs * scale, ws * scale
     shape = (b, cout, h, w) if flags & CONV_OUT_NCHW else (b, h, w, cout)
+    if flags & CONV_POOL2:
+        shape = (b, h // 2, w // 2, cout)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
     call("dream_conv3x3_nhwc_f32", ptr(x), ptr(packed), ptr(bias), ptr(y), b, h, w, cin, cout,
          int(packed.shape[1]), flags, stream())
@@ -247,6 +250,8 @@ def conv2d(x_nhwc, packed, cout, ksize, stride=1, scale=None, shift=None, residu
     pad = ksize // 2
     ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
     shape = (b, cout, ho, wo) if flags & CONV_OUT_NCHW else (b, ho, wo, cout)
+    if flags & CONV_POOL2:
+        shape = (b, ho // 2, wo // 2, cout)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
     if residual is not None and tuple(residual.shape) != shape:
         raise RuntimeError("conv2d: residual shape %s != output shape %s" % (tuple(residual.shape), shape))
@@ -454,6 +459,8 @@ def conv2d_f16x3(x_nhwc, amax_in, packed16, cout, ksize, scale=None, shift=None,
     if flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X):
         h, w = 2 * h, 2 * w
     shape = (b, cout, h, w) if flags & CONV_OUT_NCHW else (b, h, w, cout)
+    if flags & CONV_POOL2:
+        shape = (b, h // 2, w // 2, cout)
     y = torch.empty(shape, dtype=torch.float32, device=x.device)
     amax_out = new_amax(x.device) if want_amax else None
     call("dream_conv2d_f16x3_nhwc_f32", ptr(x), ptr(amax_in), ptr(hi), ptr(lo), ptr(exp), ptr(scale), ptr(shift),

@@ -37,6 +37,8 @@ extern "C" {
 #define DREAM_CONV_UPSAMPLE2X  2   /* input is [B,H/2,W/2,Cin]; nearest x2 upsample fused into the patch load
                                       (reference: nn.Upsample(scale_factor=2), dream/models.py:691,703) */
 #define DREAM_CONV_OUT_NCHW    4   /* store the result as NCHW (the belief-map head) */
+#define DREAM_CONV_POOL2      16   /* write max-pool-2x2(ReLU(conv)) instead of the conv output: [B,H/2,W/2,Cout] (floor), i.e. the
+                                      following nn.MaxPool2d(2) (dream/models.py:589,765-771) fused into the epilogue */
 #define DREAM_CONV_ZEROSTUFF2X 8   /* input is [B,H/2,W/2,Cin] placed at the even positions of a zero [B,H,W,Cin]
                                       grid: with mode-1 packed weights this is ConvTranspose2d(k=3,s=2,p=1,
                                       output_padding=1) (dream/models.py:621-686) */

@@ -48,6 +48,8 @@ def check_conv(dev, B, H, W, Cin, Cout, flags, seed=0):
     ref = F.conv2d(xr, w, bias, padding=1)
     if flags & ops.CONV_RELU:
         ref = ref.relu()
+    if flags & ops.CONV_POOL2:
+        ref = F.max_pool2d(ref, 2)
     got = y if flags & ops.CONV_OUT_NCHW else y.permute(0, 3, 1, 2)
     err = float((got - ref).abs().max())
     assert err <= tol(ref.numpy()), (B, H, W, Cin, Cout, flags, err)
@@ -215,6 +217,8 @@ def check_conv_f16x3(dev, B, H, W, Cin, Cout, k, flags, x_scale=1.0, w_scale=0.1
     ref = F.conv2d(xr.double(), w.double(), bias.double(), padding=k // 2)
     if flags & ops.CONV_RELU:
         ref = ref.relu()
+    if flags & ops.CONV_POOL2:
+        ref = F.max_pool2d(ref, 2)
     p16 = ops.pack_conv_weight_f16x3(to(dev, w), 0)
     amax_in = ops.absmax(to(dev, x))
     y, amax_out = ops.conv2d_f16x3(to(dev, _nhwc(x)), amax_in, p16, Cout, k, None, to(dev, bias), None, flags)

@@ -109,3 +109,20 @@ def test_vgg_q_inference_golden_split_precision(emu):
 
 def test_vgg_f_train_step(emu):
     pc.check_vgg_train_grads("cpu", "vgg_f", (2, 32, 48))
+
+
+def test_fused_maxpool_epilogue(emu):
+    for v in (0, 1, 3, 8):
+        emu.dream_conv3x3_set_variant(v)
+        try:
+            pc.check_conv("cpu", 2, 12, 20, 32, 48, 1 | 16, seed=v)
+            pc.check_conv("cpu", 1, 13, 9, 64, 32, 1 | 16, seed=v)        # odd extent: floor pooling drops the last row/col
+        finally:
+            emu.dream_conv3x3_set_variant(-1)
+    for v in (0, 1, 2, 4, 5):
+        emu.dream_conv_f16x3_set_variant(v)
+        try:
+            pc.check_conv_f16x3("cpu", 2, 12, 20, 32, 48, 3, 1 | 16, seed=v)
+            pc.check_conv_f16x3("cpu", 1, 13, 9, 64, 32, 3, 1 | 16, seed=v)
+        finally:
+            emu.dream_conv_f16x3_set_variant(-1)

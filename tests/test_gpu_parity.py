@@ -251,3 +251,9 @@ def test_split_precision_vs_fp32_path_full_size():
     assert same.float().mean() >= 0.97
     both = (k32 != -999.999) & (k16 != -999.999)
     assert float((k32 - k16).abs()[both].max()) < 0.05
+
+
+def test_fused_maxpool_epilogue():
+    for (res, cin, cout) in [(400, 64, 64), (200, 128, 128), (100, 256, 256), (50, 512, 512), (37, 64, 96)]:
+        pc.check_conv(DEV, 1, res, res, cin, cout, 1 | 16, seed=res)
+        pc.check_conv_f16x3(DEV, 1, res, res, cin, cout, 3, 1 | 16, seed=res)
