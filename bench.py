@@ -151,10 +151,16 @@ def main():
         return wrapper
 
     # algorithmic FLOPs of one launch = 2 * outputs * (input channels * taps); y is NHWC or NCHW [B,...]
-    ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0: 2.0 * y.numel() * x.shape[3] * 9)
-    ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y.numel() * x.shape[3] * ksize * ksize)
+    def pooled(flags):                    # a fused 2x2 max-pool stores 1/4 of the conv outputs it computed
+        return 4.0 if flags & ops.CONV_POOL2 else 1.0
+
+    ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
+    ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
+                       2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * 16)
-    ops.conv2d_f16x3 = timed(ops.conv2d_f16x3, lambda y, x, amax, p16, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
+    ops.conv2d_f16x3 = timed(ops.conv2d_f16x3,
+                             lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
+                             2.0 * y[0].numel() * pooled(flags) * x.shape[3] * ksize * ksize)
 
     def step():
         if args.mode == "train":

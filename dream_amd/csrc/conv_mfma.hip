@@ -354,9 +354,9 @@ void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, bo
 int pick_variant(long pixels, int Cin, int Cout, bool big_patch) {
     if (big_patch) return 9;
     const bool k32 = (Cin % 32 == 0);
-    // measured on MI355X (profiles/r01_microbench_conv_variants.txt): the KC=16 variants (half the LDS, 3-4
-    // workgroups per CU) win by 3-13 % up to Cin = 256; deeper reductions prefer KC=32 (fewer barriers)
-    const bool prefer16 = Cin <= 256;
+    // measured on MI355X, interleaved A/B at B=128 (profiles/r01_ab_variants_b128.txt): the KC=16 variants (half the
+    // LDS, 3-4 workgroups per CU) win by 1-8 % on every vgg_q layer shape
+    const bool prefer16 = true;
     if (Cout > 64) {
         // enough 128x128 tiles to fill 256 CUs x 2 workgroups?  otherwise the 64-px variant
         const long tiles128 = ((pixels + 127) / 128) * (long)ceil_div(Cout, 128);
