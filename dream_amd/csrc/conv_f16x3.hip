@@ -46,7 +46,7 @@ constexpr int S16 = KC + 8;         // LDS row stride in halfs (80 B: odd number
 
 DREAM_DEVICE float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
-template <int MR, int NR, int WM, int WN, int NPM>
+template <int MR, int NR, int WM, int WN, int NPM, bool PRIO = false>
 __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv16Params p) {
     constexpr int NT = 64 * WM * WN;                // 4 or 8 wavefronts per workgroup
     constexpr int BN = 32 * NR * WN;
@@ -203,6 +203,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
                 wh[ns] = *(const f16x8 *)(bh + b_frag[ns] + kk);
                 wl[ns] = *(const f16x8 *)(bl + b_frag[ns] + kk);
             }
+            if (PRIO) __builtin_amdgcn_s_setprio(1);     // co-resident waves of the other workgroup are in their load phase
 #pragma unroll
             for (int ms = 0; ms < MR; ++ms)
 #pragma unroll
@@ -211,6 +212,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
                     acc[ms][ns] = mfma_f32_32x32x16_f16(ah[ms], wl[ns], acc[ms][ns]);
                     acc[ms][ns] = mfma_f32_32x32x16_f16(ah[ms], wh[ns], acc[ms][ns]);
                 }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
 
         if (have_next) store_b(buf ^ 1);
@@ -334,8 +336,10 @@ const Variant16 kVariants16[] = {
     {"f16x3 m1n2w2x2", 64, 128, 128, 256, conv_f16x3_kernel<1, 2, 2, 2, 128>},
     {"f16x3 m2n2w4x2", 256, 128, 352, 512, conv_f16x3_kernel<2, 2, 4, 2, 352>},   // 8 waves, 1 workgroup per CU
     {"f16x3 m2n2w8x1", 512, 64, 640, 512, conv_f16x3_kernel<2, 2, 8, 1, 640>},    // 512 px x 64 cout
+    {"f16x3 m2n2w4x1 prio", 256, 64, 352, 256, conv_f16x3_kernel<2, 2, 4, 1, 352, true>},   // A/B arm: s_setprio around the MFMAs
+    {"f16x3 m2n2w4x2 prio", 256, 128, 352, 512, conv_f16x3_kernel<2, 2, 4, 2, 352, true>},
 };
-constexpr int kNum16 = 6;
+constexpr int kNum16 = 8;
 bool g_attr16[kNum16] = {};
 int g_forced16 = -1;
 

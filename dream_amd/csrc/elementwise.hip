@@ -193,6 +193,24 @@ __global__ void __launch_bounds__(256) mse_kernel(const float *o, const float *t
     if (threadIdx.x == 0) atomicAdd(loss_sum, (float)(part[0] + part[1] + part[2] + part[3]));
 }
 
+// SmoothL1Loss (beta = 1, mean): 0.5 d^2 for |d| < 1 else |d| - 0.5;  gradient d or sign(d), times 1/N
+__global__ void __launch_bounds__(256) smoothl1_kernel(const float *o, const float *t, float *g, float *loss_sum,
+                                                       size_t n, float scale) {
+    __shared__ double part[4];
+    double acc = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float d = o[i] - t[i];
+        const float ad = fabsf(d);
+        acc += ad < 1.0f ? 0.5 * (double)d * (double)d : (double)ad - 0.5;
+        if (g) g[i] = (ad < 1.0f ? d : (d > 0.0f ? 1.0f : -1.0f)) * scale;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) acc += lane_xor(acc, m);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_sum, (float)(part[0] + part[1] + part[2] + part[3]));
+}
+
 // ---- optimizers ------------------------------------------------------------------------------------
 // torch.optim.Adam defaults (no weight decay, no amsgrad):  m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2
 // p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
@@ -494,6 +512,14 @@ extern "C" int dream_mse_fwd_bwd_f32(const float *out, const float *target, floa
     DREAM_REQUIRE(out && target && loss_sum && n > 0 && n_total > 0, "mse: bad arguments");
     hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, target, grad, loss_sum,
                        n, (float)(2.0 / n_total));
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_smoothl1_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+                                          size_t n, double n_total, void *stream) {
+    DREAM_REQUIRE(out && target && loss_sum && n > 0 && n_total > 0, "smoothl1: bad arguments");
+    hipLaunchKernelGGL(smoothl1_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, target, grad, loss_sum,
+                       n, (float)(1.0 / n_total));
     DREAM_LAUNCH_OK();
     return 0;
 }

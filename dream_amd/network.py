@@ -23,7 +23,7 @@ import torch
 from PIL import Image as PILImage
 
 from . import image_proc, models, ops
-from .optim import HipAdam, HipSGD, HipMSELoss
+from .optim import HipAdam, HipSGD, HipMSELoss, HipSmoothL1Loss
 
 KNOWN_ARCHITECTURES = ["vgg", "resnet"]
 KNOWN_OPTIMIZERS = ["adam", "sgd"]
@@ -190,7 +190,7 @@ class DreamNetwork:
         if loss_type == "mse":
             self.criterion = HipMSELoss()
         elif loss_type == "huber":
-            raise NotImplementedError("dream_amd: the Huber (SmoothL1) loss kernel is not built yet")
+            self.criterion = HipSmoothL1Loss()
         else:
             assert False, "Loss not yet implemented."
 

@@ -135,15 +135,17 @@ def softargmax(maps_bkhw, beta, size_mult=1.0):
 
 
 # ---- training operators -------------------------------------------------------------------------------
-def mse_fwd_bwd(out, target, want_grad=True):
-    """Returns (loss 0-dim tensor, grad or None): mean((o-t)^2) and 2(o-t)/N."""
+def mse_fwd_bwd(out, target, want_grad=True, kind="mse"):
+    """Returns (loss 0-dim tensor, grad or None): mean((o-t)^2) and 2(o-t)/N  (kind "mse"), or the SmoothL1 (beta 1)
+    mean loss and its gradient (kind "huber")."""
     o, t = _f32(out), _f32(target)
     if o.shape != t.shape:
-        raise RuntimeError("mse: shape mismatch %s vs %s" % (tuple(o.shape), tuple(t.shape)))
+        raise RuntimeError("loss: shape mismatch %s vs %s" % (tuple(o.shape), tuple(t.shape)))
     n = o.numel()
     loss_sum = torch.zeros((1,), dtype=torch.float32, device=o.device)
     grad = torch.empty_like(o) if want_grad else None
-    call("dream_mse_fwd_bwd_f32", ptr(o), ptr(t), ptr(grad), ptr(loss_sum), n, float(n), stream())
+    fn = "dream_mse_fwd_bwd_f32" if kind == "mse" else "dream_smoothl1_fwd_bwd_f32"
+    call(fn, ptr(o), ptr(t), ptr(grad), ptr(loss_sum), n, float(n), stream())
     return loss_sum[0] / n, grad
 
 

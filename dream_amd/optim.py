@@ -9,7 +9,7 @@ from . import ops
 class _MSEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, out, target):
-        loss, grad = ops.mse_fwd_bwd(out.detach(), target.detach(), want_grad=out.requires_grad)
+        loss, grad = ops.mse_fwd_bwd(out.detach(), target.detach(), want_grad=out.requires_grad, kind="mse")
         ctx.grad = grad
         return loss
 
@@ -25,6 +25,27 @@ class HipMSELoss(torch.nn.Module):
 
     def forward(self, input, target):
         return _MSEFunction.apply(input, target)
+
+
+class _SmoothL1Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, target):
+        loss, grad = ops.mse_fwd_bwd(out.detach(), target.detach(), want_grad=out.requires_grad, kind="huber")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        ctx.grad = None
+        return (grad * g if grad is not None else None), None
+
+
+class HipSmoothL1Loss(torch.nn.Module):
+    """torch.nn.SmoothL1Loss() (beta 1, mean) -- the reference's "huber" loss type (dream/network.py:262-263)."""
+
+    def forward(self, input, target):
+        return _SmoothL1Function.apply(input, target)
 
 
 class HipAdam(torch.optim.Optimizer):

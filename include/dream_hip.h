@@ -175,6 +175,9 @@ int dream_softargmax_f32(const float *maps, const float *beta, float *scratch, f
  * loss_sum[0] += sum((o-t)^2) (caller zeroes it and divides by n_total); grad = 2*(o-t)/n_total. */
 int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
                           size_t n, double n_total, void *stream);
+/* SmoothL1Loss(beta 1, mean) = the "huber" loss type (dream/network.py:262-263,290-291): same contract as the MSE */
+int dream_smoothl1_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+                               size_t n, double n_total, void *stream);
 /* elementwise ReLU backward on NHWC tensors: dx = dy * (y > 0) (inplace allowed) */
 int dream_relu_bwd_f32(const float *dy, const float *y, float *dx, size_t n, void *stream);
 /* MaxPool2d(2) backward: dy [B,H/2,W/2,C], x [B,H,W,C] (forward input), dx [B,H,W,C];

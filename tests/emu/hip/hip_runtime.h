@@ -131,6 +131,7 @@ inline unsigned atomicMax(unsigned *p, unsigned v) {
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     return old;
 }
+inline void __builtin_amdgcn_s_setprio(int) {}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline double __dmul_rn(double a, double b) { return a * b; }
 inline double __dadd_rn(double a, double b) { return a + b; }

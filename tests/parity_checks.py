@@ -14,6 +14,7 @@ import torch.nn.functional as F
 import cases
 from dream_amd import ops
 import dream_amd
+import dream_amd.optim
 from oracle import models as om
 from oracle import peaks as op
 
@@ -325,6 +326,15 @@ def check_backward_ops(dev):
     l, gr = ops.mse_fwd_bwd(to(dev, o), to(dev, t))
     assert abs(l.item() - F.mse_loss(o, t).item()) < 1e-6
     assert float((gr.cpu() - 2 * (o - t) / o.numel()).abs().max()) < 1e-7
+    o2 = (o * 2).requires_grad_()
+    lh = F.smooth_l1_loss(o2, t)
+    lh.backward()
+    l, gr = ops.mse_fwd_bwd(to(dev, o2.detach()), to(dev, t), kind="huber")
+    assert abs(l.item() - lh.item()) < 1e-6 and float((gr.cpu() - o2.grad).abs().max()) < 1e-7
+    crit = dream_amd.optim.HipSmoothL1Loss()
+    o3 = to(dev, (o * 2)).requires_grad_()
+    crit(o3, to(dev, t)).backward()
+    assert float((o3.grad.cpu() - o2.grad).abs().max()) < 1e-7
 
 
 def check_resnet_train_step(dev, arch="resnet_h", shape=(2, 64, 64), steps=1):

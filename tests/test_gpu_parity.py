@@ -162,8 +162,7 @@ def test_unbuilt_paths_refuse_instead_of_falling_back():
             dream_amd.create_network_from_config_data(cfg)
     cfg = dream_amd.default_network_config("vgg_q")
     cfg["architecture"]["loss"]["type"] = "huber"
-    with pytest.raises(NotImplementedError):
-        dream_amd.create_network_from_config_data(cfg)
+    assert type(dream_amd.create_network_from_config_data(cfg).criterion).__name__ == "HipSmoothL1Loss"
 
 
 def test_full_size_batch_properties():

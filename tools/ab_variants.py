@@ -33,5 +33,32 @@ def main():
         print("%4d %3d->%3d | " % (res, cin, cout) + "  ".join("%s: %.3f ms (%.1f TF)" % (lib.dream_conv3x3_variant_name(v).decode(), statistics.median(t), flops / statistics.median(t) / 1e9) for v, t in times.items()), flush=True)
         del x
 
+def main16():
+    """f16x3 arms: 256x64 tile vs 8-wave 256x128 vs the s_setprio builds of both."""
+    lib = _hip.lib()
+    for (res, cin, cout, flags) in LAYERS:
+        x = torch.randn(128, res, res, cin, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        bias = torch.randn(cout, device="cuda")
+        p16 = ops.pack_conv_weight_f16x3(w, 0)
+        amax = ops.absmax(x)
+        arms = [1, 6, 4, 7] if cout > 64 else [1, 6, 5]
+        flops = 2.0 * 128 * res * res * cin * cout * 9
+        times = {v: [] for v in arms}
+        for r in range(6):
+            for v in arms:
+                lib.dream_conv_f16x3_set_variant(v)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record(); ops.conv2d_f16x3(x, amax, p16, cout, 3, None, bias, None, flags); e.record(); torch.cuda.synchronize()
+                if r > 0: times[v].append(s.elapsed_time(e))
+        lib.dream_conv_f16x3_set_variant(-1)
+        print("f16x3 %4d %3d->%3d | " % (res, cin, cout) + "  ".join("v%d: %.3f ms (%.0f TF)" % (v, statistics.median(t), flops / statistics.median(t) / 1e9) for v, t in times.items()), flush=True)
+        del x
+
+
 if __name__ == "__main__":
-    main()
+    if "--f16x3" in sys.argv:
+        sys.argv.remove("--f16x3")
+        main16()
+    else:
+        main()
