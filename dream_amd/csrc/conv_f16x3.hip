@@ -427,6 +427,9 @@ extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_
     // measured (profiles/r01_microbench_f16x3.txt): the 256-px x 64-cout tile beats 128 x 128 on every layer (the
     // weight tile is the dominant LDS fill at this MFMA rate and is amortised over twice the pixels)
     int v = Cout > 32 ? 1 : 2;
+    // interleaved A/B at B=128 (profiles/r01_ab_f16x3_b128.txt): from 128 channels on, the 8-wave 256 x 128 tile with
+    // s_setprio around the MFMA cluster wins by 1-5 %; s_setprio alone on the 4-wave tile loses 2-5 %
+    if (Cout >= 128 && Cin >= 128) v = 7;
     if (Cout > 64 && ((pixels + 255) / 256) * ceil_div(Cout, 64) < 512) v = 3;       // tiny grids: 64-px tiles
     if (g_forced16 >= 0) v = g_forced16;
     const Variant16 &var = kVariants16[v];

@@ -27,7 +27,7 @@ def _setup_paths():
             sys.path.insert(0, p)
 
 
-def _train_once(x, t, steps=2):
+def _train_once(x, t, steps=1):
     import cases
     import parity_checks as pc
     from oracle import models as om
@@ -42,7 +42,8 @@ def _worker(rank, world, port, out_dir):
     _setup_paths()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=10))
     import cases
     from emu_util import emulated_hip
     x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=9))
@@ -56,6 +57,9 @@ def _worker(rank, world, port, out_dir):
 
 def test_allreduce_gradients_two_ranks(tmp_path):
     _setup_paths()
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    import build_emu
+    build_emu.build()                      # build the emulated kernels once, before the two ranks need them
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
