@@ -105,3 +105,37 @@ def convert_keypoints_to_raw_from_netin(keypoints_netin, net_input_resolution, i
     (cw, ch), (x0, y0) = shrink_and_crop_resolution(image_raw_resolution, net_input_resolution)
     return np.stack([k[:, 0] / net_input_resolution[0] * cw + x0,
                      k[:, 1] / net_input_resolution[1] * ch + y0], axis=1)
+
+
+# ---- the steps right before the hot path, on the device ---------------------------------------
+def normalize_images_u8(images_u8_bhwc, mean, stdev):
+    """uint8 RGB frames [B,H,W,3] (device) -> normalised fp32 [B,3,H,W]: ToTensor + Normalize(mean, stdev) as the
+    dataset does (dream/datasets.py:87-94), bit-identical to the torchvision transforms, without the 4x larger fp32
+    upload."""
+    import ctypes
+    x = _hip.device_tensor(images_u8_bhwc)
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3, "expected uint8 [B,H,W,3]"
+    x = x.contiguous()
+    b, h, w = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+    out = torch.empty((b, 3, h, w), dtype=torch.float32, device=x.device)
+    m = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s = (ctypes.c_float * 3)(*[float(v) for v in stdev])
+    _hip.call("dream_normalize_u8_hwc_to_chw_f32", ops.ptr(x), ops.ptr(out), b, h, w, m, s, ops.stream())
+    return out
+
+
+def create_belief_map_batch(image_resolution, keypoints_bk2, sigma=2):
+    """Batched, on-device create_belief_map (dream/image_proc.py:866-910): keypoints [B,K,2] (x, y) in the belief-map
+    frame -> fp32 [B,K,H,W], bit-identical to torch.tensor(create_belief_map(res, kps)).float() per frame."""
+    assert len(image_resolution) == 2, \
+        'Expected "image_resolution" to have length 2, but it has length {}.'.format(len(image_resolution))
+    width, height = int(image_resolution[0]), int(image_resolution[1])
+    kps = _hip.device_tensor(torch.as_tensor(keypoints_bk2, dtype=torch.float32)).contiguous()
+    b, k = int(kps.shape[0]), int(kps.shape[1])
+    w = int(sigma * 2)
+    dy, dx = np.mgrid[-w:w + 1, -w:w + 1]
+    blob64 = np.exp(-((dx ** 2 + dy ** 2) / (2 * (sigma ** 2))))           # float64, as the reference computes it
+    blob = torch.from_numpy(blob64.astype(np.float32)).to(kps.device)        # the .float() cast of the reference
+    out = torch.empty((b, k, height, width), dtype=torch.float32, device=kps.device)
+    _hip.call("dream_create_belief_maps_f32", ops.ptr(kps), ops.ptr(blob), ops.ptr(out), b * k, height, width, w, ops.stream())
+    return out

@@ -170,6 +170,15 @@ int dream_gaussian_sigma3_f32(const float *maps, float *tmp, float *out, int N, 
 int dream_softargmax_f32(const float *maps, const float *beta, float *scratch, float *out,
                          int N, int K, int H, int W, float size_mult, void *stream);
 
+/* ---- the steps right before the path, on the device ------------------------------------------
+ * ToTensor + Normalize of uint8 RGB frames [B,H,W,3] -> fp32 [B,3,H,W] (dream/datasets.py:87-94; mean3/stdev3 are HOST
+ * pointers to 3 floats), and create_belief_map (dream/image_proc.py:866-910) for N = B*K keypoints: kps [N,2] (x,y),
+ * blob = the (2w+1)^2 Gaussian window computed on the host exactly as the reference does, out [N,H,W]. */
+int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float *out, int B, int H, int W,
+                                      const float *mean3, const float *stdev3, void *stream);
+int dream_create_belief_maps_f32(const float *kps, const float *blob, float *out, int N, int H, int W, int w,
+                                 void *stream);
+
 /* ---- training operators --------------------------------------------------------------------------
  * MSELoss(mean) forward + gradient (dream/network.py:260-261,359; loss.backward() at :335):
  * loss_sum[0] += sum((o-t)^2) (caller zeroes it and divides by n_total); grad = 2*(o-t)/n_total. */

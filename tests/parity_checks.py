@@ -482,3 +482,23 @@ def check_vgg_train_grads(dev, arch="vgg_f", shape=(2, 32, 48)):
         scale = g1.abs().max().item() + 1e-12
         assert (g1 - g2).abs().max().item() <= 2e-2 * scale, name
         assert float((g1 * g2).sum() / (g1.norm() * g2.norm() + 1e-300)) >= 0.9999, name
+
+
+def check_dataprep(dev):
+    """On-device ToTensor+Normalize and create_belief_map are bit-identical to the reference semantics."""
+    rs = np.random.RandomState(4)
+    u8 = rs.randint(0, 256, (3, 37, 41, 3)).astype(np.uint8)
+    mean, std = [0.5, 0.4, 0.6], [0.5, 0.25, 0.3]
+    got = dream_amd.image_proc.normalize_images_u8(to(dev, torch.from_numpy(u8)), mean, std).cpu()
+    ref = torch.from_numpy(u8).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    ref = (ref - torch.tensor(mean).view(1, 3, 1, 1)) / torch.tensor(std).view(1, 3, 1, 1)     # torchvision Normalize
+    assert torch.equal(got, ref)
+    assert torch.equal(dream_amd.image_proc.normalize_images_u8(to(dev, torch.from_numpy(u8[:1])), [0.5] * 3, [0.5] * 3).cpu()[0],
+                       torch.from_numpy(cases.image_batch(1, 37, 41, seed=4)[0]) * 0 + ((torch.from_numpy(u8[0]).permute(2, 0, 1).float() / 255 - 0.5) / 0.5))
+    kps = np.array([[[65.0, 20.0], [100.0, 80.0], [4.0, 4.0], [3.9, 10.0], [74.9, 55.2], [75.0, 30.0], [-0.5, 20.0]],
+                    [[10.2, 10.7], [40.0, 54.0], [40.0, 55.0], [12.0, 4.0], [12.0, 3.99], [79.0, 59.0], [30.5, 30.5]]], np.float32)
+    got = dream_amd.image_proc.create_belief_map_batch((80, 60), to(dev, torch.from_numpy(kps))).cpu()
+    for b in range(2):
+        ref = torch.tensor(op.create_belief_map((80, 60), kps[b])).float()
+        assert torch.equal(got[b], ref), b
+    assert float(got[0, 0].max()) == 1.0 and float(got[0, 1].abs().max()) == 0.0 and float(got[0, 6].abs().max()) == 0.0

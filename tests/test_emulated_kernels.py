@@ -126,3 +126,7 @@ def test_fused_maxpool_epilogue(emu):
             pc.check_conv_f16x3("cpu", 1, 13, 9, 64, 32, 3, 1 | 16, seed=v)
         finally:
             emu.dream_conv_f16x3_set_variant(-1)
+
+
+def test_on_device_dataprep(emu):
+    pc.check_dataprep("cpu")

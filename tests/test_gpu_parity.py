@@ -256,3 +256,7 @@ def test_fused_maxpool_epilogue():
     for (res, cin, cout) in [(400, 64, 64), (200, 128, 128), (100, 256, 256), (50, 512, 512), (37, 64, 96)]:
         pc.check_conv(DEV, 1, res, res, cin, cout, 1 | 16, seed=res)
         pc.check_conv_f16x3(DEV, 1, res, res, cin, cout, 3, 1 | 16, seed=res)
+
+
+def test_on_device_dataprep():
+    pc.check_dataprep(DEV)
