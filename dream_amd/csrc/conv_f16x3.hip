@@ -44,9 +44,6 @@ namespace {
 constexpr int KC = 32;              // k's per stage (two 32x32x16 MFMA k-steps)
 constexpr int S16 = KC + 8;         // LDS row stride in halfs (80 B: odd number of 16-B slots)
 
-template <int V>
-struct RegSet { static constexpr int value = V; };   // compile-time tag: which register set a staging call touches
-
 DREAM_DEVICE float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 
 template <int MR, int NR, int WM, int WN, int NPM, bool PRIO = false>
@@ -131,7 +128,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
             for (int r = 0; r < 16; ++r) acc[ms][ns][r] = 0.0f;
 
     f32x4 a_reg[NA_IT];
-    f16x8 bh_reg[2][NB_IT], bl_reg[2][NB_IT];        // two register sets: weight tiles are fetched TWO stages ahead
+    f16x8 bh_reg[NB_IT], bl_reg[NB_IT];
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
     auto load_a = [&](int c0) {
@@ -155,50 +152,40 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
             }
         }
     };
-    const int ntaps = p.ntaps, nchunks = p.Cin / KC, nstages = nchunks * ntaps;
-    // stage index -> weight tile address (stage = chunk * ntaps + tap)
-    auto load_b = [&](auto SETC, int stage) {
-        constexpr int SET = decltype(SETC)::value;
-        const int ch = stage / ntaps, tp = stage - ch * ntaps;
-        const size_t base = (size_t)tp * w_tap_stride + (size_t)ch * KC;
+    auto load_b = [&](int tap, int c0) {
+        const size_t base = (size_t)tap * w_tap_stride + c0;
 #pragma unroll
         for (int it = 0; it < NB_IT; ++it)
             if (b_soff[it] >= 0) {
-                bh_reg[SET][it] = *(const f16x8 *)(p.w_hi + base + b_goff[it]);
-                bl_reg[SET][it] = *(const f16x8 *)(p.w_lo + base + b_goff[it]);
+                bh_reg[it] = *(const f16x8 *)(p.w_hi + base + b_goff[it]);
+                bl_reg[it] = *(const f16x8 *)(p.w_lo + base + b_goff[it]);
             }
     };
-    auto store_b = [&](auto SETC, int buf) {
-        constexpr int SET = decltype(SETC)::value;
+    auto store_b = [&](int buf) {
         _Float16 *dh = sB + (buf * 2 + 0) * BN * S16, *dl = sB + (buf * 2 + 1) * BN * S16;
 #pragma unroll
         for (int it = 0; it < NB_IT; ++it)
             if (b_soff[it] >= 0) {
-                *(f16x8 *)(dh + b_soff[it]) = bh_reg[SET][it];
-                *(f16x8 *)(dl + b_soff[it]) = bl_reg[SET][it];
+                *(f16x8 *)(dh + b_soff[it]) = bh_reg[it];
+                *(f16x8 *)(dl + b_soff[it]) = bl_reg[it];
             }
     };
-    using Set0 = RegSet<0>;
-    using Set1 = RegSet<1>;
 
-    // prologue: patch of chunk 0, weight tiles of stages 0 (-> LDS) and 1 (stays in registers)
+    const int nchunks = p.Cin / KC;
     load_a(0);
-    load_b(Set0{}, 0);
-    if (nstages > 1) load_b(Set1{}, 1);
+    load_b(0, 0);
     store_a();
-    store_b(Set0{}, 0);
+    store_b(0);
     __syncthreads();
 
-    int tap = 0, chunk = 0;
-    // the next chunk's patch is requested a few stages before it is needed (global latency >> one 768-cycle stage)
-    const int a_issue_tap = ntaps >= 3 ? ntaps - 3 : 0;
-    // one stage; CUR = register set that will receive the tile of stage st + 2, the other set holds stage st + 1
-    auto stage = [&](auto CURC, auto NXTC, int st) {
-        const int buf = st & 1;
+    int buf = 0, tap = 0, chunk = 0;
+    const int ntaps = p.ntaps, nstages = nchunks * ntaps;
+    for (int st = 0; st < nstages; ++st) {
         const bool last_tap = (tap == ntaps - 1);
         const bool more_chunks = (chunk + 1 < nchunks);
-        if (st + 2 < nstages) load_b(CURC, st + 2);
-        if (tap == a_issue_tap && more_chunks) load_a((chunk + 1) * KC);
+        const bool have_next = (st + 1 < nstages);
+        if (have_next) load_b(last_tap ? 0 : tap + 1, last_tap ? (chunk + 1) * KC : chunk * KC);
+        if (last_tap && more_chunks) load_a((chunk + 1) * KC);
 
         const int tdy = (int)((p.tap_dy >> (4 * tap)) & 15), tdx = (int)((p.tap_dx >> (4 * tap)) & 15);
         const int toff = (tdy * PW + tdx) * S16;
@@ -217,33 +204,25 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
                 wl[ns] = *(const f16x8 *)(bl + b_frag[ns] + kk);
             }
             if (PRIO) __builtin_amdgcn_s_setprio(1);     // co-resident waves of the other workgroup are in their load phase
-            // term-major order: consecutive MFMAs hit different accumulators (no back-to-back dependent pairs)
 #pragma unroll
             for (int ms = 0; ms < MR; ++ms)
 #pragma unroll
-                for (int ns = 0; ns < NR; ++ns) acc[ms][ns] = mfma_f32_32x32x16_f16(al[ms], wh[ns], acc[ms][ns]);
-#pragma unroll
-            for (int ms = 0; ms < MR; ++ms)
-#pragma unroll
-                for (int ns = 0; ns < NR; ++ns) acc[ms][ns] = mfma_f32_32x32x16_f16(ah[ms], wl[ns], acc[ms][ns]);
-#pragma unroll
-            for (int ms = 0; ms < MR; ++ms)
-#pragma unroll
-                for (int ns = 0; ns < NR; ++ns) acc[ms][ns] = mfma_f32_32x32x16_f16(ah[ms], wh[ns], acc[ms][ns]);
+                for (int ns = 0; ns < NR; ++ns) {
+                    acc[ms][ns] = mfma_f32_32x32x16_f16(al[ms], wh[ns], acc[ms][ns]);
+                    acc[ms][ns] = mfma_f32_32x32x16_f16(ah[ms], wl[ns], acc[ms][ns]);
+                    acc[ms][ns] = mfma_f32_32x32x16_f16(ah[ms], wh[ns], acc[ms][ns]);
+                }
             if (PRIO) __builtin_amdgcn_s_setprio(0);
         }
 
-        if (st + 1 < nstages) store_b(NXTC, buf ^ 1);    // tile of stage st+1: requested during stage st-1
+        if (have_next) store_b(buf ^ 1);
         if (last_tap && more_chunks) {
-            __syncthreads();                              // every wave is done with this chunk's patch
+            __syncthreads();
             store_a();
         }
         __syncthreads();
+        buf ^= 1;
         if (last_tap) { tap = 0; ++chunk; } else ++tap;
-    };
-    for (int st = 0; st < nstages; st += 2) {
-        stage(Set0{}, Set1{}, st);
-        if (st + 1 < nstages) stage(Set1{}, Set0{}, st + 1);
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------------
