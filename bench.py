@@ -158,6 +158,8 @@ def main():
     ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
                        2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * 16)
+    ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 16)
+    ops.conv2d_amax = timed(ops.conv2d_amax, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
     ops.conv2d_f16x3 = timed(ops.conv2d_f16x3,
                              lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
                              2.0 * y[0].numel() * pooled(flags) * x.shape[3] * ksize * ksize)
@@ -204,7 +206,7 @@ def main():
     # second, informational leg: the same workload on the split-precision conv kernel (fp32 in/out, 3 fp16 MFMAs per
     # product).  The headline `value` stays the exact-fp32 path unless --precision fp16x3 is given explicitly.
     split = None
-    if args.mode == "inference" and args.precision == "fp32" and args.arch.startswith("vgg") and not args.no_split_leg:
+    if args.mode == "inference" and args.precision == "fp32" and not args.no_split_leg:
         net.model.module.precision = "fp16x3"
         dt2, ms2, fl2, n2, out2 = timed_region()
         net.model.module.precision = "fp32"

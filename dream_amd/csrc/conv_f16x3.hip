@@ -403,27 +403,25 @@ extern "C" int dream_pack_conv_weight_f16x3(const float *w_oihw, void *hi, void 
     return 0;
 }
 
-// k x k (1 | 3) / stride (1 | 2) conv, same contract as dream_conv2d_nhwc_f32, on the split-precision path.
-// amax_in: device scalar with the bit pattern of max|x| (from the producer's amax_out or dream_absmax_f32);
-// amax_out: optional, atomicMax of max|y| (caller zeroes it).  Cin % 32 == 0.
-extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi, const void *w_lo,
-                                           const int *w_exp, const float *scale, const float *shift, const float *residual,
-                                           float *y, unsigned *amax_out, int B, int H, int W, int Cin, int Cout, int CoutPad,
-                                           int ksize, int stride, int flags, void *stream) {
-    DREAM_REQUIRE(x && amax_in && w_hi && w_lo && w_exp && y, "conv2d_f16x3: null pointer");
-    DREAM_REQUIRE(ksize == 1 || ksize == 3, "conv2d_f16x3: kernel size %d not supported", ksize);
-    DREAM_REQUIRE(stride == 1, "conv2d_f16x3: stride %d not supported yet", stride);
-    DREAM_REQUIRE(Cin % KC == 0, "conv2d_f16x3: Cin=%d must be a multiple of %d", Cin, KC);
-    const bool ups = (flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X)) != 0;
-    DREAM_REQUIRE(!(flags & DREAM_CONV_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample needs even H, W");
-    const int pad = ksize / 2;
+namespace {
+struct Geom16 {
+    int H, W, Hin, Win, Hs, Ws, Ho, Wo;      // position grid, logical / stored input extent, output extent
+    int pad, kext, ntaps;
+    int tap_dy[16], tap_dx[16];
+    int out_scale, out_oy, out_ox;
+};
+
+int launch16(const float *x, const unsigned *amax_in, const void *w_hi, const void *w_lo, const int *w_exp,
+             const float *scale, const float *shift, const float *residual, float *y, unsigned *amax_out, int B, int Cin,
+             int Cout, int CoutPad, const Geom16 &g, int flags, void *stream) {
+    DREAM_REQUIRE(x && amax_in && w_hi && w_lo && w_exp && y, "conv_f16x3: null pointer");
+    DREAM_REQUIRE(Cin % KC == 0, "conv_f16x3: Cin=%d must be a multiple of %d", Cin, KC);
     Conv16Params p;
     p.x = x; p.w_hi = (const _Float16 *)w_hi; p.w_lo = (const _Float16 *)w_lo; p.w_exp = w_exp; p.amax_in = amax_in;
     p.scale = scale; p.shift = shift; p.residual = residual; p.y = y; p.amax_out = amax_out;
-    p.B = B; p.Hin = H; p.Win = W; p.Hs = ups ? (H + 1) / 2 : H; p.Ws = ups ? (W + 1) / 2 : W;
-    p.Ho = H; p.Wo = W; p.H = H; p.W = W;
+    p.B = B; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws; p.Ho = g.Ho; p.Wo = g.Wo; p.H = g.H; p.W = g.W;
     p.Cin = Cin; p.Cout = Cout; p.CoutPad = CoutPad;
-    const long pixels = (long)B * H * W;
+    const long pixels = (long)B * g.H * g.W;
     // measured (profiles/r01_microbench_f16x3.txt): the 256-px x 64-cout tile beats 128 x 128 on every layer (the
     // weight tile is the dominant LDS fill at this MFMA rate and is amortised over twice the pixels)
     int v = Cout > 32 ? 1 : 2;
@@ -435,20 +433,21 @@ extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_
     const Variant16 &var = kVariants16[v];
     DREAM_REQUIRE(CoutPad % var.BN == 0 && CoutPad >= Cout, "CoutPad=%d must be a multiple of %d", CoutPad, var.BN);
     const bool pool = (flags & DREAM_CONV_POOL2) != 0;
-    DREAM_REQUIRE(!pool || (!(flags & DREAM_CONV_OUT_NCHW) && residual == nullptr && H >= 2 && W >= 2), "fused max-pool: NHWC output, no residual");
-    choose_tile16(H, W, var.BM, var.NP_MAX, 1, ksize, pool, &p.TH, &p.TW);
-    p.PH = p.TH - 1 + ksize; p.PW = p.TW - 1 + ksize;
-    p.tiles_x = ceil_div(W, p.TW); p.tiles_y = ceil_div(H, p.TH);
+    DREAM_REQUIRE(!pool || (!(flags & DREAM_CONV_OUT_NCHW) && residual == nullptr && g.H >= 2 && g.W >= 2 && g.out_scale == 1),
+                  "fused max-pool: NHWC output, no residual");
+    choose_tile16(g.H, g.W, var.BM, var.NP_MAX, 1, g.kext, pool, &p.TH, &p.TW);
+    p.PH = p.TH - 1 + g.kext; p.PW = p.TW - 1 + g.kext;
+    p.tiles_x = ceil_div(g.W, p.TW); p.tiles_y = ceil_div(g.H, p.TH);
     p.rcpTW = pool ? (65536 + p.TW / 2 - 1) / (p.TW / 2) : (65536 + p.TW - 1) / p.TW;
-    if (pool) { p.Ho = H / 2; p.Wo = W / 2; }
-    p.in_scale = 1; p.in_step = 1; p.lane_stride = 1; p.pad_y = pad; p.pad_x = pad;
-    p.ntaps = ksize * ksize;
+    if (pool) { p.Ho = g.H / 2; p.Wo = g.W / 2; }
+    p.in_scale = 1; p.in_step = 1; p.lane_stride = 1; p.pad_y = g.pad; p.pad_x = g.pad;
+    p.ntaps = g.ntaps;
     p.tap_dy = 0; p.tap_dx = 0;
-    for (int t = 0; t < p.ntaps; ++t) {
-        p.tap_dy |= (unsigned long long)(t / ksize) << (4 * t);
-        p.tap_dx |= (unsigned long long)(t % ksize) << (4 * t);
+    for (int t = 0; t < g.ntaps; ++t) {
+        p.tap_dy |= (unsigned long long)g.tap_dy[t] << (4 * t);
+        p.tap_dx |= (unsigned long long)g.tap_dx[t] << (4 * t);
     }
-    p.out_scale = 1; p.out_oy = 0; p.out_ox = 0;
+    p.out_scale = g.out_scale; p.out_oy = g.out_oy; p.out_ox = g.out_ox;
     p.flags = flags;
     const size_t lds = ((size_t)2 * p.PH * p.PW + (size_t)4 * var.BN) * S16 * sizeof(_Float16);
     DREAM_REQUIRE(lds <= 160 * 1024, "LDS request %zu too large", lds);
@@ -461,3 +460,89 @@ extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_
     DREAM_LAUNCH_OK();
     return 0;
 }
+
+// ConvTranspose2d(k4,s2,p1) weight [Cin][Cout][4][4] -> two fp16 planes [phase][tap][RowsPad][ColsPad] of w * 2^exp
+__global__ void __launch_bounds__(256) pack_wT4_16_kernel(const float *wT, _Float16 *hi, _Float16 *lo, const unsigned *amax,
+                                                          int *exp_out, int Cin, int Cout, int RowsPad, int ColsPad) {
+    const unsigned abits = *amax;
+    int e = (abits == 0u) ? 0 : 13 - ((int)((abits >> 23) & 255) - 127);
+    e = e < -100 ? -100 : (e > 100 ? 100 : e);
+    const float sc = pow2f(e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *exp_out = e;
+    const size_t total = (size_t)16 * RowsPad * ColsPad;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int c = (int)(idx % ColsPad);
+        size_t q = idx / ColsPad;
+        const int r = (int)(q % RowsPad);
+        const int pt = (int)(q / RowsPad);
+        const int ph = pt >> 2, t = pt & 3;
+        const int ky = 3 - 2 * (t >> 1) - (ph >> 1), kx = 3 - 2 * (t & 1) - (ph & 1);
+        const float v = ((r < Cout && c < Cin) ? wT[(((size_t)c * Cout + r) * 4 + ky) * 4 + kx] : 0.0f) * sc;
+        const _Float16 h = (_Float16)v;
+        hi[idx] = h;
+        lo[idx] = (_Float16)(v - (float)h);
+    }
+}
+}  // namespace
+
+extern "C" int dream_pack_convT4x4_weight_f16x3(const float *wT, void *hi, void *lo, int *exp_out, unsigned *scratch, int Cin,
+                                                int Cout, int RowsPad, int ColsPad, void *stream) {
+    DREAM_REQUIRE(wT && hi && lo && exp_out && scratch && Cin > 0 && Cout > 0 && RowsPad >= Cout && ColsPad >= Cin,
+                  "pack_convT4x4_weight_f16x3: bad arguments");
+    DREAM_HIP_OK(hipMemsetAsync(scratch, 0, sizeof(unsigned), (hipStream_t)stream));
+    const size_t n = (size_t)Cin * Cout * 16;
+    size_t g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, wT, n, scratch);
+    DREAM_LAUNCH_OK();
+    const size_t total = (size_t)16 * RowsPad * ColsPad;
+    g = (total + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(pack_wT4_16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, wT, (_Float16 *)hi, (_Float16 *)lo,
+                       (const unsigned *)scratch, exp_out, Cin, Cout, RowsPad, ColsPad);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// ConvTranspose2d(k=4,s=2,p=1) on the split-precision path: same sub-pixel decomposition as
+// dream_conv_transpose4x4s2_nhwc_f32 (four 2x2-tap launches); planes from dream_pack_convT4x4_weight_f16x3.
+extern "C" int dream_conv_transpose4x4s2_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi,
+                                                        const void *w_lo, const int *w_exp, const float *scale,
+                                                        const float *shift, float *y, unsigned *amax_out, int B, int H, int W,
+                                                        int Cin, int Cout, int CoutPad, int flags, void *stream) {
+    DREAM_REQUIRE((flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X | DREAM_CONV_OUT_NCHW | DREAM_CONV_POOL2)) == 0,
+                  "convT4x4_f16x3: unsupported flags");
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        Geom16 g;
+        g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W; g.Ho = 2 * H; g.Wo = 2 * W;
+        g.pad = 1; g.kext = 3; g.ntaps = 4;
+        for (int t = 0; t < 4; ++t) { g.tap_dy[t] = (t >> 1) + a; g.tap_dx[t] = (t & 1) + b; }
+        g.out_scale = 2; g.out_oy = a; g.out_ox = b;
+        const size_t off = (size_t)ph * 4 * CoutPad * Cin;
+        if (int rc = launch16(x, amax_in, (const _Float16 *)w_hi + off, (const _Float16 *)w_lo + off, w_exp, scale, shift, nullptr,
+                              y, amax_out, B, Cin, Cout, CoutPad, g, flags, stream))
+            return rc;
+    }
+    return 0;
+}
+
+// k x k (1 | 3) stride-1 conv, same contract as dream_conv2d_nhwc_f32, on the split-precision path.
+// amax_in: device scalar with the bit pattern of max|x| (from the producer's amax_out or dream_absmax_f32);
+// amax_out: optional, atomicMax of max|y| (caller zeroes it).  Cin % 32 == 0.
+extern "C" int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi, const void *w_lo,
+                                           const int *w_exp, const float *scale, const float *shift, const float *residual,
+                                           float *y, unsigned *amax_out, int B, int H, int W, int Cin, int Cout, int CoutPad,
+                                           int ksize, int stride, int flags, void *stream) {
+    DREAM_REQUIRE(ksize == 1 || ksize == 3, "conv2d_f16x3: kernel size %d not supported", ksize);
+    DREAM_REQUIRE(stride == 1, "conv2d_f16x3: stride %d not supported (strided convs stay on the fp32 kernel)", stride);
+    const bool ups = (flags & (DREAM_CONV_UPSAMPLE2X | DREAM_CONV_ZEROSTUFF2X)) != 0;
+    DREAM_REQUIRE(!(flags & DREAM_CONV_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample needs even H, W");
+    Geom16 g;
+    g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = ups ? (H + 1) / 2 : H; g.Ws = ups ? (W + 1) / 2 : W; g.Ho = H; g.Wo = W;
+    g.pad = ksize / 2; g.kext = ksize; g.ntaps = ksize * ksize;
+    for (int t = 0; t < g.ntaps; ++t) { g.tap_dy[t] = t / ksize; g.tap_dx[t] = t % ksize; }
+    g.out_scale = 1; g.out_oy = 0; g.out_ox = 0;
+    return launch16(x, amax_in, w_hi, w_lo, w_exp, scale, shift, residual, y, amax_out, B, Cin, Cout, CoutPad, g, flags, stream);
+}
+

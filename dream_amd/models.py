@@ -342,6 +342,7 @@ class ResnetSimple(nn.Module):
         self.full = full
         self.n_keypoints = n_keypoints
         self._cache = {}
+        self.precision = "fp32"        # "fp16x3": evaluation-mode forward on the split-precision conv kernel
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
@@ -405,9 +406,60 @@ class ResnetSimple(nn.Module):
         scale, shift = self._fold(name, bn, conv.bias)
         return ops.conv2d(x, packed, rows, k, stride, scale, shift, residual, CONV_RELU if relu else 0)
 
+    # ---- inference on the split-precision conv kernel (strided convs stay on the fp32 kernel) ------------------
+    def _conv_bn16(self, name, x, amax, conv, bn, relu, residual=None):
+        """-> (y, amax_y).  Stride-1 1x1 / 3x3 convs run on conv_f16x3; the six stride-2 convs of the trunk run on
+        the fp32 kernel, which publishes max|y| all the same."""
+        k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
+        scale, shift = self._fold(name, bn, conv.bias)
+        flags = CONV_RELU if relu else 0
+        if stride != 1:
+            packed, rows, _ = self._cached(("w", name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), 0))
+            return ops.conv2d_amax(x, packed, rows, k, stride, scale, shift, residual, flags)
+        p16 = self._cached(("w16", name), [conv.weight], lambda: ops.pack_conv_weight_f16x3(conv.weight.detach(), 0))
+        return ops.conv2d_f16x3(x, amax, p16, p16[3], k, scale, shift, residual, flags)
+
+    def run_forward_f16x3(self, x):
+        col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
+        amax = ops.absmax(x)                               # im2col only rearranges (and zero-pads) the image
+        w1 = self._cached(("w16", "conv1"), [self.conv1.weight],
+                          lambda: ops.pack_conv_weight_f16x3(self.conv1.weight.detach().reshape(64, 147, 1, 1), 0))
+        s1, t1 = self._fold("bn1", self.bn1)
+        y, amax = ops.conv2d_f16x3(col, amax, w1, 64, 1, s1, t1, None, CONV_RELU)
+        del col
+        y = ops.maxpool3s2(y)                              # pooling cannot raise the maximum: amax carries over
+        for li in (1, 2, 3, 4):
+            for bi, blk in enumerate(getattr(self, "layer%d" % li)):
+                name = "layer%d.%d" % (li, bi)
+                idt = y
+                if hasattr(blk, "downsample"):
+                    idt, _ = self._conv_bn16(name + ".ds", y, amax, blk.downsample[0], blk.downsample[1], relu=False)
+                o, a1 = self._conv_bn16(name + ".1", y, amax, blk.conv1, blk.bn1, relu=True)
+                o, a2 = self._conv_bn16(name + ".2", o, a1, blk.conv2, blk.bn2, relu=True)
+                y, amax = self._conv_bn16(name + ".3", o, a2, blk.conv3, blk.bn3, relu=True, residual=idt)
+        seqs = [("upsample", self.upsample)] + ([("upsample2", self.upsample2)] if self.full else [])
+        for sname, seq in seqs:
+            mods = list(seq)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                name = "%s.%d" % (sname, i)
+                if isinstance(m, nn.ConvTranspose2d):
+                    p16 = self._cached(("w16", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight_f16x3(m.weight.detach()))
+                    scale, shift = self._fold(name, mods[i + 1], m.bias)
+                    y, amax = ops.conv_transpose4x4s2_f16x3(y, amax, p16, p16[3], scale, shift, CONV_RELU)
+                    i += 3
+                else:
+                    p16 = self._cached(("w16", name), [m.weight], lambda m=m: ops.pack_conv_weight_f16x3(m.weight.detach(), 0))
+                    y, _ = ops.conv2d_f16x3(y, amax, p16, p16[3], 1, None, m.bias.detach(), None, CONV_OUT_NCHW, want_amax=False)
+                    i += 1
+        return y
+
     def run_forward(self, x):
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("expected [B,3,H,W] input, got %s" % (tuple(x.shape),))
+        if self.precision == "fp16x3":
+            return self.run_forward_f16x3(x)
         # stem: 7x7 s2 conv as im2col (K = 147 -> 160) + 1-tap MFMA conv, BN+ReLU fused; then MaxPool(3,2,1)
         col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
         w1 = self._cached(("w", "conv1"), [self.conv1.weight],

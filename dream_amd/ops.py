@@ -494,3 +494,41 @@ def convT_wgrad(x_nhwc, dy_nhwc, ksize):
     dw = torch.empty((cin, cout, ksize, ksize), dtype=torch.float32, device=x.device)
     call("dream_unpack_conv_weight", ptr(dwp), ptr(dw), cin, cout, nt, rows_pad, cout, stream())
     return dw
+
+
+def pack_convT4x4_weight_f16x3(wT):
+    """ConvTranspose2d weight [Cin,Cout,4,4] -> (hi, lo, exp, cout): fp16 planes [4][4][rows_pad][cols_pad]."""
+    w = _f32(wT)
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    rows_pad, cols_pad = _hip.cout_pad(cout), round_up(cin, 32)
+    hi = torch.empty((4, 4, rows_pad, cols_pad), dtype=torch.float16, device=w.device)
+    lo = torch.empty_like(hi)
+    exp = torch.zeros((1,), dtype=torch.int32, device=w.device)
+    scratch = torch.zeros((1,), dtype=torch.int32, device=w.device)
+    call("dream_pack_convT4x4_weight_f16x3", ptr(w), ptr(hi), ptr(lo), ptr(exp), ptr(scratch), cin, cout, rows_pad, cols_pad,
+         stream())
+    return hi, lo, exp, cout
+
+
+def conv_transpose4x4s2_f16x3(x_nhwc, amax_in, packed16, cout, scale=None, shift=None, flags=0):
+    hi, lo, exp, _ = packed16
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    amax_out = new_amax(x.device)
+    call("dream_conv_transpose4x4s2_f16x3_nhwc_f32", ptr(x), ptr(amax_in), ptr(hi), ptr(lo), ptr(exp), ptr(scale), ptr(shift),
+         ptr(y), ptr(amax_out), b, h, w, cin, cout, int(hi.shape[-2]), flags, stream())
+    return y, amax_out
+
+
+def conv2d_amax(x_nhwc, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0):
+    """fp32 MFMA conv that also publishes max|y| (feeds the split-precision kernel's input scaling)."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    pad = ksize // 2
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    y = torch.empty((b, ho, wo, cout), dtype=torch.float32, device=x.device)
+    amax = new_amax(x.device)
+    call("dream_conv2d_amax_nhwc_f32", ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(residual), ptr(y), ptr(amax), b, h, w,
+         cin, cout, int(packed.shape[-2]), ksize, stride, flags, stream())
+    return y, amax

@@ -123,6 +123,12 @@ int dream_conv2d_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const v
                                 const int *w_exp, const float *scale, const float *shift, const float *residual,
                                 float *y, unsigned *amax_out, int B, int H, int W, int Cin, int Cout, int CoutPad,
                                 int ksize, int stride, int flags, void *stream);
+int dream_pack_convT4x4_weight_f16x3(const float *wT, void *hi, void *lo, int *exp_out, unsigned *scratch, int Cin,
+                                     int Cout, int RowsPad, int ColsPad, void *stream);
+int dream_conv_transpose4x4s2_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi,
+                                             const void *w_lo, const int *w_exp, const float *scale,
+                                             const float *shift, float *y, unsigned *amax_out, int B, int H, int W,
+                                             int Cin, int Cout, int CoutPad, int flags, void *stream);
 int dream_conv_f16x3_set_variant(int variant);
 /* variant selection for benchmarking: -1 = heuristic; otherwise index into the variant table */
 int dream_conv3x3_set_variant(int variant);

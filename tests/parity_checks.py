@@ -502,3 +502,19 @@ def check_dataprep(dev):
         ref = torch.tensor(op.create_belief_map((80, 60), kps[b])).float()
         assert torch.equal(got[b], ref), b
     assert float(got[0, 0].max()) == 1.0 and float(got[0, 1].abs().max()) == 0.0 and float(got[0, 6].abs().max()) == 0.0
+
+
+def check_conv_transpose4x4_f16x3(dev, B, H, W, Cin, Cout, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    x[0, 0, 0, 0] = 30.0
+    wT = torch.randn(Cin, Cout, 4, 4, generator=g) * (2.0 / (4 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x.double(), wT.double(), bias.double(), stride=2, padding=1).relu()
+    p16 = ops.pack_convT4x4_weight_f16x3(to(dev, wT))
+    y, amax = ops.conv_transpose4x4s2_f16x3(to(dev, _nhwc(x)), ops.absmax(to(dev, x)), p16, p16[3], None, to(dev, bias), ops.CONV_RELU)
+    got = y.cpu().permute(0, 3, 1, 2)
+    scale = float(ref.abs().max())
+    assert float((got.double() - ref).abs().max()) / scale <= 5e-6
+    am = float(np.frombuffer(amax.cpu().numpy().tobytes(), dtype=np.float32)[0])
+    assert abs(am - float(got.abs().max())) <= 1e-6 * scale

@@ -130,3 +130,8 @@ def test_fused_maxpool_epilogue(emu):
 
 def test_on_device_dataprep(emu):
     pc.check_dataprep("cpu")
+
+
+def test_resnet_split_precision(emu):
+    pc.check_conv_transpose4x4_f16x3("cpu", 1, 5, 6, 32, 48)
+    pc.check_model_inference("cpu", "resnet_h", (2, 64, 96), precision="fp16x3")

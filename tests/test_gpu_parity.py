@@ -260,3 +260,10 @@ def test_fused_maxpool_epilogue():
 
 def test_on_device_dataprep():
     pc.check_dataprep(DEV)
+
+
+def test_resnet_split_precision():
+    pc.check_conv_transpose4x4_f16x3(DEV, 2, 13, 13, 2048, 256)
+    pc.check_conv_transpose4x4_f16x3(DEV, 1, 52, 52, 256, 256)
+    pc.check_model_inference(DEV, "resnet_h", (2, 64, 96), precision="fp16x3")
+    pc.check_model_inference(DEV, "resnet_f", (1, 64, 64), precision="fp16x3")
