@@ -51,6 +51,9 @@ _SIGNATURES = {
     "dream_channel_sum_nhwc_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
     "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
+    "dream_add_f32": (_I, [_P, _P, _P, _SZ, _P, _P]),
+    "dream_stage_input_nhwc_f32": (_I, [_P, _P, _P] + [_I] * 7 + [_P, _P]),
+    "dream_stage_input_bwd_f32": (_I, [_P, _P] + [_I] * 8 + [_P]),
     "dream_conv2d_amax_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_first_nchw_amax_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_absmax_f32": (_I, [_P, _SZ, _P, _P]),

@@ -371,6 +371,72 @@ __global__ void __launch_bounds__(256) add_inplace_kernel(float *dst, const floa
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] += src[i];
 }
 
+// out = a + b (encoder skip tensors joining the decoder, dream/models.py:774-799); optionally publishes max|out|.
+__global__ void __launch_bounds__(256) add_kernel(const float *a, const float *b, float *out, size_t n, unsigned *amax) {
+    const size_t n4 = n / 4;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 u = ((const f32x4 *)a)[i];
+        const f32x4 v = ((const f32x4 *)b)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u[k] += v[k];
+            m = fmaxf(m, fabsf(u[k]));
+        }
+        ((f32x4 *)out)[i] = u;
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float u = a[i] + b[i];
+        out[i] = u;
+        m = fmaxf(m, fabsf(u));
+    }
+    if (amax) publish_amax(amax, m);
+}
+
+// Multi-stage input (dream/models.py:487-493): NHWC [B,H,W,Cpad] <- cat(image NCHW [B,Ci,H,W], maps NCHW [B,K,H/up,W/up]
+// nearest-upsampled by `up`), channels >= Ci+K zero.  One thread per (pixel, channel quad).
+__global__ void __launch_bounds__(256) stage_input_kernel(const float *img, const float *maps, float *out, int B, int H, int W,
+                                                          int Ci, int K, int up, int Cpad, unsigned *amax) {
+    const size_t total = (size_t)B * H * W * (Cpad / 4);
+    const int Hm = H / up, Wm = W / up;
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cq = (int)(i % (Cpad / 4));
+        const size_t pix = i / (Cpad / 4);
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = cq * 4 + k;
+            float t = 0.f;
+            if (c < Ci) t = img[(((size_t)b * Ci + c) * H + y) * W + x];
+            else if (c < Ci + K) {
+                const int ym = y / up, xm = x / up;
+                t = maps[(((size_t)b * K + (c - Ci)) * Hm + ym) * Wm + xm];
+            }
+            v[k] = t;
+            m = fmaxf(m, fabsf(t));
+        }
+        ((f32x4 *)out)[i] = v;
+    }
+    if (amax) publish_amax(amax, m);
+}
+
+// Backward of the map half of stage_input: dmaps[b,k,ym,xm] (+)= sum over the up x up block of g[b,y,x,Ci+k].
+__global__ void __launch_bounds__(256) stage_input_bwd_kernel(const float *g, float *dmaps, int B, int H, int W, int Ci, int K,
+                                                              int up, int Cpad, int accumulate) {
+    const int Hm = H / up, Wm = W / up;
+    const size_t total = (size_t)B * K * Hm * Wm;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int xm = (int)(i % Wm), ym = (int)((i / Wm) % Hm), k = (int)((i / ((size_t)Wm * Hm)) % K);
+        const int b = (int)(i / ((size_t)Wm * Hm * K));
+        float s = 0.f;
+        for (int y = ym * up; y < (ym + 1) * up; ++y)
+            for (int x = xm * up; x < (xm + 1) * up; ++x) s += g[(((size_t)b * H + y) * W + x) * Cpad + Ci + k];
+        dmaps[i] = accumulate ? dmaps[i] + s : s;
+    }
+}
+
 }  // namespace
 
 extern "C" int dream_maxpool2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream) {
@@ -504,6 +570,32 @@ extern "C" int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, fl
 extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream) {
     DREAM_REQUIRE(dst && src, "add_inplace: null pointer");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_add_f32(const float *a, const float *b, float *out, size_t n, unsigned *amax_out, void *stream) {
+    DREAM_REQUIRE(a && b && out, "add: null pointer");
+    if (amax_out) DREAM_HIP_OK(hipMemsetAsync(amax_out, 0, sizeof(unsigned), (hipStream_t)stream));
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, amax_out);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_stage_input_nhwc_f32(const float *img_nchw, const float *maps_nchw, float *out_nhwc, int B, int H, int W,
+                                          int Ci, int K, int up, int Cpad, unsigned *amax_out, void *stream) {
+    DREAM_REQUIRE(img_nchw && maps_nchw && out_nhwc && B > 0 && H > 0 && W > 0 && Ci > 0 && K > 0, "stage_input: bad arguments");
+    DREAM_REQUIRE(up >= 1 && H % up == 0 && W % up == 0 && Cpad % 4 == 0 && Cpad >= Ci + K, "stage_input: bad up / Cpad");
+    if (amax_out) DREAM_HIP_OK(hipMemsetAsync(amax_out, 0, sizeof(unsigned), (hipStream_t)stream));
+    hipLaunchKernelGGL(stage_input_kernel, dim3(grid_for((size_t)B * H * W * (Cpad / 4))), dim3(256), 0, (hipStream_t)stream,
+                       img_nchw, maps_nchw, out_nhwc, B, H, W, Ci, K, up, Cpad, amax_out);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_stage_input_bwd_f32(const float *g_nhwc, float *dmaps_nchw, int B, int H, int W, int Ci, int K, int up,
+                                         int Cpad, int accumulate, void *stream) {
+    DREAM_REQUIRE(g_nhwc && dmaps_nchw && B > 0 && H > 0 && W > 0 && Ci > 0 && K > 0, "stage_input_bwd: bad arguments");
+    DREAM_REQUIRE(up >= 1 && H % up == 0 && W % up == 0 && Cpad >= Ci + K, "stage_input_bwd: bad up / Cpad");
+    hipLaunchKernelGGL(stage_input_bwd_kernel, dim3(grid_for((size_t)B * K * (H / up) * (W / up))), dim3(256), 0,
+                       (hipStream_t)stream, g_nhwc, dmaps_nchw, B, H, W, Ci, K, up, Cpad, accumulate);
     DREAM_LAUNCH_OK();
     return 0;
 }

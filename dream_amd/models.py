@@ -77,11 +77,10 @@ class DreamHourglass(nn.Module):
         else:
             self.n_output_heads = 1
             self.learned_beta = False
-        if skip_connections:
-            raise NotImplementedError("dream_amd: skip_connections is not built yet (SURVEY.md 8f rank 3)")
-        if n_image_input_channels > 4:
-            raise NotImplementedError("dream_amd: first conv supports <= 4 input channels")
-
+        # plan entries: (kind, container name, child name, flags).  kinds: "first" (VALU conv on the NCHW image, <= 4
+        # channels), "wide" (first conv of a multi-stage hourglass: image + previous maps, NHWC zero-padded to the MFMA
+        # kernel's channel granularity), "conv", "deconv", "pool", and "add" (skip connection; flags = plan index of the
+        # entry whose output is added, models.py:774-799).
         def conv(ci, co):
             return nn.Conv2d(ci, co, kernel_size=3, stride=1, padding=1)
 
@@ -94,33 +93,45 @@ class DreamHourglass(nn.Module):
                 seq.add_module(str(name), mod)
             return seq
 
-        # plan entries: (kind, container name, child name, flags)
         plan = []
+        x1 = None                                            # plan index of x_0_1 (last conv of the first block)
+        pooled = {}                                          # block k -> plan index of x_0_k_d
         for bi, (cname, convs) in enumerate(_ENCODER):
             items = []
             for (idx, ci, co) in convs:
                 if idx == 0:
                     ci = n_image_input_channels
                 items.append((idx, conv(ci, co)))
-                plan.append(("first" if idx == 0 else "conv", cname, str(idx), CONV_RELU))
+                kind = "conv" if idx else ("first" if n_image_input_channels <= 4 else "wide")
+                plan.append((kind, cname, str(idx), CONV_RELU))
             setattr(self, cname, container(items))
+            if bi == 0:
+                x1 = len(plan) - 1
             if bi + 1 < len(_ENCODER):
                 plan.append(("pool", None, None, 0))
+                pooled[bi + 1] = len(plan) - 1
 
+        def skip(src):
+            if skip_connections:
+                plan.append(("add", None, None, src))
+
+        skip(pooled[4])                                      # decoder_input = x_0_5 + x_0_4_d (models.py:774-777)
         if deconv_decoder:                                   # models.py:618-686
-            for cname, ci, co, has_conv in [("deconv_0_4", 512, 256, True), ("deconv_0_3", 256, 128, True),
-                                            ("deconv_0_2", 128, 64, True), ("deconv_0_1", 64, 64, False)]:
+            for cname, ci, co, has_conv, src in [("deconv_0_4", 512, 256, True, pooled[3]), ("deconv_0_3", 256, 128, True, pooled[2]),
+                                                 ("deconv_0_2", 128, 64, True, pooled[1]), ("deconv_0_1", 64, 64, False, x1)]:
                 items = [(0, deconv(ci, co))]
                 plan.append(("deconv", cname, "0", CONV_RELU | CONV_ZEROSTUFF2X))
                 if has_conv:
                     items.append((2, conv(co, co)))
                     plan.append(("conv", cname, "2", CONV_RELU))
                 setattr(self, cname, container(items))
+                skip(src)                                    # models.py:780-799
         else:                                                # models.py:688-733
             self.upsample_0_4 = container([(4, conv(512, 256)), (6, conv(256, 256))])
             self.upsample_0_3 = container([(4, conv(256, 128)), (6, conv(128, 64))])
-            plan += [("conv", "upsample_0_4", "4", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_4", "6", 0),
-                     ("conv", "upsample_0_3", "4", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_3", "6", 0)]
+            plan += [("conv", "upsample_0_4", "4", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_4", "6", 0)]
+            skip(pooled[3])                                  # models.py:804-807
+            plan += [("conv", "upsample_0_3", "4", CONV_RELU | CONV_UPSAMPLE2X), ("conv", "upsample_0_3", "6", 0)]
             if full_output:
                 self.upsample_0_2 = container([(2, conv(64, 64)), (4, conv(64, 64))])
                 self.upsample_0_1 = container([(2, conv(64, 64)), (4, conv(64, 64))])
@@ -132,6 +143,7 @@ class DreamHourglass(nn.Module):
         if internalize_spatial_softmax:                      # models.py:750-759
             self.softmax = container([(0, SoftArgmaxPavlo(n_keypoints, learned_beta, initial_beta))])
         self._plan = plan
+        self._skip_sources = {e[3] for e in plan if e[0] == "add"}
         self._packed = _PackedCache()
         # "fp32": exact fp32 MFMA kernel everywhere.  "fp16x3": inference runs the split-precision kernel
         # (fp32 in/out, 3 fp16 MFMAs per product, fp32-class error); training always uses the fp32 kernels.
@@ -171,80 +183,120 @@ class DreamHourglass(nn.Module):
         for kind, _, flags in self.plan_layers():
             if kind == "pool":
                 w, h = w // 2, h // 2
-            elif flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X):
+            elif kind in ("conv", "deconv") and flags & (CONV_UPSAMPLE2X | CONV_ZEROSTUFF2X):
                 w, h = w * 2, h * 2
         return (w, h)
 
+    def input_channel_pad(self):
+        """Channel count of the NHWC tensor a "wide" first conv reads (fp32 kernel: multiples of 16; split kernel: 32)."""
+        return ops.round_up(self.n_image_input_channels, 32 if self.precision == "fp16x3" else 16)
+
+    def _check_input(self, x, x_is_nhwc):
+        ok = x.dim() == 4 and (int(x.shape[3]) == self.input_channel_pad() if x_is_nhwc
+                               else int(x.shape[1]) == self.n_image_input_channels)
+        if not ok:
+            raise RuntimeError("expected [B,%d,H,W] input, got %s" % (self.n_image_input_channels, tuple(x.shape)))
+
+    @staticmethod
+    def _join(a, b):
+        if a.shape != b.shape:        # what the reference's `+` raises for resolutions the pools do not divide
+            raise RuntimeError("The size of tensor a %s must match the size of tensor b %s" % (tuple(a.shape), tuple(b.shape)))
+
     # ---- execution -------------------------------------------------------------------------------------
-    def run_forward_f16x3(self, x, params):
+    def run_forward_f16x3(self, x, params, x_is_nhwc=False, x_amax=None):
         """Inference plan on the split-precision conv kernel.  Each kernel publishes max|y| of its output (amax side
         channel) so the next conv can scale its input into fp16 range; pooling cannot raise the maximum."""
-        act, amax = x, None
+        act, amax = x, x_amax
         pi = 0
         layers = self.plan_layers()
+        keep = {}
         for li, (kind, mod, flags) in enumerate(layers):
             if kind == "pool":
-                if li > 0 and layers[li - 1][0] in ("conv", "deconv"):
-                    continue                         # fused into the previous conv's epilogue
-                act = ops.maxpool2(act)
-                continue
-            w, bias = params[pi], params[pi + 1]
-            pi += 2
-            if kind == "first":
-                act, amax = ops.conv3x3_first_amax(act, w, bias, relu=bool(flags & CONV_RELU))
+                if not (li > 0 and layers[li - 1][0] in ("conv", "deconv") and (li - 1) not in self._skip_sources):
+                    act = ops.maxpool2(act)
+            elif kind == "add":
+                self._join(act, keep[flags])
+                act, amax = ops.add(act, keep[flags], want_amax=True)
             else:
-                if li + 1 < len(layers) and layers[li + 1][0] == "pool":
-                    flags = flags | CONV_POOL2
-                p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
-                act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
-                                             want_amax=not (flags & CONV_OUT_NCHW))
+                w, bias = params[pi], params[pi + 1]
+                pi += 2
+                if kind == "first":
+                    act, amax = ops.conv3x3_first_amax(act, w, bias, relu=bool(flags & CONV_RELU))
+                else:
+                    if kind == "wide" and not x_is_nhwc:
+                        amax = ops.absmax(act)
+                        act = ops.nchw_to_nhwc(act, cpad=self.input_channel_pad())
+                    if li + 1 < len(layers) and layers[li + 1][0] == "pool" and li not in self._skip_sources:
+                        flags = flags | CONV_POOL2
+                    p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
+                    act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
+                                                 want_amax=not (flags & CONV_OUT_NCHW))
+            if li in self._skip_sources:
+                keep[li] = act
         return act
 
-    def run_forward(self, x, params, save):
+    def run_forward(self, x, params, save, x_is_nhwc=False, x_amax=None):
         """Executes the plan.  ``params`` is plan_parameters() (possibly autograd-detached).  With
-        ``save`` the per-layer inputs/outputs needed by run_backward are returned as well."""
-        if x.dim() != 4 or x.shape[1] != self.n_image_input_channels:
-            raise RuntimeError("expected [B,%d,H,W] input, got %s" % (self.n_image_input_channels, tuple(x.shape)))
+        ``save`` the per-layer inputs/outputs needed by run_backward are returned as well.  ``x_is_nhwc``: the
+        caller (multi-stage) already built the zero-padded NHWC input of a "wide" first conv."""
+        self._check_input(x, x_is_nhwc)
         if self.precision == "fp16x3" and not save:
-            return self.run_forward_f16x3(x, params), []
+            return self.run_forward_f16x3(x, params, x_is_nhwc, x_amax), []
         if self.precision not in ("fp32", "fp16x3"):
             raise ValueError("unknown precision %r" % (self.precision,))
         saved = []
+        keep = {}
         act = x
         pi = 0
         layers = self.plan_layers()
         for li, (kind, mod, flags) in enumerate(layers):
             inp = act
             if kind == "pool":
-                if not save and li > 0 and layers[li - 1][0] in ("conv", "deconv"):
-                    continue                         # inference: fused into the previous conv's epilogue
-                act = ops.maxpool2(inp)
+                # inference: fused into the previous conv's epilogue unless the un-pooled tensor is a skip source
+                if save or not (li > 0 and layers[li - 1][0] in ("conv", "deconv") and (li - 1) not in self._skip_sources):
+                    act = ops.maxpool2(inp)
+            elif kind == "add":
+                self._join(inp, keep[flags])
+                act, _ = ops.add(inp, keep[flags])
             else:
-                if not save and kind != "first" and li + 1 < len(layers) and layers[li + 1][0] == "pool":
+                if (not save and kind not in ("first", "wide") and li + 1 < len(layers) and layers[li + 1][0] == "pool"
+                        and li not in self._skip_sources):
                     flags = flags | CONV_POOL2
                 w, bias = params[pi], params[pi + 1]
                 pi += 2
                 if kind == "first":
                     act = ops.conv3x3_first(inp, w, bias, relu=bool(flags & CONV_RELU))
                 else:
+                    if kind == "wide" and not x_is_nhwc:
+                        inp = ops.nchw_to_nhwc(inp, cpad=self.input_channel_pad())
                     mode = 1 if kind == "deconv" else 0      # ConvTranspose weight is [Cin,Cout,3,3]
                     packed, rows, _, _ = self._packed.get(mod.weight, mode)
                     act = ops.conv3x3(inp, packed, bias, rows, flags)
             if save:
                 saved.append((inp, act))
+            if li in self._skip_sources:
+                keep[li] = act
         return act, saved
 
-    def run_backward(self, saved, grad_out_nchw):
-        """dL/d(belief maps) [B,K,Ho,Wo] -> list of parameter gradients in plan_parameters() order."""
+    def run_backward(self, saved, grad_out_nchw, need_input_grad=False):
+        """dL/d(belief maps) [B,K,Ho,Wo] -> list of parameter gradients in plan_parameters() order (and, for a
+        multi-stage hourglass, dL/d(NHWC input of the "wide" first conv))."""
         layers = self.plan_layers()
         grads = [None] * (2 * sum(1 for k, m, _ in layers if m is not None))
         pi = len(grads)
         g = None
+        g_input = None
+        pending = {}                                       # skip source plan index -> gradient that branched off
         for li in range(len(layers) - 1, -1, -1):
             kind, mod, flags = layers[li]
             inp, out = saved[li]
+            if li in pending:                              # two consumers of this activation: gradients add
+                g = ops.add_(g, pending.pop(li))
             if kind == "pool":
                 g = ops.maxpool2_bwd(g, inp)
+                continue
+            if kind == "add":
+                pending[flags] = g.clone()                 # later in-place ReLU masks must not touch this copy
                 continue
             pi -= 2
             if kind == "deconv":
@@ -265,6 +317,14 @@ class DreamHourglass(nn.Module):
                 grads[pi], grads[pi + 1] = ops.conv3x3_first_wgrad(inp, g)
                 g = None
                 continue
+            if kind == "wide":
+                dw, db = ops.conv3x3_wgrad(inp, g, cout, int(inp.shape[3]), 0)
+                grads[pi], grads[pi + 1] = dw[:, :cin].contiguous(), db
+                if need_input_grad:
+                    packed_t, rows, _, _ = self._packed.get(mod.weight, 1)
+                    g_input = ops.conv3x3(g, packed_t, None, rows, 0)         # [B,H,W,cin]
+                g = None
+                continue
             dw, db = ops.conv3x3_wgrad(inp, g, cout, cin, flags & CONV_UPSAMPLE2X)
             grads[pi], grads[pi + 1] = dw, db
             packed_t, rows, _, cols_pad = self._packed.get(mod.weight, 1)
@@ -273,6 +333,8 @@ class DreamHourglass(nn.Module):
             g = ops.conv3x3(g, packed_t, None, rows, 0)
             if flags & CONV_UPSAMPLE2X:
                 g = ops.upsample2_bwd(g)
+        if need_input_grad:
+            return grads, g_input
         return grads
 
     def forward(self, x):
@@ -326,6 +388,143 @@ def allreduce_gradients(grads):
         out.append(flat[o:o + n].view_as(g))
         o += n
     return out
+
+
+class DreamHourglassMultiStage(nn.Module):
+    """The reference's DreamHourglassMultiStage (models.py:350-553): ``stage1`` .. ``stageS`` hourglasses (same
+    ``state_dict()`` keys); stage s > 1 reads cat([image, belief maps of stage s-1]) -- the maps nearest-upsampled x4
+    unless the decoder already reaches input resolution (:487-493).  Here the concatenation, the upsampling and the
+    NCHW->NHWC conversion are one kernel (dream_stage_input_nhwc_f32) writing the zero-padded NHWC tensor the MFMA first
+    conv of the stage reads; the whole S-stage network is one autograd node."""
+
+    def __init__(self, n_keypoints, n_image_input_channels=3, internalize_spatial_softmax=True, learned_beta=True,
+                 initial_beta=1.0, n_stages=2, skip_connections=False, deconv_decoder=False, full_output=False):
+        super().__init__()
+        self.n_keypoints = n_keypoints
+        self.n_image_input_channels = n_image_input_channels
+        self.internalize_spatial_softmax = internalize_spatial_softmax
+        self.skip_connections = skip_connections
+        self.deconv_decoder = deconv_decoder
+        self.full_output = full_output
+        if internalize_spatial_softmax:
+            # models.py:373-378: the soft-argmax head of every stage is built (it owns parameters) but never returned
+            print("WARNING: Keypoint softmax output head is currently unused. Prefer training new models of this type "
+                  "with internalize_spatial_softmax = False.")
+            self.n_output_heads = 2
+            self.learned_beta = learned_beta
+            self.initial_beta = initial_beta
+        else:
+            self.n_output_heads = 1
+            self.learned_beta = False
+        assert isinstance(n_stages, int), 'Expected "n_stages" to be an integer, but it is {}.'.format(type(n_stages))
+        assert 0 < n_stages and n_stages <= 6, \
+            "DreamHourglassMultiStage can only be constructed with 1 to 6 stages at this time."
+        self.num_stages = n_stages
+        for s in range(1, n_stages + 1):
+            cin = n_image_input_channels + (n_keypoints if s > 1 else 0)
+            setattr(self, "stage%d" % s, DreamHourglass(
+                n_keypoints, cin, internalize_spatial_softmax, learned_beta, initial_beta,
+                skip_connections=skip_connections, deconv_decoder=deconv_decoder, full_output=full_output))
+
+    @property
+    def precision(self):
+        return self.stage1.precision
+
+    @precision.setter
+    def precision(self, value):
+        for st in self.stages():
+            st.precision = value
+
+    def stages(self):
+        return [getattr(self, "stage%d" % s) for s in range(1, self.num_stages + 1)]
+
+    def map_upsampling(self):
+        return 1 if (self.deconv_decoder or self.full_output) else 4
+
+    def output_resolution(self, input_wh):
+        return self.stage1.output_resolution(input_wh)
+
+    def plan_parameters(self):
+        return [p for st in self.stages() for p in st.plan_parameters()]
+
+    def run_forward(self, x, stage_params, save):
+        """-> ([maps of stage 1..S], per-stage saved activations)."""
+        if x.dim() != 4 or int(x.shape[1]) != self.n_image_input_channels:
+            raise RuntimeError("expected [B,%d,H,W] input, got %s" % (self.n_image_input_channels, tuple(x.shape)))
+        outs, saved = [], []
+        up = self.map_upsampling()
+        for s, (st, params) in enumerate(zip(self.stages(), stage_params)):
+            if s == 0:
+                y, sv = st.run_forward(x, params, save)
+            else:
+                prev = outs[-1]
+                if (int(prev.shape[2]) * up, int(prev.shape[3]) * up) != (int(x.shape[2]), int(x.shape[3])):
+                    # what torch.cat raises in the reference when the pools do not divide the input resolution
+                    raise RuntimeError("Sizes of tensors must match except in dimension 1. Expected size %d but got size %d"
+                                       % (int(x.shape[2]), int(prev.shape[2]) * up))
+                want_amax = st.precision == "fp16x3" and not save
+                inp, amax = ops.stage_input(x, prev, up, st.input_channel_pad(), want_amax=want_amax)
+                y, sv = st.run_forward(inp, params, save, x_is_nhwc=True, x_amax=amax)
+            outs.append(y)
+            saved.append(sv)
+        return outs, saved
+
+    def run_backward(self, saved, grad_outs):
+        """grad_outs: dL/d(maps of stage s) or None, s = 1..S -> parameter gradients in plan_parameters() order."""
+        stages = self.stages()
+        up = self.map_upsampling()
+        ci, k = self.n_image_input_channels, self.n_keypoints
+        per_stage = [None] * len(stages)
+        carry = None                                       # dL/d(maps of stage s) through stage s+1's input
+        for s in range(len(stages) - 1, -1, -1):
+            g = grad_outs[s]
+            if g is None and carry is None:
+                per_stage[s] = [torch.zeros_like(p) for p in stages[s].plan_parameters()]
+                continue
+            if g is None:
+                g = carry
+            elif carry is not None:
+                g = ops.add_(g.contiguous().clone(), carry)
+            if s > 0:
+                per_stage[s], g_in = stages[s].run_backward(saved[s], g.contiguous(), need_input_grad=True)
+                b, h, w, c = (int(v) for v in g_in.shape)
+                carry = ops.stage_input_bwd(g_in, ci, k, up)
+            else:
+                per_stage[s] = stages[s].run_backward(saved[s], g.contiguous())
+        return [g for grads in per_stage for g in grads]
+
+    def forward(self, x, verbose=False):
+        stage_params = [st.plan_parameters() for st in self.stages()]
+        flat = [p for ps in stage_params for p in ps]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in flat):
+            return list(_MultiStageFunction.apply(self, x, *flat))
+        with torch.no_grad():
+            outs, _ = self.run_forward(x, [[p.detach() for p in ps] for ps in stage_params], save=False)
+        return outs
+
+
+class _MultiStageFunction(torch.autograd.Function):
+    """All S hourglasses as one autograd node with S outputs (same exchange step as _HourglassFunction)."""
+
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        stage_params, o = [], 0
+        for st in module.stages():
+            n = len(st.plan_parameters())
+            stage_params.append([p.detach() for p in params[o:o + n]])
+            o += n
+        outs, saved = module.run_forward(x.detach(), stage_params, save=True)
+        ctx.module = module
+        ctx.saved_acts = saved
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grad_outs):
+        module = ctx.module
+        grads = module.run_backward(ctx.saved_acts, list(grad_outs))
+        ctx.saved_acts = None
+        grads = allreduce_gradients(grads)
+        return (None, None) + tuple(grads)
 
 
 class ResnetSimple(nn.Module):

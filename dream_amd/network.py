@@ -168,12 +168,14 @@ class DreamNetwork:
             elif "full_output" in arch:
                 vgg_kwargs["deconv_decoder"] = arch["deconv_decoder"]
                 vgg_kwargs["full_output"] = True
+                if "n_stages" in arch:                    # network.py:225-230: only read together with full_output
+                    vgg_kwargs["n_stages"] = arch["n_stages"]
             if "skip_connections" in arch:
                 vgg_kwargs["skip_connections"] = arch["skip_connections"]
-            if "n_stages" in arch:
-                raise NotImplementedError("dream_amd: DreamHourglassMultiStage (n_stages) is not built yet "
-                                          "(SURVEY.md 8f rank 3)")
-            net = models.DreamHourglass(self.n_keypoints, **vgg_kwargs)
+            if "n_stages" in arch:                        # network.py:243-249
+                net = models.DreamHourglassMultiStage(self.n_keypoints, **vgg_kwargs)
+            else:
+                net = models.DreamHourglass(self.n_keypoints, **vgg_kwargs)
         elif self.architecture_type == "resnet":
             assert arch["output_heads"] == ["belief_maps"]
             resnet_kwargs = {}
@@ -225,7 +227,13 @@ class DreamNetwork:
     def loss(self, network_input_heads, target):
         network_output_heads = self.model(self._to_device(network_input_heads[0]))
         if self.network_config["architecture"]["output_heads"] == ["belief_maps"]:
-            loss = self.criterion(network_output_heads[0], self._to_device(target))
+            target = self._to_device(target)
+            if "n_stages" in self.network_config["architecture"]:      # network.py:345-352: mean over all stages
+                n_stages = len(network_output_heads)
+                target_expanded = target.unsqueeze(0).expand([n_stages] + [-1] * target.dim())
+                loss = self.criterion(torch.stack(network_output_heads), target_expanded)
+            else:
+                loss = self.criterion(network_output_heads[0], target)
         else:
             assert False, "Not yet implemented."
         return loss

@@ -424,6 +424,37 @@ def add_(dst, src):
     return dst
 
 
+def add(a, b, want_amax=False):
+    """-> (a + b, amax or None)."""
+    a, b = _f32(a), _f32(b)
+    out = torch.empty_like(a)
+    amax = new_amax(a.device) if want_amax else None
+    call("dream_add_f32", ptr(a), ptr(b), ptr(out), a.numel(), ptr(amax), stream())
+    return out, amax
+
+
+def stage_input(img_nchw, maps_nchw, up, cpad, want_amax=False):
+    """cat([image, nearest-upsample(maps, up)], dim=1) as zero-padded NHWC [B,H,W,cpad] (models.py:487-493)."""
+    img, maps = _f32(img_nchw), _f32(maps_nchw)
+    b, ci, h, w = (int(v) for v in img.shape)
+    k = int(maps.shape[1])
+    if (int(maps.shape[2]) * up, int(maps.shape[3]) * up) != (h, w) or int(maps.shape[0]) != b:
+        raise RuntimeError("stage_input: maps %s x%d do not match image %s" % (tuple(maps.shape), up, tuple(img.shape)))
+    out = torch.empty((b, h, w, cpad), dtype=torch.float32, device=img.device)
+    amax = new_amax(img.device) if want_amax else None
+    call("dream_stage_input_nhwc_f32", ptr(img), ptr(maps), ptr(out), b, h, w, ci, k, up, cpad, ptr(amax), stream())
+    return out, amax
+
+
+def stage_input_bwd(g_nhwc, ci, k, up):
+    """Gradient of stage_input w.r.t. the maps: [B,H,W,C>=ci+k] -> [B,k,H/up,W/up] (sums over the up x up blocks)."""
+    g = _f32(g_nhwc)
+    b, h, w, c = (int(v) for v in g.shape)
+    out = torch.empty((b, k, h // up, w // up), dtype=torch.float32, device=g.device)
+    call("dream_stage_input_bwd_f32", ptr(g), ptr(out), b, h, w, ci, k, up, c, 0, stream())
+    return out
+
+
 # ---- split-precision (fp16x3) path ----------------------------------------------------------------------
 def new_amax(device):
     """Device scalar (uint32 bit pattern of a non-negative float) that kernels atomicMax their max|y| into."""

@@ -240,6 +240,18 @@ int dream_channel_sum_nhwc_f32(const float *x, float *out, void *workspace, size
 int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
 /* dst += src (gradient accumulation where two branches meet) */
 int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream);
+/* out = a + b: the encoder skip tensors joining the decoder (`x_0_5 + x_0_4_d`, `y_0_5 + x_0_3_d`, ...,
+ * dream/models.py:774-807).  amax_out (optional) receives the bit pattern of max|out| for the split-precision kernel. */
+int dream_add_f32(const float *a, const float *b, float *out, size_t n, unsigned *amax_out, void *stream);
+/* Multi-stage hourglass input (dream/models.py:487-493,:500-553): torch.cat([x, F.interpolate(y_prev, scale_factor=up)], 1)
+ * written straight into the NHWC layout the MFMA first conv of stage s>1 reads: img NCHW [B,Ci,H,W], maps NCHW
+ * [B,K,H/up,W/up] (up = 4, or 1 when the decoder is full-resolution) -> out [B,H,W,Cpad], channels >= Ci+K zero.
+ * _bwd: g NHWC [B,H,W,Cpad] -> dmaps NCHW [B,K,H/up,W/up] = sums of channels Ci..Ci+K-1 over each up x up block
+ * (accumulate != 0: added to dmaps). */
+int dream_stage_input_nhwc_f32(const float *img_nchw, const float *maps_nchw, float *out_nhwc, int B, int H, int W,
+                               int Ci, int K, int up, int Cpad, unsigned *amax_out, void *stream);
+int dream_stage_input_bwd_f32(const float *g_nhwc, float *dmaps_nchw, int B, int H, int W, int Ci, int K, int up,
+                              int Cpad, int accumulate, void *stream);
 /* first-layer weight gradient: x NCHW [B,Cin,H,W], dy NHWC [B,H,W,Cout] -> dw OIHW, dbias */
 size_t dream_conv3x3_first_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
 int dream_conv3x3_first_wgrad_f32(const float *x_nchw, const float *dy_nhwc, float *dw_oihw,

@@ -128,6 +128,37 @@ class DreamHourglass(nn.Module):
         return outs
 
 
+class DreamHourglassMultiStage(nn.Module):
+    """models.py:350-553.  S in [1,6] hourglasses; stage s>1 sees cat([image, maps of stage s-1]) with the maps
+    nearest-upsampled x4 unless the decoder already reaches input resolution (:487-493); returns the S belief-map
+    tensors (the soft-argmax head of each stage is computed and dropped, :481)."""
+
+    def __init__(self, n_keypoints, n_image_input_channels=3, internalize_spatial_softmax=True, learned_beta=True,
+                 initial_beta=1.0, n_stages=2, skip_connections=False, deconv_decoder=False, full_output=False):
+        super().__init__()
+        assert isinstance(n_stages, int), \
+            'Expected "n_stages" to be an integer, but it is {}.'.format(type(n_stages))
+        assert 0 < n_stages and n_stages <= 6, \
+            "DreamHourglassMultiStage can only be constructed with 1 to 6 stages at this time."
+        self.num_stages = n_stages
+        self.deconv_decoder = deconv_decoder
+        self.full_output = full_output
+        for s in range(1, n_stages + 1):
+            cin = n_image_input_channels + (n_keypoints if s > 1 else 0)                       # :400-478
+            setattr(self, "stage%d" % s, DreamHourglass(
+                n_keypoints, cin, internalize_spatial_softmax, learned_beta, initial_beta,
+                skip_connections=skip_connections, deconv_decoder=deconv_decoder, full_output=full_output))
+
+    def forward(self, x):                                                                      # :480-553
+        outs = [self.stage1(x)[0]]
+        for s in range(2, self.num_stages + 1):
+            prev = outs[-1]
+            if not (self.deconv_decoder or self.full_output):
+                prev = F.interpolate(prev, scale_factor=4)
+            outs.append(getattr(self, "stage%d" % s)(torch.cat([x, prev], dim=1))[0])
+        return outs
+
+
 class ResnetSimple(nn.Module):
     """models.py:17-155.  ResNet101 trunk, 4 (or 5) x [ConvT 4x4 s2 p1 -> BN -> ReLU], 1x1 -> K."""
 
@@ -158,9 +189,44 @@ class ResnetSimple(nn.Module):
         return [x]
 
 
+# Architecture-block overrides (on the shipped vgg_q / vgg_f YAML) that reach the remaining constructor branches of
+# network.py:194-256: skip connections, the full-resolution upsample decoder, the soft-argmax head, multi-stage.
+VARIANTS = {
+    "vgg_q_skip": ("vgg_q", {"skip_connections": True}),
+    "vgg_f_skip": ("vgg_f", {"skip_connections": True}),
+    "vgg_full": ("vgg_q", {"deconv_decoder": False, "full_output": True}),
+    "vgg_q_softmax": ("vgg_q", {"spatial_softmax": {"learned_beta": True, "initial_beta": 25.0},
+                                "output_heads": ["belief_maps", "keypoints"]}),
+    "vgg_ms2": ("vgg_q", {"n_stages": 2}),                      # n_stages only read with full_output (:225-230) -> default 2
+    "vgg_f_ms2_skip": ("vgg_f", {"n_stages": 2, "skip_connections": True}),
+    "vgg_ms3_full": ("vgg_q", {"deconv_decoder": False, "full_output": True, "n_stages": 3}),
+}
+
+
+def build_variant(name, n_keypoints):
+    """What DreamNetwork.__init__ (network.py:194-256) builds for VARIANTS[name], minus DataParallel."""
+    base, over = VARIANTS[name]
+    kw = {"internalize_spatial_softmax": False}
+    if "spatial_softmax" in over:
+        kw = {"internalize_spatial_softmax": True, "learned_beta": over["spatial_softmax"]["learned_beta"],
+              "initial_beta": over["spatial_softmax"]["initial_beta"]}
+    deconv = over.get("deconv_decoder", base == "vgg_f")
+    kw["deconv_decoder"] = deconv
+    if "full_output" in over:
+        kw["full_output"] = True
+        if "n_stages" in over:
+            kw["n_stages"] = over["n_stages"]
+    if "skip_connections" in over:
+        kw["skip_connections"] = over["skip_connections"]
+    cls = DreamHourglassMultiStage if "n_stages" in over else DreamHourglass
+    return cls(n_keypoints, **kw)
+
+
 def build_model(arch, n_keypoints):
     """arch in {vgg_q, vgg_f, resnet_h, resnet_f}: what DreamNetwork.__init__ builds for the four
     shipped arch_configs (network.py:194-284), minus the DataParallel wrapper."""
+    if arch in VARIANTS:
+        return build_variant(arch, n_keypoints)
     if arch == "vgg_q":
         return DreamHourglass(n_keypoints, internalize_spatial_softmax=False)
     if arch == "vgg_f":

@@ -107,6 +107,19 @@ CNN_CASES = {
     "resnet_f": (17, "baxter", [(1, 64, 64)]),
 }
 
+# Constructor branches the shipped YAMLs do not reach (oracle.models.VARIANTS gives the architecture overrides):
+# variant -> ([(B, H, W)] inference cases, training golden? (2 Adam steps at B=2, 64x96))
+VARIANT_CASES = {
+    "vgg_q_skip": ([(1, 64, 80)], True),
+    "vgg_f_skip": ([(1, 48, 64)], True),
+    "vgg_full": ([(1, 48, 64)], False),
+    "vgg_q_softmax": ([(2, 64, 80)], False),
+    "vgg_ms2": ([(1, 64, 80)], True),
+    "vgg_f_ms2_skip": ([(1, 32, 48)], True),
+    "vgg_ms3_full": ([(1, 32, 48)], False),
+}
+VARIANT_TRAIN_SHAPE = (2, 64, 96)
+
 # one-training-step golden (G5): learning rates and the recipe tweak that keep the loss finite
 TRAIN_LR = {"adam": 1e-5, "sgd": 1e-6}
 TRAIN_FINAL_KEYS = ("heads_0.4.weight", "heads_0.4.bias")

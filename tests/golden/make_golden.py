@@ -7,6 +7,7 @@ Fixtures are data only (inputs are regenerated from seeds by cases.py; outputs a
   cnn_<arch>.npz        G4     model(x)[0] for recipe weights (oracle.models.recipe_weights)
   train_vgg_q.npz       G5     one DreamNetwork.train() step (loss, grad norms, post-Adam samples)
   state_dict_manifest.json G6  key -> shape for the four archs (module.-prefixed, as saved)
+  variant_<name>.npz    G7     skip / full_output / soft-argmax / multi-stage hourglasses (--only-variants)
 """
 import json
 import os
@@ -33,9 +34,63 @@ def flatten_peaks(all_peaks):
     return counts, xy, sc, ids
 
 
+def variants(dream):
+    """G7: the hourglass constructor branches no shipped YAML reaches (skip connections, full-resolution upsample
+    decoder, soft-argmax head, multi-stage) -- inference outputs, every stage's maps, and two training steps."""
+    manifest = {}
+    for name, (shapes, train) in cases.VARIANT_CASES.items():
+        base, over = omodels.VARIANTS[name]
+        net = dream.create_network_from_config_data(ref_import.network_config(base, overrides=over))
+        sd = net.model.state_dict()
+        manifest[name] = {key: list(v.shape) for key, v in sd.items()}
+        w = omodels.recipe_weights({key[len("module."):]: v for key, v in sd.items()})
+        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+        net.enable_evaluation()
+        out = {}
+        for (b, h, wd) in shapes:
+            x = torch.from_numpy(cases.image_batch(b, h, wd, seed=b * 1000 + h))
+            tag = "%dx%dx%d" % (b, h, wd)
+            with torch.no_grad():
+                res = net.inference(x)
+                heads = net.model(x)
+            out[tag + "/maps"] = res[0].numpy()
+            out[tag + "/keypoints"] = res[1].numpy()
+            for i, t in enumerate(heads):
+                out[tag + "/head%d" % i] = t.numpy()
+            print(name, tag, "->", [tuple(t.shape) for t in heads], "absmax %.3f" % float(res[0].abs().max()))
+        if train:
+            b, h, wd = cases.VARIANT_TRAIN_SHAPE
+            cfg = ref_import.network_config(base, lr=cases.TRAIN_LR["adam"], optimizer="adam", overrides=over)
+            cfg["training"]["config"]["net_input_resolution"] = [wd, h]
+            net = dream.create_network_from_config_data(cfg)
+            w = omodels.recipe_weights({key[len("module."):]: v for key, v in net.model.state_dict().items()},
+                                       final_keys=cases.TRAIN_FINAL_KEYS, final_scale=cases.TRAIN_FINAL_SCALE)
+            net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+            net.enable_training()
+            ow, oh = net.trained_net_output_resolution()
+            x = torch.from_numpy(cases.image_batch(b, h, wd, seed=7))
+            tgt = torch.from_numpy(cases.target_batch(b, 7, (ow, oh), in_wh=(wd, h), seed=7))
+            losses = []
+            for step in range(2):
+                losses.append(net.train([x], tgt).item())
+                if step == 0:
+                    for key, p in net.model.named_parameters():
+                        if p.grad is not None:
+                            out["train/gradnorm/" + key] = np.array(float(p.grad.double().norm()))
+            out["train/losses"] = np.array(losses, np.float64)
+            for key, p in net.model.named_parameters():
+                out["train/param_sample/" + key] = p.detach().flatten()[:: max(1, p.numel() // 64)][:64].numpy().copy()
+            print(name, "train losses", losses)
+        np.savez_compressed(os.path.join(HERE, "variant_%s.npz" % name), **out)
+    with open(os.path.join(HERE, "variant_state_dict_manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=False)
+
+
 def main():
     dream = ref_import.import_reference()
     torch.manual_seed(0)
+    if "--only-variants" in sys.argv:
+        return variants(dream)
 
     # ---- G1 + G2 -------------------------------------------------------------------------
     out = {}
@@ -118,6 +173,7 @@ def main():
             out["param_sample/" + key] = p.detach().flatten()[:: max(1, p.numel() // 64)][:64].numpy().copy()
         np.savez_compressed(os.path.join(HERE, "train_vgg_q_%s.npz" % opt), **out)
         print("train", opt, "losses", losses)
+    variants(dream)
 
 
 if __name__ == "__main__":

@@ -83,7 +83,7 @@ def import_reference():
     return dream
 
 
-def network_config(arch, manip="panda", n_keypoints=None, lr=1e-4, optimizer="adam"):
+def network_config(arch, manip="panda", n_keypoints=None, lr=1e-4, optimizer="adam", overrides=None):
     """The dict scripts/train_network.py:259-323 assembles from manip + arch YAML."""
     import yaml
     dream = import_reference()
@@ -93,6 +93,7 @@ def network_config(arch, manip="panda", n_keypoints=None, lr=1e-4, optimizer="ad
     with open(os.path.join(REFERENCE_ROOT, "manip_configs", "%s.yaml" % manip)) as f:
         manip_cfg = data_parser.load(f)
     architecture = dict(arch_cfg["architecture"])
+    architecture.update(overrides or {})
     architecture["image_preprocessing"] = arch_cfg["training"]["config"]["image_preprocessing"]
     return {
         "data_path": "synthetic",

@@ -191,9 +191,15 @@ def check_softargmax(dev):
 def build_network(arch, dev, weights=None, optimizer="adam", lr=1e-4, in_res=None, quiet=True):
     import contextlib
     import io
-    k = cases.CNN_CASES[arch][0]
-    manip = cases.CNN_CASES[arch][1]
-    cfg = dream_amd.default_network_config(arch, manip, optimizer=optimizer, learning_rate=lr)
+    if arch in om.VARIANTS:
+        base, over = om.VARIANTS[arch]
+        k, manip = 7, "panda"
+        cfg = dream_amd.default_network_config(base, manip, optimizer=optimizer, learning_rate=lr)
+        cfg["architecture"].update(over)
+    else:
+        k = cases.CNN_CASES[arch][0]
+        manip = cases.CNN_CASES[arch][1]
+        cfg = dream_amd.default_network_config(arch, manip, optimizer=optimizer, learning_rate=lr)
     if in_res is not None:
         cfg["training"]["config"]["net_input_resolution"] = list(in_res)
     with contextlib.redirect_stdout(io.StringIO()) if quiet else contextlib.nullcontext():
@@ -518,3 +524,60 @@ def check_conv_transpose4x4_f16x3(dev, B, H, W, Cin, Cout, seed=0):
     assert float((got.double() - ref).abs().max()) / scale <= 5e-6
     am = float(np.frombuffer(amax.cpu().numpy().tobytes(), dtype=np.float32)[0])
     assert abs(am - float(got.abs().max())) <= 1e-6 * scale
+
+
+def check_variant(dev, name, precision="fp32", train=True):
+    """Hourglass constructor branches outside the shipped YAMLs (oracle.models.VARIANTS) against the reference's golden
+    outputs: inference (last stage maps + keypoints), every head / stage of model(x), and two Adam steps."""
+    shapes, has_train = cases.VARIANT_CASES[name]
+    g = np.load(os.path.join(GOLD, "variant_%s.npz" % name))
+    net = build_network(name, dev)
+    assert list(net.model.state_dict().keys()) == ["module." + k for k in om.build_model(name, 7).state_dict().keys()]
+    net.enable_evaluation()
+    net.model.module.precision = precision
+    for (b, h, w) in shapes:
+        tag = "%dx%dx%d" % (b, h, w)
+        x = to(dev, torch.from_numpy(cases.image_batch(b, h, w, seed=b * 1000 + h)))
+        with torch.no_grad():
+            res = net.inference(x)
+            heads = net.model(x)
+        for i, t in enumerate(heads):
+            ref = g[tag + "/head%d" % i]
+            lim = tol(ref) if ref.ndim == 4 else 2e-2          # soft-argmax coordinates (px) amplify 1e-5 map noise
+            assert np.abs(t.cpu().numpy() - ref).max() <= lim, (name, tag, i, np.abs(t.cpu().numpy() - ref).max())
+        assert np.abs(res[0].cpu().numpy() - g[tag + "/maps"]).max() <= tol(g[tag + "/maps"])
+        ref_k, got_k = g[tag + "/keypoints"], res[1].cpu().numpy()
+        if ref_k.dtype == got_k.dtype and name != "vgg_q_softmax":
+            same = (got_k == np.float32(-999.999)) == (ref_k == np.float32(-999.999))
+            assert same.mean() >= 0.85
+            both = (got_k != np.float32(-999.999)) & (ref_k != np.float32(-999.999))
+            assert np.abs(got_k - ref_k)[both].max(initial=0.0) < 0.5
+        else:
+            assert np.abs(got_k - ref_k).max() <= 2e-2
+    if not (train and has_train and precision == "fp32"):
+        return
+    b, h, w = cases.VARIANT_TRAIN_SHAPE
+    wts = om.recipe_weights(om.build_model(name, 7).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    net = build_network(name, dev, weights=wts, optimizer="adam", lr=cases.TRAIN_LR["adam"], in_res=(w, h))
+    net.enable_training()
+    ow, oh = net.trained_net_output_resolution()
+    x = to(dev, torch.from_numpy(cases.image_batch(b, h, w, seed=7)))
+    t = to(dev, torch.from_numpy(cases.target_batch(b, 7, (ow, oh), in_wh=(w, h), seed=7)))
+    losses = []
+    for step in range(2):
+        losses.append(net.train([x], t).item())
+        if step == 0:
+            for key, p in net.model.named_parameters():
+                ref = float(g["train/gradnorm/" + key])
+                assert abs(float(p.grad.double().norm()) - ref) <= 2e-3 * max(ref, 1e-9), (key, float(p.grad.double().norm()), ref)
+    assert np.allclose(losses, g["train/losses"], rtol=2e-4), (losses, g["train/losses"])
+    # Adam moves every element by ~lr per step whatever the gradient's size, so an element whose gradient is rounding
+    # noise around zero may step the other way: bound every element by that worst case, and require the bulk to agree.
+    lr, close, total = cases.TRAIN_LR["adam"], 0, 0
+    for key, p in net.model.named_parameters():
+        s_ = p.detach().flatten()[:: max(1, p.numel() // 64)][:64].cpu().numpy()
+        ref = g["train/param_sample/" + key]
+        assert np.abs(s_ - ref).max() <= 2 * 2 * lr * 1.05 + 1e-3 * np.abs(ref).max(), key
+        close += int(np.isclose(s_, ref, rtol=1e-3, atol=3e-6).sum())
+        total += ref.size
+    assert close >= 0.97 * total, (close, total)

@@ -3,6 +3,8 @@
 against the oracle and the reference's golden outputs.  This validates index arithmetic, LDS layouts,
 barrier placement, the documented MFMA lane layout and all host logic without a GPU; the same checks run
 on the real device in the -m gpu suite."""
+import os
+
 import pytest
 
 import cases
@@ -135,3 +137,17 @@ def test_on_device_dataprep(emu):
 def test_resnet_split_precision(emu):
     pc.check_conv_transpose4x4_f16x3("cpu", 1, 5, 6, 32, 48)
     pc.check_model_inference("cpu", "resnet_h", (2, 64, 96), precision="fp16x3")
+
+
+_FULL = os.environ.get("DREAM_EMU_FULL", "0") == "1"    # the emulator is ~1e4x slower than the GPU: the default CPU suite
+                                                        # runs two inference cases, DREAM_EMU_FULL=1 all of them + training
+
+
+@pytest.mark.parametrize("name", sorted(cases.VARIANT_CASES) if _FULL else ["vgg_f_ms2_skip", "vgg_ms2"])
+def test_hourglass_variants(emu, name):
+    pc.check_variant("cpu", name, train=_FULL)
+
+
+@pytest.mark.skipif(not _FULL, reason="set DREAM_EMU_FULL=1 (several minutes under the emulator); covered on the GPU")
+def test_hourglass_variants_split_precision(emu):
+    pc.check_variant("cpu", "vgg_f_ms2_skip", precision="fp16x3")

@@ -267,3 +267,13 @@ def test_resnet_split_precision():
     pc.check_conv_transpose4x4_f16x3(DEV, 1, 52, 52, 256, 256)
     pc.check_model_inference(DEV, "resnet_h", (2, 64, 96), precision="fp16x3")
     pc.check_model_inference(DEV, "resnet_f", (1, 64, 64), precision="fp16x3")
+
+
+@pytest.mark.parametrize("name", sorted(cases.VARIANT_CASES))
+def test_hourglass_variants(name):
+    pc.check_variant(DEV, name)
+
+
+@pytest.mark.parametrize("name", ["vgg_q_skip", "vgg_f_ms2_skip", "vgg_ms2", "vgg_ms3_full"])
+def test_hourglass_variants_split_precision(name):
+    pc.check_variant(DEV, name, precision="fp16x3")

@@ -92,3 +92,52 @@ def test_softargmax_matches_reference_outputs():
         assert np.allclose(y, g[name], rtol=0, atol=1e-4), name
     # SURVEY.md 8a6 KAT (border bias from the zero-padded avg-pool is expected behaviour)
     assert np.allclose(g["kat_b25"][0], [[7.5230, 5.3138], [14.9651, 9.9651], [25.0729, 16.0064]], atol=1e-3)
+
+
+@pytest.mark.parametrize("name", sorted(cases.VARIANT_CASES))
+def test_variant_hourglasses_match_reference(name):
+    """Skip connections, full-resolution upsample decoder, soft-argmax head and DreamHourglassMultiStage: state_dict
+    layout, every head / stage output and two Adam steps against the stub-imported reference (variant_*.npz)."""
+    shapes, train = cases.VARIANT_CASES[name]
+    g = np.load(os.path.join(GOLD, "variant_%s.npz" % name))
+    man = json.load(open(os.path.join(GOLD, "variant_state_dict_manifest.json")))[name]
+    m = om.build_model(name, 7)
+    sd = m.state_dict()
+    assert ["module." + key for key in sd.keys()] == list(man.keys())
+    assert all(list(sd[key[len("module."):]].shape) == shp for key, shp in man.items())
+    m.load_state_dict(om.recipe_weights(sd))
+    m.eval()
+    for (b, h, w) in shapes:
+        tag = "%dx%dx%d" % (b, h, w)
+        x = torch.from_numpy(cases.image_batch(b, h, w, seed=b * 1000 + h))
+        with torch.no_grad():
+            heads = m(x)
+        for i, t in enumerate(heads):
+            ref = g[tag + "/head%d" % i]
+            assert np.abs(t.numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max()), (name, tag, i)
+    if train:
+        b, h, w = cases.VARIANT_TRAIN_SHAPE
+        m = om.build_model(name, 7)
+        m.load_state_dict(om.recipe_weights(m.state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE))
+        m.train()
+        o = torch.optim.Adam(m.parameters(), lr=cases.TRAIN_LR["adam"])
+        x = torch.from_numpy(cases.image_batch(b, h, w, seed=7))
+        with torch.no_grad():
+            oh, ow = m(x[:1])[0].shape[2:]
+        t = torch.from_numpy(cases.target_batch(b, 7, (ow, oh), in_wh=(w, h), seed=7))
+        losses = []
+        for step in range(2):
+            o.zero_grad()
+            outs = m(x)
+            if "n_stages" in om.VARIANTS[name][1]:           # network.py:345-352
+                loss = torch.nn.functional.mse_loss(torch.stack(outs), t.unsqueeze(0).expand(len(outs), -1, -1, -1, -1))
+            else:
+                loss = torch.nn.functional.mse_loss(outs[0], t)
+            loss.backward()
+            o.step()
+            losses.append(loss.item())
+            if step == 0:
+                for key, p in m.named_parameters():
+                    ref = float(g["train/gradnorm/module." + key])
+                    assert abs(float(p.grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-6), key
+        assert np.allclose(losses, g["train/losses"], rtol=1e-5)

@@ -24,7 +24,7 @@ def main():
         for name, start, dur, gx, gy, lds, vg in cur.execute(
                 "select name, start, duration, grid_x, grid_y, lds_size, vgpr_count from kernels order by start"):
             t0 = start if t0 is None else t0
-            if "conv3x3_mfma" in name or "wgrad" in name:
+            if "conv_mfma" in name or "conv_f16x3" in name or "wgrad" in name:
                 f.write('"%s",%.3f,%.1f,%d,%d,%d,%d\n' % (name.split("(")[0], (start - t0) / 1e6, dur / 1e3, gx, gy, lds, vg))
     # PMC, if present
     try:
