@@ -1,29 +1,32 @@
-// conv3x3 weight + bias gradient (replaces ATen's conv backward-weight reached from loss.backward(),
-// /root/reference/dream/network.py:335, for the Conv2d layers of dream/models.py:594-615,695-747).
+// Convolution weight + bias gradients (replace ATen's conv backward-weight reached from loss.backward(),
+// /root/reference/dream/network.py:335, for the Conv2d / ConvTranspose2d layers of dream/models.py:22-136,594-747).
 //
-//   dW[t][o][i] = sum over (b, pixel p) of  dy[b,p][o] * x[b, p + d(t)][i]        d(t) = (ky-1, kx-1)
-//   db[o]       = sum over (b, p) of dy[b,p][o]
+//   dW[t][r][c] = sum over (b, position m) of  T[b,m][r] * P[b, m + d(t)][c]
 //
-// GEMM view per tap:  dW_t (Cout x Cin) = dY^T (Cout x P) * X_t (P x Cin): the reduction runs over
-// PIXELS (up to 20.5 M at 128x400x400), so the work is split over pixel tiles ("split-K") and every
-// workgroup keeps all NINE tap accumulators of its 64(cout) x 64(cin) tile in registers
-// (one 32x32 MFMA tile per wave per tap = 144 accumulator VGPRs): the dY tile and the X patch are
-// staged in LDS once per pixel tile and feed 9 MFMAs per k-step (k = 2 pixels for
-// v_mfma_f32_32x32x2_f32).  Partials go to a workspace and are summed in a FIXED order by a second
-// kernel, so the result is deterministic (no fp32 atomics).
+// T ("tile tensor") is sampled at the positions themselves and gives the ROWS of dW, P ("patch tensor") is sampled
+// through the taps and gives the COLUMNS:  Conv2d: T = dy, P = x;  ConvTranspose2d: T = x, P = dy.
+// GEMM view per tap: dW_t (R x C) = T^T (R x M) * P_t (M x C): the reduction runs over POSITIONS (up to 20.5 M at
+// 128x400x400), so the work is split over position tiles ("split-K"); partials go to a workspace and are summed in a
+// FIXED order by a second kernel, so the result is deterministic (no fp32 atomics).
 //
-// LDS: dY tile [128 px][64 cout] (32 KB) + X patch [<=192 px][64 cin] (48 KB): operand reads are
-// ds_read_b32 of 32 consecutive floats per half-wave (conflict-free for any row stride).
+// One kernel template, three register blockings of the wave's 32x32 fp32 MFMA tiles (<= 9 accumulators = 144 VGPRs):
+//   <1,1,9,128>  3x3 convs: all NINE tap accumulators of a 64x64 (rows x cols) workgroup tile; T tile and P patch are
+//                staged in LDS once per 128-position tile and feed 9 MFMAs per k-step (k = 2 positions);
+//   <2,1,4,64>   stride-2 transposed convs, one launch per output PHASE (a,b): the dy pixels of one phase form a
+//                stride-1 grid, so each phase is a 2x2-tap (k=4) or 1/2/2/4-tap (k=3) stride-1 problem with a compact
+//                patch -- no zero-stuffing and no 4x oversized stride-2 patch; 128x64 tile, 2 row blocks x 4 taps;
+//   <2,2,1,64>   1x1 convs: 128x128 tile (2x2 blocks per wave) -- a plain split-K GEMM that re-reads its operands half
+//                as often as 64x64 tiles would.
+// LDS operand reads are ds_read_b32 of 32 consecutive floats per half-wave (conflict-free for any row stride).
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
 
 namespace {
 
-constexpr int WG_PIX = 128;       // pixels per tile (k extent 128, 64 MFMA k-steps)
-constexpr int WG_NPMAX = 192;     // patch pixels (stride-1 taps)
-constexpr int WG_NPMAX_STRIDED = 352;   // stride-2 taps need ~4x the tile; 1 workgroup per CU then
-constexpr int WG_C = 64;          // channel tile (cout and cin)
+constexpr int WG_MAXSLOT = 9;
+constexpr int WG_NPMAX = 192;     // patch pixels for the 128-position variants
+constexpr int WG_NPMAX_STRIDED = 352;   // stride-2 3x3 taps need ~4x the tile; 1 workgroup per CU then
 
 struct WgradParams {
     const float *tile_t;     // tensor whose channels become the ROWS of dW, sampled at the tile positions
@@ -34,41 +37,45 @@ struct WgradParams {
     int Hin, Win, Hs, Ws;    // logical / stored extent of the patch tensor
     int Ct, Cp, RowsPad;     // channels of tile / patch tensor
     int TH, TW, PH, PW, tiles_x, tiles_y, rcpTW;
-    int in_scale, in_step, lane_stride, pad;
-    int ntaps_total, tap_base, ntaps;          // this launch handles taps [tap_base, tap_base + ntaps), ntaps <= 9
-    unsigned long long tap_dy, tap_dx;         // 16 x 4-bit patch offsets
+    int in_scale, in_step, lane_stride, pad_y, pad_x;
+    int ntaps_total, ntaps;                    // ntaps = taps of THIS launch (<= NT)
+    unsigned long long tap_dy, tap_dx, tap_out;   // per launch slot: 4-bit patch offsets and output tap index
     int tiles_total, splitk, flags;
 };
 
+template <int RB, int CB, int NT, int PIX>
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
+    constexpr int RW = 64 * RB, CW = 64 * CB;       // workgroup tile: RW rows x CW cols (waves 2 x 2)
+    constexpr int QY = RW / 4, QX = CW / 4;         // float4 per staged row
+    constexpr int RPY = 256 / QY, RPX = 256 / QX;   // rows staged per pass
+    static_assert(RB * CB * NT <= WG_MAXSLOT, "too many accumulators");
     DREAM_DYNAMIC_LDS(float, smem);
-    float *sY = smem;                      // [128][64]
-    float *sX = smem + WG_PIX * WG_C;      // [NP][64]
+    float *sY = smem;                      // [PIX][RW]
+    float *sX = smem + PIX * RW;           // [NP][CW]
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
     const int wo = wave >> 1, wi = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int co0 = blockIdx.x * WG_C, ci0 = blockIdx.y * WG_C, ks = blockIdx.z;
+    const int co0 = blockIdx.x * RW, ci0 = blockIdx.y * CW, ks = blockIdx.z;
     const int PW = p.PW, TW = p.TW, npix = p.TH * p.TW, NP = p.PH * PW;
     const bool zst = (p.flags & DREAM_CONV_ZEROSTUFF2X) != 0;
     const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0 || zst;
 
-    f32x16 acc[9];
+    f32x16 acc[RB * CB * NT];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < RB * CB * NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
     f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};          // this thread's share of the column sums of tile_t
 
-    int toff[9];                                    // LDS offsets of this launch's taps (wave-uniform)
+    int toff[NT];                                   // LDS offsets of this launch's taps (wave-uniform)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int tt = p.tap_base + t;
-        toff[t] = ((int)((p.tap_dy >> (4 * tt)) & 15) * PW + (int)((p.tap_dx >> (4 * tt)) & 15)) * WG_C;
-    }
+    for (int t = 0; t < NT; ++t)
+        toff[t] = ((int)((p.tap_dy >> (4 * t)) & 15) * PW + (int)((p.tap_dx >> (4 * t)) & 15)) * CW;
 
-    const int q = tid & 15, prow = tid >> 4;        // staging: 16 float4 per 64-channel row, 16 rows per pass
-    const bool y_chan_ok = (co0 + q * 4) < p.Ct;    // channel counts are multiples of 4 (host wrapper)
-    const bool x_chan_ok = (ci0 + q * 4) < p.Cp;
+    const int qy = tid % QY, prow_y = tid / QY;     // staging of the tile tensor
+    const int qx = tid % QX, prow_x = tid / QX;     // staging of the patch
+    const bool y_chan_ok = (co0 + qy * 4) < p.Ct;   // channel counts are multiples of 4 (host wrapper)
+    const bool x_chan_ok = (ci0 + qx * 4) < p.Cp;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
     for (int tile = ks; tile < p.tiles_total; tile += p.splitk) {
@@ -84,67 +91,83 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         __syncthreads();                            // previous tile fully consumed
         // ---- stage the tile tensor (rows m >= npix or outside the image are zero) ------------------
 #pragma unroll
-        for (int it = 0; it < WG_PIX / 16; ++it) {
-            const int m = prow + it * 16;
+        for (int it = 0; it < PIX / RPY; ++it) {
+            const int m = prow_y + it * RPY;
             const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
             const int oy = y0 + ty, ox = x0 + tx;
             f32x4 v = zero4;
             if (m < npix && oy < p.Ht && ox < p.Wt && y_chan_ok)
-                v = *(const f32x4 *)(dyb + ((size_t)oy * p.Wt + ox) * p.Ct + co0 + q * 4);
-            *(f32x4 *)(sY + m * WG_C + q * 4) = v;
+                v = *(const f32x4 *)(dyb + ((size_t)oy * p.Wt + ox) * p.Ct + co0 + qy * 4);
+            *(f32x4 *)(sY + m * RW + qy * 4) = v;
             bsum += v;
         }
         // ---- stage the patch --------------------------------------------------------------------------
-        for (int pp = prow; pp < NP; pp += 16) {
+        for (int pp = prow_x; pp < NP; pp += RPX) {
             const int py = pp / PW, px = pp - py * PW;
-            const int gy = y0 * p.in_scale - p.pad + py * p.in_step, gx = x0 * p.in_scale - p.pad + px * p.in_step;
+            const int gy = y0 * p.in_scale - p.pad_y + py * p.in_step, gx = x0 * p.in_scale - p.pad_x + px * p.in_step;
             f32x4 v = zero4;
             if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && x_chan_ok && !(zst && ((gy | gx) & 1))) {
                 const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
-                v = *(const f32x4 *)(xb + ((size_t)sy * p.Ws + sx) * p.Cp + ci0 + q * 4);
+                v = *(const f32x4 *)(xb + ((size_t)sy * p.Ws + sx) * p.Cp + ci0 + qx * 4);
             }
-            *(f32x4 *)(sX + pp * WG_C + q * 4) = v;
+            *(f32x4 *)(sX + pp * CW + qx * 4) = v;
         }
         __syncthreads();
 
-        // ---- k-steps (2 positions each) x taps --------------------------------------------------------
-        const float *aY = sY + wo * 32 + li;
-        const float *bX = sX + wi * 32 + li;
+        // ---- k-steps (2 positions each) x (row block, col block, tap) ----------------------------------
+        const float *aY = sY + wo * (32 * RB) + li;
+        const float *bX = sX + wi * (32 * CB) + li;
         const int nsteps = (npix + 1) >> 1;
         for (int s = 0; s < nsteps; ++s) {
             const int m = 2 * s + lh;
             const int mc = m < npix ? m : 0;         // tile row m is zero there; keep the patch address legal
             const int ty = (mc * p.rcpTW) >> 16, tx = mc - ty * TW;
-            const float a = aY[m * WG_C];
-            const float *bp = bX + (ty * PW + tx) * p.lane_stride * WG_C;
+            float a[RB];
 #pragma unroll
-            for (int tp = 0; tp < 9; ++tp)
-                if (tp < p.ntaps) acc[tp] = mfma_f32_32x32x2(a, bp[toff[tp]], acc[tp]);
+            for (int rb = 0; rb < RB; ++rb) a[rb] = aY[m * RW + rb * 32];
+            const float *bp = bX + (ty * PW + tx) * p.lane_stride * CW;
+#pragma unroll
+            for (int tp = 0; tp < NT; ++tp) {
+                if (NT == 1 || tp < p.ntaps) {
+#pragma unroll
+                    for (int cb = 0; cb < CB; ++cb) {
+                        const float bv = bp[toff[tp] + cb * 32];
+#pragma unroll
+                        for (int rb = 0; rb < RB; ++rb)
+                            acc[(rb * CB + cb) * NT + tp] = mfma_f32_32x32x2(a[rb], bv, acc[(rb * CB + cb) * NT + tp]);
+                    }
+                }
+            }
         }
     }
 
     // ---- write partials ----------------------------------------------------------------------------
-    float *part = p.part + ((size_t)ks * p.ntaps_total + p.tap_base) * p.RowsPad * p.Cp;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (t < p.ntaps) {
+    for (int tp = 0; tp < NT; ++tp) {
+        if (tp < p.ntaps) {
+            const int tout = (int)((p.tap_out >> (4 * tp)) & 15);
+            float *part = p.part + ((size_t)ks * p.ntaps_total + tout) * p.RowsPad * p.Cp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = co0 + wo * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int i = ci0 + wi * 32 + li;
-                if (o < p.RowsPad && i < p.Cp) part[((size_t)t * p.RowsPad + o) * p.Cp + i] = acc[t][r];
-            }
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = co0 + wo * (32 * RB) + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int i = ci0 + wi * (32 * CB) + cb * 32 + li;
+                        if (o < p.RowsPad && i < p.Cp) part[(size_t)o * p.Cp + i] = acc[(rb * CB + cb) * NT + tp][r];
+                    }
         }
     }
     if (blockIdx.y == 0 && p.bias_part != nullptr) {
-        // threads sharing q (same 4 channels) differ in prow: reduce the 16 rows through LDS
+        // threads sharing qy (same 4 channels) differ in prow_y: reduce the RPY rows through LDS
         __syncthreads();
-        *(f32x4 *)(smem + (prow * 16 + q) * 4) = bsum;
+        *(f32x4 *)(smem + (prow_y * QY + qy) * 4) = bsum;
         __syncthreads();
-        if (tid < WG_C) {
+        if (tid < RW) {
             float s = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += smem[(r * 16 + (tid >> 2)) * 4 + (tid & 3)];
+            for (int r = 0; r < RPY; ++r) s += smem[(r * QY + (tid >> 2)) * 4 + (tid & 3)];
             if (co0 + tid < p.RowsPad) p.bias_part[(size_t)ks * p.RowsPad + co0 + tid] = s;
         }
     }
@@ -152,26 +175,67 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
 
 // fixed-order reduction over the split-K partials
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *part, float *out, size_t n, int splitk) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float s = 0.0f;
-        for (int k = 0; k < splitk; ++k) s += part[(size_t)k * n + i];
-        out[i] = s;
+    const size_t n4 = n / 4;                        // n is a multiple of 4 (channel counts are)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 *src = (const f32x4 *)part + i;
+        int k = 0;
+        for (; k + 4 <= splitk; k += 4) {           // four independent loads in flight, summed in index order
+            const f32x4 v0 = src[(size_t)k * n4], v1 = src[(size_t)(k + 1) * n4];
+            const f32x4 v2 = src[(size_t)(k + 2) * n4], v3 = src[(size_t)(k + 3) * n4];
+            s += v0;
+            s += v1;
+            s += v2;
+            s += v3;
+        }
+        for (; k < splitk; ++k) s += src[(size_t)k * n4];
+        ((f32x4 *)out)[i] = s;
     }
 }
 
+struct WgradVariant {
+    void (*kernel)(WgradParams);
+    int RW, CW, NT, PIX;
+    bool attr_set;
+};
+WgradVariant g_wvariants[] = {
+    {wgrad_kernel<1, 1, 9, 128>, 64, 64, 9, 128, false},
+    {wgrad_kernel<2, 1, 4, 64>, 128, 64, 4, 64, false},
+    {wgrad_kernel<2, 2, 1, 64>, 128, 128, 1, 64, false},
+    {wgrad_kernel<1, 1, 4, 128>, 64, 64, 4, 128, false},
+};
+int g_wgrad_forced = -1;          // A/B switch (dream_wgrad_set_variant)
+
+
+// One launch group = the taps that share a patch origin (all taps of a conv; one output phase of a transposed conv).
+struct TapGroup {
+    int pad_y, pad_x, ntaps;
+    int dy[WG_MAXSLOT], dx[WG_MAXSLOT], out[WG_MAXSLOT];
+};
 struct WgradGeom {
     int Ht, Wt, Hin, Win, Hs, Ws;
-    int in_scale, in_step, lane_stride, pad, kext;
-    int ntaps;
-    int tap_dy[16], tap_dx[16];
+    int in_scale, in_step, lane_stride, kext;
+    int ntaps;                    // total taps of dW
+    int ngroups;
+    TapGroup group[4];
 };
 
-void choose_tile_w(const WgradGeom &g, int *th_out, int *tw_out) {
-    const int np_max = g.lane_stride > 1 ? WG_NPMAX_STRIDED : WG_NPMAX;
+int pick_wvariant(const WgradGeom &g, int Cp, int RowsPad) {
+    int maxt = 0;
+    for (int i = 0; i < g.ngroups; ++i) maxt = g.group[i].ntaps > maxt ? g.group[i].ntaps : maxt;
+    int v = 0;
+    if (maxt == 1 && g.lane_stride == 1 && Cp >= 128 && RowsPad >= 128) v = 2;
+    else if (maxt <= 4 && g.lane_stride == 1 && g.ngroups > 1) v = RowsPad >= 128 ? 1 : 3;
+    if (g_wgrad_forced >= 0 && g_wvariants[g_wgrad_forced].NT >= maxt && (g.lane_stride == 1 || g_wgrad_forced == 0)) v = g_wgrad_forced;
+    return v;
+}
+
+void choose_tile_w(const WgradGeom &g, int pix, int *th_out, int *tw_out) {
+    const int np_max = g.lane_stride > 1 ? WG_NPMAX_STRIDED : (pix >= 128 ? WG_NPMAX : 2 * pix);
     long best = -1;
     int bnp = 0, bth = 1, btw = 1;
-    for (int tw = 1; tw <= WG_PIX; ++tw) {
-        for (int th = WG_PIX / tw; th >= 1; th = (g.lane_stride > 1 ? th - 1 : 0)) {
+    for (int tw = 1; tw <= pix; ++tw) {
+        for (int th = pix / tw; th >= 1; th = (g.lane_stride > 1 ? th - 1 : 0)) {
             int thc = th > g.Ht ? g.Ht : th;
             const int twc = tw > g.Wt ? g.Wt : tw;
             const int np = ((thc - 1) * g.lane_stride + g.kext) * ((twc - 1) * g.lane_stride + g.kext);
@@ -186,11 +250,14 @@ void choose_tile_w(const WgradGeom &g, int *th_out, int *tw_out) {
 }
 
 int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
+    const WgradVariant &var = g_wvariants[pick_wvariant(g, Cp, RowsPad)];
     int th, tw;
-    choose_tile_w(g, &th, &tw);
+    choose_tile_w(g, var.PIX, &th, &tw);
     const long tiles = (long)B * ceil_div(g.Ht, th) * ceil_div(g.Wt, tw);
-    const long ctiles = (long)ceil_div(RowsPad, WG_C) * ceil_div(Cp, WG_C);
-    long sk = 1024 / ctiles;
+    const long ctiles = (long)ceil_div(RowsPad, var.RW) * ceil_div(Cp, var.CW);
+    // 512 workgroups = 256 CUs x 2 resident: every extra split adds a RowsPad x Cp partial to write and re-read, which
+    // for the 1x1 layers of the ResNet trunk outweighs the operands themselves (profiles/r01_ab_wgrad.txt)
+    long sk = 512 / ctiles;
     if (sk < 1) sk = 1;
     if (sk > tiles) sk = tiles;
     if (sk > 1024) sk = 1024;
@@ -198,52 +265,61 @@ int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
 }
 
 size_t wgrad_workspace_bytes(int B, const WgradGeom &g, int Cp, int RowsPad) {
-    const int sk = pick_splitk_g(B, g, Cp, RowsPad);
+    // the A/B switch may change the split: size for the largest any variant would ask for
+    const int saved = g_wgrad_forced;
+    int sk = 0;
+    for (int f = -1; f < (int)(sizeof(g_wvariants) / sizeof(g_wvariants[0])); ++f) {
+        g_wgrad_forced = f;
+        const int s = pick_splitk_g(B, g, Cp, RowsPad);
+        sk = s > sk ? s : sk;
+    }
+    g_wgrad_forced = saved;
     return ((size_t)sk * g.ntaps * RowsPad * Cp + (size_t)(sk + 1) * RowsPad) * sizeof(float);
 }
 
 int launch_wgrad(const float *tile_t, const float *patch_t, float *dw_packed, float *dbias, int nbias, void *workspace,
                  int B, int Ct, int RowsPad, int Cp, const WgradGeom &g, int flags, void *stream) {
     DREAM_REQUIRE(tile_t && patch_t && dw_packed && workspace, "wgrad: null pointer");
-    DREAM_REQUIRE(B > 0 && Ct % 4 == 0 && Cp % 4 == 0 && RowsPad >= Ct, "wgrad: bad channels (%d, %d, pad %d)", Ct, Cp, RowsPad);
+    DREAM_REQUIRE(B > 0 && Ct % 4 == 0 && Cp % 4 == 0 && RowsPad >= Ct && RowsPad % 4 == 0, "wgrad: bad channels (%d, %d, pad %d)", Ct, Cp, RowsPad);
+    WgradVariant &var = g_wvariants[pick_wvariant(g, Cp, RowsPad)];
     WgradParams p;
     p.tile_t = tile_t; p.patch_t = patch_t;
     p.B = B; p.Ht = g.Ht; p.Wt = g.Wt; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws;
     p.Ct = Ct; p.Cp = Cp; p.RowsPad = RowsPad; p.flags = flags;
-    choose_tile_w(g, &p.TH, &p.TW);
+    choose_tile_w(g, var.PIX, &p.TH, &p.TW);
     p.PH = (p.TH - 1) * g.lane_stride + g.kext;
     p.PW = (p.TW - 1) * g.lane_stride + g.kext;
     p.tiles_x = ceil_div(g.Wt, p.TW); p.tiles_y = ceil_div(g.Ht, p.TH);
     p.rcpTW = (65536 + p.TW - 1) / p.TW;
-    p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride; p.pad = g.pad;
+    p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride;
     p.ntaps_total = g.ntaps;
-    p.tap_dy = 0; p.tap_dx = 0;
-    for (int t = 0; t < g.ntaps; ++t) {
-        p.tap_dy |= (unsigned long long)g.tap_dy[t] << (4 * t);
-        p.tap_dx |= (unsigned long long)g.tap_dx[t] << (4 * t);
-    }
     p.tiles_total = B * p.tiles_x * p.tiles_y;
     p.splitk = pick_splitk_g(B, g, Cp, RowsPad);
     p.part = (float *)workspace;
     float *bias_part = p.part + (size_t)p.splitk * g.ntaps * RowsPad * Cp;
-    const size_t lds = ((size_t)WG_PIX + (size_t)p.PH * p.PW) * WG_C * sizeof(float);
+    const size_t lds = ((size_t)var.PIX * var.RW + (size_t)p.PH * p.PW * var.CW) * sizeof(float);
     DREAM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
+    if (!var.attr_set) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        var.attr_set = true;
     }
-    const dim3 grid(ceil_div(RowsPad, WG_C), ceil_div(Cp, WG_C), p.splitk);
-    for (int base = 0; base < g.ntaps; base += 8) {        // <= 9 tap accumulators per launch
-        p.tap_base = base;
-        p.ntaps = (g.ntaps - base > 9) ? 8 : (g.ntaps - base);
-        p.bias_part = (dbias != nullptr && base == 0) ? bias_part : nullptr;
-        hipLaunchKernelGGL(wgrad_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    const dim3 grid(ceil_div(RowsPad, var.RW), ceil_div(Cp, var.CW), p.splitk);
+    for (int gi = 0; gi < g.ngroups; ++gi) {
+        const TapGroup &tg = g.group[gi];
+        DREAM_REQUIRE(tg.ntaps <= var.NT, "internal: %d taps in a group, variant holds %d", tg.ntaps, var.NT);
+        p.pad_y = tg.pad_y; p.pad_x = tg.pad_x; p.ntaps = tg.ntaps;
+        p.tap_dy = 0; p.tap_dx = 0; p.tap_out = 0;
+        for (int t = 0; t < tg.ntaps; ++t) {
+            p.tap_dy |= (unsigned long long)tg.dy[t] << (4 * t);
+            p.tap_dx |= (unsigned long long)tg.dx[t] << (4 * t);
+            p.tap_out |= (unsigned long long)tg.out[t] << (4 * t);
+        }
+        p.bias_part = (dbias != nullptr && gi == 0) ? bias_part : nullptr;
+        hipLaunchKernelGGL(var.kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
         DREAM_LAUNCH_OK();
-        if (p.ntaps == g.ntaps - base) break;
     }
     const size_t n = (size_t)g.ntaps * RowsPad * Cp;
-    size_t gr = (n + 255) / 256;
+    size_t gr = (n / 4 + 255) / 256;
     if (gr > 2048) gr = 2048;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gr), dim3(256), 0, (hipStream_t)stream,
                        (const float *)p.part, dw_packed, n, p.splitk);
@@ -270,21 +346,40 @@ WgradGeom conv_geom(int H, int W, int ksize, int stride, int flags) {
     g.in_scale = stride;
     g.in_step = (ksize == 1) ? stride : 1;
     g.lane_stride = (ksize == 1) ? 1 : stride;
-    g.pad = pad;
     g.kext = ksize;
     g.ntaps = ksize * ksize;
-    for (int t = 0; t < g.ntaps; ++t) { g.tap_dy[t] = t / ksize; g.tap_dx[t] = t % ksize; }
+    g.ngroups = 1;
+    TapGroup &tg = g.group[0];
+    tg.pad_y = pad; tg.pad_x = pad; tg.ntaps = g.ntaps;
+    for (int t = 0; t < g.ntaps; ++t) { tg.dy[t] = t / ksize; tg.dx[t] = t % ksize; tg.out[t] = t; }
     return g;
 }
 
 WgradGeom convT_geom(int H, int W, int k) {
     // ConvTranspose2d(k, stride 2, pad 1, output 2H x 2W; k = 4, or k = 3 with output_padding 1):
-    // dW_T[i][o][ky][kx] = sum_m x[m][i] * dy[2m - 1 + k][o]: tile = x (H x W), patch = dy (2H x 2W), stride-2 taps
+    //   dW_T[i][o][ky][kx] = sum_m x[m][i] * dy[2m - 1 + (ky,kx)][o]          tile = x (H x W), patch = dy
+    // Output row 2j + a is reached through ky of parity (a+1)&1 only, from input row j + (a + 1 - ky)/2.  So per
+    // phase (a, b) the dy pixels form the stride-1 grid dyP[j][i] = dy[2j+a][2i+b] and
+    //   dW_T[.][.][ky][kx] = sum_m x[m] * dyP[m - (a + 1 - ky)/2, ...]:
+    // a = 0: ky = 1 -> offset 0, ky = 3 -> offset +1 (patch origin m);  a = 1: ky = 0 -> -1, ky = 2 -> 0 (origin m-1).
+    // In the kernel's patch addressing g = m0*in_scale - pad + p*in_step with in_scale = in_step = 2, pad = a (0 | 1).
     WgradGeom g;
     g.Ht = H; g.Wt = W; g.Hin = 2 * H; g.Win = 2 * W; g.Hs = 2 * H; g.Ws = 2 * W;
-    g.in_scale = 2; g.in_step = 1; g.lane_stride = 2; g.pad = 1; g.kext = k;
+    g.in_scale = 2; g.in_step = 2; g.lane_stride = 1; g.kext = 2;
     g.ntaps = k * k;
-    for (int t = 0; t < k * k; ++t) { g.tap_dy[t] = t / k; g.tap_dx[t] = t % k; }
+    g.ngroups = 4;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            TapGroup &tg = g.group[a * 2 + b];
+            tg.pad_y = a; tg.pad_x = b; tg.ntaps = 0;
+            for (int ky = (a + 1) & 1; ky < k; ky += 2)
+                for (int kx = (b + 1) & 1; kx < k; kx += 2) {
+                    const int t = tg.ntaps++;
+                    tg.dy[t] = (a == 0) ? (ky - 1) / 2 : ky / 2;      // patch row of this tap relative to the origin
+                    tg.dx[t] = (b == 0) ? (kx - 1) / 2 : kx / 2;
+                    tg.out[t] = ky * k + kx;
+                }
+        }
     return g;
 }
 
@@ -411,6 +506,13 @@ extern "C" int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float
 extern "C" int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                              int H, int W, int Cin, int CinPad, int Cout, void *stream) {
     return launch_wgrad(x, dy, dw_packed, nullptr, 0, workspace, B, Cin, CinPad, Cout, convT_geom(H, W, 4), 0, stream);
+}
+
+// A/B switch for the tap-group variants (tools/microbench.py): -1 = heuristic
+extern "C" int dream_wgrad_set_variant(int variant) {
+    DREAM_REQUIRE(variant >= -1 && variant < (int)(sizeof(g_wvariants) / sizeof(g_wvariants[0])), "wgrad variant %d out of range", variant);
+    g_wgrad_forced = variant;
+    return 0;
 }
 
 static int first_wgrad_blocks(int B, int H, int W) {

@@ -197,6 +197,14 @@ class DreamHourglass(nn.Module):
         if not ok:
             raise RuntimeError("expected [B,%d,H,W] input, got %s" % (self.n_image_input_channels, tuple(x.shape)))
 
+    def _fuse_pool(self, layers, li, x_nhwc):
+        """Inference: fold the 2x2 max-pool that follows conv ``li`` into its epilogue?  Not when the un-pooled tensor is
+        a skip source, and only at >= 160 px: the fused kernel needs even tile sides, which costs 25 % more tiles at
+        50x50 (13.8 vs 11.3 + 0.15 ms, profiles/r01_pool_fusion.txt) but saves a 1.3 ms pass at 400x400."""
+        if not (li + 1 < len(layers) and layers[li + 1][0] == "pool") or li in self._skip_sources:
+            return False
+        return min(int(x_nhwc.shape[1]), int(x_nhwc.shape[2])) >= 160
+
     @staticmethod
     def _join(a, b):
         if a.shape != b.shape:        # what the reference's `+` raises for resolutions the pools do not divide
@@ -210,10 +218,12 @@ class DreamHourglass(nn.Module):
         pi = 0
         layers = self.plan_layers()
         keep = {}
+        pool_done = False
         for li, (kind, mod, flags) in enumerate(layers):
             if kind == "pool":
-                if not (li > 0 and layers[li - 1][0] in ("conv", "deconv") and (li - 1) not in self._skip_sources):
+                if not pool_done:
                     act = ops.maxpool2(act)
+                pool_done = False
             elif kind == "add":
                 self._join(act, keep[flags])
                 act, amax = ops.add(act, keep[flags], want_amax=True)
@@ -226,8 +236,8 @@ class DreamHourglass(nn.Module):
                     if kind == "wide" and not x_is_nhwc:
                         amax = ops.absmax(act)
                         act = ops.nchw_to_nhwc(act, cpad=self.input_channel_pad())
-                    if li + 1 < len(layers) and layers[li + 1][0] == "pool" and li not in self._skip_sources:
-                        flags = flags | CONV_POOL2
+                    if self._fuse_pool(layers, li, act):
+                        flags, pool_done = flags | CONV_POOL2, True
                     p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
                     act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
                                                  want_amax=not (flags & CONV_OUT_NCHW))
@@ -249,19 +259,19 @@ class DreamHourglass(nn.Module):
         act = x
         pi = 0
         layers = self.plan_layers()
+        pool_done = False
         for li, (kind, mod, flags) in enumerate(layers):
             inp = act
             if kind == "pool":
-                # inference: fused into the previous conv's epilogue unless the un-pooled tensor is a skip source
-                if save or not (li > 0 and layers[li - 1][0] in ("conv", "deconv") and (li - 1) not in self._skip_sources):
+                if not pool_done:
                     act = ops.maxpool2(inp)
+                pool_done = False
             elif kind == "add":
                 self._join(inp, keep[flags])
                 act, _ = ops.add(inp, keep[flags])
             else:
-                if (not save and kind not in ("first", "wide") and li + 1 < len(layers) and layers[li + 1][0] == "pool"
-                        and li not in self._skip_sources):
-                    flags = flags | CONV_POOL2
+                if not save and kind not in ("first", "wide") and self._fuse_pool(layers, li, inp):
+                    flags, pool_done = flags | CONV_POOL2, True
                 w, bias = params[pi], params[pi + 1]
                 pi += 2
                 if kind == "first":

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 import cases
-from dream_amd import ops
+from dream_amd import _hip, ops
 import dream_amd
 import dream_amd.optim
 from oracle import models as om
@@ -424,25 +424,34 @@ def check_resnet_training_ops(dev):
         assert float((dgam.cpu() - bn.weight.grad).abs().max()) < 1e-4 and float((dbet.cpu() - bn.bias.grad).abs().max()) < 1e-4
         gm = dy * (y_ref > 0) if relu else dy
         assert float((nchw(g.cpu()) - gm).abs().max()) == 0.0
+    # (.., 128/192 x 128/160 1x1) -> the 128x128-tile blocking, with a ragged last row / column block and a bias
     for (B, H, W, Cin, Cout, k, s_) in [(2, 9, 11, 64, 48, 1, 1), (1, 13, 13, 32, 128, 1, 2), (2, 12, 10, 32, 64, 3, 2),
-                                        (1, 13, 25, 64, 32, 3, 2)]:
+                                        (1, 13, 25, 64, 32, 3, 2), (2, 9, 11, 128, 192, 1, 1), (1, 13, 13, 160, 128, 1, 2)]:
         x = torch.randn(B, Cin, H, W, requires_grad=True)
         w = (torch.randn(Cout, Cin, k, k) * 0.1).requires_grad_()
         y = F.conv2d(x, w, None, stride=s_, padding=k // 2)
         dy = torch.randn_like(y)
         y.backward(dy)
-        dw, _ = ops.conv2d_wgrad(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)), Cout, Cin, k, s_)
+        dw, db = ops.conv2d_wgrad(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)), Cout, Cin, k, s_, want_bias=True)
+        assert float((db.cpu() - dy.sum((0, 2, 3))).abs().max()) <= tol(dy.sum((0, 2, 3)).numpy())
         packed_t, rows, _ = ops.pack_conv_weight(to(dev, w.detach()), 1)
         dx = ops.conv2d_bwd_data(to(dev, _nhwc(dy)), packed_t, Cin, k, s_, (H, W))
         assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy())
         assert float((nchw(dx.cpu()) - x.grad).abs().max()) <= tol(x.grad.numpy())
-    for (B, H, W, Cin, Cout) in [(1, 5, 6, 32, 48), (2, 13, 13, 64, 32)]:
+    # Cin 32 / 64 -> 64-row blocking, Cin 128 / 160 -> 128-row blocking of the per-phase launches; variant 0 = the
+    # nine-tap blocking run on the same phase groups
+    for (B, H, W, Cin, Cout, force) in [(1, 5, 6, 32, 48, -1), (2, 13, 13, 64, 32, -1), (2, 13, 13, 128, 64, -1),
+                                        (1, 9, 7, 160, 32, -1), (1, 9, 7, 160, 32, 0), (1, 9, 7, 160, 32, 3)]:
         x = torch.randn(B, Cin, H, W, requires_grad=True)
         wT = (torch.randn(Cin, Cout, 4, 4) * 0.1).requires_grad_()
         y = F.conv_transpose2d(x, wT, None, stride=2, padding=1)
         dy = torch.randn_like(y)
         y.backward(dy)
-        dw = ops.convT4x4_wgrad(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)))
+        _hip.call("dream_wgrad_set_variant", force)
+        try:
+            dw = ops.convT4x4_wgrad(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)))
+        finally:
+            _hip.call("dream_wgrad_set_variant", -1)
         pk, rows = ops.pack_convT4x4_bwd_weight(to(dev, wT.detach()))
         dx = ops.conv4x4s2(to(dev, _nhwc(dy)), pk, rows)
         assert float((dw.cpu() - wT.grad).abs().max()) <= tol(wT.grad.numpy())
