@@ -139,7 +139,7 @@ def main():
 
     def timed(orig, flops_of):
         def wrapper(*a, **k):
-            if not recording[0]:
+            if not recording[0] or k.get("relu_mask") is not None:     # conv3x3(relu_mask=..) forwards to conv2d: timed there
                 return orig(*a, **k)
             s_ev = torch.cuda.Event(enable_timing=True)
             e_ev = torch.cuda.Event(enable_timing=True)
@@ -154,7 +154,7 @@ def main():
     def pooled(flags):                    # a fused 2x2 max-pool stores 1/4 of the conv outputs it computed
         return 4.0 if flags & ops.CONV_POOL2 else 1.0
 
-    ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
+    ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0, relu_mask=None: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
     ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
                        2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * 16)

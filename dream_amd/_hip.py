@@ -85,6 +85,7 @@ _SIGNATURES = {
     "dream_smoothl1_fwd_bwd_f32": (_I, [_P, _P, _P, _P, _SZ, _D, _P]),
     "dream_relu_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "dream_maxpool2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_maxpool2_relu_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_upsample2_bwd_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_conv3x3_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "dream_conv3x3_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -81,22 +81,38 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float *x, const fl
     }
 }
 
-// finalize kernels: 64 channels per workgroup, 4 waves each summing every 4th partial row (coalesced over channels),
-// then a fixed-order combine through LDS -> deterministic and ~4x shorter dependent chains than one thread per channel
+// finalize kernels: 64 channels per workgroup, kSlices waves each summing every kSlices-th partial row (coalesced over
+// channels), then a fixed-order combine through LDS -> deterministic, and the dependent load->add chain per thread is
+// <= 512/16 = 32 long (these tiny kernels run 216 times per ResNet-101 step: their latency, not bandwidth, matters)
+constexpr int kSlices = 16;
 DREAM_DEVICE void sum_partials(const double *partials, int nblk, int C, int c, int slice, double *s, double *ss) {
     double a = 0, b = 0;
-    if (c < C)
-        for (int r = slice; r < nblk; r += 4) { a += partials[((size_t)r * C + c) * 2]; b += partials[((size_t)r * C + c) * 2 + 1]; }
-    __shared__ double red[2][4][64];
-    red[0][slice][threadIdx.x & 63] = a;
-    red[1][slice][threadIdx.x & 63] = b;
-    __syncthreads();
+    if (c < C) {
+        const double2 *src = (const double2 *)partials + c;
+        int r = slice;
+        for (; r + 3 * kSlices < nblk; r += 4 * kSlices) {        // four independent loads in flight
+            const double2 v0 = src[(size_t)r * C], v1 = src[(size_t)(r + kSlices) * C];
+            const double2 v2 = src[(size_t)(r + 2 * kSlices) * C], v3 = src[(size_t)(r + 3 * kSlices) * C];
+            a += v0.x; b += v0.y;
+            a += v1.x; b += v1.y;
+            a += v2.x; b += v2.y;
+            a += v3.x; b += v3.y;
+        }
+        for (; r < nblk; r += kSlices) { const double2 v = src[(size_t)r * C]; a += v.x; b += v.y; }
+    }
+    __shared__ double red[2][kSlices][64];
     const int l = threadIdx.x & 63;
-    *s = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
-    *ss = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    red[0][slice][l] = a;
+    red[1][slice][l] = b;
+    __syncthreads();
+    double t0 = 0, t1 = 0;
+#pragma unroll
+    for (int k = 0; k < kSlices; ++k) { t0 += red[0][k][l]; t1 += red[1][k][l]; }
+    *s = t0;
+    *ss = t1;
 }
 
-__global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const double *partials, int nblk, int C, double n, float eps,
+__global__ void __launch_bounds__(64 * kSlices) bn_stats_finalize_kernel(const double *partials, int nblk, int C, double n, float eps,
                                                                 float momentum, float *mean, float *invstd,
                                                                 float *running_mean, float *running_var,
                                                                 long long *num_batches_tracked) {
@@ -118,7 +134,7 @@ __global__ void __launch_bounds__(256) bn_stats_finalize_kernel(const double *pa
     if (blockIdx.x == 0 && threadIdx.x == 0 && num_batches_tracked) *num_batches_tracked += 1;
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double *partials, int nblk, int C, float *dgamma, float *dbeta) {
+__global__ void __launch_bounds__(64 * kSlices) bn_bwd_finalize_kernel(const double *partials, int nblk, int C, float *dgamma, float *dbeta) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     double s, ss;
     sum_partials(partials, nblk, C, c, slice, &s, &ss);
@@ -204,7 +220,7 @@ extern "C" int dream_bn_train_fwd_nhwc_f32(const float *x, const float *gamma, c
     hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, x, (const float *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, (double *)workspace, npix, C, 0);
     DREAM_LAUNCH_OK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * kSlices), 0, (hipStream_t)stream,
                        (const double *)workspace, (int)nb, C, (double)npix, eps, momentum, save_mean, save_invstd,
                        running_mean, running_var, num_batches_tracked);
     DREAM_LAUNCH_OK();
@@ -227,7 +243,7 @@ extern "C" int dream_channel_sum_nhwc_f32(const float *x, float *out, void *work
     DREAM_LAUNCH_OK();
     // dbeta slot (sum of v0) is what we want; dgamma slot (sum of squares) goes to a scratch tail of the workspace
     float *scratch = (float *)((double *)workspace + (size_t)kStatBlocks * C * 2);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * kSlices), 0, (hipStream_t)stream,
                        (const double *)workspace, (int)nb, C, scratch, out);
     DREAM_LAUNCH_OK();
     return 0;
@@ -246,7 +262,7 @@ extern "C" int dream_bn_train_bwd_nhwc_f32(const float *x, const float *dy, cons
     hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((unsigned)nb), dim3(256), lds, (hipStream_t)stream, x, dy, y_act, save_mean,
                        save_invstd, (double *)workspace, npix, C, relu);
     DREAM_LAUNCH_OK();
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(C, 64)), dim3(64 * kSlices), 0, (hipStream_t)stream,
                        (const double *)workspace, (int)nb, C, dgamma, dbeta);
     DREAM_LAUNCH_OK();
     const size_t n4 = npix * C4;

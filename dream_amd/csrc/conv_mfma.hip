@@ -225,6 +225,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     // ---- epilogue: (BN scale), bias/shift, residual, ReLU, store ---------------------------------------
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
     const bool nchw = (p.flags & DREAM_CONV_OUT_NCHW) != 0;
+    const bool mask = (p.flags & DREAM_CONV_RELUMASK) != 0;
     float scale_v[NR], shift_v[NR];
     int ncol[NR];
 #pragma unroll
@@ -254,7 +255,10 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                         float v = acc[ms][ns][r];
                         if (p.scale != nullptr) v = v * scale_v[ns];
                         v = v + shift_v[ns];
-                        if (p.residual != nullptr) v = v + p.residual[o];
+                        if (p.residual != nullptr) {
+                            const float rv = p.residual[o];
+                            v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
+                        }
                         if (relu) v = fmaxf(v, 0.0f);
                         p.y[o] = v;
                         amax = fmaxf(amax, fabsf(v));

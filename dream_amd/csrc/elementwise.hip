@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const f32x4 *x, f32x4 *y,
 
 // backward: the gradient goes to the first maximal element in (row-major) window order, which is
 // what ATen's max_pool2d_with_indices records.  Rows/cols beyond 2*floor(H/2) get zero.
+template <bool RELU>
 __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const f32x4 *dy, const f32x4 *x, f32x4 *dx,
                                                            int B, int H, int W, int C4) {
     const int Ho = H / 2, Wo = W / 2;
@@ -68,7 +69,8 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const f32x4 *dy, cons
 #pragma unroll
                 for (int j = 1; j < 4; ++j)
                     if (v[j][k] > best) { best = v[j][k]; arg = j; }
-                o[k] = (arg == me) ? g[k] : 0.0f;
+                // RELU: x is a ReLU output, and the gradient continues through that ReLU (mask x > 0) in the same pass
+                o[k] = (arg == me && (!RELU || best > 0.0f)) ? g[k] : 0.0f;
             }
         }
         dx[i] = o;
@@ -450,7 +452,15 @@ extern "C" int dream_maxpool2_nhwc_f32(const float *x, float *y, int B, int H, i
 extern "C" int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream) {
     DREAM_REQUIRE(dy && x && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0, "maxpool2_bwd: bad arguments");
     const size_t total = (size_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_maxpool2_relu_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(dy && x && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0, "maxpool2_relu_bwd: bad arguments");
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4);
     DREAM_LAUNCH_OK();
     return 0;

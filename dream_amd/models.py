@@ -297,32 +297,47 @@ class DreamHourglass(nn.Module):
         g = None
         g_input = None
         pending = {}                                       # skip source plan index -> gradient that branched off
+        masked = False                                     # g already carries the ReLU gradient of layer li
+
+        def relu_feeds(idx):
+            """Entry idx is a ReLU conv whose output is consumed ONLY by entry idx+1: its ReLU gradient can be applied
+            by whatever produces d/d(output) (a data-gradient conv epilogue or the max-pool backward)."""
+            return (idx >= 0 and layers[idx][0] in ("first", "wide", "conv", "deconv") and bool(layers[idx][2] & CONV_RELU)
+                    and idx not in self._skip_sources)
+
         for li in range(len(layers) - 1, -1, -1):
             kind, mod, flags = layers[li]
             inp, out = saved[li]
             if li in pending:                              # two consumers of this activation: gradients add
                 g = ops.add_(g, pending.pop(li))
             if kind == "pool":
-                g = ops.maxpool2_bwd(g, inp)
+                masked = relu_feeds(li - 1)
+                g = ops.maxpool2_bwd(g, inp, relu=masked)
                 continue
             if kind == "add":
                 pending[flags] = g.clone()                 # later in-place ReLU masks must not touch this copy
+                masked = False
                 continue
             pi -= 2
+            fuse = relu_feeds(li - 1)                      # this layer's data gradient can carry layer li-1's ReLU mask
             if kind == "deconv":
                 # ConvTranspose2d(3,2,1,op 1) + ReLU (models.py:621-686): bias grad = column sums, weight grad over the
                 # stride-2 taps of dy, data grad = the 3x3 stride-2 conv of dy with the (un-flipped) weight
-                g = ops.relu_bwd_(g, out)
+                if not masked:
+                    g = ops.relu_bwd_(g, out)
                 grads[pi] = ops.convT_wgrad(inp, g, 3)
                 grads[pi + 1] = ops.channel_sum(g)
                 packed_s2, rows_s2, _ = self._packed_aux(mod)
-                g = ops.conv2d(g, packed_s2, rows_s2, 3, 2)
+                g = ops.conv2d(g, packed_s2, rows_s2, 3, 2, None, None, inp if fuse else None,
+                               ops.CONV_RELUMASK if fuse else 0)
+                masked = fuse
                 continue
             cout, cin = int(mod.weight.shape[0]), int(mod.weight.shape[1])
             if flags & CONV_OUT_NCHW:
                 g = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))   # zero-padded K -> 16k channels
-            if flags & CONV_RELU:
+            if flags & CONV_RELU and not masked:
                 g = ops.relu_bwd_(g, out)
+            masked = False
             if kind == "first":
                 grads[pi], grads[pi + 1] = ops.conv3x3_first_wgrad(inp, g)
                 g = None
@@ -340,9 +355,11 @@ class DreamHourglass(nn.Module):
             packed_t, rows, _, cols_pad = self._packed.get(mod.weight, 1)
             if int(g.shape[3]) != cols_pad:
                 raise RuntimeError("internal: gradient has %d channels, packed weights expect %d" % (g.shape[3], cols_pad))
-            g = ops.conv3x3(g, packed_t, None, rows, 0)
-            if flags & CONV_UPSAMPLE2X:
-                g = ops.upsample2_bwd(g)
+            if flags & CONV_UPSAMPLE2X:                    # the mask lives at half resolution: after upsample2_bwd
+                g = ops.upsample2_bwd(ops.conv3x3(g, packed_t, None, rows, 0))
+            else:
+                g = ops.conv3x3(g, packed_t, None, rows, 0, relu_mask=inp if fuse else None)
+                masked = fuse
         if need_input_grad:
             return grads, g_input
         return grads

@@ -7,6 +7,7 @@ from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream
 
 CONV_ZEROSTUFF2X = 8
 CONV_POOL2 = 16
+CONV_RELUMASK = 32
 
 
 def _f32(t):
@@ -31,8 +32,11 @@ def pack_weight(w_oihw, mode=0):
     return packed, rows, rows_pad, cols_pad
 
 
-def conv3x3(x_nhwc, packed, bias, cout, flags=0):
-    """x: [B,Hs,Ws,Cin] NHWC (Cin == packed.shape[2]); returns [B,H,W,cout] (or NCHW with OUT_NCHW)."""
+def conv3x3(x_nhwc, packed, bias, cout, flags=0, relu_mask=None):
+    """x: [B,Hs,Ws,Cin] NHWC (Cin == packed.shape[2]); returns [B,H,W,cout] (or NCHW with OUT_NCHW).
+    relu_mask [B,H,W,cout]: y = relu_mask > 0 ? conv : 0 (data-gradient convs: the previous layer's ReLU gradient)."""
+    if relu_mask is not None:
+        return conv2d(x_nhwc, packed, cout, 3, 1, None, bias, relu_mask, flags | CONV_RELUMASK)
     x = _f32(x_nhwc)
     b, hs, ws, cin = (int(v) for v in x.shape)
     if cin != packed.shape[2]:
@@ -155,10 +159,12 @@ def relu_bwd_(dy, y):
     return dy
 
 
-def maxpool2_bwd(dy, x):
+def maxpool2_bwd(dy, x, relu=False):
+    """relu: x is a ReLU output and the gradient continues through that ReLU (dx *= x > 0) in the same pass."""
     b, h, w, c = (int(v) for v in x.shape)
     dx = torch.empty_like(x)
-    call("dream_maxpool2_bwd_nhwc_f32", ptr(_f32(dy)), ptr(x), ptr(dx), b, h, w, c, stream())
+    call("dream_maxpool2_relu_bwd_nhwc_f32" if relu else "dream_maxpool2_bwd_nhwc_f32", ptr(_f32(dy)), ptr(x), ptr(dx),
+         b, h, w, c, stream())
     return dx
 
 

@@ -39,6 +39,9 @@ extern "C" {
 #define DREAM_CONV_OUT_NCHW    4   /* store the result as NCHW (the belief-map head) */
 #define DREAM_CONV_POOL2      16   /* write max-pool-2x2(ReLU(conv)) instead of the conv output: [B,H/2,W/2,Cout] (floor), i.e. the
                                       following nn.MaxPool2d(2) (dream/models.py:589,765-771) fused into the epilogue */
+#define DREAM_CONV_RELUMASK   32   /* `residual` is not added but used as a ReLU mask: y = residual > 0 ? conv : 0.  Backward
+                                    * data-gradient convs use it to apply the previous layer's ReLU gradient in their
+                                    * epilogue (residual = that layer's output), loss.backward() of dream/network.py:335 */
 #define DREAM_CONV_ZEROSTUFF2X 8   /* input is [B,H/2,W/2,Cin] placed at the even positions of a zero [B,H,W,Cin]
                                       grid: with mode-1 packed weights this is ConvTranspose2d(k=3,s=2,p=1,
                                       output_padding=1) (dream/models.py:621-686) */
@@ -199,6 +202,9 @@ int dream_relu_bwd_f32(const float *dy, const float *y, float *dx, size_t n, voi
  * gradient goes to the first maximal element in window scan order (ATen semantics). */
 int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, float *dx,
                                 int B, int H, int W, int C, void *stream);
+/* same, continued through the ReLU that produced x (VGG blocks end conv -> ReLU -> MaxPool2d, dream/models.py:589-615):
+ * dx = maxpool_bwd(dy) * (x > 0) in one pass. */
+int dream_maxpool2_relu_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
 /* nearest x2 upsample backward: dy [B,H,W,C] -> dx [B,H/2,W/2,C] = sum of the 2x2 block */
 int dream_upsample2_bwd_nhwc_f32(const float *dy, float *dx, int B, int H, int W, int C, void *stream);
 /* conv3x3 weight+bias gradient: x [B,H,W,Cin] (or half-res with UPSAMPLE2X), dy [B,H,W,Cout] NHWC

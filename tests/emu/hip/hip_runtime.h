@@ -28,6 +28,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct uint3_emu { unsigned x, y, z; };
+struct double2 { double x, y; };
 
 typedef void *hipStream_t;
 typedef int hipError_t;

@@ -328,6 +328,22 @@ def check_backward_ops(dev):
     y.backward(dy)
     dx = ops.maxpool2_bwd(to(dev, dy.permute(0, 2, 3, 1).contiguous()), to(dev, x.detach().permute(0, 2, 3, 1).contiguous()))
     assert torch.equal(dx.cpu().permute(0, 3, 1, 2), x.grad)
+    # MaxPool2d(2) o ReLU backward in one pass, and the ReLU mask applied in a data-gradient conv's epilogue
+    x = torch.randn(2, 8, 9, 10, requires_grad=True)
+    y = F.max_pool2d(x.relu(), 2)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    dx = ops.maxpool2_bwd(to(dev, _nhwc(dy)), to(dev, _nhwc(x.detach().relu())), relu=True)
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), x.grad)
+    x = torch.randn(2, 32, 7, 9, requires_grad=True)
+    w = torch.randn(48, 32, 3, 3) * 0.1
+    y = F.conv2d(x.relu(), w, padding=1)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    packed_t, rows, _, _ = ops.pack_weight(to(dev, w), 1)
+    dx = ops.conv3x3(to(dev, _nhwc(dy)), packed_t, None, rows, 0, relu_mask=to(dev, _nhwc(x.detach().relu())))
+    assert float((dx.cpu().permute(0, 3, 1, 2) - x.grad).abs().max()) <= tol(x.grad.numpy())
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2) == 0, x.grad == 0)
     o, t = torch.randn(2, 7, 5, 6), torch.randn(2, 7, 5, 6)
     l, gr = ops.mse_fwd_bwd(to(dev, o), to(dev, t))
     assert abs(l.item() - F.mse_loss(o, t).item()) < 1e-6

@@ -153,13 +153,13 @@ def test_vgg_f_train_step():
     pc.check_vgg_train_grads(DEV, "vgg_f", (2, 64, 96))
 
 
-def test_unbuilt_paths_refuse_instead_of_falling_back():
+def test_every_architecture_branch_constructs_on_the_hip_path():
     import dream_amd
-    for patch in ({"n_stages": 2, "deconv_decoder": False, "full_output": True}, {"skip_connections": True}):
+    for patch, cls in (({"n_stages": 2, "deconv_decoder": False, "full_output": True}, "DreamHourglassMultiStage"),
+                       ({"skip_connections": True}, "DreamHourglass")):
         cfg = dream_amd.default_network_config("vgg_q")
         cfg["architecture"].update(patch)
-        with pytest.raises(NotImplementedError):
-            dream_amd.create_network_from_config_data(cfg)
+        assert type(dream_amd.create_network_from_config_data(cfg).model.module).__name__ == cls
     cfg = dream_amd.default_network_config("vgg_q")
     cfg["architecture"]["loss"]["type"] = "huber"
     assert type(dream_amd.create_network_from_config_data(cfg).criterion).__name__ == "HipSmoothL1Loss"
