@@ -41,6 +41,7 @@ struct WgradParams {
     int ntaps_total, ntaps;                    // ntaps = taps of THIS launch (<= NT)
     unsigned long long tap_dy, tap_dx, tap_out;   // per launch slot: 4-bit patch offsets and output tap index
     int tiles_total, splitk, flags;
+    int nrb, ncb;            // row / column blocks of the workgroup grid
 };
 
 template <int RB, int CB, int NT, int PIX>
@@ -55,7 +56,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
     const int wo = wave >> 1, wi = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int co0 = blockIdx.x * RW, ci0 = blockIdx.y * CW, ks = blockIdx.z;
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed, speed only).  All (row block, col block) tiles of one
+    // split-K slice re-read the same T tiles and P patches, so they are given consecutive slots on ONE XCD and meet
+    // in its L2 instead of each fetching from the fabric: b = (slice_group * nblocks + block) * 8 + xcd.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int nblk = p.nrb * p.ncb;
+    const int blk = slot % nblk, ks = (slot / nblk) * 8 + xcd;
+    if (ks >= p.splitk) return;
+    const int rbk = blk % p.nrb, cbk = blk / p.nrb;
+    const int co0 = rbk * RW, ci0 = cbk * CW;
     const int PW = p.PW, TW = p.TW, npix = p.TH * p.TW, NP = p.PH * PW;
     const bool zst = (p.flags & DREAM_CONV_ZEROSTUFF2X) != 0;
     const bool ups = (p.flags & DREAM_CONV_UPSAMPLE2X) != 0 || zst;
@@ -115,36 +124,48 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         __syncthreads();
 
         // ---- k-steps (2 positions each) x (row block, col block, tap) ----------------------------------
+        // Operands of step s+1 are read from LDS while the MFMAs of step s run (two register sets, loop unrolled by
+        // two): a ds_read -> s_waitcnt -> MFMA chain per tap leaves the matrix pipe idle for most of the LDS latency.
         const float *aY = sY + wo * (32 * RB) + li;
         const float *bX = sX + wi * (32 * CB) + li;
         const int nsteps = (npix + 1) >> 1;
-        for (int s = 0; s < nsteps; ++s) {
-            const int m = 2 * s + lh;
+        float a0[RB], a1[RB], b0[CB * NT], b1[CB * NT];
+        auto load_step = [&](int st, float (&a)[RB], float (&b)[CB * NT]) {
+            const int m = 2 * st + lh;
             const int mc = m < npix ? m : 0;         // tile row m is zero there; keep the patch address legal
             const int ty = (mc * p.rcpTW) >> 16, tx = mc - ty * TW;
-            float a[RB];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) a[rb] = aY[m * RW + rb * 32];
             const float *bp = bX + (ty * PW + tx) * p.lane_stride * CW;
 #pragma unroll
-            for (int tp = 0; tp < NT; ++tp) {
-                if (NT == 1 || tp < p.ntaps) {
+            for (int tp = 0; tp < NT; ++tp)
 #pragma unroll
-                    for (int cb = 0; cb < CB; ++cb) {
-                        const float bv = bp[toff[tp] + cb * 32];
+                for (int cb = 0; cb < CB; ++cb) b[tp * CB + cb] = bp[toff[tp] + cb * 32];
+        };
+        auto mma_step = [&](const float (&a)[RB], const float (&b)[CB * NT]) {
 #pragma unroll
-                        for (int rb = 0; rb < RB; ++rb)
-                            acc[(rb * CB + cb) * NT + tp] = mfma_f32_32x32x2(a[rb], bv, acc[(rb * CB + cb) * NT + tp]);
-                    }
-                }
-            }
+            for (int tp = 0; tp < NT; ++tp)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+                        acc[(rb * CB + cb) * NT + tp] = mfma_f32_32x32x2(a[rb], b[tp * CB + cb], acc[(rb * CB + cb) * NT + tp]);
+        };
+        load_step(0, a0, b0);
+        int st = 0;
+        for (; st + 1 < nsteps; st += 2) {
+            load_step(st + 1, a1, b1);
+            mma_step(a0, b0);
+            load_step(st + 2 < nsteps ? st + 2 : nsteps - 1, a0, b0);
+            mma_step(a1, b1);
         }
+        if (st < nsteps) mma_step(a0, b0);
     }
 
     // ---- write partials ----------------------------------------------------------------------------
 #pragma unroll
     for (int tp = 0; tp < NT; ++tp) {
-        if (tp < p.ntaps) {
+        {
             const int tout = (int)((p.tap_out >> (4 * tp)) & 15);
             float *part = p.part + ((size_t)ks * p.ntaps_total + tout) * p.RowsPad * p.Cp;
 #pragma unroll
@@ -159,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
                     }
         }
     }
-    if (blockIdx.y == 0 && p.bias_part != nullptr) {
+    if (cbk == 0 && p.bias_part != nullptr) {
         // threads sharing qy (same 4 channels) differ in prow_y: reduce the RPY rows through LDS
         __syncthreads();
         *(f32x4 *)(smem + (prow_y * QY + qy) * 4) = bsum;
@@ -198,11 +219,15 @@ struct WgradVariant {
     int RW, CW, NT, PIX;
     bool attr_set;
 };
+// NT is the EXACT tap count of a launch (no runtime tap test inside the k-loop)
 WgradVariant g_wvariants[] = {
-    {wgrad_kernel<1, 1, 9, 128>, 64, 64, 9, 128, false},
-    {wgrad_kernel<2, 1, 4, 64>, 128, 64, 4, 64, false},
-    {wgrad_kernel<2, 2, 1, 64>, 128, 128, 1, 64, false},
-    {wgrad_kernel<1, 1, 4, 128>, 64, 64, 4, 128, false},
+    {wgrad_kernel<1, 1, 9, 128>, 64, 64, 9, 128, false},     // 0: 3x3 convs
+    {wgrad_kernel<2, 1, 4, 64>, 128, 64, 4, 64, false},      // 1: transposed-conv phase with 4 taps
+    {wgrad_kernel<2, 2, 1, 64>, 128, 128, 1, 64, false},     // 2: 1x1 convs / 1-tap phase, >= 128 x 128
+    {wgrad_kernel<1, 1, 4, 128>, 64, 64, 4, 128, false},     // 3: 4-tap phase, < 128 rows
+    {wgrad_kernel<2, 1, 2, 64>, 128, 64, 2, 64, false},      // 4: 2-tap phase (k = 3 transposed conv)
+    {wgrad_kernel<1, 1, 2, 128>, 64, 64, 2, 128, false},     // 5: 2-tap phase, < 128 rows
+    {wgrad_kernel<1, 1, 1, 128>, 64, 64, 1, 128, false},     // 6: 1 tap, small
 };
 int g_wgrad_forced = -1;          // A/B switch (dream_wgrad_set_variant)
 
@@ -220,14 +245,23 @@ struct WgradGeom {
     TapGroup group[4];
 };
 
-int pick_wvariant(const WgradGeom &g, int Cp, int RowsPad) {
-    int maxt = 0;
-    for (int i = 0; i < g.ngroups; ++i) maxt = g.group[i].ntaps > maxt ? g.group[i].ntaps : maxt;
-    int v = 0;
-    if (maxt == 1 && g.lane_stride == 1 && Cp >= 128 && RowsPad >= 128) v = 2;
-    else if (maxt <= 4 && g.lane_stride == 1 && g.ngroups > 1) v = RowsPad >= 128 ? 1 : 3;
-    if (g_wgrad_forced >= 0 && g_wvariants[g_wgrad_forced].NT >= maxt && (g.lane_stride == 1 || g_wgrad_forced == 0)) v = g_wgrad_forced;
-    return v;
+// Blocking for a launch of `ntaps` taps (exact): wide tiles when both dW dimensions fill them.
+int pick_wvariant(int ntaps, int Cp, int RowsPad) {
+    const bool rows128 = RowsPad >= 128 && g_wgrad_forced != 0;
+    switch (ntaps) {
+    case 9: return 0;
+    case 4: return rows128 ? 1 : 3;
+    case 2: return rows128 ? 4 : 5;
+    case 1: return (rows128 && Cp >= 128) ? 2 : 6;
+    default: return -1;
+    }
+}
+
+int main_group(const WgradGeom &g) {
+    int best = 0;
+    for (int i = 1; i < g.ngroups; ++i)
+        if (g.group[i].ntaps > g.group[best].ntaps) best = i;
+    return best;
 }
 
 void choose_tile_w(const WgradGeom &g, int pix, int *th_out, int *tw_out) {
@@ -250,7 +284,9 @@ void choose_tile_w(const WgradGeom &g, int pix, int *th_out, int *tw_out) {
 }
 
 int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
-    const WgradVariant &var = g_wvariants[pick_wvariant(g, Cp, RowsPad)];
+    const int v = pick_wvariant(g.group[main_group(g)].ntaps, Cp, RowsPad);
+    if (v < 0) return 1;
+    const WgradVariant &var = g_wvariants[v];
     int th, tw;
     choose_tile_w(g, var.PIX, &th, &tw);
     const long tiles = (long)B * ceil_div(g.Ht, th) * ceil_div(g.Wt, tw);
@@ -265,10 +301,10 @@ int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
 }
 
 size_t wgrad_workspace_bytes(int B, const WgradGeom &g, int Cp, int RowsPad) {
-    // the A/B switch may change the split: size for the largest any variant would ask for
+    // the A/B switch may change the split: size for the larger of the two
     const int saved = g_wgrad_forced;
     int sk = 0;
-    for (int f = -1; f < (int)(sizeof(g_wvariants) / sizeof(g_wvariants[0])); ++f) {
+    for (int f = -1; f <= 0; ++f) {
         g_wgrad_forced = f;
         const int s = pick_splitk_g(B, g, Cp, RowsPad);
         sk = s > sk ? s : sk;
@@ -281,32 +317,34 @@ int launch_wgrad(const float *tile_t, const float *patch_t, float *dw_packed, fl
                  int B, int Ct, int RowsPad, int Cp, const WgradGeom &g, int flags, void *stream) {
     DREAM_REQUIRE(tile_t && patch_t && dw_packed && workspace, "wgrad: null pointer");
     DREAM_REQUIRE(B > 0 && Ct % 4 == 0 && Cp % 4 == 0 && RowsPad >= Ct && RowsPad % 4 == 0, "wgrad: bad channels (%d, %d, pad %d)", Ct, Cp, RowsPad);
-    WgradVariant &var = g_wvariants[pick_wvariant(g, Cp, RowsPad)];
     WgradParams p;
     p.tile_t = tile_t; p.patch_t = patch_t;
     p.B = B; p.Ht = g.Ht; p.Wt = g.Wt; p.Hin = g.Hin; p.Win = g.Win; p.Hs = g.Hs; p.Ws = g.Ws;
     p.Ct = Ct; p.Cp = Cp; p.RowsPad = RowsPad; p.flags = flags;
-    choose_tile_w(g, var.PIX, &p.TH, &p.TW);
-    p.PH = (p.TH - 1) * g.lane_stride + g.kext;
-    p.PW = (p.TW - 1) * g.lane_stride + g.kext;
-    p.tiles_x = ceil_div(g.Wt, p.TW); p.tiles_y = ceil_div(g.Ht, p.TH);
-    p.rcpTW = (65536 + p.TW - 1) / p.TW;
     p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride;
     p.ntaps_total = g.ntaps;
-    p.tiles_total = B * p.tiles_x * p.tiles_y;
-    p.splitk = pick_splitk_g(B, g, Cp, RowsPad);
+    p.splitk = pick_splitk_g(B, g, Cp, RowsPad);       // one split for all groups: they share the partial buffer
     p.part = (float *)workspace;
     float *bias_part = p.part + (size_t)p.splitk * g.ntaps * RowsPad * Cp;
-    const size_t lds = ((size_t)var.PIX * var.RW + (size_t)p.PH * p.PW * var.CW) * sizeof(float);
-    DREAM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
-    if (!var.attr_set) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        var.attr_set = true;
-    }
-    const dim3 grid(ceil_div(RowsPad, var.RW), ceil_div(Cp, var.CW), p.splitk);
     for (int gi = 0; gi < g.ngroups; ++gi) {
         const TapGroup &tg = g.group[gi];
-        DREAM_REQUIRE(tg.ntaps <= var.NT, "internal: %d taps in a group, variant holds %d", tg.ntaps, var.NT);
+        const int v = pick_wvariant(tg.ntaps, Cp, RowsPad);
+        DREAM_REQUIRE(v >= 0, "wgrad: no blocking for a %d-tap launch", tg.ntaps);
+        WgradVariant &var = g_wvariants[v];
+        choose_tile_w(g, var.PIX, &p.TH, &p.TW);
+        p.PH = (p.TH - 1) * g.lane_stride + g.kext;
+        p.PW = (p.TW - 1) * g.lane_stride + g.kext;
+        p.tiles_x = ceil_div(g.Wt, p.TW); p.tiles_y = ceil_div(g.Ht, p.TH);
+        p.rcpTW = (65536 + p.TW - 1) / p.TW;
+        p.tiles_total = B * p.tiles_x * p.tiles_y;
+        const size_t lds = ((size_t)var.PIX * var.RW + (size_t)p.PH * p.PW * var.CW) * sizeof(float);
+        DREAM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
+        if (!var.attr_set) {
+            DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            var.attr_set = true;
+        }
+        p.nrb = ceil_div(RowsPad, var.RW); p.ncb = ceil_div(Cp, var.CW);
+        const dim3 grid((unsigned)(p.nrb * p.ncb * ceil_div(p.splitk, 8) * 8));
         p.pad_y = tg.pad_y; p.pad_x = tg.pad_x; p.ntaps = tg.ntaps;
         p.tap_dy = 0; p.tap_dx = 0; p.tap_out = 0;
         for (int t = 0; t < tg.ntaps; ++t) {
@@ -508,9 +546,9 @@ extern "C" int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, fl
     return launch_wgrad(x, dy, dw_packed, nullptr, 0, workspace, B, Cin, CinPad, Cout, convT_geom(H, W, 4), 0, stream);
 }
 
-// A/B switch for the tap-group variants (tools/microbench.py): -1 = heuristic
+// A/B switch: -1 = heuristic, 0 = always the 64-row blockings
 extern "C" int dream_wgrad_set_variant(int variant) {
-    DREAM_REQUIRE(variant >= -1 && variant < (int)(sizeof(g_wvariants) / sizeof(g_wvariants[0])), "wgrad variant %d out of range", variant);
+    DREAM_REQUIRE(variant >= -1 && variant <= 0, "wgrad variant %d out of range", variant);
     g_wgrad_forced = variant;
     return 0;
 }

@@ -225,7 +225,7 @@ int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_pac
 size_t dream_convT_wgrad_workspace(int B, int H, int W, int CinPad, int Cout, int ksize);
 int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                int H, int W, int Cin, int CinPad, int Cout, int ksize, void *stream);
-/* A/B switch between the weight-gradient kernel's register blockings (tools/microbench.py); -1 = heuristic. */
+/* A/B switch between the weight-gradient kernel's register blockings: -1 = heuristic, 0 = always 64-row tiles. */
 int dream_wgrad_set_variant(int variant);
 /* [ntaps][RowsPad][ColsPad] -> [Rows][Cols][ntaps] (OIHW / ConvTranspose [Cin,Cout,kh,kw]) */
 int dream_unpack_conv_weight(const float *packed, float *w, int Rows, int Cols, int ntaps, int RowsPad, int ColsPad,

@@ -454,10 +454,9 @@ def check_resnet_training_ops(dev):
         dx = ops.conv2d_bwd_data(to(dev, _nhwc(dy)), packed_t, Cin, k, s_, (H, W))
         assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy())
         assert float((nchw(dx.cpu()) - x.grad).abs().max()) <= tol(x.grad.numpy())
-    # Cin 32 / 64 -> 64-row blocking, Cin 128 / 160 -> 128-row blocking of the per-phase launches; variant 0 = the
-    # nine-tap blocking run on the same phase groups
+    # Cin 32 / 64 -> 64-row blocking, Cin 128 / 160 -> 128-row blocking of the per-phase launches; variant 0 = 64-row tiles
     for (B, H, W, Cin, Cout, force) in [(1, 5, 6, 32, 48, -1), (2, 13, 13, 64, 32, -1), (2, 13, 13, 128, 64, -1),
-                                        (1, 9, 7, 160, 32, -1), (1, 9, 7, 160, 32, 0), (1, 9, 7, 160, 32, 3)]:
+                                        (1, 9, 7, 160, 32, -1), (1, 9, 7, 160, 32, 0)]:
         x = torch.randn(B, Cin, H, W, requires_grad=True)
         wT = (torch.randn(Cin, Cout, 4, 4) * 0.1).requires_grad_()
         y = F.conv_transpose2d(x, wT, None, stride=2, padding=1)

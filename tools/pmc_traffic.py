@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the default bench command with
+--kernel-trace only) into profiles/<round>_pmc_traffic.json: HBM bytes per launch of the dominant kernel.
+Usage: python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/*.db gpurun_out/pmc_WRITE_SIZE/*.db profiles/r01_pmc_traffic.json
+
+gfx950 correction (MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE counts 128-B requests as 64 B, so the raw
+value is doubled; the max-pool kernel (pure streaming, algorithmic bytes known exactly) is reported beside it as the
+calibration of that rule on this run."""
+import json
+import sqlite3
+import sys
+
+B = 128
+# vgg_q at 400x400: (cin, cout, H) per MFMA conv launch, pooled = 2x2 max-pool fused into the store
+LAYERS = [(64, 64, 400, True), (64, 128, 200, False), (128, 128, 200, True), (128, 256, 100, False), (256, 256, 100, False),
+          (256, 256, 100, False), (256, 256, 100, False), (256, 512, 50, False), (512, 512, 50, False), (512, 512, 50, False),
+          (512, 512, 50, False), (512, 512, 25, False), (512, 512, 25, False), (512, 512, 25, False), (512, 512, 25, False),
+          (512, 256, 50, "up"), (256, 256, 50, False), (256, 128, 100, "up"), (128, 64, 100, False), (64, 64, 100, False),
+          (64, 32, 100, False), (32, 7, 100, False)]
+
+
+def algorithmic_bytes():
+    total = 0
+    for cin, cout, h, mode in LAYERS:
+        hin = h // 2 if mode == "up" else h              # fused nearest-x2 upsample reads the half-resolution tensor
+        hout = h // 2 if mode is True else h
+        total += 4 * B * (hin * hin * cin + hout * hout * cout) + 4 * 9 * cin * cout
+    return total / len(LAYERS)
+
+
+def per_kernel(db, counter):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? "
+                       "group by kernel_name order by sum(value) desc", (counter,))
+    return [{"kernel": r[0][:90], "dispatches": r[1], "sum_kib": r[2]} for r in rows]
+
+
+def main():
+    fetch_db, write_db, out = sys.argv[1:4]
+    fetch, write = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+
+    def family(rows, key):
+        sel = [r for r in rows if key in r["kernel"]]
+        return sum(r["dispatches"] for r in sel), sum(r["sum_kib"] for r in sel) * 1024.0
+
+    nf, fb = family(fetch, "mfma_kernel")
+    nw, wb = family(write, "mfma_kernel")
+    npool, pool_fetch = family(fetch, "maxpool2_kernel")
+    # un-fused pools of vgg_q at B=128: 256ch@100x100 and 512ch@50x50 inputs, one of each per forward pass
+    pool_alg = 4.0 * B * (100 * 100 * 256 + 50 * 50 * 512) * (npool / 2.0)
+    res = {
+        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
+                   "--no-cpu-baseline --no-split-leg (one PMC counter per run)",
+        "workload": "DREAM-vgg-Q inference B=128 400x400",
+        "units": "counters are KiB; FETCH_SIZE doubled per the gfx950 rule (see calibration)",
+        "calibration_maxpool2_kernel": {"dispatches": npool, "fetch_gb_raw": pool_fetch / 1e9,
+                                        "fetch_gb_algorithmic": pool_alg / 1e9,
+                                        "raw_to_algorithmic": pool_alg / pool_fetch if pool_fetch else None},
+        "conv_mfma_kernel": {
+            "dispatches": nf,
+            "fetch_gb_per_launch_corrected": 2.0 * fb / nf / 1e9,
+            "write_gb_per_launch": wb / nw / 1e9,
+            "traffic_gb_per_launch": (2.0 * fb / nf + wb / nw) / 1e9,
+            "algorithmic_gb_per_launch": algorithmic_bytes() / 1e9,
+        },
+        "raw": {"FETCH_SIZE": fetch[:12], "WRITE_SIZE": write[:12]},
+    }
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps({k: res[k] for k in ("calibration_maxpool2_kernel", "conv_mfma_kernel")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
