@@ -98,28 +98,49 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
         const float *dyb = p.tile_t + (size_t)b * p.Ht * p.Wt * p.Ct;
 
         __syncthreads();                            // previous tile fully consumed
+        // Staging issues ALL of a batch's global loads before the first LDS write (loads from clamped, always-legal
+        // addresses + a select, no exec-masked branches): a load -> wait -> ds_write chain per row made the 20 rows a
+        // thread stages 20 dependent memory round trips (~35k cycles per tile, as long as the tile's MFMA work).
         // ---- stage the tile tensor (rows m >= npix or outside the image are zero) ------------------
+        {
+            f32x4 tr[PIX / RPY];
+            unsigned okm = 0;
 #pragma unroll
-        for (int it = 0; it < PIX / RPY; ++it) {
-            const int m = prow_y + it * RPY;
-            const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
-            const int oy = y0 + ty, ox = x0 + tx;
-            f32x4 v = zero4;
-            if (m < npix && oy < p.Ht && ox < p.Wt && y_chan_ok)
-                v = *(const f32x4 *)(dyb + ((size_t)oy * p.Wt + ox) * p.Ct + co0 + qy * 4);
-            *(f32x4 *)(sY + m * RW + qy * 4) = v;
-            bsum += v;
-        }
-        // ---- stage the patch --------------------------------------------------------------------------
-        for (int pp = prow_x; pp < NP; pp += RPX) {
-            const int py = pp / PW, px = pp - py * PW;
-            const int gy = y0 * p.in_scale - p.pad_y + py * p.in_step, gx = x0 * p.in_scale - p.pad_x + px * p.in_step;
-            f32x4 v = zero4;
-            if (gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && x_chan_ok && !(zst && ((gy | gx) & 1))) {
-                const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
-                v = *(const f32x4 *)(xb + ((size_t)sy * p.Ws + sx) * p.Cp + ci0 + qx * 4);
+            for (int it = 0; it < PIX / RPY; ++it) {
+                const int m = prow_y + it * RPY;
+                const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
+                const int oy = y0 + ty, ox = x0 + tx;
+                const bool ok = m < npix && oy < p.Ht && ox < p.Wt && y_chan_ok;
+                okm |= (ok ? 1u : 0u) << it;
+                tr[it] = *(const f32x4 *)(ok ? dyb + ((size_t)oy * p.Wt + ox) * p.Ct + co0 + qy * 4 : p.tile_t);
             }
-            *(f32x4 *)(sX + pp * CW + qx * 4) = v;
+#pragma unroll
+            for (int it = 0; it < PIX / RPY; ++it) {
+                const f32x4 v = ((okm >> it) & 1u) ? tr[it] : zero4;
+                *(f32x4 *)(sY + (prow_y + it * RPY) * RW + qy * 4) = v;
+                bsum += v;
+            }
+        }
+        // ---- stage the patch, XB rows per thread in flight --------------------------------------------------
+        constexpr int XB = 6;
+        for (int pp0 = prow_x; pp0 < NP; pp0 += RPX * XB) {
+            f32x4 xr[XB];
+            unsigned okm = 0;
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int pp = pp0 + j * RPX;
+                const int py = pp / PW, px = pp - py * PW;
+                const int gy = y0 * p.in_scale - p.pad_y + py * p.in_step, gx = x0 * p.in_scale - p.pad_x + px * p.in_step;
+                const bool ok = pp < NP && gy >= 0 && gy < p.Hin && gx >= 0 && gx < p.Win && x_chan_ok && !(zst && ((gy | gx) & 1));
+                const int sy = ups ? (gy >> 1) : gy, sx = ups ? (gx >> 1) : gx;
+                okm |= (ok ? 1u : 0u) << j;
+                xr[j] = *(const f32x4 *)(ok ? xb + ((size_t)sy * p.Ws + sx) * p.Cp + ci0 + qx * 4 : p.patch_t);
+            }
+#pragma unroll
+            for (int j = 0; j < XB; ++j) {
+                const int pp = pp0 + j * RPX;
+                if (pp < NP) *(f32x4 *)(sX + pp * CW + qx * 4) = ((okm >> j) & 1u) ? xr[j] : zero4;
+            }
         }
         __syncthreads();
 

@@ -59,7 +59,7 @@ def main():
         if cin % 32 == 0 and not (flags & 4 and False):
             p16 = ops.pack_conv_weight_f16x3(w, 0)
             amax = ops.absmax(x)
-            for v16 in (-1, 0, 1, 2, 4, 5):
+            for v16 in (-1, 0, 1, 2, 4, 7):
                 lib.dream_conv_f16x3_set_variant(v16)
                 try:
                     ops.conv2d_f16x3(x, amax, p16, cout, 3, None, bias, None, flags)
