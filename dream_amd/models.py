@@ -4,15 +4,17 @@ Mirrors /root/reference/dream/models.py:
   * ``DreamHourglass``  (models.py:557-827)  -- VGG19 encoder + upsample (Q) or ConvTranspose (F)
     decoder + 3-conv head; ``state_dict()`` keys/shapes are the reference's, so released ``.pth``
     files and ``dream_network.model.load_state_dict(torch.load(path))`` (dream/analysis.py:148) work.
-  * ``ResnetSimple``    (models.py:17-155)   -- parameter tree only in this round (see forward()).
+  * ``ResnetSimple``    (models.py:17-155)   -- torchvision ResNet-101 trunk + ConvTranspose/BN decoder, evaluation
+    (BatchNorm folded) and training (batch statistics) on the same kernels; identical ``state_dict()``.
+  * ``DreamHourglassMultiStage`` (models.py:350-553) -- 1..6 hourglasses, each fed the image and the previous maps.
   * ``DreamDataParallel`` stands in for ``torch.nn.DataParallel`` (dream/network.py:244-256): it only
     contributes the ``module.`` key prefix; data parallelism is one process per GPU with an RCCL
     all-reduce of the flat gradient buffer (see ``_HourglassFunction.backward``).
 
 ``nn.Conv2d`` objects are used purely as parameter containers (OIHW, as the reference stores them);
 their ATen forward is never called.  ``forward`` executes a static list of C-ABI calls on NHWC
-activations: first conv (NCHW image -> NHWC, VALU), MFMA 3x3 convs with fused bias/ReLU/upsample,
-2x2 max-pools, and an NCHW store in the last head conv.  If the HIP library or a GPU is missing the
+activations: first conv (NCHW image -> NHWC, VALU), MFMA 3x3 convs with fused bias/ReLU/upsample/max-pool,
+skip-connection adds, and an NCHW store in the last head conv; ``backward`` walks the same list in reverse.  If the HIP library or a GPU is missing the
 call raises -- there is no CPU path in this package.
 """
 import torch

@@ -133,6 +133,7 @@ inline unsigned atomicMax(unsigned *p, unsigned v) {
     return old;
 }
 inline void __builtin_amdgcn_s_setprio(int) {}
+inline void __builtin_amdgcn_s_sleep(int) {}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline double __dmul_rn(double a, double b) { return a * b; }
 inline double __dadd_rn(double a, double b) { return a + b; }
