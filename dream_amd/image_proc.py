@@ -124,6 +124,19 @@ def normalize_images_u8(images_u8_bhwc, mean, stdev):
     return out
 
 
+def create_belief_map(image_resolution, pointsBelief, sigma=2):
+    """Drop-in for dream/image_proc.py:866-910 (training targets, called per frame by dream/datasets.py:165-171):
+    -> numpy float64 [n_points, H, W].  Rendered on the device by the batched kernel; every value is the fp32 rounding
+    of the reference's float64 value, which is exactly what its only caller keeps (``torch.tensor(maps).float()``)."""
+    assert len(image_resolution) == 2, \
+        'Expected "image_resolution" to have length 2, but it has length {}.'.format(len(image_resolution))
+    pts = np.asarray([[float(p[0]), float(p[1])] for p in pointsBelief], dtype=np.float32).reshape(-1, 2)
+    if pts.shape[0] == 0:
+        return np.zeros((0, int(image_resolution[1]), int(image_resolution[0])))
+    maps = create_belief_map_batch(image_resolution, torch.from_numpy(pts)[None], sigma)
+    return maps[0].cpu().numpy().astype(np.float64)
+
+
 def create_belief_map_batch(image_resolution, keypoints_bk2, sigma=2):
     """Batched, on-device create_belief_map (dream/image_proc.py:866-910): keypoints [B,K,2] (x, y) in the belief-map
     frame -> fp32 [B,K,H,W], bit-identical to torch.tensor(create_belief_map(res, kps)).float() per frame."""

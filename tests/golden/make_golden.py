@@ -86,11 +86,50 @@ def variants(dream):
         json.dump(manifest, f, indent=0, sort_keys=False)
 
 
+def api_surface(dream):
+    """G8: names and parameter lists of the drop-in boundary, read off the reference with inspect --
+    data only: what a caller can name, not how it is implemented."""
+    import inspect
+
+    def params(fn):
+        return [[n, None if q.default is inspect._empty else repr(q.default)]
+                for n, q in inspect.signature(fn).parameters.items()]
+
+    def methods(cls):
+        return {n: params(f) for n, f in vars(cls).items()          # defined by the class itself, not inherited
+                if inspect.isfunction(f) and (not n.startswith("_") or n == "__init__")}
+
+    net = dream.create_network_from_config_data(ref_import.network_config("vgg_q"))
+    surface = {
+        "dream.network": {
+            "functions": {n: params(getattr(dream.network, n)) for n in
+                          ("create_network_from_config_file", "create_network_from_config_data")},
+            "constants": {"KNOWN_ARCHITECTURES": list(dream.network.KNOWN_ARCHITECTURES),
+                          "KNOWN_OPTIMIZERS": list(dream.network.KNOWN_OPTIMIZERS)},
+            "DreamNetwork": methods(dream.network.DreamNetwork),
+            "DreamNetwork.instance_attributes": sorted(k for k in vars(net) if not k.startswith("_")),
+        },
+        "dream.models": {c: methods(getattr(dream.models, c)) for c in
+                         ("DreamHourglass", "DreamHourglassMultiStage", "ResnetSimple")},
+        "dream.spatial_softmax": {"SoftArgmaxPavlo": methods(dream.spatial_softmax.SoftArgmaxPavlo)},
+        "dream.image_proc": {n: params(getattr(dream.image_proc, n)) for n in
+                             ("peaks_from_belief_maps", "create_belief_map", "resolution_after_preprocessing",
+                              "shrink_resolution", "shrink_and_crop_resolution", "preprocess_image",
+                              "convert_keypoints_to_raw_from_netin", "convert_keypoints_to_netin_from_netout")
+                             if hasattr(dream.image_proc, n)},
+    }
+    with open(os.path.join(HERE, "api_surface.json"), "w") as f:
+        json.dump(surface, f, indent=1, sort_keys=True)
+    print("api_surface:", {k: len(v) for k, v in surface.items()})
+
+
 def main():
     dream = ref_import.import_reference()
     torch.manual_seed(0)
     if "--only-variants" in sys.argv:
         return variants(dream)
+    if "--only-api" in sys.argv:
+        return api_surface(dream)
 
     # ---- G1 + G2 -------------------------------------------------------------------------
     out = {}
@@ -174,6 +213,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "train_vgg_q_%s.npz" % opt), **out)
         print("train", opt, "losses", losses)
     variants(dream)
+    api_surface(dream)
 
 
 if __name__ == "__main__":

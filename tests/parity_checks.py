@@ -532,6 +532,9 @@ def check_dataprep(dev):
         ref = torch.tensor(op.create_belief_map((80, 60), kps[b])).float()
         assert torch.equal(got[b], ref), b
     assert float(got[0, 0].max()) == 1.0 and float(got[0, 1].abs().max()) == 0.0 and float(got[0, 6].abs().max()) == 0.0
+    one = dream_amd.image_proc.create_belief_map((80, 60), [tuple(p) for p in kps[1]])       # the reference's per-frame call
+    assert one.dtype == np.float64 and one.shape == (7, 60, 80)
+    assert np.array_equal(one.astype(np.float32), op.create_belief_map((80, 60), kps[1]).astype(np.float32))
 
 
 def check_conv_transpose4x4_f16x3(dev, B, H, W, Cin, Cout, seed=0):

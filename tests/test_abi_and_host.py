@@ -128,3 +128,38 @@ def test_no_cpu_fallback_without_gpu():
         net.inference(torch.zeros(1, 3, 400, 400))
     with pytest.raises(RuntimeError):
         dream_amd.peaks_from_belief_maps(torch.zeros(1, 8, 8), 0.0)
+
+
+def test_python_surface_matches_reference_signatures():
+    """The drop-in boundary: every function / method / constructor parameter a caller of the reference can
+    name exists here with the same name, order and default (tests/golden/api_surface.json, read off the reference with
+    inspect by make_golden.py --only-api), and a constructed DreamNetwork carries the reference's public attributes."""
+    import inspect
+    import json
+    import dream_amd
+    from dream_amd import image_proc, models, network, spatial_softmax
+    surface = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "api_surface.json")))
+
+    def params(fn):
+        return [[n, None if q.default is inspect._empty else repr(q.default)]
+                for n, q in inspect.signature(fn).parameters.items()]
+
+    ref = surface["dream.network"]
+    for name, sig in ref["functions"].items():
+        assert params(getattr(network, name)) == sig, name
+        assert getattr(dream_amd, name) is getattr(network, name)              # dream/__init__.py re-exports them
+    assert list(network.KNOWN_ARCHITECTURES) == ref["constants"]["KNOWN_ARCHITECTURES"]
+    assert list(network.KNOWN_OPTIMIZERS) == ref["constants"]["KNOWN_OPTIMIZERS"]
+    for name, sig in ref["DreamNetwork"].items():
+        assert params(getattr(network.DreamNetwork, name)) == sig, name
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = dream_amd.create_network_from_config_data(dream_amd.default_network_config("vgg_q"))
+    assert set(ref["DreamNetwork.instance_attributes"]) <= set(vars(net))
+    for mod, key in ((models, "dream.models"), (spatial_softmax, "dream.spatial_softmax")):
+        for cls, meths in surface[key].items():
+            for name, sig in meths.items():
+                assert params(getattr(getattr(mod, cls), name)) == sig, (cls, name)
+    for name, sig in surface["dream.image_proc"].items():
+        assert params(getattr(image_proc, name)) == sig, name
