@@ -65,7 +65,9 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
     _Float16 *sAl = sAh + NP * S16;
     _Float16 *sB = sAl + NP * S16;                  // [buf][plane][BN][S16]
 
-    int t = blockIdx.x;
+    // XCD-aware placement (see conv_mfma.hip): each XCD works on a contiguous range of tiles so halos meet in its L2
+    int t = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (t >= p.B * p.tiles_x * p.tiles_y) return;
     const int tix = t % p.tiles_x;
     t /= p.tiles_x;
     const int tiy = t % p.tiles_y;
@@ -455,7 +457,7 @@ int launch16(const float *x, const unsigned *amax_in, const void *w_hi, const vo
         DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_attr16[v] = true;
     }
-    const dim3 grid((unsigned)((size_t)B * p.tiles_x * p.tiles_y), (unsigned)ceil_div(Cout, var.BN));
+    const dim3 grid((unsigned)(ceil_div((int)((size_t)B * p.tiles_x * p.tiles_y), 8) * 8), (unsigned)ceil_div(Cout, var.BN));
     hipLaunchKernelGGL(var.kernel, grid, dim3(var.threads), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;

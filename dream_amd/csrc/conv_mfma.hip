@@ -88,7 +88,11 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     float *sB1 = sB0 + BN * S;
 
     // ---- which tile -------------------------------------------------------------------------
-    int t = blockIdx.x;
+    // XCD-aware placement: workgroup b runs on XCD b % 8 (observed, speed only) and every XCD has its own L2, so each
+    // XCD gets a CONTIGUOUS range of tiles: neighbouring tiles (which share their halo rows / columns) meet in one L2
+    // instead of fetching the halo once per XCD.  gridDim.x is padded to a multiple of 8.
+    int t = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (t >= p.B * p.tiles_x * p.tiles_y) return;
     const int tix = t % p.tiles_x;
     t /= p.tiles_x;
     const int tiy = t % p.tiles_y;
@@ -431,7 +435,7 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
         DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_attr_set[v] = true;
     }
-    const dim3 grid((unsigned)((size_t)B * p.tiles_x * p.tiles_y), (unsigned)ceil_div(Cout, var.BN));
+    const dim3 grid((unsigned)(ceil_div((int)((size_t)B * p.tiles_x * p.tiles_y), 8) * 8), (unsigned)ceil_div(Cout, var.BN));
     hipLaunchKernelGGL(var.kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
