@@ -41,6 +41,8 @@ def parse():
                     help="conv kernel for inference: exact fp32 MFMA, or split-precision fp16x3 (fp32 in/out, fp32-class error)")
     ap.add_argument("--arch", choices=["vgg_q", "vgg_f", "resnet_h", "resnet_f"], default="vgg_q")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="inference through DreamNetwork.hip_graph (hipGraph replay; "
+                    "per-launch HIP events are not recorded then)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the informational fp16x3 leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -160,6 +162,7 @@ def main():
         tgt = torch.from_numpy(cases.target_batch(args.batch, n_kp, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
     else:
         net.enable_evaluation()
+        net.hip_graph = bool(args.graph)
         if args.precision != "fp32":
             net.model.module.precision = args.precision
 
@@ -211,7 +214,7 @@ def main():
             step()
         torch.cuda.synchronize()
         barrier()
-        recording[0] = True
+        recording[0] = not args.graph          # events cannot be timed inside a captured graph
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):

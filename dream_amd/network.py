@@ -197,6 +197,12 @@ class DreamNetwork:
             assert False, "Loss not yet implemented."
 
         self.optimizer = None
+        # Opt-in for latency-bound use (single frames from a camera, dream/analysis.py / the ROS node): inference()
+        # captures the whole launch sequence of one input shape -- CNN + peak extraction, 30-140 kernel launches -- into
+        # a hipGraph and replays it, so a frame costs one graph launch + one 56-byte D2H copy instead of one Python /
+        # ctypes round trip per kernel.  Results are bit-identical (same kernels, same order).  Off by default.
+        self.hip_graph = False
+        self._graphs = {}
 
         out_res = list(self.net_output_resolution_from_input_resolution(self.trained_net_input_resolution()))
         if "net_output_resolution" in tcfg:
@@ -288,14 +294,44 @@ class DreamNetwork:
         if heads == ["belief_maps", "keypoints"]:
             return self.model(self._to_device(network_input))
         if heads == ["belief_maps"]:
-            belief_maps_batch = self.model(self._to_device(network_input))[-1]
-            out_w, out_h = self.trained_net_output_resolution()
-            offset = 0.0 if (out_w >= 400 and out_h >= 400) else 0.4395           # network.py:534-538
-            with torch.no_grad():
-                kps, _ = ops.keypoints_from_belief_maps(belief_maps_batch.detach(), offset)
+            x = self._to_device(network_input)
+            if self.hip_graph and not self.model.training and not torch.is_grad_enabled() and x.is_cuda:
+                return self._inference_graphed(x)
+            belief_maps_batch, kps = self._inference_on_device(x)
             # the reference returns the keypoints as a CPU float32 tensor (network.py:581)
             return [belief_maps_batch, kps.cpu()]
         assert False, "Could not determine how to conduct inference on this network."
+
+    def _inference_on_device(self, x):
+        belief_maps_batch = self.model(x)[-1]
+        out_w, out_h = self.trained_net_output_resolution()
+        offset = 0.0 if (out_w >= 400 and out_h >= 400) else 0.4395               # network.py:534-538
+        with torch.no_grad():
+            kps, _ = ops.keypoints_from_belief_maps(belief_maps_batch.detach(), offset)
+        return belief_maps_batch, kps
+
+    def _inference_graphed(self, x):
+        """hipGraph replay of _inference_on_device for this input shape; re-captured when a parameter or buffer changed
+        (the packed weight copies the kernels read are re-created then) or the precision switch moved."""
+        state = [t._version for t in self.model.parameters()] + [t._version for t in self.model.buffers()]
+        key = (tuple(x.shape), getattr(self.model.module, "precision", "fp32"))
+        entry = self._graphs.get(key)
+        if entry is None or entry["state"] != state:
+            static_x = x.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # warm-up off the capture: first-use attribute calls, weight packing
+                for _ in range(2):
+                    self._inference_on_device(static_x)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                maps, kps = self._inference_on_device(static_x)
+            entry = {"state": state, "x": static_x, "graph": graph, "maps": maps, "kps": kps}
+            self._graphs[key] = entry
+        entry["x"].copy_(x)
+        entry["graph"].replay()
+        return [entry["maps"].clone(), entry["kps"].cpu()]
 
     # ---- persistence (network.py:592-632) --------------------------------------------------------------------------
     def save_network_config(self, config_file_path, overwrite=False):

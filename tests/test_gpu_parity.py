@@ -277,3 +277,33 @@ def test_hourglass_variants(name):
 @pytest.mark.parametrize("name", ["vgg_q_skip", "vgg_f_ms2_skip", "vgg_ms2", "vgg_ms3_full"])
 def test_hourglass_variants_split_precision(name):
     pc.check_variant(DEV, name, precision="fp16x3")
+
+
+@pytest.mark.parametrize("arch,shape", [("vgg_q", (1, 400, 400)), ("resnet_h", (2, 64, 96)), ("vgg_q", (3, 50, 75))])
+def test_hip_graph_inference_is_bit_identical(arch, shape):
+    """DreamNetwork.hip_graph: the captured launch sequence replays to exactly the eager results, for fresh inputs, after a
+    weight update (re-capture), and on the split-precision kernel."""
+    b, h, w = shape
+    net = pc.build_network(arch, DEV)
+    net.enable_evaluation()
+    xs = [torch.from_numpy(cases.image_batch(b, h, w, seed=s)).to(DEV) for s in (1, 2)]
+    with torch.no_grad():
+        eager = [net.inference(x) for x in xs]
+        net.hip_graph = True
+        for rep in range(2):
+            for x, (m0, k0) in zip(xs, eager):
+                m1, k1 = net.inference(x)
+                assert torch.equal(m0, m1) and torch.equal(k0, k1)
+        assert len(net._graphs) == 1
+        first = next(iter(net.model.parameters()))
+        first.mul_(1.5)                                      # bumps the parameter version: packed copies are stale
+        m2, k2 = net.inference(xs[0])
+        net.hip_graph = False
+        m3, k3 = net.inference(xs[0])
+        assert torch.equal(m2, m3) and torch.equal(k2, k3) and not torch.equal(m2, eager[0][0])
+        net.hip_graph = True
+        net.model.module.precision = "fp16x3"
+        m4, k4 = net.inference(xs[1])
+        net.hip_graph = False
+        m5, k5 = net.inference(xs[1])
+        assert torch.equal(m4, m5) and torch.equal(k4, k5)
