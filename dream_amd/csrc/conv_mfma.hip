@@ -327,10 +327,13 @@ const Variant kVariants[] = {
     DREAM_VARIANT(1, 2, 4, 1, 32, 192),   // 6: 128 px x  64 cout
     DREAM_VARIANT(1, 1, 4, 1, 32, 192),   // 7: 128 px x  32 cout
     DREAM_VARIANT(1, 2, 2, 2, 32, 128),   // 8:  64 px x 128 cout (small feature maps, small batch)
-    DREAM_VARIANT(2, 2, 2, 2, 16, 608),   // 9: 128 px x 128 cout, big patch (stride-2 3x3 convs)
+    DREAM_VARIANT(1, 1, 2, 2, 32, 128),   // 9:  64 px x  64 cout: one 32x32 tile per wave, shortest K loop per wave
+    DREAM_VARIANT(1, 1, 2, 2, 16, 128),   // 10: same, KC 16
+    DREAM_VARIANT(2, 2, 2, 2, 16, 608),   // 11: 128 px x 128 cout, big patch (stride-2 3x3 convs)
 };
 constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
-constexpr int kNumSelectable = 9;          // variants a caller may force (9 is picked automatically)
+constexpr int kNumSelectable = 11;         // variants a caller may force (the big-patch one is picked automatically)
+constexpr int kBigPatchVariant = 11;
 int g_forced_variant = -1;
 bool g_attr_set[kNumVariants] = {};
 
@@ -360,24 +363,26 @@ void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, bo
 }
 
 int pick_variant(long pixels, int Cin, int Cout, bool big_patch) {
-    if (big_patch) return 9;
+    if (big_patch) return kBigPatchVariant;
+    // Measured on MI355X (profiles/r01_ab_variants_b128.txt, r01_microbench_resnet.txt): the KC=16 variants (half the
+    // LDS, 3-4 workgroups per CU) win by 1-8 % whenever the grid fills the chip; when it does not (ResNet trunk at
+    // 25x25 / 13x13, small batches) the shorter per-wave K loop and the larger workgroup count of the small tiles win by
+    // up to 24 %.  Rule: the largest tile whose grid reaches ~2.3 workgroups per CU, else the tile with the most
+    // workgroups.  The KC=32 small tiles need Cin % 32 == 0.
     const bool k32 = (Cin % 32 == 0);
-    // measured on MI355X, interleaved A/B at B=128 (profiles/r01_ab_variants_b128.txt): the KC=16 variants (half the
-    // LDS, 3-4 workgroups per CU) win by 1-8 % on every vgg_q layer shape
-    const bool prefer16 = true;
-    if (Cout > 64) {
-        // enough 128x128 tiles to fill 256 CUs x 2 workgroups?  otherwise the 64-px variant
-        const long tiles128 = ((pixels + 127) / 128) * (long)ceil_div(Cout, 128);
-        if (k32 && tiles128 < 512) return 8;
-        return (k32 && !prefer16) ? 0 : 3;
+    static const int wide[] = {3, 8, 6, 9, 7}, mid[] = {4, 6, 9, 7}, narrow32[] = {2, 7}, narrow16[] = {5};
+    const int *cand = Cout > 64 ? wide : (Cout > 32 ? mid : (k32 ? narrow32 : narrow16));
+    const int ncand = Cout > 64 ? 5 : (Cout > 32 ? 4 : (k32 ? 2 : 1));
+    int best = cand[0];
+    long best_wgs = -1;
+    for (int i = 0; i < ncand; ++i) {
+        const Variant &v = kVariants[cand[i]];
+        if (v.KC == 32 && !k32) continue;
+        const long wgs = ((pixels + v.BM - 1) / v.BM) * (long)ceil_div(Cout, v.BN);
+        if (wgs >= 600) return cand[i];
+        if (wgs > best_wgs) { best_wgs = wgs; best = cand[i]; }
     }
-    const long tiles256 = (pixels + 255) / 256;
-    if (Cout > 32) {
-        if (k32 && tiles256 < 512) return 6;
-        return (k32 && !prefer16) ? 1 : 4;
-    }
-    if (k32 && tiles256 < 512) return 7;
-    return k32 ? 2 : 5;
+    return best;
 }
 
 struct ConvGeom {

@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 30 and "dream_conv3x3_nhwc_f32" in declared
     assert set(declared) == set(_hip._SIGNATURES.keys())
     assert _hip.lib().dream_hip_abi_version() == 1
-    assert _hip.lib().dream_conv3x3_num_variants() == 9   # selectable; a 10th (big-patch) variant is automatic
+    assert _hip.lib().dream_conv3x3_num_variants() == 11  # selectable; one more (big-patch) variant is automatic
 
 
 def test_argument_errors_are_reported_not_thrown():

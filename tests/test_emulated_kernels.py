@@ -18,7 +18,7 @@ def emu():
         yield lib
 
 
-@pytest.mark.parametrize("variant", range(9))
+@pytest.mark.parametrize("variant", range(11))
 def test_conv_variants(emu, variant):
     emu.dream_conv3x3_set_variant(variant)
     try:
