@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) unpack_w_kernel(const float *packed, floa
 }
 
 // ---- MSE loss (mean) forward + gradient -------------------------------------------------------------
-__global__ void __launch_bounds__(256) mse_kernel(const float *o, const float *t, float *g, float *loss_sum,
+__global__ void __launch_bounds__(256) mse_kernel(const float *o, const float *t, float *g, double *block_sums,
                                                   size_t n, float scale) {
     __shared__ double part[4];
     double acc = 0.0;
@@ -192,11 +192,26 @@ __global__ void __launch_bounds__(256) mse_kernel(const float *o, const float *t
     for (int m = 32; m >= 1; m >>= 1) acc += lane_xor(acc, m);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_sum, (float)(part[0] + part[1] + part[2] + part[3]));
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// Fixed-order sum of the per-workgroup partial sums (one workgroup; thread i takes partials i, i+256, ...; then a fixed
+// tree): the loss value is bit-reproducible run to run, which an atomicAdd of the partials is not.
+__global__ void __launch_bounds__(256) loss_finalize_kernel(const double *block_sums, int nblocks, float *loss_sum) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) acc += block_sums[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_sum[0] = (float)red[0];
 }
 
 // SmoothL1Loss (beta = 1, mean): 0.5 d^2 for |d| < 1 else |d| - 0.5;  gradient d or sign(d), times 1/N
-__global__ void __launch_bounds__(256) smoothl1_kernel(const float *o, const float *t, float *g, float *loss_sum,
+__global__ void __launch_bounds__(256) smoothl1_kernel(const float *o, const float *t, float *g, double *block_sums,
                                                        size_t n, float scale) {
     __shared__ double part[4];
     double acc = 0.0;
@@ -210,7 +225,7 @@ __global__ void __launch_bounds__(256) smoothl1_kernel(const float *o, const flo
     for (int m = 32; m >= 1; m >>= 1) acc += lane_xor(acc, m);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_sum, (float)(part[0] + part[1] + part[2] + part[3]));
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // ---- optimizers ------------------------------------------------------------------------------------
@@ -609,19 +624,26 @@ extern "C" int dream_stage_input_bwd_f32(const float *g_nhwc, float *dmaps_nchw,
     DREAM_LAUNCH_OK();
     return 0;
 }
-extern "C" int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+extern "C" size_t dream_loss_workspace(size_t n) { return (size_t)grid_for(n) * sizeof(double); }
+extern "C" int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum, void *workspace,
                                      size_t n, double n_total, void *stream) {
-    DREAM_REQUIRE(out && target && loss_sum && n > 0 && n_total > 0, "mse: bad arguments");
-    hipLaunchKernelGGL(mse_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, target, grad, loss_sum,
+    DREAM_REQUIRE(out && target && loss_sum && workspace && n > 0 && n_total > 0, "mse: bad arguments");
+    const unsigned nb = grid_for(n);
+    hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, out, target, grad, (double *)workspace,
                        n, (float)(2.0 / n_total));
+    DREAM_LAUNCH_OK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)workspace, (int)nb, loss_sum);
     DREAM_LAUNCH_OK();
     return 0;
 }
-extern "C" int dream_smoothl1_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+extern "C" int dream_smoothl1_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum, void *workspace,
                                           size_t n, double n_total, void *stream) {
-    DREAM_REQUIRE(out && target && loss_sum && n > 0 && n_total > 0, "smoothl1: bad arguments");
-    hipLaunchKernelGGL(smoothl1_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, out, target, grad, loss_sum,
+    DREAM_REQUIRE(out && target && loss_sum && workspace && n > 0 && n_total > 0, "smoothl1: bad arguments");
+    const unsigned nb = grid_for(n);
+    hipLaunchKernelGGL(smoothl1_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, out, target, grad, (double *)workspace,
                        n, (float)(1.0 / n_total));
+    DREAM_LAUNCH_OK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)workspace, (int)nb, loss_sum);
     DREAM_LAUNCH_OK();
     return 0;
 }

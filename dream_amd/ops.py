@@ -146,10 +146,11 @@ def mse_fwd_bwd(out, target, want_grad=True, kind="mse"):
     if o.shape != t.shape:
         raise RuntimeError("loss: shape mismatch %s vs %s" % (tuple(o.shape), tuple(t.shape)))
     n = o.numel()
-    loss_sum = torch.zeros((1,), dtype=torch.float32, device=o.device)
+    loss_sum = torch.empty((1,), dtype=torch.float32, device=o.device)
+    ws = _workspace(int(_hip.lib().dream_loss_workspace(n)), o.device)
     grad = torch.empty_like(o) if want_grad else None
     fn = "dream_mse_fwd_bwd_f32" if kind == "mse" else "dream_smoothl1_fwd_bwd_f32"
-    call(fn, ptr(o), ptr(t), ptr(grad), ptr(loss_sum), n, float(n), stream())
+    call(fn, ptr(o), ptr(t), ptr(grad), ptr(loss_sum), ptr(ws), n, float(n), stream())
     return loss_sum[0] / n, grad
 
 

@@ -190,11 +190,14 @@ int dream_create_belief_maps_f32(const float *kps, const float *blob, float *out
 
 /* ---- training operators --------------------------------------------------------------------------
  * MSELoss(mean) forward + gradient (dream/network.py:260-261,359; loss.backward() at :335):
- * loss_sum[0] += sum((o-t)^2) (caller zeroes it and divides by n_total); grad = 2*(o-t)/n_total. */
-int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+ * loss_sum[0] = sum((o-t)^2) (caller divides by n_total); grad = 2*(o-t)/n_total (grad may be null).  The sum is
+ * accumulated in fp64 per workgroup into `workspace` (dream_loss_workspace(n) bytes) and reduced in a fixed order,
+ * so the loss is bit-reproducible. */
+size_t dream_loss_workspace(size_t n);
+int dream_mse_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum, void *workspace,
                           size_t n, double n_total, void *stream);
 /* SmoothL1Loss(beta 1, mean) = the "huber" loss type (dream/network.py:262-263,290-291): same contract as the MSE */
-int dream_smoothl1_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum,
+int dream_smoothl1_fwd_bwd_f32(const float *out, const float *target, float *grad, float *loss_sum, void *workspace,
                                size_t n, double n_total, void *stream);
 /* elementwise ReLU backward on NHWC tensors: dx = dy * (y > 0) (inplace allowed) */
 int dream_relu_bwd_f32(const float *dy, const float *y, float *dx, size_t n, void *stream);

@@ -307,3 +307,50 @@ def test_hip_graph_inference_is_bit_identical(arch, shape):
         net.hip_graph = False
         m5, k5 = net.inference(xs[1])
         assert torch.equal(m4, m5) and torch.equal(k4, k5)
+
+
+def test_full_size_resnet_f_properties():
+    """BASELINE.json configs[4] shape (resnet_f, 17 keypoints, 400x400 -> 416x416 maps; one GPU's share is 32 frames,
+    8 suffice for the property): batch-position independence, the CPU oracle on one frame, bit-exact peak stage."""
+    net = pc.build_network("resnet_f", DEV)
+    net.enable_evaluation()
+    base = torch.from_numpy(cases.image_batch(2, 400, 400, seed=78))
+    x = base.repeat(4, 1, 1, 1).to(DEV)
+    with torch.no_grad():
+        maps, kps = net.inference(x)
+        net.model.module.precision = "fp16x3"
+        maps16, kps16 = net.inference(x)
+    maps, maps16 = maps.cpu(), maps16.cpu()
+    assert maps.shape == (8, 17, 416, 416) and kps.shape == (8, 17, 2)
+    for r in range(1, 4):
+        assert torch.equal(maps[2 * r:2 * r + 2], maps[:2]) and torch.equal(kps[2 * r:2 * r + 2], kps[:2])
+        assert torch.equal(maps16[2 * r:2 * r + 2], maps16[:2])
+    ref = om.build_model("resnet_f", 17)
+    ref.load_state_dict(om.recipe_weights(ref.state_dict()))
+    ref.eval()
+    with torch.no_grad():
+        ref_maps = ref(base[:1])[0].numpy()
+    assert np.abs(maps[:1].numpy() - ref_maps).max() <= pc.tol(ref_maps)
+    assert np.abs(maps16[:1].numpy() - ref_maps).max() <= pc.tol(ref_maps)
+    assert np.array_equal(kps[:1].numpy(), op.keypoints_from_belief_maps(maps[:1].numpy(), 0.0))
+
+
+@pytest.mark.parametrize("arch,shape", [("vgg_q", (4, 200, 200)), ("resnet_h", (4, 128, 160)), ("vgg_f_ms2_skip", (2, 64, 96))])
+def test_training_is_deterministic(arch, shape):
+    """Two runs of the same three training steps from the same weights give bit-identical losses and parameters: split-K
+    partials are reduced in a fixed order, BatchNorm statistics in fp64 with a fixed tree, and nothing uses fp32 atomics."""
+    b, h, w = shape
+    k = 7
+    results = []
+    for run in range(2):
+        wts = om.recipe_weights(om.build_model(arch, k).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+        net = pc.build_network(arch, DEV, weights=wts, optimizer="adam", lr=1e-5, in_res=(w, h))
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        x = torch.from_numpy(cases.image_batch(b, h, w, seed=3)).to(DEV)
+        t = torch.from_numpy(cases.target_batch(b, k, (ow, oh), in_wh=(w, h), seed=3)).to(DEV)
+        losses = [net.train([x], t).item() for _ in range(3)]
+        assert all(np.isfinite(losses))
+        results.append((losses, [p.detach().clone() for p in net.model.parameters()]))
+    assert all(torch.equal(a, b_) for a, b_ in zip(results[0][1], results[1][1]))
+    assert results[0][0] == results[1][0]

@@ -1,5 +1,5 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -q -k "hip_graph" 2>&1 | tail -15
+timeout 900 python -m pytest tests -m gpu -q -k "full_size_resnet or deterministic" 2>&1 | tail -15
 echo skip
