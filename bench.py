@@ -141,9 +141,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+    # One process per GPU over RCCL.  (Rehearsal of the N > 1 path on a single-GPU box: DREAM_BENCH_BACKEND=gloo lets
+    # the ranks share device 0 -- RCCL refuses two ranks on one device; numbers from such a run mean nothing.)
+    backend = os.environ.get("DREAM_BENCH_BACKEND", "nccl")
+    device_index = local_rank % torch.cuda.device_count()   # == local_rank unless the launcher exposes one device per rank
+    torch.cuda.set_device(device_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     n_kp, manip = ARCH_K[args.arch]

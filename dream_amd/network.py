@@ -386,8 +386,8 @@ def _pick_device(gpu_ids):
     On a GPU-less host the network can be constructed (config / state_dict work) but not run."""
     if not torch.cuda.is_available():
         return torch.device("cpu")
-    if "LOCAL_RANK" in os.environ:
-        idx = int(os.environ["LOCAL_RANK"])
+    if "LOCAL_RANK" in os.environ:            # modulo: launchers that expose one device per rank make every rank see only device 0
+        idx = int(os.environ["LOCAL_RANK"]) % torch.cuda.device_count()
     elif gpu_ids:
         idx = int(gpu_ids[0])
     else:
