@@ -290,11 +290,12 @@ class DreamHourglass(nn.Module):
                 keep[li] = act
         return act, saved
 
-    def run_backward(self, saved, grad_out_nchw, need_input_grad=False):
+    def run_backward(self, saved, grad_out_nchw, need_input_grad=False, reducer=None):
         """dL/d(belief maps) [B,K,Ho,Wo] -> list of parameter gradients in plan_parameters() order (and, for a
-        multi-stage hourglass, dL/d(NHWC input of the "wide" first conv))."""
+        multi-stage hourglass, dL/d(NHWC input of the "wide" first conv)).  ``reducer``: overlapped data-parallel
+        all-reduce that is fed every gradient as soon as it exists."""
         layers = self.plan_layers()
-        grads = [None] * (2 * sum(1 for k, m, _ in layers if m is not None))
+        grads = _GradList(2 * sum(1 for k, m, _ in layers if m is not None), reducer)
         pi = len(grads)
         g = None
         g_input = None
@@ -394,10 +395,10 @@ class _HourglassFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         module = ctx.module
-        grads = module.run_backward(ctx.saved_acts, grad_out.contiguous())
+        reducer = _OverlappedAllReduce.create()
+        grads = module.run_backward(ctx.saved_acts, grad_out.contiguous(), reducer=reducer)
         ctx.saved_acts = None
-        grads = allreduce_gradients(grads)
-        return (None, None) + tuple(grads)
+        return (None, None) + tuple(_reduced(reducer, grads))
 
 
 def allreduce_gradients(grads):
@@ -417,6 +418,86 @@ def allreduce_gradients(grads):
         out.append(flat[o:o + n].view_as(g))
         o += n
     return out
+
+
+class _OverlappedAllReduce:
+    """Data-parallel exchange overlapped with backward.  Gradients are handed over in the order backward produces them
+    (identical on every rank); every ~32 MB they are flattened into one buffer whose all-reduce(sum) is started
+    asynchronously (RCCL runs it on its own stream over xGMI while the remaining layers' backward kernels run);
+    ``finish()`` waits, scales by 1/world and maps each gradient to its slice.  ResNet-101 at 16 frames per GPU moves
+    216 MB per step: exposed at the end of backward that is ~6 % of the step, overlapped it disappears."""
+    BUCKET_BYTES = 32 << 20
+
+    @staticmethod
+    def create():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return _OverlappedAllReduce(dist)
+        return None
+
+    def __init__(self, dist):
+        self.dist, self.world = dist, dist.get_world_size()
+        self.current, self.current_bytes, self.inflight, self.views = [], 0, [], {}
+
+    def add(self, g):
+        self.current.append(g)
+        self.current_bytes += g.numel() * g.element_size()
+        if self.current_bytes >= self.BUCKET_BYTES:
+            self._flush()
+
+    def _flush(self):
+        if not self.current:
+            return
+        flat = torch.cat([g.reshape(-1) for g in self.current])
+        work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
+        self.inflight.append((work, flat, self.current))
+        self.current, self.current_bytes = [], 0
+
+    def finish(self):
+        self._flush()
+        for work, flat, items in self.inflight:
+            work.wait()
+            flat /= self.world
+            o = 0
+            for g in items:
+                n = g.numel()
+                self.views[id(g)] = flat[o:o + n].view_as(g)
+                o += n
+        self.inflight = []
+
+    def result(self, g):
+        return self.views.get(id(g), g)
+
+
+class _GradList(list):
+    """Gradient slots of a backward plan; every assignment is also handed to the overlapped all-reduce (if any)."""
+
+    def __init__(self, n, reducer=None):
+        super().__init__([None] * n)
+        self._reducer = reducer
+
+    def __setitem__(self, i, g):
+        super().__setitem__(i, g)
+        if self._reducer is not None and g is not None:
+            self._reducer.add(g)
+
+
+class _GradDict(dict):
+    def __init__(self, reducer=None):
+        super().__init__()
+        self._reducer = reducer
+
+    def __setitem__(self, k, g):
+        super().__setitem__(k, g)
+        if self._reducer is not None and g is not None:
+            self._reducer.add(g)
+
+
+def _reduced(reducer, grads):
+    if reducer is None:
+        return list(grads)
+    reducer.finish()
+    return [reducer.result(g) for g in grads]
 
 
 class DreamHourglassMultiStage(nn.Module):
@@ -498,7 +579,7 @@ class DreamHourglassMultiStage(nn.Module):
             saved.append(sv)
         return outs, saved
 
-    def run_backward(self, saved, grad_outs):
+    def run_backward(self, saved, grad_outs, reducer=None):
         """grad_outs: dL/d(maps of stage s) or None, s = 1..S -> parameter gradients in plan_parameters() order."""
         stages = self.stages()
         up = self.map_upsampling()
@@ -515,11 +596,11 @@ class DreamHourglassMultiStage(nn.Module):
             elif carry is not None:
                 g = ops.add_(g.contiguous().clone(), carry)
             if s > 0:
-                per_stage[s], g_in = stages[s].run_backward(saved[s], g.contiguous(), need_input_grad=True)
+                per_stage[s], g_in = stages[s].run_backward(saved[s], g.contiguous(), need_input_grad=True, reducer=reducer)
                 b, h, w, c = (int(v) for v in g_in.shape)
                 carry = ops.stage_input_bwd(g_in, ci, k, up)
             else:
-                per_stage[s] = stages[s].run_backward(saved[s], g.contiguous())
+                per_stage[s] = stages[s].run_backward(saved[s], g.contiguous(), reducer=reducer)
         return [g for grads in per_stage for g in grads]
 
     def forward(self, x, verbose=False):
@@ -550,10 +631,10 @@ class _MultiStageFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grad_outs):
         module = ctx.module
-        grads = module.run_backward(ctx.saved_acts, list(grad_outs))
+        reducer = _OverlappedAllReduce.create()
+        grads = module.run_backward(ctx.saved_acts, list(grad_outs), reducer=reducer)
         ctx.saved_acts = None
-        grads = allreduce_gradients(grads)
-        return (None, None) + tuple(grads)
+        return (None, None) + tuple(_reduced(reducer, grads))
 
 
 class ResnetSimple(nn.Module):
@@ -784,10 +865,10 @@ class ResnetSimple(nn.Module):
                     i += 1
         return y, tape
 
-    def run_backward(self, tape, grad_out_nchw):
+    def run_backward(self, tape, grad_out_nchw, reducer=None):
         """-> {parameter: gradient}.  Walks the tape backwards; gradients that meet at a Bottleneck input are summed
         by the residual input of the data-gradient conv (no separate add kernel)."""
-        grads = {}
+        grads = _GradDict(reducer)
         g = None                 # gradient w.r.t. the output of the unit being processed
         block = None             # state of the Bottleneck being unwound
         for rec in reversed(tape):
@@ -869,11 +950,10 @@ class _ResnetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        gdict = ctx.module.run_backward(ctx.tape, grad_out.contiguous())
+        reducer = _OverlappedAllReduce.create()
+        gdict = ctx.module.run_backward(ctx.tape, grad_out.contiguous(), reducer=reducer)
         ctx.tape = None
-        grads = [gdict[p] for p in ctx.params]
-        grads = allreduce_gradients(grads)
-        return (None, None) + tuple(grads)
+        return (None, None) + tuple(_reduced(reducer, [gdict[p] for p in ctx.params]))
 
 
 class DreamDataParallel(nn.Module):

@@ -48,6 +48,8 @@ def _worker(rank, world, port, out_dir):
     from emu_util import emulated_hip
     x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=9))
     t = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=9))
+    from dream_amd import models
+    models._OverlappedAllReduce.BUCKET_BYTES = 1 << 20      # several asynchronous buckets in flight during backward
     with emulated_hip():
         losses, params = _train_once(x[rank:rank + 1], t[rank:rank + 1])
     torch.save({"losses": losses, "params": params}, os.path.join(out_dir, "rank%d.pt" % rank))

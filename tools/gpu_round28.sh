@@ -6,3 +6,4 @@ run() { n=$1; shift; timeout 600 python -m torch.distributed.run --nnodes=1 --np
 run inf --steps 3 --warmup 1 --batch 16 --no-split-leg
 run train --steps 2 --warmup 1 --batch 8 --mode train
 run rtrain --steps 2 --warmup 1 --batch 4 --arch resnet_h --mode train
+timeout 600 python -m pytest tests -m gpu -q -k "train_step or deterministic" 2>&1 | tail -1
