@@ -37,27 +37,34 @@ DREAM_DEVICE int reflect_index(int i, int n) {
     return i < n ? i : period - 1 - i;
 }
 
-// one 1-D pass; `stride` is the element stride along the filtered axis, `len` its length
+// One 1-D pass.  Workgroup = 64 x 4 pixels of one map (3-D grid: no 64-bit index division per pixel); lanes run along
+// x, so both the row pass and the column pass read whole 256-B row segments.  Pixels at least R away from both ends of
+// the filtered axis take the tap loop without the reflection arithmetic (same values, same order: bit-identical).
 template <int AXIS>
 __global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float *out, int N, int H, int W) {
-    const size_t total = (size_t)N * H * W;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int x = (int)(idx % W);
-        const size_t r = idx / W;
-        const int y = (int)(r % H);
-        const size_t n = r / H;
-        const float *base = in + n * (size_t)H * W;
-        const int l = AXIS == 0 ? y : x;
-        const int len = AXIS == 0 ? H : W;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const float *base = in + (size_t)blockIdx.z * H * W;
+    const int l = AXIS == 0 ? y : x;
+    const int len = AXIS == 0 ? H : W;
+    const float *centre = base + (size_t)y * W + x;
+    const int step = AXIS == 0 ? W : 1;
+    double acc;
+    if (l >= R && l + R < len) {
+        acc = dmul((double)centre[0], kTaps[R]);
+#pragma unroll
+        for (int i = -R; i < 0; ++i)
+            acc = dadd(acc, dmul(dadd((double)centre[i * step], (double)centre[-i * step]), kTaps[R + i]));
+    } else {
         auto at = [&](int pos) -> double {
             const int q = (pos >= 0 && pos < len) ? pos : reflect_index(pos, len);
             return (double)(AXIS == 0 ? base[(size_t)q * W + x] : base[(size_t)y * W + q]);
         };
-        double acc = dmul(at(l), kTaps[R]);
+        acc = dmul(at(l), kTaps[R]);
 #pragma unroll
         for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd(at(l + i), at(l - i)), kTaps[R + i]));
-        out[idx] = (float)acc;
     }
+    out[(size_t)blockIdx.z * H * W + (size_t)y * W + x] = (float)acc;
 }
 
 DREAM_DEVICE double pairwise_sum25(const double *a) {
@@ -196,18 +203,17 @@ __global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const flo
     }
 }
 
-inline unsigned stream_grid(size_t total) {
-    size_t g = (total + 255) / 256;
-    if (g > 256 * 8) g = 256 * 8;
-    return (unsigned)(g ? g : 1);
-}
-
 int smooth_maps(const float *maps, float *tmp, float *out, int N, int H, int W, hipStream_t s) {
-    const size_t total = (size_t)N * H * W;
-    hipLaunchKernelGGL(gauss_pass_kernel<0>, dim3(stream_grid(total)), dim3(256), 0, s, maps, tmp, N, H, W);
-    DREAM_LAUNCH_OK();
-    hipLaunchKernelGGL(gauss_pass_kernel<1>, dim3(stream_grid(total)), dim3(256), 0, s, (const float *)tmp, out, N, H, W);
-    DREAM_LAUNCH_OK();
+    DREAM_REQUIRE((H + 3) / 4 <= 65535, "gaussian: more than 262140 rows");
+    for (int n0 = 0; n0 < N; n0 += 65535) {                  // grid.z limit
+        const int nn = N - n0 < 65535 ? N - n0 : 65535;
+        const size_t off = (size_t)n0 * H * W;
+        const dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)nn);
+        hipLaunchKernelGGL(gauss_pass_kernel<0>, grid, dim3(256), 0, s, maps + off, tmp + off, nn, H, W);
+        DREAM_LAUNCH_OK();
+        hipLaunchKernelGGL(gauss_pass_kernel<1>, grid, dim3(256), 0, s, (const float *)(tmp + off), out + off, nn, H, W);
+        DREAM_LAUNCH_OK();
+    }
     return 0;
 }
 
