@@ -354,3 +354,28 @@ def test_training_is_deterministic(arch, shape):
         results.append((losses, [p.detach().clone() for p in net.model.parameters()]))
     assert all(torch.equal(a, b_) for a, b_ in zip(results[0][1], results[1][1]))
     assert results[0][0] == results[1][0]
+
+
+@pytest.mark.parametrize("arch,shape", [("vgg_q", (1, 70, 93)), ("vgg_q", (2, 401, 399)), ("vgg_f", (1, 70, 93)),
+                                        ("resnet_h", (1, 75, 101)), ("resnet_f", (2, 33, 47))])
+def test_ragged_resolutions_match_oracle(arch, shape):
+    """Resolutions the pools / strides do not divide (floor semantics everywhere, ragged last tiles in every kernel):
+    HIP maps against the CPU oracle on the same weights, fp32 and split precision, and bit-exact peaks on the HIP maps."""
+    b, h, w = shape
+    k = cases.CNN_CASES[arch][0]
+    net = pc.build_network(arch, DEV, in_res=(w, h))
+    net.enable_evaluation()
+    ref = om.build_model(arch, k)
+    ref.load_state_dict(om.recipe_weights(ref.state_dict()))
+    ref.eval()
+    x = torch.from_numpy(cases.image_batch(b, h, w, seed=h))
+    with torch.no_grad():
+        want = ref(x)[0].numpy()
+        maps, kps = net.inference(x.to(DEV))
+        net.model.module.precision = "fp16x3"
+        maps16, _ = net.inference(x.to(DEV))
+    assert tuple(maps.shape) == want.shape == (b, k) + tuple(reversed(net.net_output_resolution_from_input_resolution((w, h))))
+    assert np.abs(maps.cpu().numpy() - want).max() <= pc.tol(want)
+    assert np.abs(maps16.cpu().numpy() - want).max() <= pc.tol(want)
+    off = op.upsampling_offset(*net.trained_net_output_resolution())
+    assert np.array_equal(kps.numpy(), op.keypoints_from_belief_maps(maps.cpu().numpy(), off))
