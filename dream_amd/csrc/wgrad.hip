@@ -172,13 +172,32 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(const WgradParams p) {
                     for (int rb = 0; rb < RB; ++rb)
                         acc[(rb * CB + cb) * NT + tp] = mfma_f32_32x32x2(a[rb], b[tp * CB + cb], acc[(rb * CB + cb) * NT + tp]);
         };
+        // sched_barrier: hipcc's scheduler (at ~250 VGPRs it optimises for register pressure) otherwise sinks each
+        // block of ds_reads down to its own MFMAs, which puts the LDS latency back in front of every k-step
+        // Requested instruction order inside one (loads of step s+1, MFMAs of step s) region: an MFMA first, the address
+        // arithmetic and one ds_read in the shadow of each MFMA.  Without it the two waves that share a SIMD (one per
+        // resident workgroup, barrier-aligned) do their address / LDS phase at the same time and the matrix pipe idles.
+        auto interleave = [&]() {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x006, 16, 0);           // VALU | SALU: addresses of the next step
+#pragma unroll
+            for (int i = 0; i < RB + CB * NT; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // one ds_read
+                if (i + 1 < RB * CB * NT) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, RB * CB * NT, 0); // remaining MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        };
         load_step(0, a0, b0);
         int st = 0;
         for (; st + 1 < nsteps; st += 2) {
+            __builtin_amdgcn_sched_barrier(0);
             load_step(st + 1, a1, b1);
             mma_step(a0, b0);
+            interleave();
             load_step(st + 2 < nsteps ? st + 2 : nsteps - 1, a0, b0);
             mma_step(a1, b1);
+            interleave();
         }
         if (st < nsteps) mma_step(a0, b0);
     }

@@ -134,6 +134,8 @@ inline unsigned atomicMax(unsigned *p, unsigned v) {
 }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_s_sleep(int) {}
+inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline double __dmul_rn(double a, double b) { return a * b; }
 inline double __dadd_rn(double a, double b) { return a + b; }
