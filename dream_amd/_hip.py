@@ -79,6 +79,7 @@ _SIGNATURES = {
     "dream_peaks_from_belief_maps_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P]),
     "dream_gaussian_sigma3_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "dream_softargmax_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "dream_convert_keypoints_f64": (_I, [_P, _P, _P, _I] + [_D] * 8 + [_I, _P]),
     "dream_loss_workspace": (_SZ, [_SZ]),
     "dream_mse_fwd_bwd_f32": (_I, [_P, _P, _P, _P, _P, _SZ, _D, _P]),
     "dream_normalize_u8_hwc_to_chw_f32": (_I, [_P, _P, _I, _I, _I, _c.POINTER(_F), _c.POINTER(_F), _P]),

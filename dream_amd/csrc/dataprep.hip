@@ -51,6 +51,29 @@ inline unsigned sgrid(size_t n) {
     if (g > 2048) g = 2048;
     return (unsigned)(g ? g : 1);
 }
+// Keypoint frame conversion right after peak extraction (dream/image_proc.py:135-147 net-output -> net-input,
+// :215-260 net-input -> raw image): two affine maps in float64 with the reference's operation order (divide, then
+// multiply, then add), applied to every row including the -999.999 sentinels, as the reference does.
+//   netin = k / out_res * in_res            raw = netin                      (mode 0: "none")
+//                                           raw = netin / in_res * span + origin   (mode 1: resize / shrink /
+//                                                 shrink-and-crop; span / origin = raw or cropped resolution / corner)
+__global__ void __launch_bounds__(256) convert_keypoints_kernel(const float *kps, double *netin, double *raw, int N,
+                                                                double ow, double oh, double iw, double ih, double sw,
+                                                                double sh, double x0, double y0, int mode) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double nx = dmul(ddiv((double)kps[2 * i], ow), iw), ny = dmul(ddiv((double)kps[2 * i + 1], oh), ih);
+    netin[2 * i] = nx;
+    netin[2 * i + 1] = ny;
+    if (mode == 0) {
+        raw[2 * i] = nx;
+        raw[2 * i + 1] = ny;
+    } else {
+        raw[2 * i] = dadd(dmul(ddiv(nx, iw), sw), x0);
+        raw[2 * i + 1] = dadd(dmul(ddiv(ny, ih), sh), y0);
+    }
+}
+
 }  // namespace
 
 extern "C" int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float *out, int B, int H, int W,
@@ -68,6 +91,17 @@ extern "C" int dream_create_belief_maps_f32(const float *kps, const float *blob,
     DREAM_REQUIRE(kps && blob && out && N > 0 && H > 0 && W > 0 && w >= 0, "create_belief_maps: bad arguments");
     hipLaunchKernelGGL(belief_maps_kernel, dim3(sgrid((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, kps, blob, out, N, H,
                        W, w);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" int dream_convert_keypoints_f64(const float *kps_netout, double *kps_netin, double *kps_raw, int N,
+                                           double out_w, double out_h, double in_w, double in_h, double span_w,
+                                           double span_h, double origin_x, double origin_y, int mode, void *stream) {
+    DREAM_REQUIRE(kps_netout && kps_netin && kps_raw && N > 0 && out_w > 0 && out_h > 0 && in_w > 0 && in_h > 0 &&
+                  (mode == 0 || mode == 1), "convert_keypoints: bad arguments");
+    hipLaunchKernelGGL(convert_keypoints_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, kps_netout, kps_netin,
+                       kps_raw, N, out_w, out_h, in_w, in_h, span_w, span_h, origin_x, origin_y, mode);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -107,6 +107,30 @@ def convert_keypoints_to_raw_from_netin(keypoints_netin, net_input_resolution, i
                      k[:, 1] / net_input_resolution[1] * ch + y0], axis=1)
 
 
+def convert_keypoints_batch(keypoints_netout, net_output_resolution, net_input_resolution, image_raw_resolution,
+                            image_preprocessing):
+    """The two conversions above for a whole batch on the device: keypoints [..., 2] fp32 in the
+    net-output frame (as DreamNetwork.inference computes them) -> (netin, raw) float64 tensors of the same shape, bit
+    for bit what the per-keypoint Python loops of the reference produce (dream/analysis.py:219-232)."""
+    assert image_preprocessing in KNOWN_IMAGE_PREPROC_TYPES, 'Image preprocessing type "{}" is not recognized.'.format(
+        image_preprocessing)
+    k = _hip.device_tensor(torch.as_tensor(keypoints_netout, dtype=torch.float32)).contiguous()
+    n = k.numel() // 2
+    netin = torch.empty(tuple(k.shape), dtype=torch.float64, device=k.device)
+    raw = torch.empty_like(netin)
+    (ow, oh), (iw, ih) = net_output_resolution, net_input_resolution
+    if image_preprocessing == "none":
+        mode, span, origin = 0, (1.0, 1.0), (0.0, 0.0)
+    elif image_preprocessing in ("resize", "shrink"):
+        mode, span, origin = 1, image_raw_resolution, (0.0, 0.0)
+    else:
+        span, origin = shrink_and_crop_resolution(image_raw_resolution, net_input_resolution)
+        mode = 1
+    _hip.call("dream_convert_keypoints_f64", ops.ptr(k), ops.ptr(netin), ops.ptr(raw), n, float(ow), float(oh), float(iw),
+              float(ih), float(span[0]), float(span[1]), float(origin[0]), float(origin[1]), mode, ops.stream())
+    return netin, raw
+
+
 # ---- the steps right before the hot path, on the device (SURVEY.md 8f rank 1) ---------------------------------------
 def normalize_images_u8(images_u8_bhwc, mean, stdev):
     """uint8 RGB frames [B,H,W,3] (device) -> normalised fp32 [B,3,H,W]: ToTensor + Normalize(mean, stdev) as the

@@ -187,6 +187,14 @@ int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float *out, int 
                                       const float *mean3, const float *stdev3, void *stream);
 int dream_create_belief_maps_f32(const float *kps, const float *blob, float *out, int N, int H, int W, int w,
                                  void *stream);
+/* Keypoint frames after peak extraction (dream/image_proc.py:135-147 convert_keypoints_to_netin_from_netout,
+ * :215-260 convert_keypoints_to_raw_from_netin; call sites dream/network.py:480-488, dream/analysis.py:219-232):
+ * kps_netout [N,2] fp32 (x, y) -> kps_netin, kps_raw [N,2] float64, the reference's arithmetic in its order, sentinels
+ * included.  mode 0 = preprocessing "none" (raw = netin); mode 1 = raw = netin / in * span + origin with span/origin =
+ * the raw resolution and 0 ("resize", "shrink") or the cropped resolution and corner ("shrink-and-crop"). */
+int dream_convert_keypoints_f64(const float *kps_netout, double *kps_netin, double *kps_raw, int N,
+                                double out_w, double out_h, double in_w, double in_h, double span_w, double span_h,
+                                double origin_x, double origin_y, int mode, void *stream);
 
 /* ---- training operators --------------------------------------------------------------------------
  * MSELoss(mean) forward + gradient (dream/network.py:260-261,359; loss.backward() at :335):

@@ -124,3 +124,18 @@ VARIANT_TRAIN_SHAPE = (2, 64, 96)
 TRAIN_LR = {"adam": 1e-5, "sgd": 1e-6}
 TRAIN_FINAL_KEYS = ("heads_0.4.weight", "heads_0.4.bias")
 TRAIN_FINAL_SCALE = 0.1
+
+
+def keypoint_conversion_cases():
+    """name -> (keypoints [N,2] float32 in the net-output frame, net_output_res, net_input_res, raw_res), all (W,H)."""
+    rs = np.random.RandomState(11)
+    out = {}
+    for name, out_res, in_res, raw_res in (("vgg_q_vga", (100, 100), (400, 400), (640, 480)),
+                                           ("resnet_h_hd", (208, 208), (400, 400), (1280, 720)),
+                                           ("full_portrait", (400, 400), (400, 400), (480, 640)),
+                                           ("ragged", (93, 70), (375, 281), (641, 479))):
+        kps = (rs.uniform(-5, 5, (24, 2)) + rs.uniform(0, 1, (24, 2)) * np.array(out_res)).astype(np.float32)
+        kps[3] = kps[17] = np.float32(-999.999)
+        kps[5] = (0.0, 0.0)
+        out[name] = (kps, out_res, in_res, raw_res)
+    return out

@@ -123,9 +123,25 @@ def api_surface(dream):
     print("api_surface:", {k: len(v) for k, v in surface.items()})
 
 
+def keypoint_conversions(dream):
+    """G9: the step right after the hot path: net-output -> net-input -> raw-image keypoint
+    frames (image_proc.py:135-147,215-260) for every preprocessing type, incl. the -999.999 sentinels."""
+    out = {}
+    for name, (kps, out_res, in_res, raw_res) in cases.keypoint_conversion_cases().items():
+        netin = dream.image_proc.convert_keypoints_to_netin_from_netout(kps.astype(float), out_res, in_res)
+        out[name + "/netin"] = np.asarray(netin, np.float64)
+        for prep in ("none", "resize", "shrink", "shrink-and-crop"):
+            raw = dream.image_proc.convert_keypoints_to_raw_from_netin(netin, in_res, raw_res, prep)
+            out[name + "/raw/" + prep] = np.asarray(raw, np.float64)
+    np.savez_compressed(os.path.join(HERE, "keypoint_conversion.npz"), **out)
+    print("keypoint_conversion:", sorted(out)[:4], "...")
+
+
 def main():
     dream = ref_import.import_reference()
     torch.manual_seed(0)
+    if "--only-conversions" in sys.argv:
+        return keypoint_conversions(dream)
     if "--only-variants" in sys.argv:
         return variants(dream)
     if "--only-api" in sys.argv:
@@ -214,6 +230,7 @@ def main():
         print("train", opt, "losses", losses)
     variants(dream)
     api_surface(dream)
+    keypoint_conversions(dream)
 
 
 if __name__ == "__main__":

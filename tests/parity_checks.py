@@ -608,3 +608,17 @@ def check_variant(dev, name, precision="fp32", train=True):
         close += int(np.isclose(s_, ref, rtol=1e-3, atol=3e-6).sum())
         total += ref.size
     assert close >= 0.97 * total, (close, total)
+
+
+def check_keypoint_conversions(dev):
+    """Host drop-ins and the batched device kernel against the reference's outputs (keypoint_conversion.npz), bit for bit."""
+    g = np.load(os.path.join(GOLD, "keypoint_conversion.npz"))
+    ip = dream_amd.image_proc
+    for name, (kps, out_res, in_res, raw_res) in cases.keypoint_conversion_cases().items():
+        netin = ip.convert_keypoints_to_netin_from_netout(kps.astype(float), out_res, in_res)
+        assert np.array_equal(netin, g[name + "/netin"]), name
+        for prep in ("none", "resize", "shrink", "shrink-and-crop"):
+            want = g[name + "/raw/" + prep]
+            assert np.array_equal(ip.convert_keypoints_to_raw_from_netin(netin, in_res, raw_res, prep), want), (name, prep)
+            d_in, d_raw = ip.convert_keypoints_batch(to(dev, torch.from_numpy(kps)), out_res, in_res, raw_res, prep)
+            assert np.array_equal(d_in.cpu().numpy(), g[name + "/netin"]) and np.array_equal(d_raw.cpu().numpy(), want), (name, prep)

@@ -151,3 +151,7 @@ def test_hourglass_variants(emu, name):
 @pytest.mark.skipif(not _FULL, reason="set DREAM_EMU_FULL=1 (several minutes under the emulator); covered on the GPU")
 def test_hourglass_variants_split_precision(emu):
     pc.check_variant("cpu", "vgg_f_ms2_skip", precision="fp16x3")
+
+
+def test_keypoint_frame_conversions(emu):
+    pc.check_keypoint_conversions("cpu")

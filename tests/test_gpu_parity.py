@@ -379,3 +379,7 @@ def test_ragged_resolutions_match_oracle(arch, shape):
     assert np.abs(maps16.cpu().numpy() - want).max() <= pc.tol(want)
     off = op.upsampling_offset(*net.trained_net_output_resolution())
     assert np.array_equal(kps.numpy(), op.keypoints_from_belief_maps(maps.cpu().numpy(), off))
+
+
+def test_keypoint_frame_conversions():
+    pc.check_keypoint_conversions(DEV)
