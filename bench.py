@@ -146,6 +146,10 @@ def main():
     backend = os.environ.get("DREAM_BENCH_BACKEND", "nccl")
     device_index = local_rank % torch.cuda.device_count()   # == local_rank unless the launcher exposes one device per rank
     torch.cuda.set_device(device_index)
+    if world == 1 and os.environ.get("DREAM_FORCE_REDUCER"):      # rehearsal: exercise the gradient exchange with one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("gloo", rank=0, world_size=1)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))

@@ -17,6 +17,8 @@ activations: first conv (NCHW image -> NHWC, VALU), MFMA 3x3 convs with fused bi
 skip-connection adds, and an NCHW store in the last head conv; ``backward`` walks the same list in reverse.  If the HIP library or a GPU is missing the
 call raises -- there is no CPU path in this package.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -431,16 +433,18 @@ class _OverlappedAllReduce:
     @staticmethod
     def create():
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("DREAM_FORCE_REDUCER")):
             return _OverlappedAllReduce(dist)
         return None
 
     def __init__(self, dist):
         self.dist, self.world = dist, dist.get_world_size()
-        self.current, self.current_bytes, self.inflight, self.views = [], 0, [], {}
+        self.current, self.current_bytes, self.inflight, self.views, self.producers = [], 0, [], {}, set()
 
     def add(self, g):
         self.current.append(g)
+        if g.is_cuda:
+            self.producers.add(torch.cuda.current_stream())
         self.current_bytes += g.numel() * g.element_size()
         if self.current_bytes >= self.BUCKET_BYTES:
             self._flush()
@@ -448,6 +452,12 @@ class _OverlappedAllReduce:
     def _flush(self):
         if not self.current:
             return
+        if self.producers:                                  # gradients may come from the weight-gradient side stream
+            here = torch.cuda.current_stream()
+            for st in self.producers:
+                if st != here:
+                    here.wait_stream(st)
+            self.producers = set()
         flat = torch.cat([g.reshape(-1) for g in self.current])
         work = self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, async_op=True)
         self.inflight.append((work, flat, self.current))
@@ -467,6 +477,42 @@ class _OverlappedAllReduce:
 
     def result(self, g):
         return self.views.get(id(g), g)
+
+
+class _SideStream:
+    """Runs weight-gradient kernels on a second HIP stream.  In backward the data-gradient chain (conv -> BN -> conv ..)
+    is the critical path and every weight gradient is a leaf hanging off it; at small per-GPU batches neither kind of
+    kernel fills 256 CUs (25x25 / 13x13 feature maps), so the leaves run concurrently with the chain instead of in it.
+    ``run(fn, *inputs)``: fn's launches wait for everything queued on the main stream so far; ``join()`` makes the main
+    stream wait for the leaves.  Inputs are record_stream()-ed so the caching allocator does not recycle them early."""
+    _streams = {}
+
+    @classmethod
+    def create(cls, like, enabled=True):
+        if not (enabled and like.is_cuda):
+            return None
+        dev = like.device.index
+        if dev not in cls._streams:
+            cls._streams[dev] = torch.cuda.Stream(device=like.device)
+        return cls(cls._streams[dev])
+
+    def __init__(self, stream):
+        self.side, self.main = stream, torch.cuda.current_stream()
+
+    def run(self, fn, *inputs):
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            out = fn()
+        for t in inputs:
+            t.record_stream(self.side)
+        return out
+
+    def join(self):
+        self.main.wait_stream(self.side)
+
+
+def _on_side(side, fn, *inputs):
+    return fn() if side is None else side.run(fn, *inputs)
 
 
 class _GradList(list):
@@ -652,6 +698,8 @@ class ResnetSimple(nn.Module):
         self.n_keypoints = n_keypoints
         self._cache = {}
         self.precision = "fp32"        # "fp16x3": evaluation-mode forward on the split-precision conv kernel
+        # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order)
+        self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
@@ -869,6 +917,11 @@ class ResnetSimple(nn.Module):
         """-> {parameter: gradient}.  Walks the tape backwards; gradients that meet at a Bottleneck input are summed
         by the residual input of the data-gradient conv (no separate add kernel)."""
         grads = _GradDict(reducer)
+        # Measured (resnet_h, 400x400, one MI355X): +6.5 / +5.7 / +5.3 % at 16 / 32 / 64 frames, -2.7 % at 128, where
+        # every kernel already fills the chip and the two streams only disturb each other's L2.
+        stem_x = tape[0]["x"]                                  # im2col of the input: [B, H/2, W/2, 160]
+        input_px = 4 * int(stem_x.shape[0]) * int(stem_x.shape[1]) * int(stem_x.shape[2])
+        side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= 96 * 400 * 400)
         g = None                 # gradient w.r.t. the output of the unit being processed
         block = None             # state of the Bottleneck being unwound
         for rec in reversed(tape):
@@ -877,16 +930,19 @@ class ResnetSimple(nn.Module):
                 m = rec["conv"]
                 cout, cin = int(m.weight.shape[0]), int(m.weight.shape[1])
                 gy = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))
-                dw, db = ops.conv2d_wgrad(rec["x"], gy, cout, cin, 1, 1, 0, want_bias=True)
-                grads[m.weight], grads[m.bias] = dw, db
+                def leaf(m=m, x=rec["x"], gy=gy, cout=cout, cin=cin):
+                    grads[m.weight], grads[m.bias] = ops.conv2d_wgrad(x, gy, cout, cin, 1, 1, 0, want_bias=True)
+                _on_side(side, leaf, rec["x"], gy)
                 packed_t, rows, _ = self._packed_w(rec["name"], m, 1)
                 g = ops.conv2d(gy, packed_t, rows, 1, 1)
             elif kind == "convT":
                 m, bn = rec["conv"], rec["bn"]
                 dz, _, dgam, dbet = ops.bn_train_bwd(rec["z"], g, rec["y"], bn.weight, rec["mean"], rec["invstd"], True)
                 grads[bn.weight], grads[bn.bias] = dgam, dbet
-                grads[m.weight] = ops.convT4x4_wgrad(rec["x"], dz)
-                grads[m.bias] = ops.channel_sum(dz)
+                def leaf(m=m, x=rec["x"], dz=dz):
+                    grads[m.weight] = ops.convT4x4_wgrad(x, dz)
+                    grads[m.bias] = ops.channel_sum(dz)
+                _on_side(side, leaf, rec["x"], dz)
                 pk, rows = self._cached(("wTb", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_bwd_weight(m.weight.detach()))
                 g = ops.conv4x4s2(dz, pk, rows)
             elif kind == "block_end":
@@ -901,8 +957,9 @@ class ResnetSimple(nn.Module):
                 grads[bn.weight], grads[bn.bias] = dgam, dbet
                 if rec["has_res"]:
                     block["g_idt"] = gm          # masked block-output gradient == gradient of the identity branch
-                dw, _ = ops.conv2d_wgrad(rec["x"], dz, cout, cin, rec["k"], rec["stride"])
-                grads[conv.weight] = dw
+                def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"]):
+                    grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
+                _on_side(side, leaf, rec["x"], dz)
                 packed_t, rows, _ = self._packed_w(name, conv, 1)
                 in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
                 if is_ds:
@@ -926,6 +983,8 @@ class ResnetSimple(nn.Module):
                 dw, _ = ops.conv2d_wgrad(rec["x"], dz, 64, 160, 1, 1)
                 grads[rec["conv"].weight] = dw.reshape(64, 160)[:, :147].reshape(64, 3, 7, 7).contiguous()
                 g = None
+        if side is not None:
+            side.join()
         return grads
 
     def forward(self, x):
