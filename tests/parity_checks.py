@@ -471,6 +471,9 @@ def check_resnet_training_ops(dev):
         dx = ops.conv4x4s2(to(dev, _nhwc(dy)), pk, rows)
         assert float((dw.cpu() - wT.grad).abs().max()) <= tol(wT.grad.numpy())
         assert float((nchw(dx.cpu()) - x.grad).abs().max()) <= tol(x.grad.numpy())
+        other = torch.randn_like(x.detach())                 # a second gradient meeting at the same tensor
+        dx2 = ops.conv4x4s2(to(dev, _nhwc(dy)), pk, rows, residual=to(dev, _nhwc(other)))
+        assert float((nchw(dx2.cpu()) - (x.grad + other)).abs().max()) <= tol(x.grad.numpy())
     for xin in (torch.randn(2, 8, 9, 11), torch.round(torch.randn(1, 4, 7, 7) * 2)):     # second: ties
         xin.requires_grad_()
         y = F.max_pool2d(xin, 3, 2, 1)
