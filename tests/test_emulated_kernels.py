@@ -136,7 +136,8 @@ def test_on_device_dataprep(emu):
 
 def test_resnet_split_precision(emu):
     pc.check_conv_transpose4x4_f16x3("cpu", 1, 5, 6, 32, 48)
-    pc.check_model_inference("cpu", "resnet_h", (2, 64, 96), precision="fp16x3")
+    if os.environ.get("DREAM_EMU_FULL", "0") == "1":       # ~50 s under the emulator; the GPU suite runs it always
+        pc.check_model_inference("cpu", "resnet_h", (2, 64, 96), precision="fp16x3")
 
 
 _FULL = os.environ.get("DREAM_EMU_FULL", "0") == "1"    # the emulator is ~1e4x slower than the GPU: the default CPU suite
