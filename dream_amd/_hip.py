@@ -62,11 +62,13 @@ _SIGNATURES = {
     "dream_conv2d_f16x3_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_pack_convT4x4_weight_f16x3": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_conv_transpose4x4s2_f16x3_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv_transpose3x3s2_f16x3_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv_f16x3_set_variant": (_I, [_I]),
     "dream_bn_fold_f32": (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "dream_im2col_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_maxpool3s2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_conv3x3_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv_transpose3x3s2_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_set_variant": (_I, [_I]),
     "dream_conv3x3_num_variants": (_I, []),
     "dream_conv3x3_variant_name": (_c.c_char_p, [_I]),

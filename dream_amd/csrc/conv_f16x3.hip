@@ -33,6 +33,7 @@ struct Conv16Params {
     int Cin, Cout, CoutPad;
     int TH, TW, PH, PW, tiles_x, tiles_y, rcpTW;
     int in_scale, in_step, lane_stride, pad_y, pad_x;
+    unsigned long long tap_w;   // 16 x 4-bit: weight slice of each tap of this launch
     int ntaps;
     unsigned long long tap_dy, tap_dx;
     int out_scale, out_oy, out_ox;
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
         }
     };
     auto load_b = [&](int tap, int c0) {
-        const size_t base = (size_t)tap * w_tap_stride + c0;
+        const size_t base = (size_t)((p.tap_w >> (4 * tap)) & 15) * w_tap_stride + c0;
 #pragma unroll
         for (int it = 0; it < NB_IT; ++it)
             if (b_soff[it] >= 0) {
@@ -411,6 +412,7 @@ struct Geom16 {
     int pad, kext, ntaps;
     int tap_dy[16], tap_dx[16];
     int out_scale, out_oy, out_ox;
+    int tap_w[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
 };
 
 int launch16(const float *x, const unsigned *amax_in, const void *w_hi, const void *w_lo, const int *w_exp,
@@ -444,10 +446,11 @@ int launch16(const float *x, const unsigned *amax_in, const void *w_hi, const vo
     if (pool) { p.Ho = g.H / 2; p.Wo = g.W / 2; }
     p.in_scale = 1; p.in_step = 1; p.lane_stride = 1; p.pad_y = g.pad; p.pad_x = g.pad;
     p.ntaps = g.ntaps;
-    p.tap_dy = 0; p.tap_dx = 0;
+    p.tap_dy = 0; p.tap_dx = 0; p.tap_w = 0;
     for (int t = 0; t < g.ntaps; ++t) {
         p.tap_dy |= (unsigned long long)g.tap_dy[t] << (4 * t);
         p.tap_dx |= (unsigned long long)g.tap_dx[t] << (4 * t);
+        p.tap_w |= (unsigned long long)g.tap_w[t] << (4 * t);
     }
     p.out_scale = g.out_scale; p.out_oy = g.out_oy; p.out_ox = g.out_ox;
     p.flags = flags;
@@ -524,6 +527,31 @@ extern "C" int dream_conv_transpose4x4s2_f16x3_nhwc_f32(const float *x, const un
         const size_t off = (size_t)ph * 4 * CoutPad * Cin;
         if (int rc = launch16(x, amax_in, (const _Float16 *)w_hi + off, (const _Float16 *)w_lo + off, w_exp, scale, shift, nullptr,
                               y, amax_out, B, Cin, Cout, CoutPad, g, flags, stream))
+            return rc;
+    }
+    return 0;
+}
+
+// ConvTranspose2d(k=3,s=2,p=1,output_padding 1) on the split-precision path: the sub-pixel decomposition of
+// dream_conv_transpose3x3s2_nhwc_f32 (1/2/2/4-tap launches picking their slices of the mode-1 packed planes).
+extern "C" int dream_conv_transpose3x3s2_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi,
+                                                        const void *w_lo, const int *w_exp, const float *bias, float *y,
+                                                        unsigned *amax_out, int B, int H, int W, int Cin, int Cout,
+                                                        int CoutPad, int flags, void *stream) {
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "convT3x3_f16x3: only the ReLU flag is supported");
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        Geom16 g;
+        g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W; g.Ho = 2 * H; g.Wo = 2 * W;
+        g.pad = 0; g.kext = 2; g.ntaps = 0;
+        for (int iy = 0; iy <= a; ++iy)
+            for (int ix = 0; ix <= b; ++ix) {
+                const int ky = a ? 2 - 2 * iy : 1, kx = b ? 2 - 2 * ix : 1, t = g.ntaps++;
+                g.tap_dy[t] = iy; g.tap_dx[t] = ix;
+                g.tap_w[t] = 8 - (3 * ky + kx);
+            }
+        g.out_scale = 2; g.out_oy = a; g.out_ox = b;
+        if (int rc = launch16(x, amax_in, w_hi, w_lo, w_exp, nullptr, bias, nullptr, y, amax_out, B, Cin, Cout, CoutPad, g, flags, stream))
             return rc;
     }
     return 0;

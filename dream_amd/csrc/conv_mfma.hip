@@ -50,6 +50,7 @@ struct ConvParams {
     int lane_stride;         // patch pixels between consecutive output positions (2 for a strided 3x3)
     int pad_y, pad_x;
     int ntaps;
+    unsigned long long tap_w;            // 16 x 4-bit: which [CoutPad][Cin] weight slice each tap of this launch uses
     unsigned long long tap_dy, tap_dx;   // 16 x 4-bit patch offsets of the taps (decoded with scalar ALU ops:
                                          // no kernarg load on the per-stage critical path)
     int out_scale, out_oy, out_ox;   // output pixel = position * out_scale + (out_oy, out_ox)
@@ -165,7 +166,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             if (a_soff[it] >= 0) *(f32x4 *)(sA + a_soff[it]) = a_reg[it];
     };
     auto load_b = [&](int tap, int c0) {
-        const float *wt = p.w + (size_t)tap * w_tap_stride + c0;
+        const float *wt = p.w + (size_t)((p.tap_w >> (4 * tap)) & 15) * w_tap_stride + c0;
 #pragma unroll
         for (int it = 0; it < C::NB_IT; ++it)
             if (C::NB_FULL || b_soff[it] >= 0) b_reg[it] = *(const f32x4 *)(wt + b_goff[it]);
@@ -392,6 +393,7 @@ struct ConvGeom {
     int in_scale, in_step, lane_stride, pad;
     int ntaps;
     int tap_dy[16], tap_dx[16];
+    int tap_w[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};   // weight slice of each tap
     int kext;                 // patch rows needed beyond (TH-1)*lane_stride
     int out_scale, out_oy, out_ox;
 };
@@ -426,10 +428,11 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
     p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride; p.pad_y = g.pad; p.pad_x = g.pad;
     p.ntaps = g.ntaps;
     const int S = var.KC + 4;
-    p.tap_dy = 0; p.tap_dx = 0;
+    p.tap_dy = 0; p.tap_dx = 0; p.tap_w = 0;
     for (int t = 0; t < g.ntaps; ++t) {
         p.tap_dy |= (unsigned long long)g.tap_dy[t] << (4 * t);
         p.tap_dx |= (unsigned long long)g.tap_dx[t] << (4 * t);
+        p.tap_w |= (unsigned long long)g.tap_w[t] << (4 * t);
     }
     p.out_scale = g.out_scale; p.out_oy = g.out_oy; p.out_ox = g.out_ox;
     p.flags = flags;
@@ -529,6 +532,33 @@ extern "C" int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w
         g.out_scale = 2; g.out_oy = a; g.out_ox = b;
         const float *wp = w_packed + (size_t)ph * 4 * CoutPad * Cin;
         if (int rc = launch_conv(x, wp, scale, shift, nullptr, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
+    }
+    return 0;
+}
+
+// ConvTranspose2d(k=3, s=2, p=1, output_padding=1) (dream/models.py:621-686) by sub-pixel decomposition: output row
+// 2m + a comes from ky = 1 (input row m) for a = 0 and from ky = 2 (row m) and ky = 0 (row m + 1) for a = 1, so the four
+// output phases are stride-1 convolutions with 1 / 2 / 2 / 4 taps over a (TH+1) x (TW+1) patch -- 9 MACs per four outputs
+// where the zero-stuffed form (DREAM_CONV_ZEROSTUFF2X) spends 36.  w_packed is the SAME mode-1 packing the zero-stuffed
+// form uses ([9][CoutPad][Cin], slice t = transposed weights of tap 8 - (3 ky + kx)): the launches pick their slices.
+extern "C" int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
+                                                  int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream) {
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "convT3x3: only the ReLU flag is supported");
+    for (int ph = 0; ph < 4; ++ph) {
+        const int a = ph >> 1, b = ph & 1;
+        ConvGeom g;
+        g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W; g.Ho = 2 * H; g.Wo = 2 * W;
+        g.in_scale = 1; g.in_step = 1; g.lane_stride = 1; g.pad = 0;
+        g.ntaps = 0;
+        for (int iy = 0; iy <= a; ++iy)                      // patch offset iy: ky = 1 (a = 0); ky = 2, 0 (a = 1)
+            for (int ix = 0; ix <= b; ++ix) {
+                const int ky = a ? 2 - 2 * iy : 1, kx = b ? 2 - 2 * ix : 1, t = g.ntaps++;
+                g.tap_dy[t] = iy; g.tap_dx[t] = ix;
+                g.tap_w[t] = 8 - (3 * ky + kx);
+            }
+        g.kext = 2;
+        g.out_scale = 2; g.out_oy = a; g.out_ox = b;
+        if (int rc = launch_conv(x, w_packed, nullptr, bias, nullptr, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
     }
     return 0;
 }

@@ -248,8 +248,11 @@ class DreamHourglass(nn.Module):
                     if self._fuse_pool(layers, li, act):
                         flags, pool_done = flags | CONV_POOL2, True
                     p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
-                    act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
-                                                 want_amax=not (flags & CONV_OUT_NCHW))
+                    if kind == "deconv":
+                        act, amax = ops.conv_transpose3x3s2_f16x3(act, amax, p16, p16[3], bias, relu=bool(flags & CONV_RELU))
+                    else:
+                        act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
+                                                     want_amax=not (flags & CONV_OUT_NCHW))
             if li in self._skip_sources:
                 keep[li] = act
         return act
@@ -290,7 +293,10 @@ class DreamHourglass(nn.Module):
                         inp = ops.nchw_to_nhwc(inp, cpad=self.input_channel_pad())
                     mode = 1 if kind == "deconv" else 0      # ConvTranspose weight is [Cin,Cout,3,3]
                     packed, rows, _, _ = self._packed.get(mod.weight, mode)
-                    act = ops.conv3x3(inp, packed, bias, rows, flags)
+                    if kind == "deconv":                     # sub-pixel phases: a quarter of the zero-stuffed form's MACs
+                        act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
+                    else:
+                        act = ops.conv3x3(inp, packed, bias, rows, flags)
             if save:
                 saved.append((inp, act))
             if li in self._skip_sources:

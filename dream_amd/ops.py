@@ -62,6 +62,19 @@ def conv3x3_first(x_nchw, w_oihw, bias, relu=True):
     return y
 
 
+def conv_transpose3x3s2(x_nhwc, packed_mode1, bias, cout, relu=True):
+    """ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) by sub-pixel phases: [B,H,W,Cin] -> [B,2H,2W,cout].
+    packed_mode1 = pack_weight(convT.weight, 1)[0] (the packing the zero-stuffed form uses)."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    if cin != packed_mode1.shape[2]:
+        raise RuntimeError("conv_transpose3x3s2: input has %d channels, packed weights expect %d" % (cin, packed_mode1.shape[2]))
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv_transpose3x3s2_nhwc_f32", ptr(x), ptr(packed_mode1), ptr(bias), ptr(y), b, h, w, cin, cout,
+         int(packed_mode1.shape[1]), CONV_RELU if relu else 0, stream())
+    return y
+
+
 def maxpool2(x_nhwc):
     x = _f32(x_nhwc)
     b, h, w, c = (int(v) for v in x.shape)
@@ -505,6 +518,20 @@ def conv2d_f16x3(x_nhwc, amax_in, packed16, cout, ksize, scale=None, shift=None,
     amax_out = new_amax(x.device) if want_amax else None
     call("dream_conv2d_f16x3_nhwc_f32", ptr(x), ptr(amax_in), ptr(hi), ptr(lo), ptr(exp), ptr(scale), ptr(shift),
          ptr(residual), ptr(y), ptr(amax_out), b, h, w, cin, cout, int(hi.shape[-2]), ksize, 1, flags, stream())
+    return y, amax_out
+
+
+def conv_transpose3x3s2_f16x3(x_nhwc, amax_in, packed16_mode1, cout, bias=None, relu=True):
+    """Split-precision ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) by sub-pixel phases -> (y, amax_out)."""
+    hi, lo, exp, _ = packed16_mode1
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    if cin != hi.shape[-1]:
+        raise RuntimeError("conv_transpose3x3s2_f16x3: input has %d channels, packed weights expect %d" % (cin, hi.shape[-1]))
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    amax_out = new_amax(x.device)
+    call("dream_conv_transpose3x3s2_f16x3_nhwc_f32", ptr(x), ptr(amax_in), ptr(hi), ptr(lo), ptr(exp), ptr(bias), ptr(y),
+         ptr(amax_out), b, h, w, cin, cout, int(hi.shape[-2]), CONV_RELU if relu else 0, stream())
     return y, amax_out
 
 

@@ -82,6 +82,12 @@ size_t dream_conv3x3_cout_pad(int Cout);  /* padded row count the MFMA kernel wa
 int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y,
                            int B, int H, int W, int Cin, int Cout, int CoutPad, int flags,
                            void *stream);
+/* nn.ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) of the deconv decoder (dream/models.py:621-686) by sub-pixel
+ * decomposition: four stride-1 launches with 1/2/2/4 taps, no multiplications by zero (the DREAM_CONV_ZEROSTUFF2X form
+ * of dream_conv3x3_nhwc_f32 computes the same result with 4x the MACs).  x [B,H,W,Cin] -> y [B,2H,2W,Cout];
+ * w_packed: dream_pack_conv3x3_weight(mode 1) of the [Cin,Cout,3,3] ConvTranspose weight; flags: DREAM_CONV_RELU. */
+int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
+                                       int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream);
 /* general form used by the ResNet path (torchvision Bottleneck convs, dream/models.py:22-32,138-148): k x k
  * (k = 1 or 3), stride 1 or 2, pad k/2, NHWC.  H, W = INPUT extent.  Epilogue: y = conv * scale[c] + shift[c]
  * (+ residual) (ReLU): scale/shift carry an eval-mode BatchNorm (dream_bn_fold_f32) or a bias; residual is the
@@ -132,6 +138,11 @@ int dream_conv_transpose4x4s2_f16x3_nhwc_f32(const float *x, const unsigned *ama
                                              const void *w_lo, const int *w_exp, const float *scale,
                                              const float *shift, float *y, unsigned *amax_out, int B, int H, int W,
                                              int Cin, int Cout, int CoutPad, int flags, void *stream);
+/* ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) on the split-precision path (see dream_conv_transpose3x3s2_nhwc_f32);
+ * planes from dream_pack_conv_weight_f16x3(mode 1). */
+int dream_conv_transpose3x3s2_f16x3_nhwc_f32(const float *x, const unsigned *amax_in, const void *w_hi, const void *w_lo,
+                                             const int *w_exp, const float *bias, float *y, unsigned *amax_out, int B,
+                                             int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream);
 int dream_conv_f16x3_set_variant(int variant);
 /* variant selection for benchmarking: -1 = heuristic; otherwise index into the variant table */
 int dream_conv3x3_set_variant(int variant);

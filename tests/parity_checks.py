@@ -625,3 +625,21 @@ def check_keypoint_conversions(dev):
             assert np.array_equal(ip.convert_keypoints_to_raw_from_netin(netin, in_res, raw_res, prep), want), (name, prep)
             d_in, d_raw = ip.convert_keypoints_batch(to(dev, torch.from_numpy(kps)), out_res, in_res, raw_res, prep)
             assert np.array_equal(d_in.cpu().numpy(), g[name + "/netin"]) and np.array_equal(d_raw.cpu().numpy(), want), (name, prep)
+
+
+def check_conv_transpose3x3(dev, B, H, W, Cin, Cout, relu=True, seed=0):
+    """Sub-pixel ConvTranspose2d(3,2,1,output_padding 1) against torch, and against the zero-stuffed form bit for bit
+    in exact arithmetic terms (same products, summed per output in tap order within a chunk)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wT = torch.randn(Cin, Cout, 3, 3, generator=g) * (2.0 / (2.25 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose2d(x, wT, bias, stride=2, padding=1, output_padding=1)
+    if relu:
+        ref = ref.relu()
+    packed, rows, _, _ = ops.pack_weight(to(dev, wT), 1)
+    y = ops.conv_transpose3x3s2(to(dev, _nhwc(x)), packed, to(dev, bias), rows, relu=relu)
+    assert tuple(y.shape) == (B, 2 * H, 2 * W, Cout)
+    assert float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= tol(ref.numpy())
+    z = ops.conv3x3(to(dev, _nhwc(x)), packed, to(dev, bias), rows, (ops.CONV_RELU if relu else 0) | ops.CONV_ZEROSTUFF2X)
+    assert float((y - z).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))

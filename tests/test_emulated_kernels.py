@@ -156,3 +156,8 @@ def test_hourglass_variants_split_precision(emu):
 
 def test_keypoint_frame_conversions(emu):
     pc.check_keypoint_conversions("cpu")
+
+
+def test_conv_transpose3x3_subpixel(emu):
+    pc.check_conv_transpose3x3("cpu", 2, 5, 7, 32, 48)
+    pc.check_conv_transpose3x3("cpu", 1, 9, 4, 64, 16, relu=False, seed=3)

@@ -383,3 +383,9 @@ def test_ragged_resolutions_match_oracle(arch, shape):
 
 def test_keypoint_frame_conversions():
     pc.check_keypoint_conversions(DEV)
+
+
+def test_conv_transpose3x3_subpixel():
+    pc.check_conv_transpose3x3(DEV, 2, 25, 25, 512, 256)
+    pc.check_conv_transpose3x3(DEV, 1, 50, 37, 256, 128, relu=False, seed=1)
+    pc.check_conv_transpose3x3(DEV, 1, 200, 200, 64, 64, seed=2)
