@@ -249,8 +249,8 @@ __global__ void __launch_bounds__(64 * WM * WN, 2) conv_f16x3_kernel(const Conv1
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
-                const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
                 const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
+                const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W) && oy < p.Ho && ox < p.Wo;
 #pragma unroll
                 for (int ns = 0; ns < NR; ++ns) {
                     if (ok && ncol[ns] < p.Cout) {

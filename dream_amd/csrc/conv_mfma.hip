@@ -249,8 +249,9 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = (wm * MR + ms) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int ty = (m * p.rcpTW) >> 16, tx = m - ty * TW;
-                const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W);
                 const int oy = (y0 + ty) * p.out_scale + p.out_oy, ox = (x0 + tx) * p.out_scale + p.out_ox;
+                // oy < Ho / ox < Wo only bites for the sub-pixel phases of an odd-sized transposed conv output
+                const bool ok = (m < npix) && (y0 + ty < p.H) && (x0 + tx < p.W) && oy < p.Ho && ox < p.Wo;
 #pragma unroll
                 for (int ns = 0; ns < NR; ++ns) {
                     if (ok && ncol[ns] < p.Cout) {
@@ -541,13 +542,15 @@ extern "C" int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w
 // output phases are stride-1 convolutions with 1 / 2 / 2 / 4 taps over a (TH+1) x (TW+1) patch -- 9 MACs per four outputs
 // where the zero-stuffed form (DREAM_CONV_ZEROSTUFF2X) spends 36.  w_packed is the SAME mode-1 packing the zero-stuffed
 // form uses ([9][CoutPad][Cin], slice t = transposed weights of tap 8 - (3 ky + kx)): the launches pick their slices.
-extern "C" int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
-                                                  int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream) {
+namespace {
+int conv_transpose3x3s2_impl(const float *x, const float *w_packed, const float *bias, float *y, int B, int H, int W,
+                             int Ho, int Wo, int Cin, int Cout, int CoutPad, int flags, void *stream) {
     DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "convT3x3: only the ReLU flag is supported");
+    DREAM_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1), "convT3x3: output %dx%d for input %dx%d", Ho, Wo, H, W);
     for (int ph = 0; ph < 4; ++ph) {
         const int a = ph >> 1, b = ph & 1;
         ConvGeom g;
-        g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W; g.Ho = 2 * H; g.Wo = 2 * W;
+        g.H = H; g.W = W; g.Hin = H; g.Win = W; g.Hs = H; g.Ws = W; g.Ho = Ho; g.Wo = Wo;
         g.in_scale = 1; g.in_step = 1; g.lane_stride = 1; g.pad = 0;
         g.ntaps = 0;
         for (int iy = 0; iy <= a; ++iy)                      // patch offset iy: ky = 1 (a = 0); ky = 2, 0 (a = 1)
@@ -561,6 +564,32 @@ extern "C" int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w
         if (int rc = launch_conv(x, w_packed, nullptr, bias, nullptr, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
     }
     return 0;
+}
+}  // namespace
+
+extern "C" int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
+                                                  int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream) {
+    return conv_transpose3x3s2_impl(x, w_packed, bias, y, B, H, W, 2 * H, 2 * W, Cin, Cout, CoutPad, flags, stream);
+}
+
+// Data gradient of a k x k (1 | 3) STRIDE-2 pad-k/2 convolution (the three strided 3x3 convs and three strided 1x1
+// downsample convs of ResNet-101, torchvision Bottleneck "v1.5" behind dream/models.py:22-32): the transposed conv of dy
+// [B,Hy,Wy,C] with the mode-1 packed forward weights, output dx [B,Hx,Wx,Cx] with Hx in {2Hy-1, 2Hy}.  k = 3: the
+// sub-pixel phases above (no products with stuffed zeros); k = 1: dx is zero except at even positions, which are one
+// 1x1 convolution of dy written with an output stride of 2.
+extern "C" int dream_conv2d_s2_bwd_data_nhwc_f32(const float *dy, const float *w_packed_mode1, float *dx, int B, int Hy, int Wy,
+                                                 int C, int Hx, int Wx, int Cx, int RowsPad, int ksize, void *stream) {
+    DREAM_REQUIRE(dy && w_packed_mode1 && dx && (ksize == 1 || ksize == 3), "conv2d_s2_bwd_data: bad arguments");
+    if (ksize == 3) return conv_transpose3x3s2_impl(dy, w_packed_mode1, nullptr, dx, B, Hy, Wy, Hx, Wx, C, Cx, RowsPad, 0, stream);
+    DREAM_REQUIRE((Hx == 2 * Hy || Hx == 2 * Hy - 1) && (Wx == 2 * Wy || Wx == 2 * Wy - 1), "conv2d_s2_bwd_data: output %dx%d for input %dx%d", Hx, Wx, Hy, Wy);
+    DREAM_HIP_OK(hipMemsetAsync(dx, 0, (size_t)B * Hx * Wx * Cx * sizeof(float), (hipStream_t)stream));
+    ConvGeom g;
+    g.H = Hy; g.W = Wy; g.Hin = Hy; g.Win = Wy; g.Hs = Hy; g.Ws = Wy; g.Ho = Hx; g.Wo = Wx;
+    g.in_scale = 1; g.in_step = 1; g.lane_stride = 1; g.pad = 0;
+    g.ntaps = 1; g.tap_dy[0] = 0; g.tap_dx[0] = 0;
+    g.kext = 1;
+    g.out_scale = 2; g.out_oy = 0; g.out_ox = 0;
+    return launch_conv(dy, w_packed_mode1, nullptr, nullptr, nullptr, dx, B, C, Cx, RowsPad, g, 0, stream);
 }
 
 // Data gradient of ConvTranspose2d(k4,s2,p1): dx[m] = sum_k dy[2m - 1 + k] * wT[.][.][k] -- a 4x4 stride-2 pad-1

@@ -419,14 +419,18 @@ def pack_convT4x4_bwd_weight(wT):
 
 
 def conv2d_bwd_data(dy_nhwc, packed_t, cin, ksize, stride, in_hw, residual=None):
-    """Data gradient of a k x k / stride conv: stride 1 -> same-size conv with mode-1 weights; stride 2 -> the same on
-    the zero-stuffed gradient (extent in_hw, which may be odd)."""
+    """Data gradient of a k x k / stride conv: stride 1 -> same-size conv with mode-1 weights; stride 2 -> the transposed
+    conv of the gradient (extent in_hw, which may be odd); with a residual to add, its zero-stuffed form."""
     dy = _f32(dy_nhwc)
     if stride == 1:
         return conv2d(dy, packed_t, cin, ksize, 1, None, None, residual, 0)
     b, ho, wo, c = (int(v) for v in dy.shape)
     h, w = in_hw
     y = torch.empty((b, h, w, cin), dtype=torch.float32, device=dy.device)
+    if residual is None:          # transposed conv without the stuffed zeros (3x3: sub-pixel phases, 1x1: even positions)
+        call("dream_conv2d_s2_bwd_data_nhwc_f32", ptr(dy), ptr(packed_t), ptr(y), b, ho, wo, c, h, w, cin,
+             int(packed_t.shape[-2]), ksize, stream())
+        return y
     call("dream_conv2d_nhwc_f32", ptr(dy), ptr(packed_t), None, None, ptr(residual), ptr(y), b, h, w, c, cin,
          int(packed_t.shape[-2]), ksize, 1, CONV_ZEROSTUFF2X, stream())
     return y

@@ -88,6 +88,12 @@ int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *b
  * w_packed: dream_pack_conv3x3_weight(mode 1) of the [Cin,Cout,3,3] ConvTranspose weight; flags: DREAM_CONV_RELU. */
 int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
                                        int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream);
+/* Data gradient of a k x k (1 | 3) stride-2 pad-k/2 convolution -- the strided 3x3 and 1x1 (downsample) convs of the
+ * torchvision ResNet-101 trunk behind dream/models.py:22-32, reached from loss.backward() (dream/network.py:335):
+ * dy [B,Hy,Wy,C] -> dx [B,Hx,Wx,Cx], Hx in {2Hy-1, 2Hy}; w_packed_mode1 = dream_pack_conv_weight(mode 1) of the forward
+ * weight.  No products with stuffed zeros (k = 3: sub-pixel phases; k = 1: a 1x1 conv written at the even positions). */
+int dream_conv2d_s2_bwd_data_nhwc_f32(const float *dy, const float *w_packed_mode1, float *dx, int B, int Hy, int Wy,
+                                      int C, int Hx, int Wx, int Cx, int RowsPad, int ksize, void *stream);
 /* general form used by the ResNet path (torchvision Bottleneck convs, dream/models.py:22-32,138-148): k x k
  * (k = 1 or 3), stride 1 or 2, pad k/2, NHWC.  H, W = INPUT extent.  Epilogue: y = conv * scale[c] + shift[c]
  * (+ residual) (ReLU): scale/shift carry an eval-mode BatchNorm (dream_bn_fold_f32) or a bias; residual is the
