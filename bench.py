@@ -202,9 +202,9 @@ def main():
     ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
                        2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
     ops.conv_transpose3x3s2 = timed(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9)
-    ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * 16)
+    ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16))
     ops.conv_transpose3x3s2_f16x3 = timed(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9)
-    ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 16)
+    ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16))
     ops.conv2d_amax = timed(ops.conv2d_amax, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
     ops.conv2d_f16x3 = timed(ops.conv2d_f16x3,
                              lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:

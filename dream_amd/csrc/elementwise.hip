@@ -178,6 +178,28 @@ __global__ void __launch_bounds__(256) unpack_w_kernel(const float *packed, floa
     }
 }
 
+// nn.Upsample(scale_factor=2) (nearest) followed by Conv2d(k3,s1,p1) (dream/models.py:691-710) IS a
+// ConvTranspose2d(k4,s2,p1): every output pixel (2m+a, 2n+b) sees only the 2x2 input pixels around (m, n), each through
+// the SUM of the 3x3 taps that land on it.  w3 OIHW [Cout,Cin,3,3] -> wT4 [Cin,Cout,4,4] (ConvTranspose layout) with
+//   wT4[i][o][ky][kx] = sum_{r in R(ky)} sum_{c in R(kx)} w3[o][i][r][c],   R(0)={2}, R(1)={1,2}, R(2)={0,1}, R(3)={0}
+// so the decoder's two upsample convs run 4 MACs per output instead of 9 (zero padding of the upsampled grid and of the
+// input coincide at the borders).
+__global__ void __launch_bounds__(256) upsample_conv_weight_kernel(const float *w3, float *wT4, int Cout, int Cin) {
+    const size_t total = (size_t)Cin * Cout * 16;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int kx = (int)(idx & 3), ky = (int)((idx >> 2) & 3);
+        const size_t io = idx >> 4;
+        const int o = (int)(io % Cout), i = (int)(io / Cout);
+        const int r0 = ky == 0 ? 2 : (ky == 1 ? 1 : 0), r1 = ky == 0 ? 2 : (ky == 1 ? 2 : (ky == 2 ? 1 : 0));
+        const int c0 = kx == 0 ? 2 : (kx == 1 ? 1 : 0), c1 = kx == 0 ? 2 : (kx == 1 ? 2 : (kx == 2 ? 1 : 0));
+        const float *src = w3 + ((size_t)o * Cin + i) * 9;
+        float acc = 0.0f;
+        for (int r = r0; r <= r1; ++r)
+            for (int c = c0; c <= c1; ++c) acc += src[r * 3 + c];
+        wT4[idx] = acc;
+    }
+}
+
 // ---- MSE loss (mean) forward + gradient -------------------------------------------------------------
 __global__ void __launch_bounds__(256) mse_kernel(const float *o, const float *t, float *g, double *block_sums,
                                                   size_t n, float scale) {
@@ -539,6 +561,13 @@ extern "C" int dream_pack_convT4x4_weight(const float *wT, float *packed, int Ci
     DREAM_REQUIRE(wT && packed && Cin > 0 && Cout > 0 && RowsPad >= Cout && ColsPad >= Cin, "pack_convT4x4_weight: bad arguments");
     hipLaunchKernelGGL(pack_wT4_kernel, dim3(grid_for((size_t)16 * RowsPad * ColsPad)), dim3(256), 0, (hipStream_t)stream,
                        wT, packed, Cin, Cout, RowsPad, ColsPad);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_upsample_conv3x3_weight_as_convT4x4(const float *w_oihw, float *wT4, int Cout, int Cin, void *stream) {
+    DREAM_REQUIRE(w_oihw && wT4 && Cout > 0 && Cin > 0, "upsample_conv3x3_weight: bad arguments");
+    hipLaunchKernelGGL(upsample_conv_weight_kernel, dim3(grid_for((size_t)16 * Cout * Cin)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, wT4, Cout, Cin);
     DREAM_LAUNCH_OK();
     return 0;
 }

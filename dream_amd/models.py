@@ -52,12 +52,18 @@ class _PackedCache:
         self._store = {}
 
     def get(self, weight, mode, f16x3=False):
+        """mode 0 / 1: forward / transposed tap-major packing; "ups": the conv that follows a nearest x2 upsample, as the
+        equivalent 4x4 transposed conv (ops.upsample_conv_weight) in the sub-pixel phase packing."""
         key = (id(weight), mode, f16x3)
         tag = (weight._version, weight.data_ptr(), weight.device)
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
-                packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
+                if mode == "ups":
+                    wt4 = ops.upsample_conv_weight(weight.detach())
+                    packed = ops.pack_convT4x4_weight_f16x3(wt4) if f16x3 else ops.pack_convT4x4_weight(wt4)
+                else:
+                    packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
                 hit = (tag, packed)
             self._store[key] = hit
         return hit[1]
@@ -247,10 +253,14 @@ class DreamHourglass(nn.Module):
                         act = ops.nchw_to_nhwc(act, cpad=self.input_channel_pad())
                     if self._fuse_pool(layers, li, act):
                         flags, pool_done = flags | CONV_POOL2, True
-                    p16 = self._packed.get(mod.weight, 1 if kind == "deconv" else 0, f16x3=True)
-                    if kind == "deconv":
+                    if flags & CONV_UPSAMPLE2X:              # upsample + conv == a 4x4 transposed conv (see run_forward)
+                        pk4 = self._packed.get(mod.weight, "ups", f16x3=True)
+                        act, amax = ops.conv_transpose4x4s2_f16x3(act, amax, pk4, pk4[3], None, bias, flags & CONV_RELU, direct_taps=36)
+                    elif kind == "deconv":
+                        p16 = self._packed.get(mod.weight, 1, f16x3=True)
                         act, amax = ops.conv_transpose3x3s2_f16x3(act, amax, p16, p16[3], bias, relu=bool(flags & CONV_RELU))
                     else:
+                        p16 = self._packed.get(mod.weight, 0, f16x3=True)
                         act, amax = ops.conv2d_f16x3(act, amax, p16, p16[3], 3, None, bias, None, flags,
                                                      want_amax=not (flags & CONV_OUT_NCHW))
             if li in self._skip_sources:
@@ -291,11 +301,14 @@ class DreamHourglass(nn.Module):
                 else:
                     if kind == "wide" and not x_is_nhwc:
                         inp = ops.nchw_to_nhwc(inp, cpad=self.input_channel_pad())
-                    mode = 1 if kind == "deconv" else 0      # ConvTranspose weight is [Cin,Cout,3,3]
-                    packed, rows, _, _ = self._packed.get(mod.weight, mode)
-                    if kind == "deconv":                     # sub-pixel phases: a quarter of the zero-stuffed form's MACs
+                    if flags & CONV_UPSAMPLE2X:              # upsample + conv == a 4x4 transposed conv: 4 MACs / output, not 9
+                        pk4, cout4 = self._packed.get(mod.weight, "ups")
+                        act = ops.conv_transpose4x4s2(inp, pk4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
+                    elif kind == "deconv":                   # ConvTranspose weight [Cin,Cout,3,3], mode-1 packing; sub-pixel
+                        packed, rows, _, _ = self._packed.get(mod.weight, 1)   # phases: a quarter of the zero-stuffed MACs
                         act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
                     else:
+                        packed, rows, _, _ = self._packed.get(mod.weight, 0)
                         act = ops.conv3x3(inp, packed, bias, rows, flags)
             if save:
                 saved.append((inp, act))

@@ -261,6 +261,16 @@ def pack_convT4x4_weight(wT):
     return packed, cout
 
 
+def upsample_conv_weight(w_oihw):
+    """Conv2d(k3,p1) weight [Cout,Cin,3,3] applied after a nearest x2 upsample -> the equivalent ConvTranspose2d(k4,s2,p1)
+    weight [Cin,Cout,4,4] (see dream_upsample_conv3x3_weight_as_convT4x4)."""
+    w = _f32(w_oihw)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    wt4 = torch.empty((cin, cout, 4, 4), dtype=torch.float32, device=w.device)
+    call("dream_upsample_conv3x3_weight_as_convT4x4", ptr(w), ptr(wt4), cout, cin, stream())
+    return wt4
+
+
 def conv2d(x_nhwc, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0):
     """k x k (1 or 3) conv, stride 1/2, pad k/2, fused y = conv*scale + shift (+residual) (ReLU)."""
     x = _f32(x_nhwc)
@@ -282,7 +292,9 @@ def conv2d(x_nhwc, packed, cout, ksize, stride=1, scale=None, shift=None, residu
     return y
 
 
-def conv_transpose4x4s2(x_nhwc, packed, cout, scale=None, shift=None, flags=0):
+def conv_transpose4x4s2(x_nhwc, packed, cout, scale=None, shift=None, flags=0, direct_taps=16):
+    """direct_taps: multiply-adds per (input pixel, cin, cout) of the direct algorithm this launch stands for -- 16 for a
+    4x4 transposed conv, 36 when it replaces upsample + conv3x3; only used by bench.py's FLOP accounting."""
     x = _f32(x_nhwc)
     b, h, w, cin = (int(v) for v in x.shape)
     y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
@@ -579,7 +591,7 @@ def pack_convT4x4_weight_f16x3(wT):
     return hi, lo, exp, cout
 
 
-def conv_transpose4x4s2_f16x3(x_nhwc, amax_in, packed16, cout, scale=None, shift=None, flags=0):
+def conv_transpose4x4s2_f16x3(x_nhwc, amax_in, packed16, cout, scale=None, shift=None, flags=0, direct_taps=16):
     hi, lo, exp, _ = packed16
     x = _f32(x_nhwc)
     b, h, w, cin = (int(v) for v in x.shape)

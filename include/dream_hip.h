@@ -71,6 +71,12 @@ int dream_pack_conv_weight(const float *w_oihw, float *packed, int Cout, int Cin
                            int ColsPad, int mode, void *stream);
 int dream_pack_convT4x4_weight(const float *wT, float *packed, int Cin, int Cout, int RowsPad, int ColsPad,
                                void *stream);
+/* nn.Upsample(scale_factor=2) + nn.Conv2d(k3,s1,p1) of the upsample decoder (dream/models.py:691-733) as ONE transposed
+ * conv: w_oihw [Cout,Cin,3,3] -> wT4 [Cin,Cout,4,4] = the ConvTranspose2d(k4,s2,p1) weight that gives the same result
+ * (each 4x4 tap is the sum of the 1, 2 or 4 taps of the 3x3 kernel that land on one input pixel), to be packed with
+ * dream_pack_convT4x4_weight[_f16x3] and run by dream_conv_transpose4x4s2[_f16x3]_nhwc_f32: 4 MACs per output instead
+ * of the 9 of the DREAM_CONV_UPSAMPLE2X form. */
+int dream_upsample_conv3x3_weight_as_convT4x4(const float *w_oihw, float *wT4, int Cout, int Cin, void *stream);
 size_t dream_conv3x3_cout_pad(int Cout);  /* padded row count the MFMA kernel wants (multiple of 128) */
 
 /* ---- forward operators -----------------------------------------------------------------------

@@ -643,3 +643,21 @@ def check_conv_transpose3x3(dev, B, H, W, Cin, Cout, relu=True, seed=0):
     assert float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= tol(ref.numpy())
     z = ops.conv3x3(to(dev, _nhwc(x)), packed, to(dev, bias), rows, (ops.CONV_RELU if relu else 0) | ops.CONV_ZEROSTUFF2X)
     assert float((y - z).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+
+
+def check_upsample_conv_as_convT(dev, B, H, W, Cin, Cout, relu=True, seed=0):
+    """nn.Upsample(2) + Conv2d(k3,p1) (+ReLU) through the equivalent 4x4 transposed conv, against torch and against the
+    DREAM_CONV_UPSAMPLE2X form of the same kernel."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2), w, bias, padding=1)
+    if relu:
+        ref = ref.relu()
+    pk4, cout = ops.pack_convT4x4_weight(ops.upsample_conv_weight(to(dev, w)))
+    y = ops.conv_transpose4x4s2(to(dev, _nhwc(x)), pk4, cout, None, to(dev, bias), ops.CONV_RELU if relu else 0)
+    assert float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= tol(ref.numpy())
+    packed, rows, _, _ = ops.pack_weight(to(dev, w), 0)
+    z = ops.conv3x3(to(dev, _nhwc(x)), packed, to(dev, bias), rows, (ops.CONV_RELU if relu else 0) | ops.CONV_UPSAMPLE2X)
+    assert float((y - z).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))       # two fp32 summation orders

@@ -161,3 +161,8 @@ def test_keypoint_frame_conversions(emu):
 def test_conv_transpose3x3_subpixel(emu):
     pc.check_conv_transpose3x3("cpu", 2, 5, 7, 32, 48)
     pc.check_conv_transpose3x3("cpu", 1, 9, 4, 64, 16, relu=False, seed=3)
+
+
+def test_upsample_conv_as_transposed_conv(emu):
+    pc.check_upsample_conv_as_convT("cpu", 2, 5, 7, 32, 48)
+    pc.check_upsample_conv_as_convT("cpu", 1, 3, 9, 64, 16, relu=False, seed=4)

@@ -389,3 +389,8 @@ def test_conv_transpose3x3_subpixel():
     pc.check_conv_transpose3x3(DEV, 2, 25, 25, 512, 256)
     pc.check_conv_transpose3x3(DEV, 1, 50, 37, 256, 128, relu=False, seed=1)
     pc.check_conv_transpose3x3(DEV, 1, 200, 200, 64, 64, seed=2)
+
+
+def test_upsample_conv_as_transposed_conv():
+    pc.check_upsample_conv_as_convT(DEV, 2, 25, 25, 512, 256)
+    pc.check_upsample_conv_as_convT(DEV, 1, 50, 37, 256, 128, relu=False, seed=1)
