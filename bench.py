@@ -181,7 +181,7 @@ def main():
     conv_events = []          # (start, end, flops)
     recording = [False]
 
-    def timed(orig, flops_of):
+    def timed(orig, flops_of, kernel_launches=1):
         def wrapper(*a, **k):
             if not recording[0] or k.get("relu_mask") is not None:     # conv3x3(relu_mask=..) forwards to conv2d: timed there
                 return orig(*a, **k)
@@ -190,7 +190,7 @@ def main():
             s_ev.record()
             y = orig(*a, **k)
             e_ev.record()
-            conv_events.append((s_ev, e_ev, flops_of(y, *a, **k)))
+            conv_events.append((s_ev, e_ev, flops_of(y, *a, **k), kernel_launches))
             return y
         return wrapper
 
@@ -201,10 +201,14 @@ def main():
     ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0, relu_mask=None: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
     ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
                        2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
-    ops.conv_transpose3x3s2 = timed(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9)
-    ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16))
-    ops.conv_transpose3x3s2_f16x3 = timed(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9)
-    ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16))
+    ops.conv_transpose3x3s2 = timed(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9,
+                                    kernel_launches=4)        # the sub-pixel ops are four kernel launches each
+    ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
+                                    kernel_launches=4)
+    ops.conv_transpose3x3s2_f16x3 = timed(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9,
+                                          kernel_launches=4)
+    ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
+                                          kernel_launches=4)
     ops.conv2d_amax = timed(ops.conv2d_amax, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
     ops.conv2d_f16x3 = timed(ops.conv2d_f16x3,
                              lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
@@ -240,9 +244,9 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        ms = sum(s_.elapsed_time(e_) for s_, e_, _ in conv_events)
-        fl = sum(f for _, _, f in conv_events)
-        return dt, ms, fl, len(conv_events), out
+        ms = sum(s_.elapsed_time(e_) for s_, e_, _, _ in conv_events)
+        fl = sum(f for _, _, f, _ in conv_events)
+        return dt, ms, fl, sum(n for _, _, _, n in conv_events), out
 
     dt, conv_ms, conv_flops, n_launch, out_main = timed_region()
     # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
