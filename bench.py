@@ -99,7 +99,6 @@ def synthetic_weights(state_dict):
 
 def cpu_baseline(arch, res, seconds):
     """CPU oracle on a bounded sample of the same workload: batches of 4 frames, forward + peaks."""
-    import numpy as np
     import torch
     import cases
     from oracle import models as omodels, peaks as opeaks
@@ -130,7 +129,6 @@ def cpu_baseline(arch, res, seconds):
 
 def main():
     args = parse()
-    import numpy as np
     import torch
     import torch.distributed as dist
     import cases

@@ -3,7 +3,6 @@ oracle and with the committed golden outputs of the real reference.  Nothing her
 import numpy as np
 import pytest
 import torch
-import torch.nn.functional as F
 
 import cases
 import parity_checks as pc
