@@ -1,12 +1,14 @@
-// conv 3x3 / stride 1 / pad 1 (+bias, +ReLU, optional fused nearest-x2 upsample of the input,
-// optional NCHW store) on NHWC fp32 tensors as an implicit GEMM on the CDNA4 fp32 matrix cores.
+// Convolutions on NHWC fp32 tensors as an implicit GEMM on the CDNA4 fp32 matrix cores: k x k taps given by a tap table
+// (1x1, 3x3 stride 1 / 2, 4x4 stride 2, the 2x2-tap sub-pixel phases of the transposed convs), with bias / folded
+// BatchNorm scale-shift, residual add or ReLU mask, ReLU, 2x2 max-pool, NCHW store and an output stride fused into the
+// epilogue, and a nearest-x2 upsample or zero-stuffing of the input fused into the patch loader.
 //
-// Replaces torch.nn.Conv2d(k=3,s=1,p=1) at /root/reference/dream/models.py:594-615 (VGG19 encoder),
-// :695-710 (upsample decoder, with the nn.Upsample at :691,:703 fused into the patch load) and
-// :736-747 (belief-map head).  The same kernel run on mode-1 packed weights is the data-gradient
-// (conv backward-input) operator, and with DREAM_CONV_ZEROSTUFF2X it is ConvTranspose2d(k=3,s=2,p=1,
-// output_padding=1) (dream/models.py:621-686): a transposed conv == a stride-1 conv of the
-// zero-stuffed input with the flipped kernel; the stuffing is done in the patch loader.
+// Replaces torch.nn.Conv2d(k=3,s=1,p=1) at /root/reference/dream/models.py:594-615 (VGG19 encoder), :695-710 (upsample
+// decoder) and :736-747 (belief-map head), nn.ConvTranspose2d at :621-686 and :37-136, and the torchvision ResNet-101
+// convs behind :22-32.  The same kernel run on mode-1 packed weights is the data-gradient (conv backward-input)
+// operator.  Transposed convs run as sub-pixel phases (no products with zeros); upsample + conv3x3 runs as the
+// equivalent 4x4 transposed conv; the DREAM_CONV_UPSAMPLE2X / DREAM_CONV_ZEROSTUFF2X patch-loader forms compute the same
+// results with 2.25x / 4x the MACs and are kept as the reference forms (and for a data gradient with a residual).
 //
 // GEMM view:  D[m][n] = sum_k A[m][k] * B[k][n]
 //   m = output pixel of a TH x TW patch of one image (BM = 32*MR*WM rows per workgroup)
