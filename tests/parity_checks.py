@@ -661,3 +661,16 @@ def check_upsample_conv_as_convT(dev, B, H, W, Cin, Cout, relu=True, seed=0):
     packed, rows, _, _ = ops.pack_weight(to(dev, w), 0)
     z = ops.conv3x3(to(dev, _nhwc(x)), packed, to(dev, bias), rows, (ops.CONV_RELU if relu else 0) | ops.CONV_UPSAMPLE2X)
     assert float((y - z).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))       # two fp32 summation orders
+
+
+def check_wgrad(dev, B, H, W, Cin, Cout, k=3, stride=1, seed=0):
+    """Weight + bias gradient of a k x k / stride conv against torch autograd."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).requires_grad_()
+    y = F.conv2d(x, w, None, stride=stride, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw, db = ops.conv2d_wgrad(to(dev, _nhwc(x)), to(dev, _nhwc(dy)), Cout, Cin, k, stride, want_bias=True)
+    assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy()), (B, H, W, Cin, Cout, k, stride)
+    assert float((db.cpu() - dy.sum((0, 2, 3))).abs().max()) <= tol(dy.sum((0, 2, 3)).numpy())

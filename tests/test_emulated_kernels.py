@@ -166,3 +166,25 @@ def test_conv_transpose3x3_subpixel(emu):
 def test_upsample_conv_as_transposed_conv(emu):
     pc.check_upsample_conv_as_convT("cpu", 2, 5, 7, 32, 48)
     pc.check_upsample_conv_as_convT("cpu", 1, 3, 9, 64, 16, relu=False, seed=4)
+
+
+def test_randomised_conv_geometries(emu):
+    """Seeded sweep over ragged extents (down to 1 pixel), channel counts that are not tile multiples and every fusion
+    flag, for the conv, the two transposed-conv forms and the weight gradient -- all against torch."""
+    import numpy as np
+    from dream_amd import ops
+    rs = np.random.RandomState(2026)
+    for case in range(14):
+        b = int(rs.randint(1, 3))
+        h, w = int(rs.randint(1, 19)), int(rs.randint(1, 23))
+        cin = int(rs.choice([16, 32, 48, 80]))
+        cout = int(rs.choice([7, 16, 33, 64, 130]))
+        flags = int(rs.choice([0, ops.CONV_RELU, ops.CONV_OUT_NCHW, ops.CONV_RELU | ops.CONV_OUT_NCHW]))
+        pc.check_conv("cpu", b, h, w, cin, cout, flags, seed=case)
+        he, we = 2 * int(rs.randint(1, 8)), 2 * int(rs.randint(1, 9))
+        pc.check_conv("cpu", b, he, we, cin, cout, ops.CONV_RELU | ops.CONV_POOL2, seed=case)
+        pc.check_conv("cpu", b, he, we, cin, cout, ops.CONV_UPSAMPLE2X | (flags & ops.CONV_RELU), seed=case)
+        pc.check_conv_transpose3x3("cpu", b, h, w, cin, cout, relu=bool(flags & ops.CONV_RELU), seed=case)
+        pc.check_upsample_conv_as_convT("cpu", b, h, w, cin, cout, relu=bool(flags & ops.CONV_RELU), seed=case)
+        co4 = int(rs.choice([8, 16, 64, 132]))               # weight gradients need channel counts that are multiples of 4
+        pc.check_wgrad("cpu", b, h, w, cin, co4, k=int(rs.choice([1, 3])), stride=int(rs.choice([1, 2])), seed=case)

@@ -393,3 +393,25 @@ def test_conv_transpose3x3_subpixel():
 def test_upsample_conv_as_transposed_conv():
     pc.check_upsample_conv_as_convT(DEV, 2, 25, 25, 512, 256)
     pc.check_upsample_conv_as_convT(DEV, 1, 50, 37, 256, 128, relu=False, seed=1)
+
+
+def test_randomised_conv_geometries():
+    """The emulator suite's seeded sweep (ragged extents down to 1 pixel, odd channel counts, every fusion flag, both
+    transposed-conv forms, weight gradients) on the device, with more cases."""
+    rs = np.random.RandomState(2026)
+    for case in range(40):
+        b = int(rs.randint(1, 4))
+        h, w = int(rs.randint(1, 40)), int(rs.randint(1, 45))
+        cin = int(rs.choice([16, 32, 48, 80, 256]))
+        cout = int(rs.choice([7, 16, 33, 64, 130, 256]))
+        flags = int(rs.choice([0, ops.CONV_RELU, ops.CONV_OUT_NCHW, ops.CONV_RELU | ops.CONV_OUT_NCHW]))
+        pc.check_conv(DEV, b, h, w, cin, cout, flags, seed=case)
+        he, we = 2 * int(rs.randint(1, 16)), 2 * int(rs.randint(1, 18))
+        pc.check_conv(DEV, b, he, we, cin, cout, ops.CONV_RELU | ops.CONV_POOL2, seed=case)
+        pc.check_conv(DEV, b, he, we, cin, cout, ops.CONV_UPSAMPLE2X | (flags & ops.CONV_RELU), seed=case)
+        pc.check_conv_transpose3x3(DEV, b, h, w, cin, cout, relu=bool(flags & ops.CONV_RELU), seed=case)
+        pc.check_upsample_conv_as_convT(DEV, b, h, w, cin, cout, relu=bool(flags & ops.CONV_RELU), seed=case)
+        co4 = int(rs.choice([8, 16, 64, 132, 256]))
+        pc.check_wgrad(DEV, b, h, w, cin, co4, k=int(rs.choice([1, 3])), stride=int(rs.choice([1, 2])), seed=case)
+        if cin % 32 == 0:
+            pc.check_conv_f16x3(DEV, b, max(h, 2), max(w, 2), cin, cout, 3, flags & ops.CONV_RELU, seed=case)
