@@ -27,7 +27,7 @@ __global__ void __launch_bounds__(256) normalize_u8_kernel(const unsigned char *
     }
 }
 
-__global__ void __launch_bounds__(256) belief_maps_kernel(const float *kps, const float *blob, float *out, int N, int H, int W,
+__global__ void __launch_bounds__(256) belief_maps_kernel(const double *kps, const float *blob, float *out, int N, int H, int W,
                                                           int w) {
     const int side = 2 * w + 1;
     const size_t total = (size_t)N * H * W;
@@ -36,7 +36,9 @@ __global__ void __launch_bounds__(256) belief_maps_kernel(const float *kps, cons
         const size_t r = i / W;
         const int y = (int)(r % H);
         const size_t n = r / H;
-        const int u = (int)kps[n * 2 + 0], v = (int)kps[n * 2 + 1];      // int(): truncation toward zero
+        // Python's int() on the reference's float64 coordinate: truncation toward zero, done on the float64 value
+        // (57.9999999 must stay pixel 57; an fp32 upload would round it to 58).  Clamped so the cast is defined.
+        const int u = (int)fmin(fmax(kps[n * 2 + 0], -1.0e9), 1.0e9), v = (int)fmin(fmax(kps[n * 2 + 1], -1.0e9), 1.0e9);
         float val = 0.0f;
         if (u - w >= 0 && u + w + 1 < W && v - w >= 0 && v + w + 1 < H) {
             const int dx = x - u, dy = y - v;
@@ -85,8 +87,8 @@ extern "C" int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float
     return 0;
 }
 
-// kps: [N,2] (x, y) fp32 device; blob: [(2w+1)^2] fp32 device (host-computed, see above); out: [N,H,W]
-extern "C" int dream_create_belief_maps_f32(const float *kps, const float *blob, float *out, int N, int H, int W, int w,
+// kps: [N,2] (x, y) FLOAT64 device (the reference truncates the float64 coordinate); blob: [(2w+1)^2] fp32 device (host-computed, see above); out: [N,H,W]
+extern "C" int dream_create_belief_maps_f32(const double *kps, const float *blob, float *out, int N, int H, int W, int w,
                                             void *stream) {
     DREAM_REQUIRE(kps && blob && out && N > 0 && H > 0 && W > 0 && w >= 0, "create_belief_maps: bad arguments");
     hipLaunchKernelGGL(belief_maps_kernel, dim3(sgrid((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, kps, blob, out, N, H,

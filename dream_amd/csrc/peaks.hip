@@ -118,7 +118,7 @@ DREAM_DEVICE Top2 top2_merge(Top2 a, Top2 b) {
 template <bool LIST>
 __global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const float *smooth, float *keypoints,
                                                     int32_t *counts, double *xy, float *score, int H, int W,
-                                                    int cap, double offset) {
+                                                    int cap, double offset, int use_scores, double next_best) {
     __shared__ int s_wave_cnt[4];
     __shared__ float s_s1[4], s_s2[4];
     __shared__ int s_i1[4];
@@ -187,9 +187,11 @@ __global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const flo
         for (int w = 1; w < 4; ++w) { const Top2 o = {s_s1[w], s_s2[w], s_i1[w]}; b = top2_merge(b, o); }
         if (counts) counts[n] = running;
         if (keypoints) {
-            // network.py:546-577 : one peak -> it; several -> best iff (best - second) >= 0.25 in fp32
+            // network.py:546-577 : one peak -> it; several -> (if use_belief_peak_scores) the best one iff
+            // best - second >= belief_peak_next_best_score: the fp32 difference of two fp32 scores against the Python
+            // float attribute (0.25 by default, network.py:189-191)
             float kx = -999.999f, ky = -999.999f;
-            const bool accept = (running == 1) || (running > 1 && (b.s1 - b.s2) >= 0.25f);
+            const bool accept = (running == 1) || (running > 1 && use_scores != 0 && (double)(b.s1 - b.s2) >= next_best);
             if (accept) {
                 const int y = b.i1 / W, x = b.i1 - y * W;
                 double cx, cy;
@@ -224,17 +226,26 @@ extern "C" int dream_gaussian_sigma3_f32(const float *maps, float *tmp, float *o
     return smooth_maps(maps, tmp, out, N, H, W, (hipStream_t)stream);
 }
 
-extern "C" int dream_keypoints_from_belief_maps_f32(const float *maps, float *scratch, float *keypoints,
-                                                    int32_t *peak_counts, int N, int H, int W,
-                                                    double offset_due_to_upsampling, void *stream) {
+extern "C" int dream_keypoints_from_belief_maps_rule_f32(const float *maps, float *scratch, float *keypoints,
+                                                         int32_t *peak_counts, int N, int H, int W,
+                                                         double offset_due_to_upsampling, int use_belief_peak_scores,
+                                                         double belief_peak_next_best_score, void *stream) {
     DREAM_REQUIRE(maps && scratch && keypoints && N > 0 && H > 0 && W > 0, "keypoints_from_belief_maps: bad arguments");
     const size_t total = (size_t)N * H * W;
     if (int rc = smooth_maps(maps, scratch, scratch + total, N, H, W, (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(peaks_kernel<false>, dim3(N), dim3(256), 0, (hipStream_t)stream, maps,
                        (const float *)(scratch + total), keypoints, peak_counts, (double *)nullptr, (float *)nullptr,
-                       H, W, 0, offset_due_to_upsampling);
+                       H, W, 0, offset_due_to_upsampling, use_belief_peak_scores, belief_peak_next_best_score);
     DREAM_LAUNCH_OK();
     return 0;
+}
+
+// the reference's defaults: use_belief_peak_scores = True, belief_peak_next_best_score = 0.25 (network.py:189-191)
+extern "C" int dream_keypoints_from_belief_maps_f32(const float *maps, float *scratch, float *keypoints,
+                                                    int32_t *peak_counts, int N, int H, int W,
+                                                    double offset_due_to_upsampling, void *stream) {
+    return dream_keypoints_from_belief_maps_rule_f32(maps, scratch, keypoints, peak_counts, N, H, W, offset_due_to_upsampling,
+                                                     1, 0.25, stream);
 }
 
 extern "C" int dream_peaks_from_belief_maps_f32(const float *maps, float *scratch, double *xy, float *score,
@@ -246,7 +257,7 @@ extern "C" int dream_peaks_from_belief_maps_f32(const float *maps, float *scratc
     if (int rc = smooth_maps(maps, scratch, scratch + total, N, H, W, (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(peaks_kernel<true>, dim3(N), dim3(256), 0, (hipStream_t)stream, maps,
                        (const float *)(scratch + total), (float *)nullptr, counts, xy, score, H, W, cap,
-                       offset_due_to_upsampling);
+                       offset_due_to_upsampling, 1, 0.25);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -154,7 +154,7 @@ def create_belief_map(image_resolution, pointsBelief, sigma=2):
     of the reference's float64 value, which is exactly what its only caller keeps (``torch.tensor(maps).float()``)."""
     assert len(image_resolution) == 2, \
         'Expected "image_resolution" to have length 2, but it has length {}.'.format(len(image_resolution))
-    pts = np.asarray([[float(p[0]), float(p[1])] for p in pointsBelief], dtype=np.float32).reshape(-1, 2)
+    pts = np.asarray([[float(p[0]), float(p[1])] for p in pointsBelief], dtype=np.float64).reshape(-1, 2)
     if pts.shape[0] == 0:
         return np.zeros((0, int(image_resolution[1]), int(image_resolution[0])))
     maps = create_belief_map_batch(image_resolution, torch.from_numpy(pts)[None], sigma)
@@ -167,7 +167,8 @@ def create_belief_map_batch(image_resolution, keypoints_bk2, sigma=2):
     assert len(image_resolution) == 2, \
         'Expected "image_resolution" to have length 2, but it has length {}.'.format(len(image_resolution))
     width, height = int(image_resolution[0]), int(image_resolution[1])
-    kps = _hip.device_tensor(torch.as_tensor(keypoints_bk2, dtype=torch.float32)).contiguous()
+    # float64 all the way: the reference truncates the float64 coordinate with int() (image_proc.py:889-890)
+    kps = _hip.device_tensor(torch.as_tensor(keypoints_bk2).to(torch.float64)).contiguous()
     b, k = int(kps.shape[0]), int(kps.shape[1])
     w = int(sigma * 2)
     dy, dx = np.mgrid[-w:w + 1, -w:w + 1]

@@ -307,14 +307,16 @@ class DreamNetwork:
         out_w, out_h = self.trained_net_output_resolution()
         offset = 0.0 if (out_w >= 400 and out_h >= 400) else 0.4395               # network.py:534-538
         with torch.no_grad():
-            kps, _ = ops.keypoints_from_belief_maps(belief_maps_batch.detach(), offset)
+            kps, _ = ops.keypoints_from_belief_maps(belief_maps_batch.detach(), offset, self.use_belief_peak_scores,
+                                                    self.belief_peak_next_best_score)
         return belief_maps_batch, kps
 
     def _inference_graphed(self, x):
         """hipGraph replay of _inference_on_device for this input shape; re-captured when a parameter or buffer changed
         (the packed weight copies the kernels read are re-created then) or the precision switch moved."""
         state = [t._version for t in self.model.parameters()] + [t._version for t in self.model.buffers()]
-        key = (tuple(x.shape), getattr(self.model.module, "precision", "fp32"))
+        key = (tuple(x.shape), getattr(self.model.module, "precision", "fp32"), bool(self.use_belief_peak_scores),
+               float(self.belief_peak_next_best_score))
         entry = self._graphs.get(key)
         if entry is None or entry["state"] != state:
             static_x = x.clone()

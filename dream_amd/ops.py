@@ -104,15 +104,16 @@ def nhwc_to_nchw(x):
 
 
 # ---- peak extraction --------------------------------------------------------------------------------
-def keypoints_from_belief_maps(maps_bkhw, offset):
-    """[B,K,H,W] device fp32 -> ([B,K,2] fp32 device tensor, [B,K] int32 peak counts)."""
+def keypoints_from_belief_maps(maps_bkhw, offset, use_peak_scores=True, next_best_score=0.25):
+    """[B,K,H,W] device fp32 -> ([B,K,2] fp32 device tensor, [B,K] int32 peak counts).  use_peak_scores / next_best_score:
+    DreamNetwork.use_belief_peak_scores / .belief_peak_next_best_score (dream/network.py:189-191,553-560)."""
     m = _f32(maps_bkhw)
     b, k, h, w = (int(v) for v in m.shape)
     scratch = torch.empty((2, b * k, h, w), dtype=torch.float32, device=m.device)
     kps = torch.empty((b, k, 2), dtype=torch.float32, device=m.device)
     counts = torch.empty((b, k), dtype=torch.int32, device=m.device)
-    call("dream_keypoints_from_belief_maps_f32", ptr(m), ptr(scratch), ptr(kps), ptr(counts), b * k, h, w,
-         float(offset), stream())
+    call("dream_keypoints_from_belief_maps_rule_f32", ptr(m), ptr(scratch), ptr(kps), ptr(counts), b * k, h, w,
+         float(offset), 1 if use_peak_scores else 0, float(next_best_score), stream())
     return kps, counts
 
 
@@ -347,7 +348,21 @@ def bn_train_fwd(x_nhwc, bn, residual=None, relu=True):
     call("dream_bn_train_fwd_nhwc_f32", ptr(x), ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(residual), ptr(y),
          ptr(mean), ptr(invstd), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), ptr(ws), npix, c,
          float(bn.eps), float(momentum), 1 if relu else 0, stream())
+    # the kernel wrote the running statistics through raw pointers: bump their version counters so that the folded
+    # scale/shift of the evaluation path and a captured hipGraph (both keyed on _version) are rebuilt
+    for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+        bump_version(t)
     return y, mean, invstd
+
+
+def bump_version(t):
+    """Tell autograd and the version-keyed caches that a kernel changed ``t`` in place through its raw pointer."""
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        inc(t)
+    else:
+        with torch.no_grad():
+            t.add_(0)
 
 
 def bn_train_bwd(x_nhwc, dy, y_act, gamma, mean, invstd, relu=True, want_g=False):

@@ -88,10 +88,5 @@ class HipSGD(torch.optim.Optimizer):
 
 
 def _bump_version(p):
-    """The kernels write through raw pointers; tell autograd / the packed-weight cache that the
-    parameter changed (an in-place no-op bumps ``_version``)."""
-    inc = getattr(torch.autograd.graph, "increment_version", None)
-    if inc is not None:
-        inc(p)
-    else:
-        p.add_(0)
+    """The kernels write through raw pointers; tell autograd / the packed-weight cache that the parameter changed."""
+    ops.bump_version(p)

@@ -187,6 +187,13 @@ int dream_nhwc_to_nchw_f32(const float *x, float *y, int B, int C, int H, int W,
 int dream_keypoints_from_belief_maps_f32(const float *maps, float *scratch, float *keypoints,
                                          int32_t *peak_counts, int N, int H, int W,
                                          double offset_due_to_upsampling, void *stream);
+/* same with the two DreamNetwork attributes callers may change (dream/network.py:189-191, read at :553-560):
+ * use_belief_peak_scores (0: several peaks -> no detection) and belief_peak_next_best_score (the fp32 score difference is
+ * compared against this double); the entry point above uses the reference's defaults (1, 0.25). */
+int dream_keypoints_from_belief_maps_rule_f32(const float *maps, float *scratch, float *keypoints,
+                                              int32_t *peak_counts, int N, int H, int W,
+                                              double offset_due_to_upsampling, int use_belief_peak_scores,
+                                              double belief_peak_next_best_score, void *stream);
 /* the full peak list of peaks_from_belief_maps, row-major order per map, at most `cap` per map:
  * xy: [N,cap,2] fp64, score: [N,cap] fp32, counts: [N] (true count, may exceed cap). */
 int dream_peaks_from_belief_maps_f32(const float *maps, float *scratch, double *xy, float *score,
@@ -204,11 +211,12 @@ int dream_softargmax_f32(const float *maps, const float *beta, float *scratch, f
 
 /* ---- the steps right before the path, on the device ------------------------------------------
  * ToTensor + Normalize of uint8 RGB frames [B,H,W,3] -> fp32 [B,3,H,W] (dream/datasets.py:87-94; mean3/stdev3 are HOST
- * pointers to 3 floats), and create_belief_map (dream/image_proc.py:866-910) for N = B*K keypoints: kps [N,2] (x,y),
+ * pointers to 3 floats), and create_belief_map (dream/image_proc.py:866-910) for N = B*K keypoints: kps [N,2] (x,y) FLOAT64
+ * (truncated toward zero on the device exactly as the reference's int() does on its float64 coordinates),
  * blob = the (2w+1)^2 Gaussian window computed on the host exactly as the reference does, out [N,H,W]. */
 int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float *out, int B, int H, int W,
                                       const float *mean3, const float *stdev3, void *stream);
-int dream_create_belief_maps_f32(const float *kps, const float *blob, float *out, int N, int H, int W, int w,
+int dream_create_belief_maps_f32(const double *kps, const float *blob, float *out, int N, int H, int W, int w,
                                  void *stream);
 /* Keypoint frames after peak extraction (dream/image_proc.py:135-147 convert_keypoints_to_netin_from_netout,
  * :215-260 convert_keypoints_to_raw_from_netin; call sites dream/network.py:480-488, dream/analysis.py:219-232):

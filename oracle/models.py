@@ -275,3 +275,25 @@ def recipe_weights(state_dict, final_keys=(), final_scale=1.0):
             v = v * final_scale
         out[key] = torch.as_tensor(np.asarray(v), dtype=t.dtype)
     return out
+
+
+def structured_weights(state_dict):
+    """Variant of recipe_weights for the structured end-to-end fixture of ResnetSimple (tests/golden/structured_resnet_h.npz):
+    recipe weights, except that (i) every additive term is removed (conv / BN biases and BN running means are zero), so a
+    zero background -- zero padding included -- maps to exactly zero and the belief maps are driven by the image content
+    alone, and (ii) the 4x4 stride-2 transposed convs of the decoder carry a random channel mix times the bilinear
+    kernel [1,3,3,1] x [1,3,3,1] / 16 (a partition of unity over the output phases: no checkerboard), so a blob in the
+    image comes out as a blob in the maps.  The last (1x1) layer is calibrated and stored by make_golden.py."""
+    import zlib
+    import numpy as np
+    out = recipe_weights(state_dict)
+    bil = np.outer([1.0, 3.0, 3.0, 1.0], [1.0, 3.0, 3.0, 1.0]) / 16.0
+    for key, t in out.items():
+        if t.dim() == 4 and t.shape[-1] == 4 and "upsample" in key:
+            ci, co = int(t.shape[0]), int(t.shape[1])
+            rs = np.random.RandomState(zlib.crc32(("mix:" + key).encode()) & 0x7FFFFFFF)
+            mix = rs.uniform(-1.0, 1.0, (ci, co)) * (6.0 / ci) ** 0.5
+            out[key] = torch.as_tensor(mix[:, :, None, None] * bil[None, None], dtype=t.dtype).contiguous()
+        elif key.endswith("running_mean") or key.endswith(".bias"):
+            out[key] = torch.zeros_like(t)
+    return out

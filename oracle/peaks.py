@@ -98,16 +98,17 @@ def peaks_from_belief_maps(maps, offset_due_to_upsampling):
     return all_peaks
 
 
-def select_keypoints(peaks_per_map):
-    """network.py:546-577 for one frame: exactly one peak -> it; several -> the best-scoring one
-    iff it beats the runner-up by >= 0.25 (float32 difference); otherwise (-999.999, -999.999)."""
+def select_keypoints(peaks_per_map, use_belief_peak_scores=True, belief_peak_next_best_score=NEXT_BEST_SCORE):
+    """network.py:546-577 for one frame: exactly one peak -> it; several -> (when use_belief_peak_scores, :553) the
+    best-scoring one iff it beats the runner-up by >= belief_peak_next_best_score (0.25, :189-191; float32 difference);
+    otherwise (-999.999, -999.999)."""
     out = []
     for peaks in peaks_per_map:
         if len(peaks) == 1:
             out.append([peaks[0][0], peaks[0][1]])
-        elif len(peaks) > 1:
+        elif len(peaks) > 1 and use_belief_peak_scores:
             ranked = sorted(peaks, key=lambda p: p[2], reverse=True)
-            if ranked[0][2] - ranked[1][2] >= NEXT_BEST_SCORE:
+            if float(ranked[0][2] - ranked[1][2]) >= belief_peak_next_best_score:
                 out.append([ranked[0][0], ranked[0][1]])
             else:
                 out.append([NO_DETECTION, NO_DETECTION])
@@ -121,10 +122,11 @@ def upsampling_offset(trained_out_w, trained_out_h):
     return 0.0 if (trained_out_w >= 400 and trained_out_h >= 400) else 0.4395
 
 
-def keypoints_from_belief_maps(maps_bkhw, offset):
+def keypoints_from_belief_maps(maps_bkhw, offset, use_belief_peak_scores=True, belief_peak_next_best_score=NEXT_BEST_SCORE):
     """The whole post-CNN part of DreamNetwork.inference: float32 [B,K,H,W] -> float32 [B,K,2]."""
     maps_bkhw = np.asarray(maps_bkhw)
-    res = [select_keypoints(peaks_from_belief_maps(frame, offset)) for frame in maps_bkhw]
+    res = [select_keypoints(peaks_from_belief_maps(frame, offset), use_belief_peak_scores, belief_peak_next_best_score)
+           for frame in maps_bkhw]
     return np.asarray(res, dtype=np.float64).astype(np.float32).reshape(maps_bkhw.shape[0], -1, 2)
 
 

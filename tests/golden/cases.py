@@ -63,6 +63,31 @@ def peak_cases():
     return cases
 
 
+# (use_belief_peak_scores, belief_peak_next_best_score) settings of DreamNetwork a caller may make (network.py:189-191)
+PEAK_RULE_SETTINGS = {"noscores": (False, 0.25), "thr0p1": (True, 0.1), "thr0p5": (True, 0.5), "thr0p3": (True, 0.3)}
+PEAK_RULE_CASES = ("two_blobs_gap", "q100", "edges_plateau", "noise_100")
+
+
+def belief_map_cases():
+    """name -> ((W,H), keypoints float64 [K,2], sigma) for create_belief_map (image_proc.py:866-910): in-frame blobs, windows
+    that touch each border by one pixel either way (drawn / rejected), coordinates a hair below an integer in float64
+    (int() truncation: 57.9999999 is pixel 57 although its fp32 rounding is 58.0), negative and far-outside
+    coordinates, a non-default sigma (window half-width int(2*sigma))."""
+    rs = np.random.RandomState(41)
+    c = {}
+    c["inframe_80x60"] = ((80, 60), np.stack([rs.uniform(6, 73, 7), rs.uniform(6, 53, 7)], 1), 2)
+    # window [u-4, u+4] must satisfy u-4 >= 0 and u+5 < W: u in [4, W-6]
+    c["borders_80x60"] = ((80, 60), np.array([[4.0, 30.0], [3.0, 30.0], [74.0, 30.0], [75.0, 30.0], [40.0, 4.0],
+                                              [40.0, 3.0], [40.0, 54.0], [40.0, 55.0], [4.0, 4.0], [74.0, 54.0]]), 2)
+    c["truncation_100"] = ((100, 100), np.array([[57.9999999, 20.0], [58.0, 20.0], [20.0, 41.99999999999], [3.9999999, 50.0],
+                                                 [4.0000001, 50.0], [94.0000001, 50.0], [93.9999999, 94.9999999], [-0.5, 50.0],
+                                                 [-0.9999, 4.5], [50.5, 50.5], [1e6, 50.0], [50.0, -1e6]]), 2)
+    c["sigma3_208"] = ((208, 208), np.stack([rs.uniform(0, 208, 9), rs.uniform(0, 208, 9)], 1), 3)
+    c["sigma1p5_64x48"] = ((64, 48), np.stack([rs.uniform(0, 64, 8), rs.uniform(0, 48, 8)], 1), 1.5)
+    c["ragged_133x100"] = ((133, 100), np.stack([rs.uniform(-5, 138, 17), rs.uniform(-5, 105, 17)], 1), 2)
+    return c
+
+
 def softargmax_cases():
     """name -> (maps float32 [B,K,H,W], beta)."""
     kat = np.zeros((1, 3, 20, 30), np.float32)
@@ -97,6 +122,45 @@ def target_batch(b, k, out_wh, in_wh=(400, 400), seed=0):
                         rs.uniform(0, in_wh[1], k) * ho / in_wh[1]], 1)
         out[i] = blob((wo, ho), pts).astype(np.float32)
     return out
+
+
+# Structured end-to-end fixture (G11): frames with coloured Gaussian blobs, and a last layer calibrated (by make_golden.py, on
+# the reference's own activations) so that the belief maps are O(1) with clear peaks.  arch -> (last-layer key prefix,
+# (B, H, W), weight recipe, exact-zero background?).  vgg_q: the general recipe weights on uint8-quantised noisy frames;
+# resnet_h: oracle.models.structured_weights (no additive terms, bilinear transposed convs) on frames whose background is
+# exactly zero, so the maps are exactly zero away from the blobs.  The calibrated last layer is stored in the fixture.
+STRUCTURED_CASES = {
+    "vgg_q": ("heads_0.4", (2, 200, 200), "recipe", False),
+    "resnet_h": ("upsample.12", (2, 400, 400), "structured", True),
+}
+
+
+def blob_image_batch(b, h, w, seed=0, n_blobs=3, zero_background=False):
+    """RGB frames with n_blobs coloured Gaussian blobs (sigma 8-14 px).  Default: background level + noise, quantised to uint8,
+    then ToTensor + Normalize(0.5, 0.5) as image_batch().  zero_background: float frames, exactly 0 away from the blobs.
+    Returns (NCHW float32, blob centres [b, n_blobs, 2] (x, y))."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    imgs = np.zeros((b, h, w, 3))
+    centres = np.zeros((b, n_blobs, 2))
+    for i in range(b):
+        img = np.zeros((h, w, 3)) if zero_background else np.full((h, w, 3), 96.0) + rs.normal(0, 2.0, (h, w, 3))
+        for j in range(n_blobs):
+            cx, cy = rs.uniform(0.15 * w, 0.85 * w), rs.uniform(0.15 * h, 0.85 * h)
+            sg = rs.uniform(8, 14)
+            colour = rs.uniform(-1, 1, 3) if zero_background else rs.uniform(-90, 150, 3)
+            g = np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * sg * sg))
+            if zero_background:
+                g[g < 1e-3] = 0.0
+            img += g[..., None] * colour
+            centres[i, j] = (cx, cy)
+        imgs[i] = img
+    if zero_background:
+        x = imgs.astype(np.float32)
+    else:
+        u8 = np.clip(np.rint(imgs), 0, 255).astype(np.uint8)
+        x = (u8.astype(np.float32) / np.float32(255.0) - np.float32(0.5)) / np.float32(0.5)
+    return np.ascontiguousarray(x.transpose(0, 3, 1, 2)), centres
 
 
 # CNN parity cases: arch -> (n_keypoints, manipulator, [(B, H, W), ...])

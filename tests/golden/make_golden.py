@@ -8,6 +8,9 @@ Fixtures are data only (inputs are regenerated from seeds by cases.py; outputs a
   train_vgg_q.npz       G5     one DreamNetwork.train() step (loss, grad norms, post-Adam samples)
   state_dict_manifest.json G6  key -> shape for the four archs (module.-prefixed, as saved)
   variant_<name>.npz    G7     skip / full_output / soft-argmax / multi-stage hourglasses (--only-variants)
+  belief_map_golden.npz G10    create_belief_map (--only-belief-maps)
+  peak_rule_golden.npz  G12    selection rule with use_belief_peak_scores / belief_peak_next_best_score changed (--only-peak-rules)
+  structured_<arch>.npz G11    blob-like O(1) belief maps end to end: maps, keypoints, calibrated last layer (--only-structured)
 """
 import json
 import os
@@ -137,9 +140,99 @@ def keypoint_conversions(dream):
     print("keypoint_conversion:", sorted(out)[:4], "...")
 
 
+def peak_rules(dream):
+    """G12: DreamNetwork.inference with the two public attributes of the selection rule changed (network.py:189-191,
+    553-560): use_belief_peak_scores = False, belief_peak_next_best_score in {0.1, 0.3, 0.5}."""
+    out = {}
+    net_q = dream.create_network_from_config_data(ref_import.network_config("vgg_q"))
+    all_cases = cases.peak_cases()
+    for name in cases.PEAK_RULE_CASES:
+        maps, off = all_cases[name]
+        net_q.model = lambda x, _m=maps: [torch.from_numpy(_m)[None]]
+        net_q.network_config["training"]["config"]["net_output_resolution"] = [400, 400] if off == 0.0 else [100, 100]
+        for tag, (use, thr) in cases.PEAK_RULE_SETTINGS.items():
+            net_q.use_belief_peak_scores, net_q.belief_peak_next_best_score = use, thr
+            out[name + "/" + tag] = net_q.inference(torch.zeros(1, 3, 8, 8))[1].numpy()
+    np.savez_compressed(os.path.join(HERE, "peak_rule_golden.npz"), **out)
+    print("peak_rule:", {k: int((v[..., 0] > -999).sum()) for k, v in out.items()})
+
+
+def belief_maps(dream):
+    """G10: create_belief_map (image_proc.py:866-910), the training-target renderer right before the hot path: the
+    reference's float64 output for every case of cases.belief_map_cases()."""
+    out = {}
+    for name, (res, pts, sigma) in cases.belief_map_cases().items():
+        ref = dream.image_proc.create_belief_map(res, [tuple(p) for p in pts], sigma=sigma)
+        assert ref.dtype == np.float64 and ref.shape == (len(pts), res[1], res[0])
+        out[name] = ref
+        print("belief_map", name, ref.shape, "drawn", int((ref.reshape(len(pts), -1).max(1) > 0).sum()), "/", len(pts))
+    np.savez_compressed(os.path.join(HERE, "belief_map_golden.npz"), **out)
+
+
+def structured(dream):
+    """G11: end-to-end fixture with blob-like belief maps of magnitude O(1), so that the north_star's ABSOLUTE 1e-4 bound
+    on the maps, 100 % detection agreement and <= 1e-3 px on the keypoints can be demanded (the recipe-weight fixtures give
+    noise-like maps of magnitude ~10 on which the 0.25 rule flips on 1e-5).  All layers but the last carry the weights
+    named in cases.STRUCTURED_CASES; the last layer (3x3 conv for vgg_q, 1x1 for resnet_h) gets, per keypoint, a random
+    channel mix scaled and shifted so that the map's background sits at 0 and its strongest response at 1 -- calibrated
+    here on the reference's own activations and STORED in the fixture.  The fixture is certified decidable: the
+    reference's own peak stage gives the same detections, and keypoints within 1e-3 px, on maps perturbed by +-1e-4."""
+    from oracle import peaks as opeaks
+    for arch, (last, (b, h, wd), recipe, zero_bg) in cases.STRUCTURED_CASES.items():
+        cfg = ref_import.network_config(arch)
+        cfg["training"]["config"]["net_input_resolution"] = [wd, h]
+        net = dream.create_network_from_config_data(cfg)
+        sd = {key[len("module."):]: v for key, v in net.model.state_dict().items()}
+        w = omodels.structured_weights(sd) if recipe == "structured" else omodels.recipe_weights(sd)
+        wk, bk = last + ".weight", last + ".bias"
+        k, cin, kh, kw = w[wk].shape
+        rs = np.random.RandomState(77)
+        mix = rs.uniform(-0.4 if zero_bg else 0.0, 1.0, (k, cin, 1, 1)) * (rs.uniform(0, 1, (k, cin, 1, 1)) < 0.35)
+        w[wk] = torch.as_tensor(np.broadcast_to(mix, (k, cin, kh, kw)) / (kh * kw), dtype=torch.float32).contiguous()
+        w[bk] = torch.zeros(k)
+        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+        net.enable_evaluation()
+        x_np, centres = cases.blob_image_batch(b, h, wd, seed=91, zero_background=zero_bg)
+        x = torch.from_numpy(x_np)
+        with torch.no_grad():
+            z = net.model(x)[0].double().numpy()                       # [B,K,Ho,Wo] un-calibrated responses
+        bg = np.zeros(k) if zero_bg else np.median(z.transpose(1, 0, 2, 3).reshape(k, -1), axis=1)
+        flat = (z - bg[None, :, None, None]).transpose(1, 0, 2, 3).reshape(k, -1)
+        ext = flat[np.arange(k), np.abs(flat).argmax(1)]                # strongest deviation, with its sign
+        scale = 1.0 / ext
+        w[wk] = (w[wk].double() * torch.as_tensor(scale).view(k, 1, 1, 1)).float()
+        w[bk] = torch.as_tensor(-bg * scale).float()
+        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+        with torch.no_grad():
+            maps, kps = net.inference(x)
+            net.model.double()
+            maps64 = net.model(x.double())[0]
+            net.model.float()
+        maps, kps = maps.numpy(), kps.numpy()
+        det = kps[..., 0] > -999
+        print("structured", arch, maps.shape, "absmax %.3f" % np.abs(maps).max(), "detections", int(det.sum()), "/", det.size,
+              "fp32-vs-fp64 of the reference itself: %.2e" % float(np.abs(maps - maps64.numpy()).max()))
+        assert 0.25 <= det.mean() <= 0.95, "fixture should contain both detections and rejections"
+        off = opeaks.upsampling_offset(*net.trained_net_output_resolution())
+        prs = np.random.RandomState(3)
+        for trial in range(4):                                          # decidability at the tolerance the test demands
+            pert = maps + prs.uniform(-1e-4, 1e-4, maps.shape).astype(np.float32)
+            pk = opeaks.keypoints_from_belief_maps(pert, off)
+            assert np.array_equal(pk[..., 0] > -999, det), "a detection decision flips within 1e-4"
+            assert np.abs(pk - kps)[det].max() < 1e-3, np.abs(pk - kps)[det].max()
+        np.savez_compressed(os.path.join(HERE, "structured_%s.npz" % arch), maps=maps, keypoints=kps, centres=centres,
+                            final_weight=w[wk].numpy(), final_bias=w[bk].numpy())
+
+
 def main():
     dream = ref_import.import_reference()
     torch.manual_seed(0)
+    if "--only-peak-rules" in sys.argv:
+        return peak_rules(dream)
+    if "--only-structured" in sys.argv:
+        return structured(dream)
+    if "--only-belief-maps" in sys.argv:
+        return belief_maps(dream)
     if "--only-conversions" in sys.argv:
         return keypoint_conversions(dream)
     if "--only-variants" in sys.argv:
@@ -231,6 +324,9 @@ def main():
     variants(dream)
     api_surface(dream)
     keypoint_conversions(dream)
+    belief_maps(dream)
+    structured(dream)
+    peak_rules(dream)
 
 
 if __name__ == "__main__":

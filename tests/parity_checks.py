@@ -171,6 +171,30 @@ def check_peaks_case(dev, name):
     assert np.array_equal(np.concatenate(flat_sc), g[name + "/score"])
 
 
+def check_peak_rule_settings(dev):
+    """use_belief_peak_scores / belief_peak_next_best_score (dream/network.py:189-191) reach the kernel: keypoints equal the
+    reference's for every setting of tests/golden/peak_rule_golden.npz, through ops and through DreamNetwork.inference."""
+    g = np.load(os.path.join(GOLD, "peak_rule_golden.npz"))
+    net = build_network("vgg_q", dev)
+    net.enable_evaluation()
+    for name in cases.PEAK_RULE_CASES:
+        maps, off = cases.peak_cases()[name]
+        m = to(dev, torch.from_numpy(maps))[None]
+        changed = 0
+        for tag, (use, thr) in cases.PEAK_RULE_SETTINGS.items():
+            kps, _ = ops.keypoints_from_belief_maps(m, off, use, thr)
+            assert np.array_equal(kps.cpu().numpy(), g[name + "/" + tag]), (name, tag)
+            assert np.array_equal(op.keypoints_from_belief_maps(maps[None], off, use, thr), g[name + "/" + tag]), (name, tag)
+            changed += int(not np.array_equal(g[name + "/" + tag], peak_golden()[name + "/keypoints"]))
+        if name == "two_blobs_gap":
+            assert changed >= 3                                         # the settings do change the outcome
+            net.model = lambda x, _m=m: [_m]                              # as make_golden.py drives the reference
+            net.network_config["training"]["config"]["net_output_resolution"] = [100, 100]
+            for tag, (use, thr) in cases.PEAK_RULE_SETTINGS.items():
+                net.use_belief_peak_scores, net.belief_peak_next_best_score = use, thr
+                assert np.array_equal(net.inference(m)[1].numpy(), g[name + "/" + tag]), tag
+
+
 def check_peaks_api(dev):
     """dream_amd.image_proc.peaks_from_belief_maps reproduces the reference's own KAT
     (test/test_image_proc.py:94-120) and its return structure."""
@@ -270,6 +294,36 @@ def check_model_inference(dev, arch, shape, precision="fp32"):
     both = (got_k != np.float32(-999.999)) & (ref_k != np.float32(-999.999))
     assert np.abs(got_k - ref_k)[both].max(initial=0.0) < 0.5
     return float(err)
+
+
+def check_structured(dev, arch, precision="fp32"):
+    """North-star bounds on the structured fixture (blob-like maps of magnitude 1, tests/golden/structured_<arch>.npz,
+    generated by the reference): belief maps within an ABSOLUTE 1e-4, every detection / rejection decision identical,
+    detected keypoints within 1e-3 px of the reference's."""
+    last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[arch]
+    g = np.load(os.path.join(GOLD, "structured_%s.npz" % arch))
+    sd = om.build_model(arch, 7).state_dict()
+    weights = om.structured_weights(sd) if recipe == "structured" else om.recipe_weights(sd)
+    weights[last + ".weight"] = torch.from_numpy(g["final_weight"])
+    weights[last + ".bias"] = torch.from_numpy(g["final_bias"])
+    net = build_network(arch, dev, weights=weights, in_res=(w, h))
+    net.enable_evaluation()
+    if precision != "fp32":
+        net.model.module.precision = precision
+    x, _ = cases.blob_image_batch(b, h, w, seed=91, zero_background=zero_bg)
+    with torch.no_grad():
+        maps, kps = net.inference(to(dev, torch.from_numpy(x)))
+    y, got_k, ref_k = maps.cpu().numpy(), kps.numpy(), g["keypoints"]
+    err = float(np.abs(y - g["maps"]).max())
+    assert float(np.abs(g["maps"]).max()) <= 1.0 + 1e-6
+    assert err <= 1e-4, (arch, precision, err)
+    det = ref_k[..., 0] > -999
+    assert np.array_equal(got_k[..., 0] > -999, det), "detection decisions differ from the reference"
+    assert 0 < det.sum() < det.size
+    perr = float(np.abs(got_k - ref_k)[det].max())
+    assert perr <= 1e-3, (arch, precision, perr)
+    assert np.array_equal(got_k[~det], ref_k[~det])                 # the -999.999 sentinels, bit for bit
+    return err, perr
 
 
 def check_train_steps(dev, opt, steps=3):
@@ -429,7 +483,10 @@ def check_resnet_training_ops(dev):
             y_ref = y_ref.relu()
         dy = torch.randn_like(y_ref)
         y_ref.backward(dy)
+        versions = [t._version for t in (bn2.running_mean, bn2.running_var, bn2.num_batches_tracked)]
         y, mean, invstd = ops.bn_train_fwd(to(dev, _nhwc(x.detach())), bn2, to(dev, _nhwc(r)) if res else None, relu)
+        # the version-keyed caches (folded eval-mode scale/shift, captured graphs) must see the updated statistics
+        assert all(t._version > v for t, v in zip((bn2.running_mean, bn2.running_var, bn2.num_batches_tracked), versions))
         dx, g, dgam, dbet = ops.bn_train_bwd(to(dev, _nhwc(x.detach())), to(dev, _nhwc(dy)), y, bn2.weight, mean, invstd, relu,
                                              want_g=True)
         assert float((nchw(y.cpu()) - y_ref).abs().max()) < 1e-5
@@ -528,6 +585,16 @@ def check_dataprep(dev):
     assert torch.equal(got, ref)
     assert torch.equal(dream_amd.image_proc.normalize_images_u8(to(dev, torch.from_numpy(u8[:1])), [0.5] * 3, [0.5] * 3).cpu()[0],
                        torch.from_numpy(cases.image_batch(1, 37, 41, seed=4)[0]) * 0 + ((torch.from_numpy(u8[0]).permute(2, 0, 1).float() / 255 - 0.5) / 0.5))
+    # every case of the reference-generated fixture (make_golden.py --only-belief-maps), per-frame drop-in and batched
+    gold = np.load(os.path.join(GOLD, "belief_map_golden.npz"))
+    for name, (res, pts, sigma) in cases.belief_map_cases().items():
+        ref64 = gold[name]
+        one = dream_amd.image_proc.create_belief_map(res, [tuple(p) for p in pts], sigma=sigma)
+        assert one.dtype == np.float64 and one.shape == ref64.shape, name
+        # the reference's only consumer keeps torch.tensor(maps).float() (datasets.py:165-171)
+        assert np.array_equal(one.astype(np.float32), ref64.astype(np.float32)), name
+        got = dream_amd.image_proc.create_belief_map_batch(res, to(dev, torch.from_numpy(np.stack([pts, pts[::-1]]))), sigma).cpu()
+        assert torch.equal(got[0], torch.tensor(ref64).float()) and torch.equal(got[1], torch.tensor(ref64[::-1].copy()).float()), name
     kps = np.array([[[65.0, 20.0], [100.0, 80.0], [4.0, 4.0], [3.9, 10.0], [74.9, 55.2], [75.0, 30.0], [-0.5, 20.0]],
                     [[10.2, 10.7], [40.0, 54.0], [40.0, 55.0], [12.0, 4.0], [12.0, 3.99], [79.0, 59.0], [30.5, 30.5]]], np.float32)
     got = dream_amd.image_proc.create_belief_map_batch((80, 60), to(dev, torch.from_numpy(kps))).cpu()

@@ -61,6 +61,10 @@ def test_peaks_bit_exact(emu, name):
     pc.check_peaks_case("cpu", name)
 
 
+def test_peak_rule_settings(emu):
+    pc.check_peak_rule_settings("cpu")
+
+
 def test_peaks_api_reference_kat(emu):
     pc.check_peaks_api("cpu")
 

@@ -37,7 +37,7 @@ def test_conv_layer_shapes(res, cin, cout, flags):
     pc.check_conv(DEV, 1, res, res, cin, cout, flags, seed=res + cin)
 
 
-@pytest.mark.parametrize("variant", range(9))
+@pytest.mark.parametrize("variant", range(11))              # every selectable tile variant; the big-patch one: see below
 def test_conv_variants(variant):
     lib = _hip.lib()
     lib.dream_conv3x3_set_variant(variant)
@@ -47,6 +47,13 @@ def test_conv_variants(variant):
         pc.check_conv(DEV, 1, 26, 38, 32, 64, 3, seed=variant)
     finally:
         lib.dream_conv3x3_set_variant(-1)
+
+
+def test_conv_big_patch_variant():
+    """Variant 11 (128 px x 128 cout with a 608-pixel patch) is what a strided 3x3 conv runs on, whatever is forced."""
+    assert _hip.lib().dream_conv3x3_variant_name(11) == b"m2n2w2x2k16"
+    pc.check_conv2d_general(DEV, 2, 37, 51, 64, 160, 3, 2, seed=11)
+    pc.check_conv2d_general(DEV, 1, 100, 100, 128, 128, 3, 2, seed=12)
 
 
 def test_conv_odd_shapes_and_transpose():
@@ -65,6 +72,10 @@ def test_first_conv_pool_layouts():
 @pytest.mark.parametrize("name", sorted(cases.peak_cases().keys()))
 def test_peaks_bit_exact(name):
     pc.check_peaks_case(DEV, name)
+
+
+def test_peak_rule_settings():
+    pc.check_peak_rule_settings(DEV)
 
 
 def test_peaks_api_reference_kat():
@@ -415,3 +426,57 @@ def test_randomised_conv_geometries():
         pc.check_wgrad(DEV, b, h, w, cin, co4, k=int(rs.choice([1, 3])), stride=int(rs.choice([1, 2])), seed=case)
         if cin % 32 == 0:
             pc.check_conv_f16x3(DEV, b, max(h, 2), max(w, 2), cin, cout, 3, flags & ops.CONV_RELU, seed=case)
+
+
+# ---- north-star bounds on the structured (blob-like, magnitude-1) fixtures generated by the reference -------------------
+@pytest.mark.parametrize("arch", sorted(cases.STRUCTURED_CASES))
+def test_structured_fixture_absolute_tolerance(arch):
+    err, perr = pc.check_structured(DEV, arch)
+    print("structured %s fp32: max |map error| %.2e, max keypoint error %.2e px" % (arch, err, perr))
+
+
+@pytest.mark.parametrize("arch", sorted(cases.STRUCTURED_CASES))
+def test_structured_fixture_absolute_tolerance_split_precision(arch):
+    err, perr = pc.check_structured(DEV, arch, precision="fp16x3")
+    print("structured %s fp16x3: max |map error| %.2e, max keypoint error %.2e px" % (arch, err, perr))
+
+
+# ---- full-size training (BASELINE configs[2] and one GPU's share of configs[3]) ------------------------------------------
+def _grads_of(net, x, target):
+    for p in net.model.parameters():
+        p.grad = None
+    loss = net.loss([x], target)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.item()), {k: p.grad.detach().clone() for k, p in net.model.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("arch,batch", [("vgg_q", 128), ("resnet_h", 16)])
+def test_full_size_training_batch_replication(arch, batch):
+    """Replicating a 2-frame batch batch/2 times changes neither the mean loss nor any gradient (nor, for ResNet, the batch
+    statistics): the full-size step (vgg_q: 128 x 400 x 400, split-K over 20.5 M positions) must reproduce the 2-frame step
+    up to fp32 summation order.  The 2-frame step itself is pinned to the reference by the golden training tests."""
+    net = pc.build_network(arch, DEV, weights=om.recipe_weights(om.build_model(arch, 7).state_dict(), cases.TRAIN_FINAL_KEYS
+                                                                   if arch == "vgg_q" else ("upsample.12.weight", "upsample.12.bias"),
+                                                                   cases.TRAIN_FINAL_SCALE))
+    net.enable_training()
+    ow, oh = net.trained_net_output_resolution()
+    x2 = torch.from_numpy(cases.image_batch(2, 400, 400, seed=17)).to(DEV)
+    t2 = torch.from_numpy(cases.target_batch(2, 7, (ow, oh), seed=17)).to(DEV)
+    loss2, g2 = _grads_of(net, x2, t2)
+    rep = batch // 2
+    lossn, gn = _grads_of(net, x2.repeat(rep, 1, 1, 1), t2.repeat(rep, 1, 1, 1))
+    assert np.isfinite(loss2) and abs(lossn - loss2) <= 2e-6 * abs(loss2), (loss2, lossn)
+    assert set(g2) == set(gn) and len(g2) == len(list(net.model.parameters()))
+    worst = 0.0
+    gmax = max(float(v.double().norm()) for v in g2.values())
+    bound = 2e-4 if arch == "vgg_q" else 1e-3          # ResNet: batch statistics re-summed in another order move a few ReLU masks
+    for k in g2:
+        a, b = g2[k].double(), gn[k].double()
+        if float(a.norm()) < 1e-6 * gmax:                # conv biases in front of a BatchNorm: the true gradient is 0
+            assert float(b.norm()) < 1e-4 * gmax, k
+            continue
+        rel = float((a - b).norm() / a.norm())
+        worst = max(worst, rel)
+        assert rel <= bound, (k, rel)
+    print("%s b=%d vs b=2: loss %.9g vs %.9g, worst relative gradient difference %.2e" % (arch, batch, lossn, loss2, worst))

@@ -57,6 +57,28 @@ def test_cnn_matches_reference_outputs(arch):
         assert np.abs(kps - ref_k).max() < 1e-3
 
 
+@pytest.mark.parametrize("arch", sorted(cases.STRUCTURED_CASES))
+def test_structured_fixture_regenerates_from_the_oracle(arch):
+    """The structured (blob-like, magnitude-1) fixture: weights and frames regenerate from the committed recipes and the
+    oracle reproduces the reference's maps / keypoints -- on any box, without the reference."""
+    last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[arch]
+    g = np.load(os.path.join(GOLD, "structured_%s.npz" % arch))
+    m = om.build_model(arch, 7)
+    wts = om.structured_weights(m.state_dict()) if recipe == "structured" else om.recipe_weights(m.state_dict())
+    wts[last + ".weight"], wts[last + ".bias"] = torch.from_numpy(g["final_weight"]), torch.from_numpy(g["final_bias"])
+    m.load_state_dict(wts)
+    m.eval()
+    x, centres = cases.blob_image_batch(b, h, w, seed=91, zero_background=zero_bg)
+    assert np.array_equal(centres, g["centres"])
+    with torch.no_grad():
+        y = m(torch.from_numpy(x))[0].numpy()
+    assert np.abs(y - g["maps"]).max() <= 1e-5 and 0.99 <= np.abs(g["maps"]).max() <= 1.0 + 1e-6
+    kps = op.keypoints_from_belief_maps(y, op.upsampling_offset(y.shape[3], y.shape[2]))
+    det = g["keypoints"][..., 0] > -999
+    assert np.array_equal(kps[..., 0] > -999, det) and 0 < det.sum() < det.size
+    assert np.abs(kps - g["keypoints"])[det].max() < 1e-3
+
+
 @pytest.mark.parametrize("opt", ["adam", "sgd"])
 def test_train_step_matches_reference(opt):
     g = np.load(os.path.join(GOLD, "train_vgg_q_%s.npz" % opt))

@@ -23,6 +23,16 @@ def test_reference_kat_belief_maps():
     assert len(peaks[1]) == 0
 
 
+@pytest.mark.parametrize("name", sorted(cases.belief_map_cases()))
+def test_create_belief_map_matches_reference_outputs(name, golden_dir):
+    """oracle.peaks.create_belief_map (the yardstick of the on-device renderer) pinned to the reference's own outputs:
+    float64, bit for bit, incl. border rejection and int() truncation of float64 coordinates."""
+    res, pts, sigma = cases.belief_map_cases()[name]
+    gold = np.load(os.path.join(golden_dir, "belief_map_golden.npz"))[name]
+    got = op.create_belief_map(res, [tuple(p) for p in pts], sigma=sigma)
+    assert got.dtype == np.float64 and np.array_equal(got, gold)
+
+
 @pytest.mark.parametrize("shape", [(25, 33), (100, 100), (60, 80), (208, 208), (5, 7), (1, 40), (13, 2)])
 def test_gaussian_restatement_bit_exact_vs_scipy(shape):
     rs = np.random.RandomState(shape[0] * 1000 + shape[1])
