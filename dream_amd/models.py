@@ -22,7 +22,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, pretrained as _pretrained
 from .ops import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, CONV_ZEROSTUFF2X, CONV_POOL2
 from .spatial_softmax import SoftArgmaxPavlo
 
@@ -164,6 +164,9 @@ class DreamHourglass(nn.Module):
         self.precision = "fp32"
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self._aux = {}
+        # the reference builds every hourglass on vgg19(pretrained=True).features (models.py:587): ImageNet weights for all
+        # encoder convs but the first when they can be had, one loud warning otherwise (dream_amd/pretrained.py)
+        self.imagenet_initialised = _pretrained.init_vgg19_encoder(self)
 
     # ---- helpers -------------------------------------------------------------------------------------
     def _layer(self, cname, child):
@@ -763,6 +766,9 @@ class ResnetSimple(nn.Module):
         else:
             self.upsample = nn.Sequential(*ups)
             self.upsample2 = nn.Sequential(*(up(256) + [nn.Conv2d(256, n_keypoints, 1, 1)]))
+        # models.py:22: resnet101(pretrained=pretrained) -- ImageNet trunk when it can be had, one loud warning otherwise.
+        # ``freeze`` is accepted and unused, exactly as in the reference (models.py:19: never read).
+        self.imagenet_initialised = _pretrained.init_resnet101_trunk(self) if pretrained else False
 
     def output_resolution(self, input_wh):
         def trunk(v):

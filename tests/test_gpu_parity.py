@@ -480,3 +480,32 @@ def test_full_size_training_batch_replication(arch, batch):
         worst = max(worst, rel)
         assert rel <= bound, (k, rel)
     print("%s b=%d vs b=2: loss %.9g vs %.9g, worst relative gradient difference %.2e" % (arch, batch, lossn, loss2, worst))
+
+
+# ---- checkpoint I/O (dream/network.py:29-63,592-632) -----------------------------------------------
+@pytest.mark.parametrize("arch", ["vgg_q", "resnet_h"])
+def test_checkpoint_save_load_identical_inference(arch, tmp_path):
+    """save_network -> create_network_from_config_file(yaml, pth) -> bit-identical belief maps and keypoints, and the
+    verification tool accepts the pair (manifest, round trip, inference twice)."""
+    import os
+    import sys
+    import dream_amd
+    net = pc.build_network(arch, DEV)
+    net.enable_evaluation()
+    x = torch.from_numpy(cases.image_batch(2, 128, 160, seed=23)).to(DEV)
+    with torch.no_grad():
+        maps, kps = net.inference(x)
+    net.save_network(str(tmp_path / "ckpt"), "net")
+    yaml_path, pth_path = str(tmp_path / "ckpt" / "net.yaml"), str(tmp_path / "ckpt" / "net.pth")
+    sd = torch.load(pth_path)
+    assert all(k.startswith("module.") for k in sd) and all(v.device.type in ("cuda", "cpu") for v in sd.values())
+    net2 = dream_amd.create_network_from_config_file(yaml_path, pth_path)
+    net2.enable_evaluation()
+    with torch.no_grad():
+        maps2, kps2 = net2.inference(x)
+    assert torch.equal(maps, maps2) and torch.equal(kps, kps2)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import verify_checkpoint as vc
+    lines = []
+    assert vc.verify(yaml_path, pth_path, out=lines.append) == 0, lines
+    assert lines[-1] == "OK"
