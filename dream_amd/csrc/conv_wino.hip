@@ -1,0 +1,319 @@
+// 3x3 stride-1 pad-1 convolution on NHWC fp32 tensors by the Winograd minimal-filtering algorithm F(2x2, 3x3)
+// (Lavin & Gray 2016) on the CDNA4 fp32 matrix cores: 16 multiplications per 2x2 output tile and input channel instead of
+// the direct algorithm's 36, i.e. 2.25x fewer MFMA cycles for the same fp32 result up to round-off (every product and sum is
+// IEEE fp32; the transforms only add / subtract, the weight transform is done once, in fp64, at pack time).
+//
+// Replaces torch.nn.Conv2d(k=3,s=1,p=1) (+ReLU, + the following MaxPool2d(2)) at /root/reference/dream/models.py:598-615
+// (VGG19 encoder), :695-710 (upsample decoder, the convs not preceded by an upsample), :736-747 (head), the 3x3 stride-1
+// convs of the ResNet-101 bottlenecks behind :22-32 in evaluation mode (folded BatchNorm), and -- on mode-1 packed
+// weights -- their data gradients.  The direct kernel (conv_mfma.hip) stays the reference form and runs everything
+// Winograd does not cover (strides, 1x1, transposed convs, NCHW store of the last head conv).
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          d: 4x4 input patch, g: 3x3 filter, Y: 2x2 outputs
+//
+// GEMM view: for each of the 16 positions p of the transformed 4x4 domain,  M_p[tile][cout] = sum_cin V_p[tile][cin] U_p[cin][cout].
+//   * tiles are numbered over (image, tile row, tile column) and a workgroup takes 32 consecutive ones, so every map size
+//     (400 .. 13 pixels) fills its workgroups (no 2-D tile padding);
+//   * workgroup = 4 wavefronts = 32 tiles x 64 output channels; wavefront = 32 tiles x 16 channels x all 16 positions:
+//     2 x 16 accumulators of v_mfma_f32_16x16x4_f32 (128 VGPRs), so the inverse transform is lane-local;
+//   * V (the transformed input) is computed by the workgroup for one 16-channel chunk at a time and lives in LDS
+//     (32 KB, float4 slots XOR-swizzled so that both the b128 writes and the MFMA-operand b128 reads are conflict-free);
+//   * U (the transformed weights, packed [Cin/16][16][CoutPad][16]) never touches LDS: every wavefront streams its own
+//     16-channel operand rows straight from L2 into registers, 1 KB coalesced per position, three positions ahead;
+//   * two workgroups per CU (2 waves per SIMD): one transforms its next chunk while the other one owns the matrix pipe.
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+namespace {
+
+struct WinoParams {
+    const float *x;          // [B,H,W,Cin]
+    const float *u;          // [Cin/16][16][CoutPad][16]
+    const float *scale;      // per-channel multiplier (eval-mode BatchNorm fold) or null
+    const float *shift;      // per-channel addend (bias / BN shift) or null
+    const float *residual;   // ReLU mask source (DREAM_CONV_RELUMASK) or addend of the output's shape, or null
+    float *y;                // [B,H,W,Cout]  (or [B,H/2,W/2,Cout] with DREAM_CONV_POOL2)
+    int B, H, W, Cin, Cout, CoutPad;
+    int TY, TX;              // 2x2 tiles per image
+    int ntiles;              // B * TY * TX
+    int flags;
+};
+
+constexpr int WT = 32;       // tiles per workgroup
+constexpr int WN = 64;       // output channels per workgroup
+constexpr int WKC = 16;      // input channels per chunk
+constexpr int B_AHEAD = 3;   // positions the weight stream runs ahead of the MFMAs
+
+// physical float4 slot of logical slot q (k = 4q .. 4q+3) in row t of a V plane
+DREAM_DEVICE int v_slot(int q, int t) { return q ^ ((t >> 2) & 2); }
+
+__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
+    DREAM_DYNAMIC_LDS(float, sV);                      // [16 positions][32 tiles][16 channels]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_index();
+
+    // XCD-aware placement (see conv_mfma.hip): each XCD gets a contiguous range of tile blocks
+    const int nblk = (p.ntiles + WT - 1) / WT;
+    const int tb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
+    if (tb >= nblk) return;
+    const int tile0 = tb * WT;
+    const int n0 = blockIdx.y * WN;
+    const int tiles_per_img = p.TY * p.TX;
+
+    // ---- input-transform plan: thread -> two items (tile t, channel quad q, column j of the transformed patch) ----------
+    // column j of B^T d B needs patch columns ca, cb:  w_r = d[r][ca] + sb * d[r][cb];  then B^T along the rows.
+    // Per item: element offset of patch pixel (row 0, column 0) at channel 4q, and one validity bit per (row, a|b) load;
+    // the eight addresses are rebuilt from wave-uniform strides, so the plan costs 3 VGPRs per item, not 16.
+    int gbase[2], gmask[2];
+    int soff[2];                                       // LDS float offset of V[p = j][t][slot q]; + i * 4 * WT * 16 for p = 4i + j
+    const int row_stride = p.W * p.Cin;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + it * 256;
+        const int q = e & 3, t = (e >> 2) & 31, j = e >> 7;          // j is wave-uniform: (tid >> 7) + 2 it
+        const int ca = (j == 0) ? 0 : (j == 2 ? 2 : 1);
+        const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
+        const int tau = tile0 + t;
+        const bool tv = tau < p.ntiles;
+        const int b = tau / tiles_per_img, rem = tau - b * tiles_per_img;
+        const int ty = rem / p.TX, tx = rem - ty * p.TX;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        gbase[it] = ((b * p.H + y0) * p.W + x0) * p.Cin + 4 * q;
+        int m = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool rok = tv && (y0 + r) >= 0 && (y0 + r) < p.H;
+            if (rok && (x0 + ca) >= 0 && (x0 + ca) < p.W) m |= 1 << (2 * r);
+            if (rok && (x0 + cb) >= 0 && (x0 + cb) < p.W) m |= 1 << (2 * r + 1);
+        }
+        gmask[it] = m;
+        soff[it] = (j * WT + t) * WKC + 4 * v_slot(q, t);
+    }
+
+    // ---- MFMA operand addresses ------------------------------------------------------------------------------------------
+    // A: lane l -> tile row (l & 15) (+16 for the second block), k = 4 (l >> 4) .. +3 (one float4, feeds 4 MFMAs)
+    const int lt = lane & 15, lg = lane >> 4;
+    int a_off[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+        const int t = blk * 16 + lt;
+        a_off[blk] = t * WKC + 4 * v_slot(lg, t);
+    }
+    // B: lane l -> output channel n0 + 16 wave + (l & 15), k = 4 (l >> 4) .. +3
+    const int b_lane = (wave * 16 + lt) * WKC + 4 * lg;
+    const size_t u_pos_stride = (size_t)p.CoutPad * WKC;          // floats between consecutive positions
+    const float *ub = p.u + (size_t)n0 * WKC;
+
+    f32x4 acc[16][2];
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) acc[pp][blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const int nchunks = p.Cin / WKC;
+    const int npos_total = nchunks * 16;
+    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+
+    // weight stream: ring of B_AHEAD + 1 operand registers, position s lives in bq[s & 3]
+    f32x4 bq[4];
+#pragma unroll
+    for (int s = 0; s < B_AHEAD; ++s)
+        bq[s] = (s < npos_total) ? *(const f32x4 *)(ub + (size_t)s * u_pos_stride + b_lane) : zero4;
+
+    for (int c = 0; c < nchunks; ++c) {
+        // ---- transform chunk c of the input into V ------------------------------------------------------------------------
+        const float *xc = p.x + c * WKC;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int j = (tid >> 7) + 2 * it;
+            const int ca = (j == 0) ? 0 : (j == 2 ? 2 : 1);
+            const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
+            const float sb = (j == 1) ? 1.0f : -1.0f;
+            const float *xa = xc + gbase[it] + ca * p.Cin, *xb = xc + gbase[it] + cb * p.Cin;
+            f32x4 w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 da = (gmask[it] >> (2 * r)) & 1 ? *(const f32x4 *)(xa + r * row_stride) : zero4;
+                const f32x4 db = (gmask[it] >> (2 * r + 1)) & 1 ? *(const f32x4 *)(xb + r * row_stride) : zero4;
+                w[r] = da + sb * db;
+            }
+            if (it == 0 && c > 0) __syncthreads();     // every wave is done reading the previous chunk's V
+            float *dst = sV + soff[it];
+            *(f32x4 *)(dst) = w[0] - w[2];                          // B^T rows: [1,0,-1,0]
+            *(f32x4 *)(dst + 4 * WT * WKC) = w[1] + w[2];           //           [0,1,1,0]
+            *(f32x4 *)(dst + 8 * WT * WKC) = w[2] - w[1];           //           [0,-1,1,0]
+            *(f32x4 *)(dst + 12 * WT * WKC) = w[1] - w[3];          //           [0,1,0,-1]
+        }
+        __syncthreads();
+
+        // ---- 16 positions x (2 tile blocks x 4 k-steps) MFMAs -------------------------------------------------------------
+        const int s0 = c * 16;
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const int s_next = s0 + pp + B_AHEAD;
+            if (s_next < npos_total) bq[(pp + B_AHEAD) & 3] = *(const f32x4 *)(ub + (size_t)s_next * u_pos_stride + b_lane);
+            const f32x4 a0 = *(const f32x4 *)(sV + pp * WT * WKC + a_off[0]);
+            const f32x4 a1 = *(const f32x4 *)(sV + pp * WT * WKC + a_off[1]);
+            const f32x4 bv = bq[pp & 3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc[pp][0] = mfma_f32_16x16x4(a0[r], bv[r], acc[pp][0]);
+                acc[pp][1] = mfma_f32_16x16x4(a1[r], bv[r], acc[pp][1]);
+            }
+        }
+    }
+
+    // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ----------------
+    const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
+    const bool pool = (p.flags & DREAM_CONV_POOL2) != 0;
+    const bool mask = (p.flags & DREAM_CONV_RELUMASK) != 0;
+    const int col = n0 + wave * 16 + lt;
+    const bool cok = col < p.Cout;
+    const float sc = (p.scale != nullptr && cok) ? p.scale[col] : 1.0f;
+    const float sh = (p.shift != nullptr && cok) ? p.shift[col] : 0.0f;
+    const int Ho = pool ? p.H / 2 : p.H, Wo = pool ? p.W / 2 : p.W;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tau = tile0 + blk * 16 + lg * 4 + r;          // C/D layout: row = 4 (l >> 4) + reg, col = l & 15
+            const int b = tau / tiles_per_img, rem = tau - b * tiles_per_img;
+            const int ty = rem / p.TX, tx = rem - ty * p.TX;
+            float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[0][j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
+                s[1][j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
+            }
+            float out[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                out[i][0] = s[i][0] + s[i][1] + s[i][2];
+                out[i][1] = s[i][1] - s[i][2] - s[i][3];
+            }
+            if (tau >= p.ntiles || !cok) continue;
+            float best = -__builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int oy = 2 * ty + i, ox = 2 * tx + jj;
+                    float v = out[i][jj];
+                    if (p.scale != nullptr) v = v * sc;
+                    v = v + sh;
+                    const bool inb = oy < p.H && ox < p.W;
+                    if (p.residual != nullptr && inb) {
+                        const float rv = p.residual[(((size_t)b * p.H + oy) * p.W + ox) * p.Cout + col];
+                        v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
+                    }
+                    if (relu) v = fmaxf(v, 0.0f);
+                    if (pool) best = fmaxf(best, v);
+                    else if (inb) p.y[(((size_t)b * p.H + oy) * p.W + ox) * p.Cout + col] = v;
+                }
+            if (pool && ty < Ho && tx < Wo) p.y[(((size_t)b * Ho + ty) * Wo + tx) * p.Cout + col] = best;
+        }
+    }
+}
+
+// OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1: rows = Cin_fwd, cols = Cout_fwd)
+// -> U = G g G^T in fp64, rounded once to fp32, laid out [cols/16][16 positions][RowsPad][16].
+__global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u, int Cout, int Cin, int rows, int cols,
+                                                         int RowsPad, int mode) {
+    const size_t total = (size_t)(cols / WKC) * RowsPad * WKC;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kk = (int)(i % WKC);
+        const size_t rest = i / WKC;
+        const int n = (int)(rest % RowsPad);
+        const int ch = (int)(rest / RowsPad);
+        const int k = ch * WKC + kk;
+        double g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.0f;
+                if (n < rows) {
+                    v = (mode == 0) ? w[(((size_t)n * Cin + k) * 3 + a) * 3 + b]
+                                    : w[(((size_t)k * Cin + n) * 3 + (2 - a)) * 3 + (2 - b)];
+                }
+                g[a][b] = (double)v;
+            }
+        double t[4][3];                                             // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                               // (G g) G^T
+            const double r0 = t[a][0], r1 = 0.5 * (t[a][0] + t[a][1] + t[a][2]), r2 = 0.5 * (t[a][0] - t[a][1] + t[a][2]),
+                         r3 = t[a][2];
+            const double rr[4] = {r0, r1, r2, r3};
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                u[(((size_t)ch * 16 + (a * 4 + b)) * RowsPad + n) * WKC + kk] = (float)rr[b];
+        }
+    }
+}
+
+bool g_attr_set = false;
+
+}  // namespace
+
+extern "C" size_t dream_conv3x3_winograd_weight_floats(int rows, int cols) {
+    const size_t rows_pad = (size_t)((rows + WN - 1) / WN) * WN;
+    return (size_t)(cols / WKC) * 16 * rows_pad * WKC;
+}
+
+// w: OIHW [Cout,Cin,3,3]; mode 0: forward operator (rows = Cout, cols = Cin); mode 1: data-gradient operator
+// (rows = Cin, cols = Cout, taps flipped).  u: dream_conv3x3_winograd_weight_floats(rows, cols) floats.
+extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u, int Cout, int Cin, int mode, void *stream) {
+    DREAM_REQUIRE(w_oihw && u && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "winograd pack: bad arguments");
+    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
+    DREAM_REQUIRE(cols % WKC == 0, "winograd pack: %d input channels, must be a multiple of %d", cols, WKC);
+    const int rows_pad = (rows + WN - 1) / WN * WN;
+    const size_t total = (size_t)(cols / WKC) * rows_pad * WKC;
+    size_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, rows, cols,
+                       rows_pad, mode);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32.
+// Supported flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (even H, W), DREAM_CONV_RELUMASK (residual = mask source).
+extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                               const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                                               int flags, void *stream) {
+    DREAM_REQUIRE(x && u_packed && y, "winograd conv: null pointer");
+    DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
+    DREAM_REQUIRE(Cin % WKC == 0, "winograd conv: Cin=%d must be a multiple of %d", Cin, WKC);
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (H % 2 == 0 && W % 2 == 0 && residual == nullptr), "winograd conv: fused max-pool needs even H, W and no residual");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
+    DREAM_REQUIRE((size_t)B * H * W * (size_t)Cin < ((size_t)1 << 31), "winograd conv: input too large for 32-bit offsets");
+    WinoParams p;
+    p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.CoutPad = (Cout + WN - 1) / WN * WN;
+    p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
+    const long ntiles = (long)B * p.TY * p.TX;
+    DREAM_REQUIRE(ntiles < ((long)1 << 31), "winograd conv: too many tiles");
+    p.ntiles = (int)ntiles;
+    p.flags = flags;
+    const size_t lds = (size_t)16 * WT * WKC * sizeof(float);
+    if (!g_attr_set) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_attr_set = true;
+    }
+    const int nblk = (p.ntiles + WT - 1) / WT;
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8), (unsigned)(p.CoutPad / WN));
+    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}

@@ -19,6 +19,14 @@ DREAM_DEVICE f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles/SIMD issue, 40 cycles dependent latency; same 157 TFLOP/s peak):
+//   A operand: one float per lane, lane l holds A[row = l & 15][k = l >> 4]
+//   B operand: one float per lane, lane l holds B[k = l >> 4][col = l & 15]
+//   C/D      : 4 floats per lane, reg r of lane l is D[row = 4*(l>>4) + r][col = l & 15]
+DREAM_DEVICE f32x4 mfma_f32_16x16x4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 // v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s dense, 32 cycles/SIMD issue):
 //   A operand: 8 halfs per lane, lane l holds A[row = l & 31][k = 8*(l>>5) .. 8*(l>>5)+7]
 //   B operand: 8 halfs per lane, lane l holds B[k = 8*(l>>5) .. +7][col = l & 31];  C/D as above

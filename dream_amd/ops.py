@@ -52,6 +52,31 @@ def conv3x3(x_nhwc, packed, bias, cout, flags=0, relu_mask=None):
     return y
 
 
+def pack_weight_winograd(w_oihw, mode=0):
+    """OIHW [Cout,Cin,3,3] -> the transformed weights U = G g G^T of the Winograd F(2x2,3x3) kernel
+    ([cols/16][16][rows_pad][16]).  mode 0: forward (rows = Cout); mode 1: data-gradient operator (rows = Cin).
+    Returns (packed, rows)."""
+    w = _f32(w_oihw)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    n = int(_hip.lib().dream_conv3x3_winograd_weight_floats(rows, cols))
+    packed = torch.empty((n,), dtype=torch.float32, device=w.device)
+    call("dream_pack_conv3x3_winograd_weight", ptr(w), ptr(packed), cout, cin, mode, stream())
+    return packed, rows
+
+
+def conv3x3_winograd(x_nhwc, packed_u, cout, scale=None, shift=None, residual=None, flags=0):
+    """3x3 stride-1 pad-1 conv by Winograd F(2x2,3x3): x [B,H,W,Cin] -> [B,H,W,cout] ([B,H/2,W/2,cout] with CONV_POOL2).
+    flags: CONV_RELU | CONV_POOL2 | CONV_RELUMASK (residual = mask source)."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    shape = (b, h // 2, w // 2, cout) if flags & CONV_POOL2 else (b, h, w, cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_winograd_nhwc_f32", ptr(x), ptr(packed_u), ptr(scale), ptr(shift), ptr(residual), ptr(y), b, h, w, cin,
+         cout, flags, stream())
+    return y
+
+
 def conv3x3_first(x_nchw, w_oihw, bias, relu=True):
     x, w = _f32(x_nchw), _f32(w_oihw)
     b, cin, h, wd = (int(v) for v in x.shape)

@@ -88,6 +88,20 @@ size_t dream_conv3x3_cout_pad(int Cout);  /* padded row count the MFMA kernel wa
 int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y,
                            int B, int H, int W, int Cin, int Cout, int CoutPad, int flags,
                            void *stream);
+/* The same torch.nn.Conv2d(k=3,s=1,p=1) (+ReLU, + the MaxPool2d(2) that follows it; dream/models.py:589-615,695-710,
+ * 736-747, and the stride-1 3x3 convs of the ResNet-101 bottlenecks behind :22-32) by the Winograd F(2x2,3x3) algorithm
+ * on the fp32 matrix cores: 16 instead of 36 multiplications per 2x2 outputs and input channel, fp32 throughout (the
+ * transforms only add and subtract; result equal to the direct form up to fp32 round-off, ~1e-6 of the output
+ * magnitude).  x [B,H,W,Cin] NHWC, Cin % 16 == 0; u_packed: dream_pack_conv3x3_winograd_weight of the OIHW weight
+ * (dream_conv3x3_winograd_weight_floats(rows, cols) floats; mode 0: forward, rows = Cout, cols = Cin; mode 1: the
+ * data-gradient operator, rows = Cin, cols = Cout); y = conv * scale[c] + shift[c] (+ residual, or masked by
+ * residual > 0 with DREAM_CONV_RELUMASK) (ReLU) (2x2 max-pool); flags: DREAM_CONV_RELU | DREAM_CONV_POOL2 |
+ * DREAM_CONV_RELUMASK; scale / shift / residual may be NULL. */
+size_t dream_conv3x3_winograd_weight_floats(int rows, int cols);
+int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u_packed, int Cout, int Cin, int mode, void *stream);
+int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                    const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
+                                    void *stream);
 /* nn.ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) of the deconv decoder (dream/models.py:621-686) by sub-pixel
  * decomposition: four stride-1 launches with 1/2/2/4 taps, no multiplications by zero (the DREAM_CONV_ZEROSTUFF2X form
  * of dream_conv3x3_nhwc_f32 computes the same result with 4x the MACs).  x [B,H,W,Cin] -> y [B,2H,2W,Cout];

@@ -57,6 +57,42 @@ def check_conv(dev, B, H, W, Cin, Cout, flags, seed=0):
     return err
 
 
+def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=None):
+    """Winograd F(2x2,3x3) conv vs an fp64 direct convolution: error relative to the output maximum at fp32 round-off level
+    (<= 2e-6; measured ~3e-7, the direct fp32 kernel ~1.5e-7)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5 if with_scale else None
+    if mode == 1:                                        # data-gradient operator of conv(w'): w' is [Cout_x, Cin_x] = [Cin, Cout] here
+        wsrc = torch.randn(Cin, Cout, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5
+        w = wsrc.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+        packed, rows = ops.pack_weight_winograd(to(dev, wsrc), 1)
+    else:
+        packed, rows = ops.pack_weight_winograd(to(dev, w), 0)
+    assert rows == Cout
+    res = None
+    if residual is not None:
+        res = torch.randn(B, Cout, H, W, generator=g)
+    y = ops.conv3x3_winograd(to(dev, _nhwc(x)), packed, Cout, to(dev, scale) if with_scale else None, to(dev, bias),
+                             to(dev, _nhwc(res)) if res is not None else None, flags).cpu().permute(0, 3, 1, 2)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    if with_scale:
+        ref = ref * scale.double().view(1, -1, 1, 1)
+    ref = ref + bias.double().view(1, -1, 1, 1)
+    if res is not None:
+        ref = torch.where(res.double() > 0, ref, torch.zeros_like(ref)) if flags & ops.CONV_RELUMASK else ref + res.double()
+    if flags & ops.CONV_RELU:
+        ref = ref.relu()
+    if flags & ops.CONV_POOL2:
+        ref = F.max_pool2d(ref, 2)
+    assert y.shape == ref.shape, (tuple(y.shape), tuple(ref.shape))
+    err = float((y.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err <= 2e-6, (B, H, W, Cin, Cout, flags, err)
+    return err
+
+
 def check_conv_transpose(dev, B, H, W, Cin, Cout, seed=0):
     """ConvTranspose2d(k3,s2,p1,op1) == zero-stuffed conv with mode-1 packed weights."""
     g = torch.Generator().manual_seed(seed)

@@ -8,6 +8,7 @@ import os
 import pytest
 
 import cases
+from dream_amd import ops
 import parity_checks as pc
 from emu_util import emulated_hip
 
@@ -27,6 +28,18 @@ def test_conv_variants(emu, variant):
         pc.check_conv("cpu", 1, 6, 8, 32, 64, 3, seed=variant)           # fused upsample + ReLU
     finally:
         emu.dream_conv3x3_set_variant(-1)
+
+
+def test_conv_winograd(emu):
+    errs = [pc.check_conv_winograd("cpu", 1, 8, 8, 16, 16),                                   # one workgroup, ragged cout
+            pc.check_conv_winograd("cpu", 2, 13, 25, 32, 64, ops.CONV_RELU, seed=1),           # odd extents: half tiles
+            pc.check_conv_winograd("cpu", 1, 25, 25, 48, 96, ops.CONV_RELU, seed=2),           # tiles spanning images / rows
+            pc.check_conv_winograd("cpu", 3, 5, 3, 16, 7, 0, seed=3),                          # images smaller than a block
+            pc.check_conv_winograd("cpu", 2, 12, 20, 32, 80, ops.CONV_RELU | ops.CONV_POOL2, seed=4),
+            pc.check_conv_winograd("cpu", 1, 10, 14, 64, 32, ops.CONV_RELU, seed=5, with_scale=True, residual="add"),
+            pc.check_conv_winograd("cpu", 1, 9, 11, 32, 48, ops.CONV_RELUMASK, seed=6, residual="mask"),
+            pc.check_conv_winograd("cpu", 2, 7, 9, 32, 64, 0, seed=7, mode=1)]
+    print("winograd max rel err", max(errs))
 
 
 def test_conv_heuristic_and_odd_shapes(emu):

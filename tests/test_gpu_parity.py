@@ -455,7 +455,12 @@ def _grads_of(net, x, target):
 def test_full_size_training_batch_replication(arch, batch):
     """Replicating a 2-frame batch batch/2 times changes neither the mean loss nor any gradient (nor, for ResNet, the batch
     statistics): the full-size step (vgg_q: 128 x 400 x 400, split-K over 20.5 M positions) must reproduce the 2-frame step
-    up to fp32 summation order.  The 2-frame step itself is pinned to the reference by the golden training tests."""
+    up to fp32 summation order.  The 2-frame step itself is pinned to the reference by the golden training tests.
+    Bounds: the loss to 2e-6; every gradient's direction (cosine) and norm; the element-wise difference relative to the
+    gradient norm for all layers but the first (whose 20 M-term, strongly cancelling sums are checked against fp64 in
+    test_first_conv_wgrad_full_size_vs_fp64).  ResNet: train-mode BatchNorm through 100 layers amplifies the 1e-7 relative
+    change of the re-summed batch statistics (tests/parity_checks.py::check_resnet_train_step), so only direction and norm
+    are bounded there."""
     net = pc.build_network(arch, DEV, weights=om.recipe_weights(om.build_model(arch, 7).state_dict(), cases.TRAIN_FINAL_KEYS
                                                                    if arch == "vgg_q" else ("upsample.12.weight", "upsample.12.bias"),
                                                                    cases.TRAIN_FINAL_SCALE))
@@ -468,18 +473,50 @@ def test_full_size_training_batch_replication(arch, batch):
     lossn, gn = _grads_of(net, x2.repeat(rep, 1, 1, 1), t2.repeat(rep, 1, 1, 1))
     assert np.isfinite(loss2) and abs(lossn - loss2) <= 2e-6 * abs(loss2), (loss2, lossn)
     assert set(g2) == set(gn) and len(g2) == len(list(net.model.parameters()))
-    worst = 0.0
     gmax = max(float(v.double().norm()) for v in g2.values())
-    bound = 2e-4 if arch == "vgg_q" else 1e-3          # ResNet: batch statistics re-summed in another order move a few ReLU masks
+    rows = []
     for k in g2:
-        a, b = g2[k].double(), gn[k].double()
+        a, b = g2[k].double().flatten(), gn[k].double().flatten()
         if float(a.norm()) < 1e-6 * gmax:                # conv biases in front of a BatchNorm: the true gradient is 0
             assert float(b.norm()) < 1e-4 * gmax, k
             continue
-        rel = float((a - b).norm() / a.norm())
-        worst = max(worst, rel)
-        assert rel <= bound, (k, rel)
-    print("%s b=%d vs b=2: loss %.9g vs %.9g, worst relative gradient difference %.2e" % (arch, batch, lossn, loss2, worst))
+        rows.append((float((a - b).norm() / a.norm()), float((a * b).sum() / (a.norm() * b.norm())),
+                     float(b.norm() / a.norm()), k))
+    rows.sort(reverse=True)
+    print("%s b=%d vs b=2: loss %.9g vs %.9g; relative gradient difference: worst %s, median %.2e" % (
+        arch, batch, lossn, loss2, ", ".join("%s %.1e" % (k.replace("module.", ""), r) for r, _, _, k in rows[:4]),
+        rows[len(rows) // 2][0]))
+    first = {"vgg_q": "module.layer_0_1_down.0.", "resnet_h": "module.conv1."}[arch]
+    for rel, cos, ratio, k in rows:
+        if arch == "vgg_q":
+            assert cos >= 1 - 1e-5 and abs(ratio - 1) <= 1e-3, (k, cos, ratio)
+            assert rel <= (5e-3 if k.startswith(first) else 2e-4), (k, rel)
+        else:
+            assert cos >= 0.98 and abs(ratio - 1) <= 0.05, (k, cos, ratio)
+    assert rows[len(rows) // 2][0] <= (2e-5 if arch == "vgg_q" else 2e-2)
+
+
+def test_first_conv_wgrad_full_size_vs_fp64():
+    """Weight / bias gradient of the first conv (3 -> 64 channels) at 128 x 400 x 400: sums of 20.5 M products.  Sampled
+    entries against a float64 evaluation of the same sums on the device: error relative to sum |terms| at fp32 round-off
+    level for a blocked summation (<= 2e-6), i.e. the kernel loses nothing beyond the order of summation."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    b, h, w = 128, 400, 400
+    x = torch.from_numpy(cases.image_batch(2, h, w, seed=5)).to(DEV).repeat(b // 2, 1, 1, 1) \
+        * torch.linspace(0.5, 1.5, b, device=DEV).view(b, 1, 1, 1)
+    dy = torch.randn(b, h, w, 64, generator=g).to(DEV) * 1e-3
+    dw, db = ops.conv3x3_first_wgrad(x.contiguous(), dy)
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1)).double()
+    worst = 0.0
+    for (o, c, ky, kx) in [(0, 0, 0, 0), (63, 2, 2, 2), (17, 1, 1, 1), (40, 0, 2, 1), (5, 2, 0, 2)]:
+        terms = dy[..., o].double() * xp[:, c, ky:ky + h, kx:kx + w]
+        ref, mag = float(terms.sum()), float(terms.abs().sum())
+        worst = max(worst, abs(float(dw[o, c, ky, kx]) - ref) / mag)
+    for o in (0, 31, 63):
+        col = dy[..., o].double()
+        worst = max(worst, abs(float(db[o]) - float(col.sum())) / float(col.abs().sum()))
+    print("first-conv wgrad at b=128: worst |error| / sum|terms| = %.2e" % worst)
+    assert worst <= 2e-6, worst
 
 
 # ---- checkpoint I/O (SURVEY.md 8f rank 4; dream/network.py:29-63,592-632) -----------------------------------------------
@@ -509,3 +546,20 @@ def test_checkpoint_save_load_identical_inference(arch, tmp_path):
     lines = []
     assert vc.verify(yaml_path, pth_path, out=lines.append) == 0, lines
     assert lines[-1] == "OK"
+
+
+# ---- Winograd F(2x2,3x3) conv kernel ---------------------------------------------------------------------------------------
+WINO_CASES = [
+    (1, 8, 8, 16, 16, 0, {}), (2, 13, 25, 32, 64, 1, {}), (1, 25, 25, 48, 96, 1, {}), (3, 5, 3, 16, 7, 0, {}),
+    (2, 12, 20, 32, 80, 1 | 16, {}), (1, 10, 14, 64, 32, 1, {"with_scale": True, "residual": "add"}),
+    (1, 9, 11, 32, 48, 32, {"residual": "mask"}), (2, 7, 9, 32, 64, 0, {"mode": 1}),
+    (2, 400, 400, 64, 64, 1 | 16, {}), (2, 200, 200, 128, 128, 1, {}), (4, 100, 100, 256, 256, 1, {}),
+    (4, 50, 50, 512, 512, 1, {}), (8, 25, 25, 512, 512, 1, {}), (3, 13, 13, 512, 512, 1, {"with_scale": True}),
+    (2, 133, 101, 64, 128, 1, {}),
+]
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", WINO_CASES)
+def test_conv_winograd(b, h, w, cin, cout, flags, kw):
+    err = pc.check_conv_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw)
+    print("winograd %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
