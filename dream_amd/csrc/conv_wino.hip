@@ -48,6 +48,7 @@ constexpr int B_AHEAD = 3;   // positions the weight stream runs ahead of the MF
 // physical float4 slot of logical slot q (k = 4q .. 4q+3) in row t of a V plane
 DREAM_DEVICE int v_slot(int q, int t) { return q ^ ((t >> 2) & 2); }
 
+template <int PIPE>
 __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     DREAM_DYNAMIC_LDS(float, sV);                      // [16 positions][32 tiles][16 channels]
     const int tid = threadIdx.x;
@@ -122,46 +123,81 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     for (int s = 0; s < B_AHEAD; ++s)
         bq[s] = (s < npos_total) ? *(const f32x4 *)(ub + (size_t)s * u_pos_stride + b_lane) : zero4;
 
-    for (int c = 0; c < nchunks; ++c) {
-        // ---- transform chunk c of the input into V ------------------------------------------------------------------------
-        const float *xc = p.x + c * WKC;
+    // raw patch columns of one item: issue the eight loads / combine them and store the four V rows of column j
+    f32x4 d[2][8];
+    auto item_load = [&](int it, int c) {
+        const int j = (tid >> 7) + 2 * it;
+        const int ca = (j == 0) ? 0 : (j == 2 ? 2 : 1);
+        const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
+        const float *xa = p.x + c * WKC + gbase[it] + ca * p.Cin, *xb = p.x + c * WKC + gbase[it] + cb * p.Cin;
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int j = (tid >> 7) + 2 * it;
-            const int ca = (j == 0) ? 0 : (j == 2 ? 2 : 1);
-            const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
-            const float sb = (j == 1) ? 1.0f : -1.0f;
-            const float *xa = xc + gbase[it] + ca * p.Cin, *xb = xc + gbase[it] + cb * p.Cin;
-            f32x4 w[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f32x4 da = (gmask[it] >> (2 * r)) & 1 ? *(const f32x4 *)(xa + r * row_stride) : zero4;
-                const f32x4 db = (gmask[it] >> (2 * r + 1)) & 1 ? *(const f32x4 *)(xb + r * row_stride) : zero4;
-                w[r] = da + sb * db;
-            }
-            if (it == 0 && c > 0) __syncthreads();     // every wave is done reading the previous chunk's V
-            float *dst = sV + soff[it];
-            *(f32x4 *)(dst) = w[0] - w[2];                          // B^T rows: [1,0,-1,0]
-            *(f32x4 *)(dst + 4 * WT * WKC) = w[1] + w[2];           //           [0,1,1,0]
-            *(f32x4 *)(dst + 8 * WT * WKC) = w[2] - w[1];           //           [0,-1,1,0]
-            *(f32x4 *)(dst + 12 * WT * WKC) = w[1] - w[3];          //           [0,1,0,-1]
+        for (int r = 0; r < 4; ++r) {
+            d[it][2 * r] = (gmask[it] >> (2 * r)) & 1 ? *(const f32x4 *)(xa + r * row_stride) : zero4;
+            d[it][2 * r + 1] = (gmask[it] >> (2 * r + 1)) & 1 ? *(const f32x4 *)(xb + r * row_stride) : zero4;
         }
-        __syncthreads();
+    };
+    auto item_store = [&](int it, float *vbuf) {
+        const int j = (tid >> 7) + 2 * it;
+        const float sb = (j == 1) ? 1.0f : -1.0f;
+        f32x4 w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = d[it][2 * r] + sb * d[it][2 * r + 1];
+        float *dst = vbuf + soff[it];
+        *(f32x4 *)(dst) = w[0] - w[2];                          // B^T rows: [1,0,-1,0]
+        *(f32x4 *)(dst + 4 * WT * WKC) = w[1] + w[2];           //           [0,1,1,0]
+        *(f32x4 *)(dst + 8 * WT * WKC) = w[2] - w[1];           //           [0,-1,1,0]
+        *(f32x4 *)(dst + 12 * WT * WKC) = w[1] - w[3];          //           [0,1,0,-1]
+    };
+    // 8 MFMAs of position pp on V buffer vbuf
+    auto position = [&](int pp, int s0, const float *vbuf) {
+        const int s_next = s0 + pp + B_AHEAD;
+        if (s_next < npos_total) bq[(pp + B_AHEAD) & 3] = *(const f32x4 *)(ub + (size_t)s_next * u_pos_stride + b_lane);
+        const f32x4 a0 = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[0]);
+        const f32x4 a1 = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
+        const f32x4 bv = bq[pp & 3];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[pp][0] = mfma_f32_16x16x4(a0[r], bv[r], acc[pp][0]);
+            acc[pp][1] = mfma_f32_16x16x4(a1[r], bv[r], acc[pp][1]);
+        }
+    };
 
-        // ---- 16 positions x (2 tile blocks x 4 k-steps) MFMAs -------------------------------------------------------------
-        const int s0 = c * 16;
+    if (PIPE == 0) {
+        // transform | barrier | 128 MFMAs | barrier per chunk; the second workgroup of the CU covers the transform
+        for (int c = 0; c < nchunks; ++c) {
+            item_load(0, c);
+            item_load(1, c);
+            if (c > 0) __syncthreads();                    // every wave is done reading the previous chunk's V
+            item_store(0, sV);
+            item_store(1, sV);
+            __syncthreads();
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            const int s_next = s0 + pp + B_AHEAD;
-            if (s_next < npos_total) bq[(pp + B_AHEAD) & 3] = *(const f32x4 *)(ub + (size_t)s_next * u_pos_stride + b_lane);
-            const f32x4 a0 = *(const f32x4 *)(sV + pp * WT * WKC + a_off[0]);
-            const f32x4 a1 = *(const f32x4 *)(sV + pp * WT * WKC + a_off[1]);
-            const f32x4 bv = bq[pp & 3];
+            for (int pp = 0; pp < 16; ++pp) position(pp, c * 16, sV);
+        }
+    } else {
+        // V double-buffered: the transform of chunk c + 1 rides inside the MFMA phase of chunk c (one item's eight loads in
+        // flight at a time: issued at positions 0 / 7, combined and stored six positions later), one barrier per chunk
+        constexpr int VB = 16 * WT * WKC;
+        item_load(0, 0);
+        item_load(1, 0);
+        item_store(0, sV);
+        item_store(1, sV);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const float *cur = sV + (c & 1) * VB;
+            float *nxt = sV + ((c & 1) ^ 1) * VB;
+            const bool more = c + 1 < nchunks;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[pp][0] = mfma_f32_16x16x4(a0[r], bv[r], acc[pp][0]);
-                acc[pp][1] = mfma_f32_16x16x4(a1[r], bv[r], acc[pp][1]);
+            for (int pp = 0; pp < 16; ++pp) {
+                if (more) {
+                    if (pp == 0) item_load(0, c + 1);
+                    if (pp == 6) item_store(0, nxt);
+                    if (pp == 7) item_load(1, c + 1);
+                    if (pp == 13) item_store(1, nxt);
+                }
+                position(pp, c * 16, cur);
             }
+            __syncthreads();
         }
     }
 
@@ -260,7 +296,8 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u
     }
 }
 
-bool g_attr_set = false;
+bool g_attr_set[2] = {false, false};
+int g_variant = 1;
 
 }  // namespace
 
@@ -285,6 +322,14 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
     return 0;
 }
 
+// variant 0: single V buffer, transform and MFMA phases separated by barriers; 1 (default): double-buffered V with the next
+// chunk's transform inside the MFMA phase.  Same results bit for bit.
+extern "C" int dream_conv3x3_winograd_set_variant(int variant) {
+    DREAM_REQUIRE(variant == 0 || variant == 1, "winograd variant %d out of range", variant);
+    g_variant = variant;
+    return 0;
+}
+
 // y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32.
 // Supported flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (even H, W), DREAM_CONV_RELUMASK (residual = mask source).
 extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
@@ -306,14 +351,15 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     DREAM_REQUIRE(ntiles < ((long)1 << 31), "winograd conv: too many tiles");
     p.ntiles = (int)ntiles;
     p.flags = flags;
-    const size_t lds = (size_t)16 * WT * WKC * sizeof(float);
-    if (!g_attr_set) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)conv_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attr_set = true;
+    void (*kernel)(const WinoParams) = g_variant == 0 ? conv_wino_kernel<0> : conv_wino_kernel<1>;
+    const size_t lds = (size_t)(g_variant == 0 ? 1 : 2) * 16 * WT * WKC * sizeof(float);
+    if (!g_attr_set[g_variant]) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_attr_set[g_variant] = true;
     }
     const int nblk = (p.ntiles + WT - 1) / WT;
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8), (unsigned)(p.CoutPad / WN));
-    hipLaunchKernelGGL(conv_wino_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }

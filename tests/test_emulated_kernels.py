@@ -30,7 +30,9 @@ def test_conv_variants(emu, variant):
         emu.dream_conv3x3_set_variant(-1)
 
 
-def test_conv_winograd(emu):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_conv_winograd(emu, variant):
+    emu.dream_conv3x3_winograd_set_variant(variant)
     errs = [pc.check_conv_winograd("cpu", 1, 8, 8, 16, 16),                                   # one workgroup, ragged cout
             pc.check_conv_winograd("cpu", 2, 13, 25, 32, 64, ops.CONV_RELU, seed=1),           # odd extents: half tiles
             pc.check_conv_winograd("cpu", 1, 25, 25, 48, 96, ops.CONV_RELU, seed=2),           # tiles spanning images / rows
@@ -39,6 +41,7 @@ def test_conv_winograd(emu):
             pc.check_conv_winograd("cpu", 1, 10, 14, 64, 32, ops.CONV_RELU, seed=5, with_scale=True, residual="add"),
             pc.check_conv_winograd("cpu", 1, 9, 11, 32, 48, ops.CONV_RELUMASK, seed=6, residual="mask"),
             pc.check_conv_winograd("cpu", 2, 7, 9, 32, 64, 0, seed=7, mode=1)]
+    emu.dream_conv3x3_winograd_set_variant(1)
     print("winograd max rel err", max(errs))
 
 

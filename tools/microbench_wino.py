@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from dream_amd import ops  # noqa: E402
+from dream_amd import _hip, ops  # noqa: E402
 
 LAYERS = [  # (res, cin, cout, fused pool?, count in vgg_q)
     (400, 64, 64, 1, 1), (200, 64, 128, 0, 1), (200, 128, 128, 1, 1), (100, 128, 256, 0, 1), (100, 256, 256, 0, 3),
@@ -38,7 +38,10 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variant", type=int, default=1)
     args = ap.parse_args()
+    _hip.lib().dream_conv3x3_winograd_set_variant(args.variant)
+    print("winograd variant", args.variant)
     rows, t_dir, t_win = [], 0.0, 0.0
     for (res, cin, cout, pool, count) in LAYERS:
         b = args.batch
