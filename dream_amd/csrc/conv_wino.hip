@@ -65,11 +65,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
 
     // ---- input-transform plan: thread -> two items (tile t, channel quad q, column j of the transformed patch) ----------
     // column j of B^T d B needs patch columns ca, cb:  w_r = d[r][ca] + sb * d[r][cb];  then B^T along the rows.
-    // Per item: element offset of patch pixel (row 0, column 0) at channel 4q, and one validity bit per (row, a|b) load;
-    // the eight addresses are rebuilt from wave-uniform strides, so the plan costs 3 VGPRs per item, not 16.
-    int gbase[2], gmask[2];
+    // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, row, column) relative to the first
+    // image this workgroup touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare /
+    // select per load), the chunk's channel offset in the scalar operand.
+    const int b0 = tile0 / tiles_per_img;
+    const size_t img_floats = (size_t)p.H * p.W * p.Cin;
+    const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
+    // The 16 offsets of a thread are parked in LDS ([4 quads of offsets][256 threads] uint4, conflict-free b128 access) and
+    // re-read per chunk: 16 VGPRs that the accumulators (128) + the patch (32) + the weight ring (16) cannot spare.
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 *sG = (u32x4 *)(sV + (PIPE == 0 ? 1 : 2) * 16 * WT * WKC);
     int soff[2];                                       // LDS float offset of V[p = j][t][slot q]; + i * 4 * WT * 16 for p = 4i + j
-    const int row_stride = p.W * p.Cin;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int e = tid + it * 256;
@@ -81,15 +87,17 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         const int b = tau / tiles_per_img, rem = tau - b * tiles_per_img;
         const int ty = rem / p.TX, tx = rem - ty * p.TX;
         const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        gbase[it] = ((b * p.H + y0) * p.W + x0) * p.Cin + 4 * q;
-        int m = 0;
+        unsigned goff[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool rok = tv && (y0 + r) >= 0 && (y0 + r) < p.H;
-            if (rok && (x0 + ca) >= 0 && (x0 + ca) < p.W) m |= 1 << (2 * r);
-            if (rok && (x0 + cb) >= 0 && (x0 + cb) < p.W) m |= 1 << (2 * r + 1);
+            const int gy = y0 + r, xa = x0 + ca, xb = x0 + cb;
+            const bool rok = tv && gy >= 0 && gy < p.H;
+            const int row = ((b - b0) * p.H + gy) * p.W;
+            goff[2 * r] = (rok && xa >= 0 && xa < p.W) ? (unsigned)(((row + xa) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
+            goff[2 * r + 1] = (rok && xb >= 0 && xb < p.W) ? (unsigned)(((row + xb) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
         }
-        gmask[it] = m;
+        sG[(2 * it) * 256 + tid] = u32x4{goff[0], goff[1], goff[2], goff[3]};
+        sG[(2 * it + 1) * 256 + tid] = u32x4{goff[4], goff[5], goff[6], goff[7]};
         soff[it] = (j * WT + t) * WKC + 4 * v_slot(q, t);
     }
 
@@ -102,10 +110,10 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         const int t = blk * 16 + lt;
         a_off[blk] = t * WKC + 4 * v_slot(lg, t);
     }
-    // B: lane l -> output channel n0 + 16 wave + (l & 15), k = 4 (l >> 4) .. +3
-    const int b_lane = (wave * 16 + lt) * WKC + 4 * lg;
-    const size_t u_pos_stride = (size_t)p.CoutPad * WKC;          // floats between consecutive positions
-    const float *ub = p.u + (size_t)n0 * WKC;
+    // B: lane l -> output channel n0 + 16 wave + (l & 15), k = 4 (l >> 4) .. +3; position s at scalar offset s * stride
+    const unsigned b_lane = (unsigned)(((wave * 16 + lt) * WKC + 4 * lg) * 4);
+    const unsigned u_pos_stride = (unsigned)(p.CoutPad * WKC * 4);          // bytes between consecutive positions
+    const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * WKC, ((size_t)((p.Cin / WKC) * 16 + B_AHEAD) * p.CoutPad - (size_t)n0) * WKC * sizeof(float));
 
     f32x4 acc[16][2];
 #pragma unroll
@@ -114,26 +122,23 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         for (int blk = 0; blk < 2; ++blk) acc[pp][blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int nchunks = p.Cin / WKC;
-    const int npos_total = nchunks * 16;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
     // weight stream: ring of B_AHEAD + 1 operand registers, position s lives in bq[s & 3]
     f32x4 bq[4];
 #pragma unroll
     for (int s = 0; s < B_AHEAD; ++s)
-        bq[s] = (s < npos_total) ? *(const f32x4 *)(ub + (size_t)s * u_pos_stride + b_lane) : zero4;
+        bq[s] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
 
     // raw patch columns of one item: issue the eight loads / combine them and store the four V rows of column j
     f32x4 d[2][8];
     auto item_load = [&](int it, int c) {
-        const int j = (tid >> 7) + 2 * it;
-        const int ca = (j == 0) ? 0 : (j == 2 ? 2 : 1);
-        const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
-        const float *xa = p.x + c * WKC + gbase[it] + ca * p.Cin, *xb = p.x + c * WKC + gbase[it] + cb * p.Cin;
+        const u32x4 g0 = sG[(2 * it) * 256 + tid], g1 = sG[(2 * it + 1) * 256 + tid];      // written by this thread: no barrier
+        const unsigned so = (unsigned)(c * WKC * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            d[it][2 * r] = (gmask[it] >> (2 * r)) & 1 ? *(const f32x4 *)(xa + r * row_stride) : zero4;
-            d[it][2 * r + 1] = (gmask[it] >> (2 * r + 1)) & 1 ? *(const f32x4 *)(xb + r * row_stride) : zero4;
+        for (int i = 0; i < 4; ++i) {
+            d[it][i] = buffer_load_x4(xbuf, g0[i], so);
+            d[it][4 + i] = buffer_load_x4(xbuf, g1[i], so);
         }
     };
     auto item_store = [&](int it, float *vbuf) {
@@ -148,17 +153,24 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         *(f32x4 *)(dst + 8 * WT * WKC) = w[2] - w[1];           //           [0,-1,1,0]
         *(f32x4 *)(dst + 12 * WT * WKC) = w[1] - w[3];          //           [0,1,0,-1]
     };
-    // 8 MFMAs of position pp on V buffer vbuf
-    auto position = [&](int pp, int s0, const float *vbuf) {
-        const int s_next = s0 + pp + B_AHEAD;
-        if (s_next < npos_total) bq[(pp + B_AHEAD) & 3] = *(const f32x4 *)(ub + (size_t)s_next * u_pos_stride + b_lane);
-        const f32x4 a0 = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[0]);
-        const f32x4 a1 = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
+    // The weight stream runs B_AHEAD positions ahead (issued BEFORE any patch loads of the same position: loads return in
+    // order).  Unconditional: the packed tensor ends with B_AHEAD zero positions, and a loop body without branches lets the
+    // compiler count outstanding loads exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at every merge point).
+    auto prefetch_b = [&](int pp, int s0) {
+        bq[(pp + B_AHEAD) & 3] = buffer_load_x4(ubuf, b_lane, (unsigned)(s0 + pp + B_AHEAD) * u_pos_stride);
+    };
+    // MFMA operands of position pp from V buffer vbuf (one position ahead of their use) / its 8 MFMAs
+    f32x4 a_cur[2], a_nxt[2];
+    auto read_a = [&](f32x4 *a, int pp, const float *vbuf) {
+        a[0] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[0]);
+        a[1] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
+    };
+    auto mfmas = [&](int pp) {
         const f32x4 bv = bq[pp & 3];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            acc[pp][0] = mfma_f32_16x16x4(a0[r], bv[r], acc[pp][0]);
-            acc[pp][1] = mfma_f32_16x16x4(a1[r], bv[r], acc[pp][1]);
+            acc[pp][0] = mfma_f32_16x16x4(a_cur[0][r], bv[r], acc[pp][0]);
+            acc[pp][1] = mfma_f32_16x16x4(a_cur[1][r], bv[r], acc[pp][1]);
         }
     };
 
@@ -171,12 +183,21 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
             item_store(0, sV);
             item_store(1, sV);
             __syncthreads();
+            read_a(a_cur, 0, sV);
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) position(pp, c * 16, sV);
+            for (int pp = 0; pp < 16; ++pp) {
+                prefetch_b(pp, c * 16);
+                if (pp < 15) read_a(a_nxt, pp + 1, sV);
+                mfmas(pp);
+                a_cur[0] = a_nxt[0];
+                a_cur[1] = a_nxt[1];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     } else {
         // V double-buffered: the transform of chunk c + 1 rides inside the MFMA phase of chunk c (one item's eight loads in
-        // flight at a time: issued at positions 0 / 7, combined and stored six positions later), one barrier per chunk
+        // flight at a time: issued at positions 0 / 7, combined and stored six positions later), one barrier per chunk.
+        // The last chunk re-transforms itself into the idle buffer rather than branching around the slices.
         constexpr int VB = 16 * WT * WKC;
         item_load(0, 0);
         item_load(1, 0);
@@ -186,16 +207,22 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         for (int c = 0; c < nchunks; ++c) {
             const float *cur = sV + (c & 1) * VB;
             float *nxt = sV + ((c & 1) ^ 1) * VB;
-            const bool more = c + 1 < nchunks;
+            const int cn = (c + 1 < nchunks) ? c + 1 : c;
+            read_a(a_cur, 0, cur);
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
-                if (more) {
-                    if (pp == 0) item_load(0, c + 1);
-                    if (pp == 6) item_store(0, nxt);
-                    if (pp == 7) item_load(1, c + 1);
-                    if (pp == 13) item_store(1, nxt);
-                }
-                position(pp, c * 16, cur);
+                prefetch_b(pp, c * 16);
+                if (pp == 0) item_load(0, cn);
+                if (pp == 6) item_store(0, nxt);
+                if (pp == 7) item_load(1, cn);
+                if (pp == 13) item_store(1, nxt);
+                if (pp < 15) read_a(a_nxt, pp + 1, cur);
+                mfmas(pp);
+                a_cur[0] = a_nxt[0];
+                a_cur[1] = a_nxt[1];
+                // pin the order: at ~250 VGPRs hipcc schedules for register pressure and otherwise sinks every patch load
+                // down to its use (a full memory latency with no MFMA in flight, once per pair of loads)
+                __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
         }
@@ -303,7 +330,7 @@ int g_variant = 1;
 
 extern "C" size_t dream_conv3x3_winograd_weight_floats(int rows, int cols) {
     const size_t rows_pad = (size_t)((rows + WN - 1) / WN) * WN;
-    return (size_t)(cols / WKC) * 16 * rows_pad * WKC;
+    return ((size_t)(cols / WKC) * 16 + B_AHEAD) * rows_pad * WKC;      // + the zero positions the weight stream over-reads
 }
 
 // w: OIHW [Cout,Cin,3,3]; mode 0: forward operator (rows = Cout, cols = Cin); mode 1: data-gradient operator
@@ -319,6 +346,8 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, rows, cols,
                        rows_pad, mode);
     DREAM_LAUNCH_OK();
+    DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / WKC) * 16 * rows_pad * WKC, 0, (size_t)B_AHEAD * rows_pad * WKC * sizeof(float),
+                                (hipStream_t)stream));
     return 0;
 }
 
@@ -341,7 +370,10 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
     DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (H % 2 == 0 && W % 2 == 0 && residual == nullptr), "winograd conv: fused max-pool needs even H, W and no residual");
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
-    DREAM_REQUIRE((size_t)B * H * W * (size_t)Cin < ((size_t)1 << 31), "winograd conv: input too large for 32-bit offsets");
+    // 32-bit byte offsets relative to the first image a workgroup touches: its 32 tiles span at most this many images
+    const size_t span_imgs = (size_t)WT / ((size_t)((H + 1) / 2) * ((W + 1) / 2)) + 2;
+    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31), "winograd conv: image too large for 32-bit offsets");
+    DREAM_REQUIRE(((size_t)(Cin / WKC) * 16 + B_AHEAD) * ((size_t)(Cout + WN - 1) / WN * WN) * WKC * sizeof(float) < ((size_t)1 << 31), "winograd conv: weights too large");
     WinoParams p;
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -352,7 +384,7 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     p.ntiles = (int)ntiles;
     p.flags = flags;
     void (*kernel)(const WinoParams) = g_variant == 0 ? conv_wino_kernel<0> : conv_wino_kernel<1>;
-    const size_t lds = (size_t)(g_variant == 0 ? 1 : 2) * 16 * WT * WKC * sizeof(float);
+    const size_t lds = (size_t)(g_variant == 0 ? 1 : 2) * 16 * WT * WKC * sizeof(float) + 4 * 256 * 16;   // V buffer(s) + offsets
     if (!g_attr_set[g_variant]) {
         DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         g_attr_set[g_variant] = true;

@@ -36,6 +36,22 @@ DREAM_DEVICE f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// Raw buffer loads (buffer_load_dwordx4 ... offen): 16 bytes per lane at base + voffset + soffset, voffset a 32-bit VGPR,
+// soffset a wave-uniform SGPR.  The hardware bounds-checks voffset against the descriptor's size and returns ZEROS for an
+// out-of-range lane, so zero padding costs no compare / select: an invalid element simply carries voffset = BUFFER_OOB.
+// (No 64-bit address arithmetic either.)  soffset must keep valid lanes inside the buffer; it is not bounds-checked.
+struct BufferRsrc { __amdgpu_buffer_rsrc_t r; };
+constexpr unsigned BUFFER_OOB = 0x80000000u;              // >= any size make_buffer accepts
+DREAM_DEVICE BufferRsrc make_buffer(const void *base, size_t bytes) {
+    const unsigned n = bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes;
+    return {__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n, 0x00020000)};
+}
+DREAM_DEVICE f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(b.r, voffset_bytes, soffset_bytes, 0);
+    return __builtin_bit_cast(f32x4, v);
+}
+
 // wave index within the workgroup as a provably wave-uniform (SGPR) value
 DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

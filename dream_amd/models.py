@@ -405,6 +405,26 @@ class DreamHourglass(nn.Module):
             return grads, g_input
         return grads
 
+    # ---- data-parallel interface (dream_amd/data_parallel.py): one replica's share of a step ------------------------
+    def dp_parameters(self):
+        """Parameters in the order dp_backward returns their gradients."""
+        return self.plan_parameters()
+
+    def dp_trainable(self):
+        return True
+
+    def dp_forward(self, x, save):
+        """-> ([differentiable outputs], context for dp_backward)."""
+        out, saved = self.run_forward(x, [p.detach() for p in self.plan_parameters()], save=save)
+        return [out], saved
+
+    def dp_backward(self, saved, grad_outs, reducer=None):
+        return list(self.run_backward(saved, grad_outs[0].contiguous(), reducer=reducer))
+
+    def dp_finish(self, outs):
+        """Gathered differentiable outputs -> what forward() returns (the soft-argmax head is computed on the gathered maps)."""
+        return outs + [self.softmax[0](outs[0])] if self.internalize_spatial_softmax else outs
+
     def forward(self, x):
         params = self.plan_parameters()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
@@ -684,6 +704,21 @@ class DreamHourglassMultiStage(nn.Module):
             else:
                 per_stage[s] = stages[s].run_backward(saved[s], g.contiguous(), reducer=reducer)
         return [g for grads in per_stage for g in grads]
+
+    def dp_parameters(self):
+        return self.plan_parameters()
+
+    def dp_trainable(self):
+        return True
+
+    def dp_forward(self, x, save):
+        return self.run_forward(x, [[p.detach() for p in st.plan_parameters()] for st in self.stages()], save)
+
+    def dp_backward(self, saved, grad_outs, reducer=None):
+        return self.run_backward(saved, [None if g is None else g.contiguous() for g in grad_outs], reducer=reducer)
+
+    def dp_finish(self, outs):
+        return outs
 
     def forward(self, x, verbose=False):
         stage_params = [st.plan_parameters() for st in self.stages()]
@@ -1026,6 +1061,25 @@ class ResnetSimple(nn.Module):
             side.join()
         return grads
 
+    def dp_parameters(self):
+        return list(self.parameters())
+
+    def dp_trainable(self):
+        return self.training                     # evaluation mode has no backward plan (BatchNorm folded)
+
+    def dp_forward(self, x, save):
+        if self.training:
+            out, tape = self.run_forward_train(x)
+            return [out], (tape if save else None)
+        return [self.run_forward(x)], None
+
+    def dp_backward(self, tape, grad_outs, reducer=None):
+        gdict = self.run_backward(tape, grad_outs[0].contiguous(), reducer=reducer)
+        return [gdict[p] for p in self.parameters()]
+
+    def dp_finish(self, outs):
+        return outs
+
     def forward(self, x):
         params = list(self.parameters())
         if self.training:
@@ -1054,14 +1108,4 @@ class _ResnetFunction(torch.autograd.Function):
         return (None, None) + tuple(_reduced(reducer, [gdict[p] for p in ctx.params]))
 
 
-class DreamDataParallel(nn.Module):
-    """Keeps the reference's ``module.``-prefixed state_dict (torch.nn.DataParallel wrapper at
-    dream/network.py:244-256,281-284) without DataParallel's per-call replicate/scatter/gather."""
-
-    def __init__(self, module, device_ids=None):
-        super().__init__()
-        self.module = module
-        self.device_ids = device_ids
-
-    def forward(self, *args, **kwargs):
-        return self.module(*args, **kwargs)
+from .data_parallel import DreamDataParallel  # noqa: E402,F401  (the reference's torch.nn.DataParallel wrapper, network.py:244-256)

@@ -13,8 +13,9 @@ What is different underneath:
     best-peak rule; network.py:529-581 + image_proc.py:914-1018) in ONE pass on the GPU and copies
     just the [B,K,2] float32 result to the host, instead of B*K device->host map copies;
   * ``criterion`` / ``optimizer`` are HIP-kernel-backed drop-ins for MSELoss / Adam / SGD;
-  * multi-GPU is one process per GPU (torchrun) with an RCCL all-reduce of the flat gradient
-    buffer instead of single-process nn.DataParallel (network.py:244-256).
+  * multi-GPU: ``training.platform.gpu_ids`` drives persistent single-process replicas (dream_amd/data_parallel.py) in place
+    of nn.DataParallel's per-call replicate/scatter/gather (network.py:244-256); under torchrun it is one process per GPU with
+    an RCCL all-reduce of the gradient buckets.
 """
 import os
 
@@ -185,8 +186,14 @@ class DreamNetwork:
         else:
             assert False, 'Network architecture type "{}" not defined.'.format(self.architecture_type)
 
+        # network.py:185,244-256,281-284: torch.nn.DataParallel(net, device_ids=gpu_ids or None).cuda() -- every listed GPU
+        # (all visible ones when the list is empty) takes a contiguous chunk of each batch.  Here the replicas are
+        # persistent and their parameters live in one flat buffer each (dream_amd/data_parallel.py); under torchrun the
+        # process drives the one GPU LOCAL_RANK names and the exchange is the RCCL all-reduce inside the model.
         self.device = _pick_device(gpu_ids)
         self.model = models.DreamDataParallel(net, device_ids=gpu_ids if gpu_ids else None).to(self.device)
+        self.model.flatten_parameters()
+        self._dist_state_synced = False
 
         loss_type = arch["loss"]["type"]
         if loss_type == "mse":
@@ -224,6 +231,8 @@ class DreamNetwork:
     # ---- training (network.py:328-364) -------------------------------------------------------------------
     def train(self, network_input_heads, target):
         assert self.optimizer, "Optimizer must be defined. Use enable_training() first."
+        if not self._dist_state_synced:
+            self._broadcast_initial_state()
         self.optimizer.zero_grad()
         loss = self.loss(network_input_heads, target)
         loss.backward()
@@ -295,7 +304,8 @@ class DreamNetwork:
             return self.model(self._to_device(network_input))
         if heads == ["belief_maps"]:
             x = self._to_device(network_input)
-            if self.hip_graph and not self.model.training and not torch.is_grad_enabled() and x.is_cuda:
+            if (self.hip_graph and not self.model.training and not torch.is_grad_enabled() and x.is_cuda
+                    and self.model.n_devices(x.shape[0]) == 1):
                 return self._inference_graphed(x)
             belief_maps_batch, kps = self._inference_on_device(x)
             # the reference returns the keypoints as a CPU float32 tensor (network.py:581)
@@ -303,13 +313,21 @@ class DreamNetwork:
         assert False, "Could not determine how to conduct inference on this network."
 
     def _inference_on_device(self, x):
-        belief_maps_batch = self.model(x)[-1]
         out_w, out_h = self.trained_net_output_resolution()
         offset = 0.0 if (out_w >= 400 and out_h >= 400) else 0.4395               # network.py:534-538
-        with torch.no_grad():
-            kps, _ = ops.keypoints_from_belief_maps(belief_maps_batch.detach(), offset, self.use_belief_peak_scores,
-                                                    self.belief_peak_next_best_score)
-        return belief_maps_batch, kps
+
+        def peaks(maps):
+            with torch.no_grad():
+                return ops.keypoints_from_belief_maps(maps.detach(), offset, self.use_belief_peak_scores,
+                                                      self.belief_peak_next_best_score)[0]
+        dp = self.model
+        if isinstance(dp, models.DreamDataParallel) and dp.n_devices(x.shape[0]) > 1 and not torch.is_grad_enabled():
+            # embarrassingly parallel split: every GPU runs the CNN and the peak stage on its chunk; the maps are gathered
+            # on device_ids[0] (the reference's return contract), the [b,K,2] keypoints meet on the host
+            heads, kps_chunks = dp.inference_shards(x, lambda outs: peaks(outs[-1]))
+            return heads[-1], torch.cat([k.cpu() for k in kps_chunks], dim=0)
+        belief_maps_batch = self.model(x)[-1]
+        return belief_maps_batch, peaks(belief_maps_batch)
 
     def _inference_graphed(self, x):
         """hipGraph replay of _inference_on_device for this input shape; re-captured when a parameter or buffer changed
@@ -378,6 +396,30 @@ class DreamNetwork:
 
     def enable_evaluation(self):
         self.model.eval()
+
+    def _broadcast_initial_state(self):
+        """One process per GPU (torchrun): every rank must start from rank 0's parameters and BatchNorm statistics --
+        nothing else guarantees that the ranks seeded their initialisation alike.  One broadcast of the flat parameter
+        buffer (and of the flat buffer of running statistics) before the first step; afterwards the replicas stay
+        identical because every rank applies the same update to the same all-reduced gradients."""
+        self._dist_state_synced = True
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        rec = getattr(self.model.module, "_dream_flat", None)
+        with torch.no_grad():
+            if rec is not None and rec["params"] is not None:
+                dist.broadcast(rec["params"], src=0)
+                for p in rec["param_list"]:
+                    ops.bump_version(p)
+                if rec["buffers"] is not None:
+                    dist.broadcast(rec["buffers"], src=0)
+                    for m, n in rec["buffer_list"]:
+                        ops.bump_version(m._buffers[n])
+            else:
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    dist.broadcast(t.data, src=0)
+                    ops.bump_version(t)
 
     def _to_device(self, t):
         return t if t.device == self.device else t.to(self.device, non_blocking=True)

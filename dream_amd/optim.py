@@ -48,23 +48,95 @@ class HipSmoothL1Loss(torch.nn.Module):
         return _SmoothL1Function.apply(input, target)
 
 
-class HipAdam(torch.optim.Optimizer):
+def _flat_span(tensors):
+    """If every tensor is a contiguous fp32 view into ONE storage: (flat view covering min..max extent, float offsets of the
+    tensors inside it); else None.  The parameters of a DreamNetwork model are such views (dream_amd/data_parallel.py:
+    flatten_module_), and so are the gradients the data-parallel autograd node hands out."""
+    if not tensors:
+        return None
+    t0 = tensors[0]
+    st = t0.untyped_storage()
+    base = st.data_ptr()
+    lo, hi, offs = None, None, []
+    for t in tensors:
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.untyped_storage().data_ptr() != base or t.device != t0.device:
+            return None
+        o = (t.data_ptr() - base) // 4
+        offs.append(o)
+        lo = o if lo is None else min(lo, o)
+        hi = o + t.numel() if hi is None else max(hi, o + t.numel())
+    flat = torch.empty(0, dtype=torch.float32, device=t0.device).set_(st, lo, (hi - lo,), (1,))
+    return flat, [o - lo for o in offs]
+
+
+class _FlatStepMixin:
+    """One kernel launch per optimizer step instead of one per tensor (46 for vgg_q, 318 for resnet_h): parameters that
+    are views of one flat buffer are updated as that buffer; the gradients are used in place when they form the same layout
+    (data-parallel path) or gathered into a flat buffer by one multi-tensor copy."""
+
+    def _flat_plan(self, params):
+        key = tuple((p.data_ptr(), p.numel()) for p in params)
+        plan = getattr(self, "_plan", None)
+        if plan is None or plan["key"] != key:
+            span = _flat_span([p.data for p in params])
+            plan = {"key": key, "span": span}
+            if span is not None:
+                flat, offs = span
+                plan["grad"] = torch.zeros_like(flat)
+                plan["grad_views"] = [plan["grad"][o:o + p.numel()].view(p.shape) for o, p in zip(offs, params)]
+            self._plan = plan
+        return plan
+
+    def _flat_grad(self, plan, params):
+        grads = [p.grad for p in params]
+        gspan = _flat_span(grads)
+        if gspan is not None and gspan[1] == plan["span"][1] and gspan[0].numel() == plan["span"][0].numel():
+            return gspan[0]                                   # already laid out like the parameters: use in place
+        torch._foreach_copy_(plan["grad_views"], grads)       # one multi-tensor copy (padding between tensors stays zero)
+        return plan["grad"]
+
+
+class HipAdam(_FlatStepMixin, torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    def _state_of(self, p, like_flat=None, off=0):
+        st = self.state[p]
+        if not st:
+            st["step"] = 0
+            if like_flat is None:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            else:                                             # views of the flat moment buffers
+                st["exp_avg"] = like_flat[0][off:off + p.numel()].view(p.shape)
+                st["exp_avg_sq"] = like_flat[1][off:off + p.numel()].view(p.shape)
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
-            for p in group["params"]:
+            params = group["params"]
+            plan = self._flat_plan(params) if len(self.param_groups) == 1 and all(p.grad is not None for p in params) else None
+            if plan is not None and plan["span"] is not None and not any(self.state[p] and "flat" not in self.state[p] for p in params):
+                flat, offs = plan["span"]
+                if "moments" not in plan:
+                    plan["moments"] = (torch.zeros_like(flat), torch.zeros_like(flat))
+                    plan["step"] = 0
+                    for p, o in zip(params, offs):
+                        self._state_of(p, plan["moments"], o)["flat"] = True
+                plan["step"] += 1
+                ops.adam_step_(flat, self._flat_grad(plan, params), plan["moments"][0], plan["moments"][1], group["lr"], b1, b2,
+                               group["eps"], plan["step"])
+                for p in params:
+                    self.state[p]["step"] = plan["step"]
+                    _bump_version(p)
+                continue
+            for p in params:
                 if p.grad is None:
                     continue
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st = self._state_of(p)
                 st["step"] += 1
                 ops.adam_step_(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
                                group["eps"], st["step"])
@@ -72,7 +144,7 @@ class HipAdam(torch.optim.Optimizer):
         return loss
 
 
-class HipSGD(torch.optim.Optimizer):
+class HipSGD(_FlatStepMixin, torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3):
         super().__init__(params, dict(lr=lr))
 
@@ -80,7 +152,14 @@ class HipSGD(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
-            for p in group["params"]:
+            params = group["params"]
+            plan = self._flat_plan(params) if len(self.param_groups) == 1 and all(p.grad is not None for p in params) else None
+            if plan is not None and plan["span"] is not None:
+                ops.sgd_step_(plan["span"][0], self._flat_grad(plan, params), group["lr"])
+                for p in params:
+                    _bump_version(p)
+                continue
+            for p in params:
                 if p.grad is not None:
                     ops.sgd_step_(p.data, p.grad.contiguous(), group["lr"])
                     _bump_version(p)

@@ -68,6 +68,18 @@ inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
     }
     return c;
 }
+// raw buffer loads: zeros for lanes whose voffset is outside the descriptor (see the product header)
+struct BufferRsrc { const char *base; unsigned bytes; };
+constexpr unsigned BUFFER_OOB = 0x80000000u;
+inline BufferRsrc make_buffer(const void *base, size_t bytes) {
+    return {(const char *)base, bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes};
+}
+inline f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if ((unsigned long long)voffset_bytes + 16ull <= (unsigned long long)b.bytes)
+        __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 16);
+    return v;
+}
 inline int wave_index() { return emu::wave(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }

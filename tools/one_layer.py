@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run one conv layer shape repeatedly on one kernel (for rocprofv3 --pmc passes).
-usage: one_layer.py <fp32|f16x3> <variant> <res> <cin> <cout> <batch> [reps]"""
+usage: one_layer.py <fp32|f16x3|wino> <variant> <res> <cin> <cout> <batch> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +12,12 @@ lib = _hip.lib()
 x = torch.randn(batch, res, res, cin, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
 bias = torch.randn(cout, device="cuda")
-if kind == "fp32":
+if kind == "wino":
+    u, _ = ops.pack_weight_winograd(w, 0)
+    lib.dream_conv3x3_winograd_set_variant(variant)
+    for _ in range(reps):
+        ops.conv3x3_winograd(x, u, cout, None, bias, None, 1)
+elif kind == "fp32":
     packed, rows, _, _ = ops.pack_weight(w, 0)
     lib.dream_conv3x3_set_variant(variant)
     for _ in range(reps):
