@@ -159,19 +159,19 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     auto prefetch_b = [&](int pp, int s0) {
         bq[(pp + B_AHEAD) & 3] = buffer_load_x4(ubuf, b_lane, (unsigned)(s0 + pp + B_AHEAD) * u_pos_stride);
     };
-    // MFMA operands of position pp from V buffer vbuf (one position ahead of their use) / its 8 MFMAs
-    f32x4 a_cur[2], a_nxt[2];
-    auto read_a = [&](f32x4 *a, int pp, const float *vbuf) {
-        a[0] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[0]);
-        a[1] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
+    // MFMA operands of position pp from V buffer vbuf: read one position ahead of their use into the register set of the
+    // other parity (no copies).  The schedule is pinned in groups of two MFMAs (sched_barrier): at ~200 VGPRs hipcc
+    // schedules for register pressure -- it sinks every load to its use (a full LDS / memory latency with no MFMA of this
+    // wave in flight) and issues the four MFMAs of one accumulator back to back (40-cycle dependent latency vs 32 issue).
+    f32x4 a[2][2];
+    auto read_a = [&](int set, int pp, const float *vbuf) {
+        a[set][0] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[0]);
+        a[set][1] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
     };
-    auto mfmas = [&](int pp) {
-        const f32x4 bv = bq[pp & 3];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[pp][0] = mfma_f32_16x16x4(a_cur[0][r], bv[r], acc[pp][0]);
-            acc[pp][1] = mfma_f32_16x16x4(a_cur[1][r], bv[r], acc[pp][1]);
-        }
+    auto mfma_pair = [&](int pp, int r) {
+        acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp & 3][r], acc[pp][0]);
+        acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp & 3][r], acc[pp][1]);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     if (PIPE == 0) {
@@ -183,15 +183,16 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
             item_store(0, sV);
             item_store(1, sV);
             __syncthreads();
-            read_a(a_cur, 0, sV);
+            read_a(0, 0, sV);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
                 prefetch_b(pp, c * 16);
-                if (pp < 15) read_a(a_nxt, pp + 1, sV);
-                mfmas(pp);
-                a_cur[0] = a_nxt[0];
-                a_cur[1] = a_nxt[1];
-                __builtin_amdgcn_sched_barrier(0);
+                mfma_pair(pp, 0);
+                if (pp < 15) read_a((pp + 1) & 1, pp + 1, sV);
+                mfma_pair(pp, 1);
+                mfma_pair(pp, 2);
+                mfma_pair(pp, 3);
             }
         }
     } else {
@@ -208,21 +209,20 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
             const float *cur = sV + (c & 1) * VB;
             float *nxt = sV + ((c & 1) ^ 1) * VB;
             const int cn = (c + 1 < nchunks) ? c + 1 : c;
-            read_a(a_cur, 0, cur);
+            read_a(0, 0, cur);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
                 prefetch_b(pp, c * 16);
                 if (pp == 0) item_load(0, cn);
-                if (pp == 6) item_store(0, nxt);
                 if (pp == 7) item_load(1, cn);
+                mfma_pair(pp, 0);
+                if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
+                mfma_pair(pp, 1);
+                if (pp == 6) item_store(0, nxt);
                 if (pp == 13) item_store(1, nxt);
-                if (pp < 15) read_a(a_nxt, pp + 1, cur);
-                mfmas(pp);
-                a_cur[0] = a_nxt[0];
-                a_cur[1] = a_nxt[1];
-                // pin the order: at ~250 VGPRs hipcc schedules for register pressure and otherwise sinks every patch load
-                // down to its use (a full memory latency with no MFMA in flight, once per pair of loads)
-                __builtin_amdgcn_sched_barrier(0);
+                mfma_pair(pp, 2);
+                mfma_pair(pp, 3);
             }
             __syncthreads();
         }
