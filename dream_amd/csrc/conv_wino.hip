@@ -25,6 +25,13 @@
 #include "common.h"
 #include "../../include/dream_hip.h"
 
+// Timing diagnostics only (tools/wino_diag.py builds separate libraries with -DDREAM_WINO_DIAG=k; never the product
+// library): bit 0 skips the input transform (loads + V stores), bit 1 the weight stream, bit 2 the per-chunk barrier.
+// Results are then wrong by construction; the point is what each part costs.
+#ifndef DREAM_WINO_DIAG
+#define DREAM_WINO_DIAG 0
+#endif
+
 namespace {
 
 struct WinoParams {
@@ -36,14 +43,17 @@ struct WinoParams {
     float *y;                // [B,H,W,Cout]  (or [B,H/2,W/2,Cout] with DREAM_CONV_POOL2)
     int B, H, W, Cin, Cout, CoutPad;
     int TY, TX;              // 2x2 tiles per image
-    int ntiles;              // B * TY * TX
+    int ntiles;              // B * TY * TX  (< 2^24)
+    unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX): tile -> (image, row, column) without divides
     int flags;
 };
 
 constexpr int WT = 32;       // tiles per workgroup
 constexpr int WN = 64;       // output channels per workgroup
 constexpr int WKC = 16;      // input channels per chunk
-constexpr int B_AHEAD = 3;   // positions the weight stream runs ahead of the MFMAs
+constexpr int B_RING = 8;    // operand registers of the weight stream
+constexpr int B_AHEAD = 6;   // positions the weight stream runs ahead of the MFMAs: far enough that an operand is never queued
+                             // behind the eight patch loads of an item (loads return in order)
 
 // physical float4 slot of logical slot q (k = 4q .. 4q+3) in row t of a V plane
 DREAM_DEVICE int v_slot(int q, int t) { return q ^ ((t >> 2) & 2); }
@@ -68,7 +78,7 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, row, column) relative to the first
     // image this workgroup touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare /
     // select per load), the chunk's channel offset in the scalar operand.
-    const int b0 = tile0 / tiles_per_img;
+    const int b0 = div_magic40(tile0, p.magic_tpi);
     const size_t img_floats = (size_t)p.H * p.W * p.Cin;
     const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
     // The 16 offsets of a thread are parked in LDS ([4 quads of offsets][256 threads] uint4, conflict-free b128 access) and
@@ -84,8 +94,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
         const int tau = tile0 + t;
         const bool tv = tau < p.ntiles;
-        const int b = tau / tiles_per_img, rem = tau - b * tiles_per_img;
-        const int ty = rem / p.TX, tx = rem - ty * p.TX;
+        const int b = div_magic40(tau, p.magic_tpi), rem = tau - b * tiles_per_img;
+        const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
         unsigned goff[8];
 #pragma unroll
@@ -124,8 +134,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     const int nchunks = p.Cin / WKC;
     const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    // weight stream: ring of B_AHEAD + 1 operand registers, position s lives in bq[s & 3]
-    f32x4 bq[4];
+    // weight stream: ring of B_RING operand registers, position s lives in bq[s % B_RING]
+    f32x4 bq[B_RING];
 #pragma unroll
     for (int s = 0; s < B_AHEAD; ++s)
         bq[s] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
@@ -157,7 +167,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     // order).  Unconditional: the packed tensor ends with B_AHEAD zero positions, and a loop body without branches lets the
     // compiler count outstanding loads exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at every merge point).
     auto prefetch_b = [&](int pp, int s0) {
-        bq[(pp + B_AHEAD) & 3] = buffer_load_x4(ubuf, b_lane, (unsigned)(s0 + pp + B_AHEAD) * u_pos_stride);
+        if (DREAM_WINO_DIAG & 2) return;
+        bq[(pp + B_AHEAD) % B_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)(s0 + pp + B_AHEAD) * u_pos_stride);
     };
     // MFMA operands of position pp from V buffer vbuf: read one position ahead of their use into the register set of the
     // other parity (no copies).  The schedule is pinned in groups of two MFMAs (sched_barrier): at ~200 VGPRs hipcc
@@ -169,8 +180,8 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         a[set][1] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
     };
     auto mfma_pair = [&](int pp, int r) {
-        acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp & 3][r], acc[pp][0]);
-        acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp & 3][r], acc[pp][1]);
+        acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], acc[pp][0]);
+        acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp % B_RING][r], acc[pp][1]);
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -214,21 +225,27 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp) {
                 prefetch_b(pp, c * 16);
-                if (pp == 0) item_load(0, cn);
-                if (pp == 7) item_load(1, cn);
+                if (!(DREAM_WINO_DIAG & 1)) {
+                    if (pp == 0) item_load(0, cn);
+                    if (pp == 7) item_load(1, cn);
+                }
                 mfma_pair(pp, 0);
                 if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
                 mfma_pair(pp, 1);
-                if (pp == 6) item_store(0, nxt);
-                if (pp == 13) item_store(1, nxt);
+                if (!(DREAM_WINO_DIAG & 1)) {
+                    if (pp == 6) item_store(0, nxt);
+                    if (pp == 13) item_store(1, nxt);
+                }
                 mfma_pair(pp, 2);
                 mfma_pair(pp, 3);
             }
-            __syncthreads();
+            if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
         }
     }
 
     // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ----------------
+    // Output addresses are 32-bit byte offsets from the first image of the workgroup, BUFFER_OOB for everything that must
+    // not be written (tile beyond the batch, channel beyond Cout, odd-extent overhang): masked stores without branches.
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
     const bool pool = (p.flags & DREAM_CONV_POOL2) != 0;
     const bool mask = (p.flags & DREAM_CONV_RELUMASK) != 0;
@@ -237,13 +254,20 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     const float sc = (p.scale != nullptr && cok) ? p.scale[col] : 1.0f;
     const float sh = (p.shift != nullptr && cok) ? p.shift[col] : 0.0f;
     const int Ho = pool ? p.H / 2 : p.H, Wo = pool ? p.W / 2 : p.W;
+    const size_t out_img = (size_t)Ho * Wo * p.Cout;
+    const BufferRsrc ybuf = make_buffer(p.y + (size_t)b0 * out_img, (size_t)(p.B - b0) * out_img * sizeof(float));
+    const BufferRsrc rbuf = make_buffer(p.residual != nullptr ? p.residual + (size_t)b0 * out_img : p.y,
+                                        p.residual != nullptr ? (size_t)(p.B - b0) * out_img * sizeof(float) : 0);
+    const unsigned px_b = (unsigned)(p.Cout * 4), row_b = (unsigned)(Wo * p.Cout * 4);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
+        // the lane's four tiles of this block are consecutive: decompose the first, step the others
+        const int tau0 = tile0 + blk * 16 + lg * 4;                 // C/D layout: row = 4 (l >> 4) + reg, col = l & 15
+        int b = div_magic40(tau0, p.magic_tpi);
+        const int rem = tau0 - b * tiles_per_img;
+        int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int tau = tile0 + blk * 16 + lg * 4 + r;          // C/D layout: row = 4 (l >> 4) + reg, col = l & 15
-            const int b = tau / tiles_per_img, rem = tau - b * tiles_per_img;
-            const int ty = rem / p.TX, tx = rem - ty * p.TX;
             float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -256,26 +280,32 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
                 out[i][0] = s[i][0] + s[i][1] + s[i][2];
                 out[i][1] = s[i][1] - s[i][2] - s[i][3];
             }
-            if (tau >= p.ntiles || !cok) continue;
+            const bool tok = cok && (tau0 + r) < p.ntiles;
+            const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
+            const unsigned base = (unsigned)(((((b - b0) * Ho + oy) * Wo + ox) * p.Cout + col) * 4);
             float best = -__builtin_huge_valf();
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const int oy = 2 * ty + i, ox = 2 * tx + jj;
                     float v = out[i][jj];
                     if (p.scale != nullptr) v = v * sc;
                     v = v + sh;
-                    const bool inb = oy < p.H && ox < p.W;
-                    if (p.residual != nullptr && inb) {
-                        const float rv = p.residual[(((size_t)b * p.H + oy) * p.W + ox) * p.Cout + col];
+                    const bool inb = tok && (oy + i) < Ho && (ox + jj) < Wo;      // (pool: the window, always inside)
+                    const unsigned off = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
+                    if (p.residual != nullptr) {
+                        const float rv = buffer_load_f32(rbuf, off, 0);
                         v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
                     }
                     if (relu) v = fmaxf(v, 0.0f);
                     if (pool) best = fmaxf(best, v);
-                    else if (inb) p.y[(((size_t)b * p.H + oy) * p.W + ox) * p.Cout + col] = v;
+                    else buffer_store_f32(ybuf, v, off, 0);
                 }
-            if (pool && ty < Ho && tx < Wo) p.y[(((size_t)b * Ho + ty) * Wo + tx) * p.Cout + col] = best;
+            if (pool) buffer_store_f32(ybuf, best, tok ? base : BUFFER_OOB, 0);
+            if (++tx == p.TX) {                                     // next tile
+                tx = 0;
+                if (++ty == p.TY) { ty = 0; ++b; }
+            }
         }
     }
 }
@@ -372,7 +402,7 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
     // 32-bit byte offsets relative to the first image a workgroup touches: its 32 tiles span at most this many images
     const size_t span_imgs = (size_t)WT / ((size_t)((H + 1) / 2) * ((W + 1) / 2)) + 2;
-    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31), "winograd conv: image too large for 32-bit offsets");
+    DREAM_REQUIRE(span_imgs * H * W * (size_t)(Cin > Cout ? Cin : Cout) * sizeof(float) < ((size_t)1 << 31), "winograd conv: image too large for 32-bit offsets");
     DREAM_REQUIRE(((size_t)(Cin / WKC) * 16 + B_AHEAD) * ((size_t)(Cout + WN - 1) / WN * WN) * WKC * sizeof(float) < ((size_t)1 << 31), "winograd conv: weights too large");
     WinoParams p;
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
@@ -381,7 +411,10 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
     const long ntiles = (long)B * p.TY * p.TX;
     DREAM_REQUIRE(ntiles < ((long)1 << 31), "winograd conv: too many tiles");
+    DREAM_REQUIRE(ntiles < ((long)1 << 24), "winograd conv: %ld tiles, the tile decomposition handles < 2^24", ntiles);
     p.ntiles = (int)ntiles;
+    p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(p.TY * p.TX) - 1) / (unsigned long long)(p.TY * p.TX);
+    p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
     void (*kernel)(const WinoParams) = g_variant == 0 ? conv_wino_kernel<0> : conv_wino_kernel<1>;
     const size_t lds = (size_t)(g_variant == 0 ? 1 : 2) * 16 * WT * WKC * sizeof(float) + 4 * 256 * 16;   // V buffer(s) + offsets

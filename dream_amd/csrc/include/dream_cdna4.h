@@ -52,6 +52,16 @@ DREAM_DEVICE f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned
     return __builtin_bit_cast(f32x4, v);
 }
 
+DREAM_DEVICE float buffer_load_f32(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voffset_bytes, soffset_bytes, 0));
+}
+// an out-of-range lane (voffset = BUFFER_OOB) stores nothing: masked stores without branches
+DREAM_DEVICE void buffer_store_f32(BufferRsrc b, float v, unsigned voffset_bytes, unsigned soffset_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voffset_bytes, soffset_bytes, 0);
+}
+// n / d for n < 2^24 with magic = ceil(2^40 / d) (host side: magic_div40): exact, 3 VALU instead of ~40
+DREAM_DEVICE int div_magic40(int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); }
+
 // wave index within the workgroup as a provably wave-uniform (SGPR) value
 DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -80,6 +80,17 @@ inline f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffs
         __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 16);
     return v;
 }
+inline float buffer_load_f32(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    float v = 0.0f;
+    if ((unsigned long long)voffset_bytes + 4ull <= (unsigned long long)b.bytes)
+        __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 4);
+    return v;
+}
+inline void buffer_store_f32(BufferRsrc b, float v, unsigned voffset_bytes, unsigned soffset_bytes) {
+    if ((unsigned long long)voffset_bytes + 4ull <= (unsigned long long)b.bytes)
+        __builtin_memcpy(const_cast<char *>(b.base) + (size_t)voffset_bytes + soffset_bytes, &v, 4);
+}
+inline int div_magic40(int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); }
 inline int wave_index() { return emu::wave(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }

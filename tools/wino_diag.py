@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Knock-out timing of the Winograd kernel: libraries built with -DDREAM_WINO_DIAG=k (bit 0: no input transform, bit 1: no
+weight stream, bit 2: no per-chunk barrier; results are wrong by construction) against the product library, same layer,
+same box.  `build` runs here (hipcc), `run` on the GPU box.   python tools/wino_diag.py build | run [--batch 128]"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+KS = [1, 2, 4, 3, 7]
+OUT = os.path.join(ROOT, "build", "diag")
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    csrc = os.path.join(ROOT, "dream_amd", "csrc")
+    procs = []
+    for k in KS:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-I", os.path.join(csrc, "include"), "-DDREAM_WINO_DIAG=%d" % k, os.path.join(csrc, "conv_wino.hip"),
+               os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino_diag_%d.so" % k)]
+        procs.append(subprocess.Popen(cmd))
+    assert all(p.wait() == 0 for p in procs)
+
+
+def run(batch):
+    import torch
+    from dream_amd import _hip, ops
+    libs = {0: _hip.lib()}
+    for k in KS:
+        h = ctypes.CDLL(os.path.join(OUT, "libwino_diag_%d.so" % k))
+        fn = h.dream_conv3x3_winograd_nhwc_f32
+        fn.restype, fn.argtypes = _hip._SIGNATURES["dream_conv3x3_winograd_nhwc_f32"]
+        libs[k] = h
+    names = {0: "product", 1: "no transform", 2: "no weight stream", 4: "no barrier", 3: "no transform, no weights",
+             7: "MFMAs + operand reads only"}
+    for (res, cin, cout) in [(400, 64, 64), (100, 256, 256), (50, 512, 512)]:
+        x = torch.randn(batch, res, res, cin, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        u, _ = ops.pack_weight_winograd(w, 0)
+        y = torch.empty(batch, res, res, cout, device="cuda")
+        flops = 2.0 * batch * res * res * cin * cout * 9 / 2.25
+        line = []
+        for k in [0] + KS:
+            fn = libs[k].dream_conv3x3_winograd_nhwc_f32
+
+            def call():
+                rc = fn(x.data_ptr(), u.data_ptr(), None, None, None, y.data_ptr(), batch, res, res, cin, cout, 1,
+                        torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+            call()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                call()
+                e.record()
+                torch.cuda.synchronize()
+                best = min(best, s.elapsed_time(e))
+            line.append("%s %.3f ms (%.2f of MFMA peak)" % (names[k], best, flops / best / 1e9 / 157.3))
+        print("%d %d->%d b=%d: " % (res, cin, cout, batch) + " | ".join(line), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 128)
