@@ -14,19 +14,29 @@
 // GEMM view: for each of the 16 positions p of the transformed 4x4 domain,  M_p[tile][cout] = sum_cin V_p[tile][cin] U_p[cin][cout].
 //   * tiles are numbered over (image, tile row, tile column) and a workgroup takes 32 consecutive ones, so every map size
 //     (400 .. 13 pixels) fills its workgroups (no 2-D tile padding);
-//   * workgroup = 4 wavefronts = 32 tiles x 64 output channels; wavefront = 32 tiles x 16 channels x all 16 positions:
-//     2 x 16 accumulators of v_mfma_f32_16x16x4_f32 (128 VGPRs), so the inverse transform is lane-local;
-//   * V (the transformed input) is computed by the workgroup for one 16-channel chunk at a time and lives in LDS
-//     (32 KB, float4 slots XOR-swizzled so that both the b128 writes and the MFMA-operand b128 reads are conflict-free);
+//   * workgroup = NW wavefronts (4 or 8) = 32 tiles x 16 NW output channels; wavefront = 32 tiles x 16 channels x all 16
+//     positions: 2 x 16 accumulators of v_mfma_f32_16x16x4_f32 (128 VGPRs), so the inverse transform is lane-local.
+//     NW = 8 (128 channels, one workgroup per CU) halves the input-transform work per MFMA; NW = 4 (two workgroups per CU)
+//     serves the 64-channel layers;
+//   * V (the transformed input) is computed by the workgroup for one 16-channel chunk at a time into a double-buffered LDS
+//     tile (2 x 33 KB; float4 slots XOR-swizzled and planes skewed by 16 bytes so that the b128 transform stores and the
+//     b128 MFMA-operand reads are both conflict-free) WHILE the MFMAs of the previous chunk run: a thread owns (tile,
+//     channel quad, patch row), loads the row's four pixels once, transforms along the row, gets the other rows' values
+//     for the column transform from its quad neighbours (DPP quad_perm) -- no element of the input is loaded twice;
 //   * U (the transformed weights, packed [Cin/16][16][CoutPad][16]) never touches LDS: every wavefront streams its own
-//     16-channel operand rows straight from L2 into registers, 1 KB coalesced per position, three positions ahead;
-//   * two workgroups per CU (2 waves per SIMD): one transforms its next chunk while the other one owns the matrix pipe.
+//     16-channel operand rows straight from L2 into a ring of eight registers, 1 KB coalesced per position, six positions
+//     ahead (loads return in order: an operand must never queue behind a patch load that misses to HBM);
+//   * all global traffic goes through buffer descriptors: 32-bit offsets, zero padding and store masking by the hardware's
+//     bounds check (offset BUFFER_OOB), no 64-bit address arithmetic; tile -> (image, row, column) by magic multiplication;
+//   * the instruction order of the main loop is pinned (sched_barrier per pair of MFMAs): one patch load per pair, MFMA
+//     operands read one position ahead into the register set of the other parity, alternating accumulators.
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
 
 // Timing diagnostics only (tools/wino_diag.py builds separate libraries with -DDREAM_WINO_DIAG=k; never the product
-// library): bit 0 skips the input transform (loads + V stores), bit 1 the weight stream, bit 2 the per-chunk barrier.
+// library): bit 0 skips the input transform (loads + V stores), bit 1 the weight stream, bit 2 the per-chunk barrier,
+// bit 3 makes all 32 tiles read the first tile's patch, bit 4 makes every chunk read the first chunk's channels.
 // Results are then wrong by construction; the point is what each part costs.
 #ifndef DREAM_WINO_DIAG
 #define DREAM_WINO_DIAG 0
@@ -36,7 +46,7 @@ namespace {
 
 struct WinoParams {
     const float *x;          // [B,H,W,Cin]
-    const float *u;          // [Cin/16][16][CoutPad][16]
+    const float *u;          // [Cin/16][16][CoutPad][16] (+ B_AHEAD zero positions)
     const float *scale;      // per-channel multiplier (eval-mode BatchNorm fold) or null
     const float *shift;      // per-channel addend (bias / BN shift) or null
     const float *residual;   // ReLU mask source (DREAM_CONV_RELUMASK) or addend of the output's shape, or null
@@ -49,18 +59,25 @@ struct WinoParams {
 };
 
 constexpr int WT = 32;       // tiles per workgroup
-constexpr int WN = 64;       // output channels per workgroup
 constexpr int WKC = 16;      // input channels per chunk
+constexpr int WPAD = 128;    // output channels the packed weights are padded to (a multiple of every workgroup width)
+constexpr int PS = WT * WKC + 4;   // floats per V plane: 512 + a 16-byte skew (planes 4r + j of a quad's four rows r land on
+                                   // banks 0 / 16 / 32 / 48, so the transform's b128 stores do not collide)
+constexpr int VB = 16 * PS;  // floats per V buffer
 constexpr int B_RING = 8;    // operand registers of the weight stream
 constexpr int B_AHEAD = 6;   // positions the weight stream runs ahead of the MFMAs: far enough that an operand is never queued
-                             // behind the eight patch loads of an item (loads return in order)
+                             // behind the patch loads of an item (loads return in order)
 
 // physical float4 slot of logical slot q (k = 4q .. 4q+3) in row t of a V plane
 DREAM_DEVICE int v_slot(int q, int t) { return q ^ ((t >> 2) & 2); }
 
-template <int PIPE>
-__global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
-    DREAM_DYNAMIC_LDS(float, sV);                      // [16 positions][32 tiles][16 channels]
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams p) {
+    constexpr int NT = 64 * NW;                        // threads
+    constexpr int ITEMS = 512 / NT;                    // (tile, quad, row) items per thread and chunk: 2 (NW 4) or 1 (NW 8)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    DREAM_DYNAMIC_LDS(float, sV);                      // 2 x [16 positions][PS]  then the load-offset table
+    u32x4 *sG = (u32x4 *)(sV + 2 * VB);                // [ITEMS][NT]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = wave_index();
@@ -70,46 +87,39 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
     const int tb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
     if (tb >= nblk) return;
     const int tile0 = tb * WT;
-    const int n0 = blockIdx.y * WN;
+    const int n0 = blockIdx.y * (16 * NW);
     const int tiles_per_img = p.TY * p.TX;
 
-    // ---- input-transform plan: thread -> two items (tile t, channel quad q, column j of the transformed patch) ----------
-    // column j of B^T d B needs patch columns ca, cb:  w_r = d[r][ca] + sb * d[r][cb];  then B^T along the rows.
-    // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, row, column) relative to the first
-    // image this workgroup touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare /
-    // select per load), the chunk's channel offset in the scalar operand.
+    // ---- input-transform plan: thread -> ITEMS items (tile t, channel quad q, patch row r); r = the lane's index in its quad
+    // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, column) relative to the first image
+    // this workgroup touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare / select
+    // per load), the chunk's channel offset in the scalar operand.  The offsets are parked in LDS ([ITEMS][NT] uint4,
+    // conflict-free b128 access) and re-read per chunk: VGPRs that accumulators + weight ring + patch cannot spare.
     const int b0 = div_magic40(tile0, p.magic_tpi);
     const size_t img_floats = (size_t)p.H * p.W * p.Cin;
     const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
-    // The 16 offsets of a thread are parked in LDS ([4 quads of offsets][256 threads] uint4, conflict-free b128 access) and
-    // re-read per chunk: 16 VGPRs that the accumulators (128) + the patch (32) + the weight ring (16) cannot spare.
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 *sG = (u32x4 *)(sV + (PIPE == 0 ? 1 : 2) * 16 * WT * WKC);
-    int soff[2];                                       // LDS float offset of V[p = j][t][slot q]; + i * 4 * WT * 16 for p = 4i + j
+    int soff[ITEMS];                                   // LDS float offset of V[p = 4r][t][slot q]; + j * PS for p = 4r + j
+    const int qr = lane & 3;                           // patch row of this lane's items (e & 3 with NT a multiple of 4)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int e = tid + it * 256;
-        const int q = e & 3, t = (e >> 2) & 31, j = e >> 7;          // j is wave-uniform: (tid >> 7) + 2 it
-        const int ca = (j == 0) ? 0 : (j == 2 ? 2 : 1);
-        const int cb = (j == 3) ? 3 : (j == 2 ? 1 : 2);
-        const int tau = tile0 + t;
+    for (int it = 0; it < ITEMS; ++it) {
+        const int e = tid + it * NT;
+        const int q = (e >> 2) & 3, t = (e >> 4) & 31;
+        const int tau = (DREAM_WINO_DIAG & 8) ? tile0 : tile0 + t;
         const bool tv = tau < p.ntiles;
         const int b = div_magic40(tau, p.magic_tpi), rem = tau - b * tiles_per_img;
         const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        unsigned goff[8];
+        const int gy = 2 * ty - 1 + qr, x0 = 2 * tx - 1;
+        const bool rok = tv && gy >= 0 && gy < p.H;
+        const int row = ((b - b0) * p.H + gy) * p.W;
+        u32x4 g;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int gy = y0 + r, xa = x0 + ca, xb = x0 + cb;
-            const bool rok = tv && gy >= 0 && gy < p.H;
-            const int row = ((b - b0) * p.H + gy) * p.W;
-            goff[2 * r] = (rok && xa >= 0 && xa < p.W) ? (unsigned)(((row + xa) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
-            goff[2 * r + 1] = (rok && xb >= 0 && xb < p.W) ? (unsigned)(((row + xb) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
-        }
-        sG[(2 * it) * 256 + tid] = u32x4{goff[0], goff[1], goff[2], goff[3]};
-        sG[(2 * it + 1) * 256 + tid] = u32x4{goff[4], goff[5], goff[6], goff[7]};
-        soff[it] = (j * WT + t) * WKC + 4 * v_slot(q, t);
+        for (int c = 0; c < 4; ++c)
+            g[c] = (rok && (x0 + c) >= 0 && (x0 + c) < p.W) ? (unsigned)(((row + x0 + c) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
+        sG[it * NT + tid] = g;
+        soff[it] = 4 * qr * PS + t * WKC + 4 * v_slot(q, t);
     }
+    // column transform across the quad: V[r][j] = sa * u[r][j] + sb * u[partner(r)][j], partner = {2, 2, 1, 1}
+    const float sa = (qr == 3) ? -1.0f : 1.0f, sb = (qr == 1 || qr == 3) ? 1.0f : -1.0f;
 
     // ---- MFMA operand addresses ------------------------------------------------------------------------------------------
     // A: lane l -> tile row (l & 15) (+16 for the second block), k = 4 (l >> 4) .. +3 (one float4, feeds 4 MFMAs)
@@ -132,52 +142,46 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         for (int blk = 0; blk < 2; ++blk) acc[pp][blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     const int nchunks = p.Cin / WKC;
-    const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
 
-    // weight stream: ring of B_RING operand registers, position s lives in bq[s % B_RING]
+    // weight stream: ring of B_RING operand registers, position s lives in bq[s % B_RING].  Unconditional: the packed
+    // tensor ends with B_AHEAD zero positions, and a loop body without branches lets the compiler count outstanding loads
+    // exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at every merge point).
     f32x4 bq[B_RING];
 #pragma unroll
-    for (int s = 0; s < B_AHEAD; ++s)
-        bq[s] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
-
-    // raw patch columns of one item: issue the eight loads / combine them and store the four V rows of column j
-    f32x4 d[2][8];
-    auto item_load = [&](int it, int c) {
-        const u32x4 g0 = sG[(2 * it) * 256 + tid], g1 = sG[(2 * it + 1) * 256 + tid];      // written by this thread: no barrier
-        const unsigned so = (unsigned)(c * WKC * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            d[it][i] = buffer_load_x4(xbuf, g0[i], so);
-            d[it][4 + i] = buffer_load_x4(xbuf, g1[i], so);
-        }
-    };
-    auto item_store = [&](int it, float *vbuf) {
-        const int j = (tid >> 7) + 2 * it;
-        const float sb = (j == 1) ? 1.0f : -1.0f;
-        f32x4 w[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w[r] = d[it][2 * r] + sb * d[it][2 * r + 1];
-        float *dst = vbuf + soff[it];
-        *(f32x4 *)(dst) = w[0] - w[2];                          // B^T rows: [1,0,-1,0]
-        *(f32x4 *)(dst + 4 * WT * WKC) = w[1] + w[2];           //           [0,1,1,0]
-        *(f32x4 *)(dst + 8 * WT * WKC) = w[2] - w[1];           //           [0,-1,1,0]
-        *(f32x4 *)(dst + 12 * WT * WKC) = w[1] - w[3];          //           [0,1,0,-1]
-    };
-    // The weight stream runs B_AHEAD positions ahead (issued BEFORE any patch loads of the same position: loads return in
-    // order).  Unconditional: the packed tensor ends with B_AHEAD zero positions, and a loop body without branches lets the
-    // compiler count outstanding loads exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at every merge point).
+    for (int s = 0; s < B_AHEAD; ++s) bq[s] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
     auto prefetch_b = [&](int pp, int s0) {
         if (DREAM_WINO_DIAG & 2) return;
         bq[(pp + B_AHEAD) % B_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)(s0 + pp + B_AHEAD) * u_pos_stride);
     };
+
+    // patch row of an item: its four loads / row transform, quad exchange, column transform, four V stores
+    f32x4 d[ITEMS][4];
+    u32x4 goff[ITEMS];
+    auto item_offsets = [&](int it) { goff[it] = sG[it * NT + tid]; };       // written by this thread: no barrier
+    auto item_load_one = [&](int it, int c, int chunk) {
+        d[it][c] = buffer_load_x4(xbuf, goff[it][c], (DREAM_WINO_DIAG & 16) ? 0u : (unsigned)(chunk * WKC * 4));
+    };
+    auto item_store = [&](int it, float *vbuf) {
+        // row transform (B^T d B = (B^T (d B))): u_j = sum_c d_c B[c][j]
+        const f32x4 u[4] = {d[it][0] - d[it][2], d[it][1] + d[it][2], d[it][2] - d[it][1], d[it][1] - d[it][3]};
+        float *dst = vbuf + soff[it];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = sa * u[j][k] + sb * quad_perm_2211(u[j][k]);
+            *(f32x4 *)(dst + j * PS) = v;
+        }
+    };
+
     // MFMA operands of position pp from V buffer vbuf: read one position ahead of their use into the register set of the
     // other parity (no copies).  The schedule is pinned in groups of two MFMAs (sched_barrier): at ~200 VGPRs hipcc
     // schedules for register pressure -- it sinks every load to its use (a full LDS / memory latency with no MFMA of this
     // wave in flight) and issues the four MFMAs of one accumulator back to back (40-cycle dependent latency vs 32 issue).
     f32x4 a[2][2];
     auto read_a = [&](int set, int pp, const float *vbuf) {
-        a[set][0] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[0]);
-        a[set][1] = *(const f32x4 *)(vbuf + pp * WT * WKC + a_off[1]);
+        a[set][0] = *(const f32x4 *)(vbuf + pp * PS + a_off[0]);
+        a[set][1] = *(const f32x4 *)(vbuf + pp * PS + a_off[1]);
     };
     auto mfma_pair = [&](int pp, int r) {
         acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], acc[pp][0]);
@@ -185,62 +189,46 @@ __global__ void __launch_bounds__(256, 2) conv_wino_kernel(const WinoParams p) {
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    if (PIPE == 0) {
-        // transform | barrier | 128 MFMAs | barrier per chunk; the second workgroup of the CU covers the transform
-        for (int c = 0; c < nchunks; ++c) {
-            item_load(0, c);
-            item_load(1, c);
-            if (c > 0) __syncthreads();                    // every wave is done reading the previous chunk's V
-            item_store(0, sV);
-            item_store(1, sV);
-            __syncthreads();
-            read_a(0, 0, sV);
-            __builtin_amdgcn_sched_barrier(0);
+    // prologue: chunk 0 into buffer 0
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) {
-                prefetch_b(pp, c * 16);
-                mfma_pair(pp, 0);
-                if (pp < 15) read_a((pp + 1) & 1, pp + 1, sV);
-                mfma_pair(pp, 1);
-                mfma_pair(pp, 2);
-                mfma_pair(pp, 3);
-            }
-        }
-    } else {
-        // V double-buffered: the transform of chunk c + 1 rides inside the MFMA phase of chunk c (one item's eight loads in
-        // flight at a time: issued at positions 0 / 7, combined and stored six positions later), one barrier per chunk.
-        // The last chunk re-transforms itself into the idle buffer rather than branching around the slices.
-        constexpr int VB = 16 * WT * WKC;
-        item_load(0, 0);
-        item_load(1, 0);
-        item_store(0, sV);
-        item_store(1, sV);
-        __syncthreads();
-        for (int c = 0; c < nchunks; ++c) {
-            const float *cur = sV + (c & 1) * VB;
-            float *nxt = sV + ((c & 1) ^ 1) * VB;
-            const int cn = (c + 1 < nchunks) ? c + 1 : c;
-            read_a(0, 0, cur);
-            __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < ITEMS; ++it) {
+        item_offsets(it);
 #pragma unroll
-            for (int pp = 0; pp < 16; ++pp) {
-                prefetch_b(pp, c * 16);
-                if (!(DREAM_WINO_DIAG & 1)) {
-                    if (pp == 0) item_load(0, cn);
-                    if (pp == 7) item_load(1, cn);
-                }
-                mfma_pair(pp, 0);
-                if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
-                mfma_pair(pp, 1);
-                if (!(DREAM_WINO_DIAG & 1)) {
-                    if (pp == 6) item_store(0, nxt);
-                    if (pp == 13) item_store(1, nxt);
-                }
-                mfma_pair(pp, 2);
-                mfma_pair(pp, 3);
-            }
-            if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
+        for (int c = 0; c < 4; ++c) item_load_one(it, c, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) item_store(it, sV);
+    __syncthreads();
+
+    // V double-buffered: the transform of chunk c + 1 rides inside the MFMA phase of chunk c, one barrier per chunk.  Patch
+    // loads: ONE per pair of MFMAs (a load touches 16 separate 64-byte segments and the texture-address unit takes tens of
+    // cycles to accept it; issued back to back they stall the wave's in-order instruction stream, MFMAs included); item it
+    // loads during position it, is transformed and stored ten positions later.  The last chunk re-transforms itself into
+    // the idle buffer rather than branching around the slices.
+    for (int c = 0; c < nchunks; ++c) {
+        const float *cur = sV + (c & 1) * VB;
+        float *nxt = sV + ((c & 1) ^ 1) * VB;
+        const int cn = (c + 1 < nchunks) ? c + 1 : c;
+        read_a(0, 0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            const bool tf = !(DREAM_WINO_DIAG & 1);
+            const int li = (pp < ITEMS) ? pp : -1;                          // item loaded during this position
+            const int si = (pp >= 10 && pp < 10 + ITEMS) ? pp - 10 : -1;    // item stored during this position
+            prefetch_b(pp, c * 16);
+            if (tf && li >= 0) { item_offsets(li); item_load_one(li, 0, cn); }
+            mfma_pair(pp, 0);
+            if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
+            if (tf && li >= 0) item_load_one(li, 1, cn);
+            mfma_pair(pp, 1);
+            if (tf && li >= 0) item_load_one(li, 2, cn);
+            if (tf && si >= 0) item_store(si, nxt);
+            mfma_pair(pp, 2);
+            if (tf && li >= 0) item_load_one(li, 3, cn);
+            mfma_pair(pp, 3);
         }
+        if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
     }
 
     // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ----------------
@@ -353,13 +341,28 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u
     }
 }
 
-bool g_attr_set[2] = {false, false};
-int g_variant = 1;
+template <int NW>
+int launch_wino(const WinoParams &p, void *stream) {
+    static bool attr_set = false;
+    void (*kernel)(const WinoParams) = conv_wino_kernel<NW>;
+    const size_t lds = (size_t)2 * VB * sizeof(float) + (size_t)512 * 16;          // V buffers + the offset table
+    if (!attr_set) {
+        DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int nblk = (p.ntiles + WT - 1) / WT;
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8), (unsigned)((p.Cout + 16 * NW - 1) / (16 * NW)));
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+int g_variant = 0;
 
 }  // namespace
 
 extern "C" size_t dream_conv3x3_winograd_weight_floats(int rows, int cols) {
-    const size_t rows_pad = (size_t)((rows + WN - 1) / WN) * WN;
+    const size_t rows_pad = (size_t)((rows + WPAD - 1) / WPAD) * WPAD;
     return ((size_t)(cols / WKC) * 16 + B_AHEAD) * rows_pad * WKC;      // + the zero positions the weight stream over-reads
 }
 
@@ -369,7 +372,7 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
     DREAM_REQUIRE(w_oihw && u && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "winograd pack: bad arguments");
     const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
     DREAM_REQUIRE(cols % WKC == 0, "winograd pack: %d input channels, must be a multiple of %d", cols, WKC);
-    const int rows_pad = (rows + WN - 1) / WN * WN;
+    const int rows_pad = (rows + WPAD - 1) / WPAD * WPAD;
     const size_t total = (size_t)(cols / WKC) * rows_pad * WKC;
     size_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
@@ -381,10 +384,10 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
     return 0;
 }
 
-// variant 0: single V buffer, transform and MFMA phases separated by barriers; 1 (default): double-buffered V with the next
-// chunk's transform inside the MFMA phase.  Same results bit for bit.
+// Workgroup width: 0 (default) = by layer (128 output channels per workgroup when the layer has more than 64, else 64);
+// 4 / 8 force the 64- / 128-channel kernel.  Same results bit for bit.
 extern "C" int dream_conv3x3_winograd_set_variant(int variant) {
-    DREAM_REQUIRE(variant == 0 || variant == 1, "winograd variant %d out of range", variant);
+    DREAM_REQUIRE(variant == 0 || variant == 4 || variant == 8, "winograd variant %d: 0 (by layer), 4 or 8 wavefronts", variant);
     g_variant = variant;
     return 0;
 }
@@ -403,28 +406,18 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     // 32-bit byte offsets relative to the first image a workgroup touches: its 32 tiles span at most this many images
     const size_t span_imgs = (size_t)WT / ((size_t)((H + 1) / 2) * ((W + 1) / 2)) + 2;
     DREAM_REQUIRE(span_imgs * H * W * (size_t)(Cin > Cout ? Cin : Cout) * sizeof(float) < ((size_t)1 << 31), "winograd conv: image too large for 32-bit offsets");
-    DREAM_REQUIRE(((size_t)(Cin / WKC) * 16 + B_AHEAD) * ((size_t)(Cout + WN - 1) / WN * WN) * WKC * sizeof(float) < ((size_t)1 << 31), "winograd conv: weights too large");
     WinoParams p;
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-    p.CoutPad = (Cout + WN - 1) / WN * WN;
+    p.CoutPad = (Cout + WPAD - 1) / WPAD * WPAD;
+    DREAM_REQUIRE(((size_t)(Cin / WKC) * 16 + B_AHEAD) * (size_t)p.CoutPad * WKC * sizeof(float) < ((size_t)1 << 31), "winograd conv: weights too large");
     p.TY = (H + 1) / 2; p.TX = (W + 1) / 2;
     const long ntiles = (long)B * p.TY * p.TX;
-    DREAM_REQUIRE(ntiles < ((long)1 << 31), "winograd conv: too many tiles");
     DREAM_REQUIRE(ntiles < ((long)1 << 24), "winograd conv: %ld tiles, the tile decomposition handles < 2^24", ntiles);
     p.ntiles = (int)ntiles;
     p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(p.TY * p.TX) - 1) / (unsigned long long)(p.TY * p.TX);
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
-    void (*kernel)(const WinoParams) = g_variant == 0 ? conv_wino_kernel<0> : conv_wino_kernel<1>;
-    const size_t lds = (size_t)(g_variant == 0 ? 1 : 2) * 16 * WT * WKC * sizeof(float) + 4 * 256 * 16;   // V buffer(s) + offsets
-    if (!g_attr_set[g_variant]) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attr_set[g_variant] = true;
-    }
-    const int nblk = (p.ntiles + WT - 1) / WT;
-    const dim3 grid((unsigned)((nblk + 7) / 8 * 8), (unsigned)(p.CoutPad / WN));
-    hipLaunchKernelGGL(kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
-    DREAM_LAUNCH_OK();
-    return 0;
+    const int nw = g_variant ? g_variant : (Cout > 64 ? 8 : 4);
+    return nw == 8 ? launch_wino<8>(p, stream) : launch_wino<4>(p, stream);
 }

@@ -62,6 +62,11 @@ DREAM_DEVICE void buffer_store_f32(BufferRsrc b, float v, unsigned voffset_bytes
 // n / d for n < 2^24 with magic = ceil(2^40 / d) (host side: magic_div40): exact, 3 VALU instead of ~40
 DREAM_DEVICE int div_magic40(int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); }
 
+// DPP quad_perm [2,2,1,1]: lane 4k + r receives v from lane 4k + {2, 2, 1, 1}[r] (a VALU operand modifier, no LDS traffic)
+DREAM_DEVICE float quad_perm_2211(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
+}
+
 // wave index within the workgroup as a provably wave-uniform (SGPR) value
 DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

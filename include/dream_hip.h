@@ -98,7 +98,7 @@ int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *b
  * residual > 0 with DREAM_CONV_RELUMASK) (ReLU) (2x2 max-pool); flags: DREAM_CONV_RELU | DREAM_CONV_POOL2 |
  * DREAM_CONV_RELUMASK; scale / shift / residual may be NULL. */
 size_t dream_conv3x3_winograd_weight_floats(int rows, int cols);
-int dream_conv3x3_winograd_set_variant(int variant);   /* 0: separate transform / MFMA phases; 1 (default): pipelined */
+int dream_conv3x3_winograd_set_variant(int variant);   /* workgroup width: 0 = by layer (default), 4 / 8 wavefronts = 64 / 128 channels */
 int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u_packed, int Cout, int Cin, int mode, void *stream);
 int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,

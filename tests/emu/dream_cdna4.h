@@ -91,6 +91,10 @@ inline void buffer_store_f32(BufferRsrc b, float v, unsigned voffset_bytes, unsi
         __builtin_memcpy(const_cast<char *>(b.base) + (size_t)voffset_bytes + soffset_bytes, &v, 4);
 }
 inline int div_magic40(int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); }
+inline float quad_perm_2211(float v) {
+    const int l = emu::lane(), src = (l & ~3) | ((l & 3) < 2 ? 2 : 1);
+    return emu_exchange(v, src);
+}
 inline int wave_index() { return emu::wave(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }

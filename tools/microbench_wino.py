@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--variant", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=0, help="0: workgroup width by layer, 4 / 8: forced")
     args = ap.parse_args()
     _hip.lib().dream_conv3x3_winograd_set_variant(args.variant)
     print("winograd variant", args.variant)
