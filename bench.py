@@ -34,7 +34,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=128, help="frames per GPU (weak scaling, the default)")
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: this many frames in total, split evenly over "
+                    "the GPUs (BASELINE configs[3]: 128 over 8, configs[4]: 256 over 8); overrides --batch")
+    ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process through training.platform.gpu_ids "
+                    "(the reference's nn.DataParallel contract, dream_amd/data_parallel.py) instead of one process per GPU")
+    ap.add_argument("--conv-algorithm", choices=["winograd", "direct"], default="winograd",
+                    help="fp32 3x3 stride-1 convs: Winograd F(2x2,3x3) on the fp32 MFMA (default) or the direct implicit GEMM")
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--mode", choices=["inference", "train"], default="inference")
     ap.add_argument("--precision", choices=["fp32", "fp16x3"], default="fp32",
@@ -53,12 +59,20 @@ def pmc_traffic(args):
     WRITE_SIZE, separate runs of this same command, FETCH_SIZE doubled per the gfx950 note in
     MI355X_MICROARCH.md and calibrated on the max-pool kernel).  Counters cannot be read from inside the
     process, so the latest committed profile summary is reported; null for any other workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if args.arch != "vgg_q" or args.mode != "inference" or args.batch != 128 or args.res != 400 or not os.path.exists(path):
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            break
+    else:
+        return None
+    if args.arch != "vgg_q" or args.mode != "inference" or args.batch != 128 or args.res != 400:
         return None
     with open(path) as f:
-        d = json.load(f)["conv_mfma_kernel"]
-    return d["traffic_gb_per_launch"] * 1e9
+        d = json.load(f)
+    key = "conv_kernels" if "conv_kernels" in d else "conv_mfma_kernel"
+    if args.conv_algorithm == "direct" and key == "conv_kernels":
+        return None
+    return d[key]["traffic_gb_per_launch"] * 1e9
 
 
 ARCH_K = {"vgg_q": (7, "panda"), "vgg_f": (7, "panda"), "resnet_h": (7, "panda"), "resnet_f": (17, "baxter")}
@@ -137,6 +151,11 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    single = args.single_process and world == 1 and args.gpus > 1
+    n_dev = args.gpus if single else world
+    if args.global_batch:
+        assert args.global_batch % max(n_dev, 1) == 0, "--global-batch must divide evenly over the GPUs"
+        args.batch = args.global_batch // max(n_dev, 1)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # One process per GPU over RCCL.  (Rehearsal of the N > 1 path on a single-GPU box: DREAM_BENCH_BACKEND=gloo lets
@@ -154,21 +173,26 @@ def main():
         else:
             dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+    total_batch = args.batch * (n_dev if single else 1)            # frames this PROCESS handles per step
 
     n_kp, manip = ARCH_K[args.arch]
     cfg = dream_amd.default_network_config(args.arch, manip, batch_size=args.batch)
     cfg["training"]["config"]["net_input_resolution"] = [args.res, args.res]
+    if single:                                      # DREAM_BENCH_GPU_IDS=0,0: rehearsal of the N-replica path on a one-GPU box
+        ids = os.environ.get("DREAM_BENCH_GPU_IDS")
+        cfg["training"]["platform"]["gpu_ids"] = [int(v) for v in ids.split(",")] if ids else list(range(args.gpus))
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         net = dream_amd.create_network_from_config_data(cfg)
     net.model.load_state_dict(synthetic_weights(net.model.state_dict()))
+    net.model.module.conv_algorithm = args.conv_algorithm
 
-    x = torch.from_numpy(cases.image_batch(args.batch, args.res, args.res, seed=rank)).cuda()
+    x = torch.from_numpy(cases.image_batch(total_batch, args.res, args.res, seed=rank)).cuda()
     if args.mode == "train":
         net.enable_training()
         ow, oh = net.trained_net_output_resolution()
-        tgt = torch.from_numpy(cases.target_batch(args.batch, n_kp, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
+        tgt = torch.from_numpy(cases.target_batch(total_batch, n_kp, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
     else:
         net.enable_evaluation()
         net.hip_graph = bool(args.graph)
@@ -179,7 +203,8 @@ def main():
     conv_events = []          # (start, end, flops)
     recording = [False]
 
-    def timed(orig, flops_of, kernel_launches=1):
+    def timed(orig, flops_of, kernel_launches=1, executed=1.0):
+        """executed: executed MACs / direct-algorithm MACs of this operator (Winograd: 16 / 36), or a callable of the kwargs."""
         def wrapper(*a, **k):
             if not recording[0] or k.get("relu_mask") is not None:     # conv3x3(relu_mask=..) forwards to conv2d: timed there
                 return orig(*a, **k)
@@ -188,7 +213,8 @@ def main():
             s_ev.record()
             y = orig(*a, **k)
             e_ev.record()
-            conv_events.append((s_ev, e_ev, flops_of(y, *a, **k), kernel_launches))
+            fl = flops_of(y, *a, **k)
+            conv_events.append((s_ev, e_ev, fl, kernel_launches, fl * (executed(k) if callable(executed) else executed)))
             return y
         return wrapper
 
@@ -199,14 +225,16 @@ def main():
     ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0, relu_mask=None: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
     ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
                        2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
+    ops.conv3x3_winograd = timed(ops.conv3x3_winograd, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
+                                 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=16.0 / 36.0)
     ops.conv_transpose3x3s2 = timed(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9,
                                     kernel_launches=4)        # the sub-pixel ops are four kernel launches each
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
-                                    kernel_launches=4)
+                                    kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
     ops.conv_transpose3x3s2_f16x3 = timed(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9,
                                           kernel_launches=4)
     ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
-                                          kernel_launches=4)
+                                          kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
     ops.conv2d_amax = timed(ops.conv2d_amax, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
     ops.conv2d_f16x3 = timed(ops.conv2d_f16x3,
                              lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
@@ -242,11 +270,14 @@ def main():
             tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
-        ms = sum(s_.elapsed_time(e_) for s_, e_, _, _ in conv_events)
-        fl = sum(f for _, _, f, _ in conv_events)
-        return dt, ms, fl, sum(n for _, _, _, n in conv_events), out
+        ms = sum(ev[0].elapsed_time(ev[1]) for ev in conv_events)
+        fl = sum(ev[2] for ev in conv_events)
+        executed_flops[0] = sum(ev[4] for ev in conv_events)
+        return dt, ms, fl, sum(ev[3] for ev in conv_events), out
 
+    executed_flops = [0.0]
     dt, conv_ms, conv_flops, n_launch, out_main = timed_region()
+    conv_executed = executed_flops[0]
     # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
     # fp16 MFMA MACs, so its ceiling in ALGORITHMIC flops is the dense fp16 MFMA peak / 3
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" or args.mode == "train" else PEAK_F16_MFMA_TFLOPS / 3.0
@@ -262,7 +293,7 @@ def main():
         scale = max(1.0, float(out_main[0].abs().max()))
         k32, k16 = out_main[1], out2[1]
         both = (k32 != -999.999) & (k16 != -999.999)
-        split = {"value": args.batch * args.steps * world / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
+        split = {"value": total_batch * args.steps * world / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
                  "dtype": "f32 in/out; products as 3 x f16 MFMA (hi*hi + hi*lo + lo*hi), f32 accumulate",
                  "roofline": {"bound": "mfma", "kernel": "conv_f16x3_kernel",
                               "achieved": fl2 / (ms2 * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s",
@@ -273,11 +304,11 @@ def main():
                  "detections_agree": float(((k32 == -999.999) == (k16 == -999.999)).float().mean())}
 
     if rank == 0:
-        frames = args.batch * args.steps * world
+        frames = total_batch * args.steps * world
         line = {
             "metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
-            "value": frames / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": frames / dt, "unit": "frames/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "DREAM-%s (%s, %d keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames "
@@ -285,13 +316,22 @@ def main():
                                    % (args.arch, manip, n_kp, args.mode, args.batch, args.res, args.res,
                                       " (BASELINE.json configs[%d])" % (2 if args.mode == "train" else 1)
                                       if args.arch == "vgg_q" else ""),
-                       "batch_per_gpu": args.batch, "resolution": [args.res, args.res], "parallelism": "dp%d" % world},
+                       "batch_per_gpu": args.batch, "resolution": [args.res, args.res],
+                       "parallelism": "dp%d%s" % (n_dev, " (single process, gpu_ids)" if single else ""),
+                       "conv_algorithm": ("winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 64 output channels, direct "
+                                          "implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else "direct implicit GEMM")},
             "roofline": {
-                "bound": "mfma", "kernel": "conv_mfma_kernel" if args.precision == "fp32" else "conv_f16x3_kernel",
+                "bound": "mfma",
+                "kernel": ("conv_wino_kernel + conv_mfma_kernel" if args.conv_algorithm == "winograd" else "conv_mfma_kernel")
+                if args.precision == "fp32" or args.mode == "train" else "conv_f16x3_kernel",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                 "peak": peak, "unit": "TFLOP/s",
                 "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
-                "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_traffic.json)",
+                # frac above counts the DIRECT algorithm's FLOPs; executed_frac counts the multiplications the
+                # kernels actually issue (Winograd 16/36 of direct, upsample+conv as a 4x4 transposed conv 16/36)
+                "executed_frac": (conv_executed / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
+                "executed_over_direct": conv_executed / conv_flops if conv_flops > 0 else None,
+                "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (PMC, profiles/r0N_pmc_traffic.json)",
                 "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
                 "algorithmic_gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
                 "share_of_step_time": conv_ms * 1e-3 / dt,

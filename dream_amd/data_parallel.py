@@ -189,7 +189,7 @@ class DreamDataParallel(nn.Module):
         stamp = _version_stamp(self.module)
         for rep in self._replicas[:n - 1]:
             rep.train(self.module.training)
-            for attr in ("precision",):
+            for attr in ("precision", "conv_algorithm"):
                 if hasattr(self.module, attr) and getattr(rep, attr) != getattr(self.module, attr):
                     setattr(rep, attr, getattr(self.module, attr))
         if stamp == self._stamp:

@@ -59,7 +59,9 @@ class _PackedCache:
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
             with torch.no_grad():
-                if mode == "ups":
+                if mode in ("wino0", "wino1"):                    # Winograd F(2x2,3x3) transformed weights (fwd / data gradient)
+                    packed = ops.pack_weight_winograd(weight.detach(), int(mode[-1]))
+                elif mode == "ups":
                     wt4 = ops.upsample_conv_weight(weight.detach())
                     packed = ops.pack_convT4x4_weight_f16x3(wt4) if f16x3 else ops.pack_convT4x4_weight(wt4)
                 else:
@@ -162,6 +164,10 @@ class DreamHourglass(nn.Module):
         # "fp32": exact fp32 MFMA kernel everywhere.  "fp16x3": inference runs the split-precision kernel
         # (fp32 in/out, 3 fp16 MFMAs per product, fp32-class error); training always uses the fp32 kernels.
         self.precision = "fp32"
+        # fp32 3x3 stride-1 convs: "winograd" = F(2x2,3x3) on the fp32 matrix cores wherever it is the faster exact-fp32
+        # form (csrc/conv_wino.hip: 2.25x fewer MFMA cycles, same IEEE fp32 arithmetic up to round-off), "direct" = the
+        # implicit-GEMM kernel everywhere (csrc/conv_mfma.hip, the reference form)
+        self.conv_algorithm = os.environ.get("DREAM_CONV_ALGORITHM", "winograd")
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self._aux = {}
         # the reference builds every hourglass on vgg19(pretrained=True).features (models.py:587): ImageNet weights for all
@@ -222,6 +228,15 @@ class DreamHourglass(nn.Module):
         if not (li + 1 < len(layers) and layers[li + 1][0] == "pool") or li in self._skip_sources:
             return False
         return min(int(x_nhwc.shape[1]), int(x_nhwc.shape[2])) >= 160
+
+    def _use_winograd(self, cin, cout, flags):
+        """Winograd serves the plain 3x3 convs (bias, ReLU, fused max-pool); measured faster than the direct kernel for every
+        DREAM layer with >= 64 output channels (profiles/r02_microbench_wino_b128.txt: 1.5-2.05x), on par at 32."""
+        if self.conv_algorithm != "winograd":
+            if self.conv_algorithm != "direct":
+                raise ValueError("unknown conv_algorithm %r" % (self.conv_algorithm,))
+            return False
+        return cin % 16 == 0 and cout >= 64 and not (flags & ~(CONV_RELU | CONV_POOL2 | ops.CONV_RELUMASK))
 
     @staticmethod
     def _join(a, b):
@@ -310,6 +325,9 @@ class DreamHourglass(nn.Module):
                     elif kind == "deconv":                   # ConvTranspose weight [Cin,Cout,3,3], mode-1 packing; sub-pixel
                         packed, rows, _, _ = self._packed.get(mod.weight, 1)   # phases: a quarter of the zero-stuffed MACs
                         act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
+                    elif int(mod.weight.shape[1]) == int(inp.shape[3]) and self._use_winograd(int(inp.shape[3]), int(mod.weight.shape[0]), flags):
+                        u, rows = self._packed.get(mod.weight, "wino0")
+                        act = ops.conv3x3_winograd(inp, u, rows, None, bias, None, flags)
                     else:
                         packed, rows, _, _ = self._packed.get(mod.weight, 0)
                         act = ops.conv3x3(inp, packed, bias, rows, flags)
@@ -396,6 +414,10 @@ class DreamHourglass(nn.Module):
                 raise RuntimeError("internal: gradient has %d channels, packed weights expect %d" % (g.shape[3], cols_pad))
             if flags & CONV_UPSAMPLE2X:                    # the mask lives at half resolution: after upsample2_bwd
                 g = ops.upsample2_bwd(ops.conv3x3(g, packed_t, None, rows, 0))
+            elif self._use_winograd(int(g.shape[3]), cin, ops.CONV_RELUMASK if fuse else 0) and int(g.shape[3]) == cout:
+                u_t, rows_t = self._packed.get(mod.weight, "wino1")       # data gradient = conv with the transposed, flipped taps
+                g = ops.conv3x3_winograd(g, u_t, rows_t, None, None, inp if fuse else None, ops.CONV_RELUMASK if fuse else 0)
+                masked = fuse
             else:
                 g = ops.conv3x3(g, packed_t, None, rows, 0, relu_mask=inp if fuse else None)
                 masked = fuse
@@ -647,6 +669,15 @@ class DreamHourglassMultiStage(nn.Module):
         for st in self.stages():
             st.precision = value
 
+    @property
+    def conv_algorithm(self):
+        return self.stage1.conv_algorithm
+
+    @conv_algorithm.setter
+    def conv_algorithm(self, value):
+        for st in self.stages():
+            st.conv_algorithm = value
+
     def stages(self):
         return [getattr(self, "stage%d" % s) for s in range(1, self.num_stages + 1)]
 
@@ -769,6 +800,7 @@ class ResnetSimple(nn.Module):
         self.n_keypoints = n_keypoints
         self._cache = {}
         self.precision = "fp32"        # "fp16x3": evaluation-mode forward on the split-precision conv kernel
+        self.conv_algorithm = os.environ.get("DREAM_CONV_ALGORITHM", "winograd")   # see DreamHourglass.conv_algorithm
         # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
@@ -833,8 +865,13 @@ class ResnetSimple(nn.Module):
 
     def _conv_bn(self, name, x, conv, bn, relu, residual=None):
         k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
-        packed, rows, _ = self._cached(("w", name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), 0))
         scale, shift = self._fold(name, bn, conv.bias)
+        cout, cin = int(conv.weight.shape[0]), int(conv.weight.shape[1])
+        if k == 3 and stride == 1 and self.conv_algorithm == "winograd" and cin % 16 == 0 and cout >= 64:
+            # the stride-1 3x3 convs of the bottlenecks: Winograd F(2x2,3x3) with the folded BatchNorm in the epilogue
+            u, rows = self._cached(("wino", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 0))
+            return ops.conv3x3_winograd(x, u, rows, scale, shift, residual, CONV_RELU if relu else 0)
+        packed, rows, _ = self._cached(("w", name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), 0))
         return ops.conv2d(x, packed, rows, k, stride, scale, shift, residual, CONV_RELU if relu else 0)
 
     # ---- inference on the split-precision conv kernel (strided convs stay on the fp32 kernel) ------------------

@@ -566,3 +566,72 @@ WINO_CASES = [
 def test_conv_winograd(b, h, w, cin, cout, flags, kw):
     err = pc.check_conv_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw)
     print("winograd %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
+
+
+# ---- single-process data parallelism behind gpu_ids (dream_amd/data_parallel.py; reference network.py:244-256) ------------
+def _dp_network(arch, gpu_ids, optimizer="adam", lr=1e-5, in_res=(96, 64), weights=None):
+    import contextlib
+    import io
+    import dream_amd
+    cfg = dream_amd.default_network_config(arch, "panda", optimizer=optimizer, learning_rate=lr)
+    cfg["training"]["config"]["net_input_resolution"] = list(in_res)
+    cfg["training"]["platform"]["gpu_ids"] = list(gpu_ids)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = dream_amd.create_network_from_config_data(cfg)
+    if weights is None:
+        weights = om.recipe_weights(om.build_model(arch, 7).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    net.model.load_state_dict({"module." + k: v for k, v in weights.items()})
+    return net
+
+
+def test_single_process_data_parallel_two_replicas_on_one_gpu():
+    """gpu_ids = [0, 0]: two persistent replicas (threads, scatter, per-replica peak extraction, flat gradient reduce, flat
+    parameter refresh) on the one GPU this box has.  Inference: bit-identical to the single-replica network, in order;
+    training: two Adam steps equal the single-replica steps on the whole batch."""
+    x = torch.from_numpy(cases.image_batch(5, 64, 96, seed=31)).to(DEV)
+    t = torch.from_numpy(cases.target_batch(5, 7, (24, 16), in_wh=(96, 64), seed=31)).to(DEV)
+    dp, one = _dp_network("vgg_q", [0, 0]), _dp_network("vgg_q", [0])
+    dp.enable_evaluation()
+    one.enable_evaluation()
+    with torch.no_grad():
+        m2, k2 = dp.inference(x)
+        m1, k1 = one.inference(x)
+    assert len(dp.model.devices()) == 2 and len(dp.model._replicas) == 1 and len(one.model.devices()) == 1
+    assert torch.equal(m2, m1) and torch.equal(k2, k1) and m2.device == x.device
+    dp.enable_training()
+    one.enable_training()
+    l2 = [dp.train([x], t).item() for _ in range(2)]
+    l1 = [one.train([x], t).item() for _ in range(2)]
+    assert np.allclose(l2, l1, rtol=2e-6), (l2, l1)
+    for (k, a), (_, b) in zip(dp.model.named_parameters(), one.model.named_parameters()):
+        assert float((a - b).abs().max()) <= 1e-7 + 2e-5 * float(b.abs().max()), k
+    grads = [p.grad for p in dp.model.parameters()]
+    assert all(g.untyped_storage().data_ptr() == grads[0].untyped_storage().data_ptr() for g in grads)
+    dp.model._sync_replicas(2)
+    torch.cuda.synchronize()
+    for a, b in zip(dp.model.module.parameters(), dp.model._replicas[0].parameters()):
+        assert torch.equal(a, b)
+
+
+def test_single_process_data_parallel_resnet_batchnorm_semantics():
+    """ResNet under gpu_ids = [0, 0]: per-replica batch statistics (as nn.DataParallel), running statistics of replica 0 kept
+    in the master module: one training step on 4 frames = the average of the gradients of two independent 2-frame steps."""
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(4, 64, 64, seed=33)).to(DEV)
+    dp = _dp_network("resnet_h", [0, 0], optimizer="sgd", lr=0.0, in_res=(64, 64), weights=wts)
+    dp.enable_training()
+    ow, oh = dp.trained_net_output_resolution()
+    t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=(64, 64), seed=33)).to(DEV)
+    loss = dp.train([x], t).item()
+    halves = []
+    for sl in (slice(0, 2), slice(2, 4)):
+        one = _dp_network("resnet_h", [0], optimizer="sgd", lr=0.0, in_res=(64, 64), weights=wts)
+        one.enable_training()
+        halves.append((one.train([x[sl]], t[sl]).item(), [p.grad.clone() for p in one.model.parameters()], one))
+    assert abs(loss - 0.5 * (halves[0][0] + halves[1][0])) <= 1e-6 * abs(loss)
+    gmax = max(float(p.grad.norm()) for p in dp.model.parameters())
+    for p, ga, gb in zip(dp.model.parameters(), halves[0][1], halves[1][1]):
+        ref = 0.5 * (ga + gb)
+        assert float((p.grad - ref).norm()) <= 1e-4 * max(float(ref.norm()), 1e-6 * gmax)
+    # running statistics: replica 0's (the first chunk), as DataParallel keeps them
+    assert torch.equal(dp.model.module.bn1.running_mean, halves[0][2].model.module.bn1.running_mean)
