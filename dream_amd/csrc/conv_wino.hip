@@ -118,8 +118,10 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         sG[it * NT + tid] = g;
         soff[it] = 4 * qr * PS + t * WKC + 4 * v_slot(q, t);
     }
-    // column transform across the quad: V[r][j] = sa * u[r][j] + sb * u[partner(r)][j], partner = {2, 2, 1, 1}
-    const float sa = (qr == 3) ? -1.0f : 1.0f, sb = (qr == 1 || qr == 3) ? 1.0f : -1.0f;
+    // column transform across the quad: row r of B^T (u_0..u_3) = u_r + sb * u_partner(r), partner = {2, 2, 1, 1}, for
+    // r = 0, 1, 2; the lane of r = 3 computes u_3 - u_1 = MINUS row 3 -- the packed weights carry the matching sign in their
+    // positions 12..15 (wino_pack_kernel), so the product is unchanged and every lane needs one fma per value.
+    const float sb = (qr == 1) ? 1.0f : -1.0f;
 
     // ---- MFMA operand addresses ------------------------------------------------------------------------------------------
     // A: lane l -> tile row (l & 15) (+16 for the second block), k = 4 (l >> 4) .. +3 (one float4, feeds 4 MFMAs)
@@ -169,7 +171,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         for (int j = 0; j < 4; ++j) {
             f32x4 v;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = sa * u[j][k] + sb * quad_perm_2211(u[j][k]);
+            for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(sb, quad_perm_2211(u[j][k]), u[j][k]);     // exact: sb = +-1
             *(f32x4 *)(dst + j * PS) = v;
         }
     };
@@ -268,7 +270,8 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                 out[i][0] = s[i][0] + s[i][1] + s[i][2];
                 out[i][1] = s[i][1] - s[i][2] - s[i][3];
             }
-            const bool tok = cok && (tau0 + r) < p.ntiles;
+            // pooled output (floor(H/2) x floor(W/2)): the window of a tile with ty < Ho, tx < Wo lies entirely inside the image
+            const bool tok = cok && (tau0 + r) < p.ntiles && (!pool || (ty < Ho && tx < Wo));
             const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
             const unsigned base = (unsigned)(((((b - b0) * Ho + oy) * Wo + ox) * p.Cout + col) * 4);
             float best = -__builtin_huge_valf();
@@ -279,7 +282,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                     float v = out[i][jj];
                     if (p.scale != nullptr) v = v * sc;
                     v = v + sh;
-                    const bool inb = tok && (oy + i) < Ho && (ox + jj) < Wo;      // (pool: the window, always inside)
+                    const bool inb = tok && (pool || ((oy + i) < Ho && (ox + jj) < Wo));
                     const unsigned off = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
                     if (p.residual != nullptr) {
                         const float rv = buffer_load_f32(rbuf, off, 0);
@@ -335,8 +338,8 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u
                          r3 = t[a][2];
             const double rr[4] = {r0, r1, r2, r3};
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
-                u[(((size_t)ch * 16 + (a * 4 + b)) * RowsPad + n) * WKC + kk] = (float)rr[b];
+            for (int b = 0; b < 4; ++b)                             // row 3 negated: the kernel computes -V[3][.] (see there)
+                u[(((size_t)ch * 16 + (a * 4 + b)) * RowsPad + n) * WKC + kk] = (float)(a == 3 ? -rr[b] : rr[b]);
         }
     }
 }
@@ -393,7 +396,7 @@ extern "C" int dream_conv3x3_winograd_set_variant(int variant) {
 }
 
 // y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32.
-// Supported flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (even H, W), DREAM_CONV_RELUMASK (residual = mask source).
+// Supported flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor), DREAM_CONV_RELUMASK (residual = mask source).
 extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                                const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
                                                int flags, void *stream) {
@@ -401,7 +404,7 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
     DREAM_REQUIRE(Cin % WKC == 0, "winograd conv: Cin=%d must be a multiple of %d", Cin, WKC);
     DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
-    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (H % 2 == 0 && W % 2 == 0 && residual == nullptr), "winograd conv: fused max-pool needs even H, W and no residual");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd conv: fused max-pool takes no residual");
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
     // 32-bit byte offsets relative to the first image a workgroup touches: its 32 tiles span at most this many images
     const size_t span_imgs = (size_t)WT / ((size_t)((H + 1) / 2) * ((W + 1) / 2)) + 2;

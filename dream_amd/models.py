@@ -972,12 +972,30 @@ class ResnetSimple(nn.Module):
     def _unit_fwd(self, tape, name, x, conv, bn, relu, residual=None):
         """conv -> BN(batch stats) (+residual) (ReLU); records what the backward needs."""
         k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
-        packed, rows, _ = self._packed_w(name, conv, 0)
-        z = ops.conv2d(x, packed, rows, k, stride, None, conv.bias.detach() if conv.bias is not None else None, None, 0)
+        bias = conv.bias.detach() if conv.bias is not None else None
+        if self._wino_train(conv):
+            u, rows = self._cached(("wino", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 0))
+            z = ops.conv3x3_winograd(x, u, rows, None, bias, None, 0)
+        else:
+            packed, rows, _ = self._packed_w(name, conv, 0)
+            z = ops.conv2d(x, packed, rows, k, stride, None, bias, None, 0)
         y, mean, invstd = ops.bn_train_fwd(z, bn, residual, relu)
         tape.append(dict(kind="conv", name=name, conv=conv, bn=bn, relu=relu, x=x, z=z, y=y, mean=mean, invstd=invstd,
                          k=k, stride=stride, has_res=residual is not None))
         return y
+
+    def _wino_train(self, conv):
+        """Training: the stride-1 3x3 convs of the bottlenecks (forward and data gradient) on the Winograd kernel."""
+        return (self.conv_algorithm == "winograd" and int(conv.kernel_size[0]) == 3 and int(conv.stride[0]) == 1
+                and int(conv.weight.shape[1]) % 16 == 0 and int(conv.weight.shape[0]) % 16 == 0
+                and min(int(conv.weight.shape[0]), int(conv.weight.shape[1])) >= 64)
+
+    def _bwd_data(self, name, conv, dz, cin, k, stride, in_hw, residual=None):
+        if self._wino_train(conv):
+            u_t, rows = self._cached(("wino1", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 1))
+            return ops.conv3x3_winograd(dz, u_t, rows, None, None, residual, 0)
+        packed_t, rows, _ = self._packed_w(name, conv, 1)
+        return ops.conv2d_bwd_data(dz, packed_t, cin, k, stride, in_hw, residual=residual)
 
     def run_forward_train(self, x):
         tape = []
@@ -1071,19 +1089,18 @@ class ResnetSimple(nn.Module):
                 def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"]):
                     grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
                 _on_side(side, leaf, rec["x"], dz)
-                packed_t, rows, _ = self._packed_w(name, conv, 1)
                 in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
                 if is_ds:
-                    block["g_ds"] = ops.conv2d_bwd_data(dz, packed_t, cin, rec["k"], rec["stride"], in_hw)
+                    block["g_ds"] = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
                 elif name.endswith(".1"):
                     # block input: main-path gradient + identity / downsample gradient
-                    block["dz1"] = (dz, packed_t, cin, rec["k"], rec["stride"], in_hw)
+                    block["dz1"] = (name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
                 else:
-                    g = ops.conv2d_bwd_data(dz, packed_t, cin, rec["k"], rec["stride"], in_hw)
+                    g = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
             elif kind == "block_begin":
-                dz, packed_t, cin, k, stride, in_hw = block["dz1"]
+                name1, conv1, dz, cin, k, stride, in_hw = block["dz1"]
                 other = block["g_ds"] if rec["ds"] else block["g_idt"]
-                g = ops.conv2d_bwd_data(dz, packed_t, cin, k, stride, in_hw, residual=other)
+                g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
                 block = None
             elif kind == "pool":
                 g = ops.maxpool3s2_bwd(g, rec["x"])

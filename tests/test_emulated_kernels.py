@@ -38,6 +38,7 @@ def test_conv_winograd(emu, variant):
             pc.check_conv_winograd("cpu", 1, 25, 25, 48, 96, ops.CONV_RELU, seed=2),           # tiles spanning images / rows
             pc.check_conv_winograd("cpu", 3, 5, 3, 16, 7, 0, seed=3),                          # images smaller than a block
             pc.check_conv_winograd("cpu", 2, 12, 20, 32, 80, ops.CONV_RELU | ops.CONV_POOL2, seed=4),
+            pc.check_conv_winograd("cpu", 2, 13, 9, 16, 64, ops.CONV_RELU | ops.CONV_POOL2, seed=8),   # odd extents: floor
             pc.check_conv_winograd("cpu", 1, 10, 14, 64, 32, ops.CONV_RELU, seed=5, with_scale=True, residual="add"),
             pc.check_conv_winograd("cpu", 1, 9, 11, 32, 48, ops.CONV_RELUMASK, seed=6, residual="mask"),
             pc.check_conv_winograd("cpu", 2, 7, 9, 32, 64, 0, seed=7, mode=1)]

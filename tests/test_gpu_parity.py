@@ -554,7 +554,7 @@ def test_checkpoint_save_load_identical_inference(arch, tmp_path):
 # ---- Winograd F(2x2,3x3) conv kernel ---------------------------------------------------------------------------------------
 WINO_CASES = [
     (1, 8, 8, 16, 16, 0, {}), (2, 13, 25, 32, 64, 1, {}), (1, 25, 25, 48, 96, 1, {}), (3, 5, 3, 16, 7, 0, {}),
-    (2, 12, 20, 32, 80, 1 | 16, {}), (1, 10, 14, 64, 32, 1, {"with_scale": True, "residual": "add"}),
+    (2, 12, 20, 32, 80, 1 | 16, {}), (2, 13, 9, 16, 64, 1 | 16, {}), (1, 399, 201, 64, 64, 1 | 16, {}), (1, 10, 14, 64, 32, 1, {"with_scale": True, "residual": "add"}),
     (1, 9, 11, 32, 48, 32, {"residual": "mask"}), (2, 7, 9, 32, 64, 0, {"mode": 1}),
     (2, 400, 400, 64, 64, 1 | 16, {}), (2, 200, 200, 128, 128, 1, {}), (4, 100, 100, 256, 256, 1, {}),
     (4, 50, 50, 512, 512, 1, {}), (8, 25, 25, 512, 512, 1, {}), (3, 13, 13, 512, 512, 1, {"with_scale": True}),
@@ -587,10 +587,12 @@ def _dp_network(arch, gpu_ids, optimizer="adam", lr=1e-5, in_res=(96, 64), weigh
 def test_single_process_data_parallel_two_replicas_on_one_gpu():
     """gpu_ids = [0, 0]: two persistent replicas (threads, scatter, per-replica peak extraction, flat gradient reduce, flat
     parameter refresh) on the one GPU this box has.  Inference: bit-identical to the single-replica network, in order;
-    training: two Adam steps equal the single-replica steps on the whole batch."""
+    training: two SGD steps equal the single-replica steps on the whole batch."""
     x = torch.from_numpy(cases.image_batch(5, 64, 96, seed=31)).to(DEV)
     t = torch.from_numpy(cases.target_batch(5, 7, (24, 16), in_wh=(96, 64), seed=31)).to(DEV)
-    dp, one = _dp_network("vgg_q", [0, 0]), _dp_network("vgg_q", [0])
+    # SGD: parameter differences are lr x gradient differences (Adam's g / sqrt(v) turns a 1e-9 difference of a near-zero
+    # gradient into a full lr-sized step; the single-launch Adam path is checked by the CPU suite)
+    dp, one = _dp_network("vgg_q", [0, 0], "sgd", 1e-4), _dp_network("vgg_q", [0], "sgd", 1e-4)
     dp.enable_evaluation()
     one.enable_evaluation()
     with torch.no_grad():
@@ -604,7 +606,7 @@ def test_single_process_data_parallel_two_replicas_on_one_gpu():
     l1 = [one.train([x], t).item() for _ in range(2)]
     assert np.allclose(l2, l1, rtol=2e-6), (l2, l1)
     for (k, a), (_, b) in zip(dp.model.named_parameters(), one.model.named_parameters()):
-        assert float((a - b).abs().max()) <= 1e-7 + 2e-5 * float(b.abs().max()), k
+        assert float((a - b).abs().max()) <= 1e-7 + 1e-5 * float(b.abs().max()), k
     grads = [p.grad for p in dp.model.parameters()]
     assert all(g.untyped_storage().data_ptr() == grads[0].untyped_storage().data_ptr() for g in grads)
     dp.model._sync_replicas(2)

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [1, 2, 16]
+KS = [1, 100]              # 100: the product source built with -fno-slp-vectorize (no packed-f32 VALU)
 OUT = os.path.join(ROOT, "build", "diag")
 
 
@@ -19,7 +19,8 @@ def build():
     procs = []
     for k in KS:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-I", os.path.join(csrc, "include"), "-DDREAM_WINO_DIAG=%d" % k, os.path.join(csrc, "conv_wino.hip"),
+               "-I", os.path.join(csrc, "include"), "-DDREAM_WINO_DIAG=%d" % (k if k < 100 else 0)] + (
+                   ["-fno-slp-vectorize"] if k == 100 else []) + [os.path.join(csrc, "conv_wino.hip"),
                os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino_diag_%d.so" % k)]
         procs.append(subprocess.Popen(cmd))
     assert all(p.wait() == 0 for p in procs)
@@ -36,7 +37,7 @@ def run(batch):
         libs[k] = h
     names = {0: "product", 1: "no transform", 2: "no weight stream", 4: "no barrier", 3: "no transform, no weights",
              7: "MFMAs + operand reads only", 8: "all tiles read one patch", 16: "all chunks read chunk 0",
-             18: "chunk 0 only, no weight stream"}
+             18: "chunk 0 only, no weight stream", 100: "product, -fno-slp-vectorize"}
     for (res, cin, cout) in [(400, 64, 64), (100, 256, 256), (50, 512, 512)]:
         x = torch.randn(batch, res, res, cin, device="cuda")
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
