@@ -45,11 +45,26 @@ def main():
         sel = [r for r in rows if key in r["kernel"]]
         return sum(r["dispatches"] for r in sel), sum(r["sum_kib"] for r in sel) * 1024.0
 
-    nf, fb = family(fetch, "mfma_kernel")
-    nw, wb = family(write, "mfma_kernel")
+    # the conv kernel families of the fp32 path: the Winograd kernel and the direct implicit-GEMM kernel
+    nf, fb = [a + b for a, b in zip(family(fetch, "mfma_kernel"), family(fetch, "wino_kernel"))]
+    nw, wb = [a + b for a, b in zip(family(write, "mfma_kernel"), family(write, "wino_kernel"))]
+    n_wino = family(fetch, "wino_kernel")[0]
     npool, pool_fetch = family(fetch, "maxpool2_kernel")
     # un-fused pools of vgg_q at B=128: 256ch@100x100 and 512ch@50x50 inputs, one of each per forward pass
     pool_alg = 4.0 * B * (100 * 100 * 256 + 50 * 50 * 512) * (npool / 2.0)
+    if len(sys.argv) > 4:                                   # generic mode: just the per-family totals of another workload
+        fams = sys.argv[4].split(",")
+        out_d = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py " + " ".join(sys.argv[5:]),
+                 "units": "GB per profiled run; FETCH_SIZE doubled per the gfx950 rule", "families": {}}
+        for fam in fams:
+            n1, b1 = family(fetch, fam)
+            n2, b2 = family(write, fam)
+            out_d["families"][fam] = {"dispatches": n1, "fetch_gb_corrected": 2.0 * b1 / 1e9, "write_gb": b2 / 1e9}
+        out_d["raw"] = {"FETCH_SIZE": fetch[:16], "WRITE_SIZE": write[:16]}
+        with open(out, "w") as f:
+            json.dump(out_d, f, indent=1)
+        print(json.dumps(out_d["families"], indent=1))
+        return
     res = {
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
                    "--no-cpu-baseline --no-split-leg (one PMC counter per run)",
@@ -58,7 +73,8 @@ def main():
         "calibration_maxpool2_kernel": {"dispatches": npool, "fetch_gb_raw": pool_fetch / 1e9,
                                         "fetch_gb_algorithmic": pool_alg / 1e9,
                                         "raw_to_algorithmic": pool_alg / pool_fetch if pool_fetch else None},
-        "conv_mfma_kernel": {
+        "conv_kernels": {
+            "families": "conv_wino_kernel (%d dispatches) + conv_mfma_kernel (%d)" % (n_wino, nf - n_wino),
             "dispatches": nf,
             "fetch_gb_per_launch_corrected": 2.0 * fb / nf / 1e9,
             "write_gb_per_launch": wb / nw / 1e9,
@@ -69,7 +85,7 @@ def main():
     }
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: res[k] for k in ("calibration_maxpool2_kernel", "conv_mfma_kernel")}, indent=1))
+    print(json.dumps({k: res[k] for k in ("calibration_maxpool2_kernel", "conv_kernels")}, indent=1))
 
 
 if __name__ == "__main__":
