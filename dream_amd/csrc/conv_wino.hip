@@ -19,7 +19,7 @@
 //     NW = 8 (128 channels, one workgroup per CU) halves the input-transform work per MFMA; NW = 4 (two workgroups per CU)
 //     serves the 64-channel layers;
 //   * V (the transformed input) is computed by the workgroup for one 16-channel chunk at a time into a double-buffered LDS
-//     tile (2 x 33 KB; float4 slots XOR-swizzled and planes skewed by 16 bytes so that the b128 transform stores and the
+//     tile (2 x 32 KB; float4 slots XOR-swizzled and plane groups skewed by 32 bytes so that the b128 transform stores and the
 //     b128 MFMA-operand reads are both conflict-free) WHILE the MFMAs of the previous chunk run: a thread owns (tile,
 //     channel quad, patch row), loads the row's four pixels once, transforms along the row, gets the other rows' values
 //     for the column transform from its quad neighbours (DPP quad_perm) -- no element of the input is loaded twice;
@@ -61,9 +61,11 @@ struct WinoParams {
 constexpr int WT = 32;       // tiles per workgroup
 constexpr int WKC = 16;      // input channels per chunk
 constexpr int WPAD = 128;    // output channels the packed weights are padded to (a multiple of every workgroup width)
-constexpr int PS = WT * WKC + 4;   // floats per V plane: 512 + a 16-byte skew (planes 4r + j of a quad's four rows r land on
-                                   // banks 0 / 16 / 32 / 48, so the transform's b128 stores do not collide)
-constexpr int VB = 16 * PS;  // floats per V buffer
+// float offset of V plane p = 4i + j inside a buffer: 512 floats per plane plus a 32-byte skew per row group i, so that the
+// b128 transform stores of a quad's four lanes (planes 4r + j, r = 0..3, same tile) fall on banks 0 / 8 / 16 / 24 of the 32
+// the LDS store path distinguishes (MI355X_MICROARCH.md: ds_write_b128 is serviced 8 lanes at a time, bank = (a/4) mod 32)
+DREAM_DEVICE constexpr int v_plane(int p) { return p * (WT * WKC) + 8 * (p >> 2); }
+constexpr int VB = 16 * WT * WKC + 32;   // floats per V buffer
 constexpr int B_RING = 8;    // operand registers of the weight stream
 constexpr int B_AHEAD = 6;   // positions the weight stream runs ahead of the MFMAs: far enough that an operand is never queued
                              // behind the patch loads of an item (loads return in order)
@@ -76,7 +78,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     constexpr int NT = 64 * NW;                        // threads
     constexpr int ITEMS = 512 / NT;                    // (tile, quad, row) items per thread and chunk: 2 (NW 4) or 1 (NW 8)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    DREAM_DYNAMIC_LDS(float, sV);                      // 2 x [16 positions][PS]  then the load-offset table
+    DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer (16 skewed planes of [32 tiles][16 channels]), then the offset table
     u32x4 *sG = (u32x4 *)(sV + 2 * VB);                // [ITEMS][NT]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     const int b0 = div_magic40(tile0, p.magic_tpi);
     const size_t img_floats = (size_t)p.H * p.W * p.Cin;
     const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
-    int soff[ITEMS];                                   // LDS float offset of V[p = 4r][t][slot q]; + j * PS for p = 4r + j
+    int soff[ITEMS];                                   // LDS float offset of V[p = 4r][t][slot q]; + j * 512 for p = 4r + j
     const int qr = lane & 3;                           // patch row of this lane's items (e & 3 with NT a multiple of 4)
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
@@ -116,7 +118,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         for (int c = 0; c < 4; ++c)
             g[c] = (rok && (x0 + c) >= 0 && (x0 + c) < p.W) ? (unsigned)(((row + x0 + c) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
         sG[it * NT + tid] = g;
-        soff[it] = 4 * qr * PS + t * WKC + 4 * v_slot(q, t);
+        soff[it] = v_plane(4 * qr) + t * WKC + 4 * v_slot(q, t);
     }
     // column transform across the quad: row r of B^T (u_0..u_3) = u_r + sb * u_partner(r), partner = {2, 2, 1, 1}, for
     // r = 0, 1, 2; the lane of r = 3 computes u_3 - u_1 = MINUS row 3 -- the packed weights carry the matching sign in their
@@ -172,7 +174,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(sb, quad_perm_2211(u[j][k]), u[j][k]);     // exact: sb = +-1
-            *(f32x4 *)(dst + j * PS) = v;
+            *(f32x4 *)(dst + j * (WT * WKC)) = v;
         }
     };
 
@@ -182,8 +184,8 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     // wave in flight) and issues the four MFMAs of one accumulator back to back (40-cycle dependent latency vs 32 issue).
     f32x4 a[2][2];
     auto read_a = [&](int set, int pp, const float *vbuf) {
-        a[set][0] = *(const f32x4 *)(vbuf + pp * PS + a_off[0]);
-        a[set][1] = *(const f32x4 *)(vbuf + pp * PS + a_off[1]);
+        a[set][0] = *(const f32x4 *)(vbuf + v_plane(pp) + a_off[0]);
+        a[set][1] = *(const f32x4 *)(vbuf + v_plane(pp) + a_off[1]);
     };
     auto mfma_pair = [&](int pp, int r) {
         acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], acc[pp][0]);

@@ -8,11 +8,15 @@ export TMPDIR=/tmp
 R="$PWD"
 echo "== pytest gpu (all)"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 echo "== default bench"; timeout 900 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
-echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; tail -1 $O/rocprof_default.log | cut -c1-200
+# raw rocprofv3 databases stay on the box (gpurun copies back at most 64 MiB): summarised here, then removed
+summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" > /dev/null 2>&1; echo "summary $2 rc=$?"; rm -rf "$1"; }
+echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; grep -h '^{"metric' $O/rocprof_default.log | cut -c1-200
+summ $O/prof_default $O/bench_default
 for C in FETCH_SIZE WRITE_SIZE; do
   echo "== pmc $C"; (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_$C" -o pmc -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-split-leg > "$R/$O/pmc_$C.log" 2>&1); echo "rc=$?"
 done
 python tools/pmc_traffic.py $(ls $O/pmc_FETCH_SIZE/*/*.db $O/pmc_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_WRITE_SIZE/*/*.db $O/pmc_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic.json | head -30
+rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 C1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 C2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
 for pass in 1 2; do
@@ -22,11 +26,13 @@ done
 python tools/pmc_mfma.py $O/pmc_sq_1 $O/pmc_sq_2 > $O/pmc_mfma.json 2> $O/pmc_mfma.err; python -c "
 import json; d=json.load(open('$O/pmc_mfma.json'))['kernels']
 for k,v in d.items(): print(k, {a: round(b,3) for a,b in v.items() if a in ('mfma_util','lds_conflict_frac','wait_frac','issue_stall_frac','valu_insts_per_mfma')})"
+rm -rf $O/pmc_sq_1 $O/pmc_sq_2
 # ResNet training traffic (one GPU's share of configs[3])
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_rt_$C" -o pmc -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 --no-cpu-baseline > "$R/$O/pmc_rt_$C.log" 2>&1); echo "resnet train pmc $C rc=$?"
 done
 python tools/pmc_traffic.py $(ls $O/pmc_rt_FETCH_SIZE/*/*.db $O/pmc_rt_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_rt_WRITE_SIZE/*/*.db $O/pmc_rt_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic_resnet_train.json "bn_,mfma_kernel,wino_kernel,wgrad_kernel,adam,pack" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 | head -40
+rm -rf $O/pmc_rt_FETCH_SIZE $O/pmc_rt_WRITE_SIZE
 line() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | cut -c1-160; }
 line train --mode train --steps 4 --warmup 1
 line resnet_h_train16 --arch resnet_h --mode train --batch 16 --steps 5 --warmup 2
@@ -36,5 +42,7 @@ line resnet_h_b128 --arch resnet_h --batch 128
 line vgg_f_b32 --arch vgg_f --batch 32
 line vgg_f_train32 --arch vgg_f --mode train --batch 32 --steps 3 --warmup 1
 echo "== rocprof train"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_train" -o train -- python "$R/bench.py" --mode train --steps 2 --warmup 1 --no-cpu-baseline > "$R/$O/rocprof_train.log" 2>&1); echo "rc=$?"
+summ $O/prof_train $O/bench_train
 echo "== rocprof resnet_h train16"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
-find $O -name "*_kernel_stats.csv" | head
+summ $O/prof_rtrain $O/bench_resnet_h_train16
+ls -la $O | head -60; du -sh $O

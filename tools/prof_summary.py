@@ -17,8 +17,8 @@ def main():
         for name, n, tot, avg, mn, mx in rows:
             f.write('"%s",%d,%.3f,%.1f,%.1f,%.1f,%.2f\n' % (name, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
         # template families (what bench.py's roofline.avg_launch_ms averages over)
-        for fam in ("conv_mfma_kernel", "conv_f16x3_kernel", "wgrad_kernel"):
-            sel = [r for r in rows if fam + "<" in r[0]]
+        for fam in ("conv_wino_kernel", "conv_mfma_kernel", "conv_f16x3_kernel", "wgrad_kernel", "bn_"):
+            sel = [r for r in rows if fam + "<" in r[0] or (fam.endswith("_") and fam in r[0])]
             if sel:
                 n = sum(r[1] for r in sel)
                 tot = sum(r[2] for r in sel)
@@ -32,7 +32,7 @@ def main():
         for name, start, dur, gx, gy, lds, vg in cur.execute(
                 "select name, start, duration, grid_x, grid_y, lds_size, vgpr_count from kernels order by start"):
             t0 = start if t0 is None else t0
-            if "conv_mfma" in name or "conv_f16x3" in name or "wgrad" in name:
+            if "conv_mfma" in name or "conv_wino" in name or "conv_f16x3" in name or "wgrad" in name:
                 f.write('"%s",%.3f,%.1f,%d,%d,%d,%d\n' % (name.split("(")[0], (start - t0) / 1e6, dur / 1e3, gx, gy, lds, vg))
     # PMC, if present
     try:
