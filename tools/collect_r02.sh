@@ -1,0 +1,14 @@
+#!/bin/bash
+# Turn gpurun_out/r02final/ (tools/gpu_r02_final.sh) into the committed summaries under profiles/.
+cd /root/repo
+O=gpurun_out/r02final
+for n in default train resnet_h_train16; do
+  cp $O/bench_${n}_kernel_stats.csv profiles/r02_bench_${n}_kernel_stats.csv
+  cp $O/bench_${n}_conv_dispatches.csv profiles/r02_bench_${n}_conv_dispatches.csv
+done
+cp $O/pmc_traffic.json profiles/r02_pmc_traffic.json
+cp $O/pmc_traffic_resnet_train.json profiles/r02_pmc_traffic_resnet_train.json
+cp $O/pmc_mfma.json profiles/r02_pmc_mfma.json
+for n in default train resnet_h_train16 resnet_h_train128 resnet_f_b32 resnet_h_b128 vgg_f_b32 vgg_f_train32; do tail -1 $O/bench_$n.log > profiles/r02_bench_${n}_line.json; done
+grep -h '^{"metric' $O/rocprof_default.log > profiles/r02_bench_default_under_rocprof_line.json
+tail -3 $O/pytest_gpu.log > profiles/r02_pytest_gpu_tail.txt
