@@ -407,7 +407,11 @@ class DreamHourglass(nn.Module):
                 g = None
                 continue
             def leaf(pi=pi, inp=inp, g=g, cout=cout, cin=cin, ups=flags & CONV_UPSAMPLE2X):
-                grads[pi], grads[pi + 1] = ops.conv3x3_wgrad(inp, g, cout, cin, ups)
+                if (not ups and self.conv_algorithm == "winograd" and cin % 64 == 0 and cout % 16 == 0 and cout >= 32
+                        and int(inp.shape[3]) == cin):
+                    grads[pi], grads[pi + 1] = ops.conv3x3_wgrad_winograd(inp, g, cout, cin)     # 16/36 of the multiplications
+                else:
+                    grads[pi], grads[pi + 1] = ops.conv3x3_wgrad(inp, g, cout, cin, ups)
             _on_side(side, leaf, inp, g)
             packed_t, rows, _, cols_pad = self._packed.get(mod.weight, 1)
             if int(g.shape[3]) != cols_pad:
@@ -1087,7 +1091,10 @@ class ResnetSimple(nn.Module):
                 if rec["has_res"]:
                     block["g_idt"] = gm          # masked block-output gradient == gradient of the identity branch
                 def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"]):
-                    grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
+                    if self._wino_train(conv) and cin % 64 == 0:
+                        grads[conv.weight] = ops.conv3x3_wgrad_winograd(x, dz, cout, cin, want_bias=False)[0]
+                    else:
+                        grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
                 _on_side(side, leaf, rec["x"], dz)
                 in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
                 if is_ds:

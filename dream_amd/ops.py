@@ -233,6 +233,21 @@ def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
     return dw, dbias[:cout].contiguous()
 
 
+def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True):
+    """Weight (+ bias) gradient of a 3x3 stride-1 conv in the Winograd F(2x2,3x3) domain -> (dW OIHW [cout,cin,3,3], dbias
+    [cout] or None).  cin % 64 == 0, cout % 16 == 0; dy may carry padded channels (>= cout)."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    b, h, w, cdy = (int(v) for v in dy.shape)
+    if int(x.shape[3]) != cin:
+        raise RuntimeError("wgrad: x has %d channels, expected %d" % (x.shape[3], cin))
+    nbytes = int(_hip.lib().dream_conv3x3_wgrad_winograd_workspace(b, h, w, cin, cout))
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_wgrad_winograd_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), b, h, w, cin, cout, cdy, stream())
+    db = channel_sum(dy)[:cout].contiguous() if want_bias else None
+    return dw, db
+
+
 def conv3x3_first_wgrad(x_nchw, dy_nhwc):
     x, dy = _f32(x_nchw), _f32(dy_nhwc)
     b, cin, h, w = (int(v) for v in x.shape)

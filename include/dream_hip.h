@@ -271,6 +271,14 @@ size_t dream_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad);
 int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias,
                                  void *workspace, int B, int H, int W, int Cin, int Cout,
                                  int CoutPad, int flags, void *stream);
+/* The same weight gradient in the Winograd F(2x2,3x3) domain (16 instead of 36 multiplications per 2x2 outputs, fp32
+ * throughout): dU_p = sum_tiles (A dY A^T)_p x (B^T d B)_p on the fp32 matrix cores, dW = G^T dU G, deterministic split-K.
+ * x [B,H,W,Cin], dy [B,H,W,Cdy] (Cdy >= Cout, both multiples of 16), Cin % 64 == 0 -> dw_oihw [Cout,Cin,3,3] (OIHW,
+ * overwritten); the bias gradient is dream_channel_sum_nhwc_f32(dy).  Replaces ATen conv backward-weight reached from
+ * loss.backward() (dream/network.py:335) for the stride-1 3x3 convs of dream/models.py:598-615,695-710,736-747,22-32. */
+size_t dream_conv3x3_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout);
+int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
+                                          int W, int Cin, int Cout, int Cdy, void *stream);
 /* general forms for the ResNet path (1x1 / 3x3, stride 1 / 2) and the 4x4 transposed conv */
 size_t dream_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad, int ksize, int stride);
 int dream_conv2d_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias, void *workspace,

@@ -93,6 +93,26 @@ def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_s
     return err
 
 
+def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0):
+    """Winograd-domain weight gradient vs an fp64 evaluation of the direct sums: error relative to sum |terms| at fp32
+    round-off level (the direct MFMA kernel is checked the same way)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wref, None, padding=1).backward(dy.double())
+    aref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)      # sum |terms|: the error scale
+    F.conv2d(x.double().abs(), aref, None, padding=1).backward(dy.double().abs())
+    dyn = _nhwc(dy)
+    if pad_dy:
+        dyn = torch.cat([dyn, torch.zeros(B, H, W, pad_dy)], dim=3).contiguous()
+    dw, db = ops.conv3x3_wgrad_winograd(to(dev, _nhwc(x)), to(dev, dyn), Cout, Cin)
+    err = float(((dw.cpu().double() - wref.grad).abs() / aref.grad).max())
+    assert dw.shape == (Cout, Cin, 3, 3) and err <= 3e-6, (B, H, W, Cin, Cout, err)
+    assert float((db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())
+    return err
+
+
 def check_conv_transpose(dev, B, H, W, Cin, Cout, seed=0):
     """ConvTranspose2d(k3,s2,p1,op1) == zero-stuffed conv with mode-1 packed weights."""
     g = torch.Generator().manual_seed(seed)

@@ -46,6 +46,15 @@ def test_conv_winograd(emu, variant):
     print("winograd max rel err", max(errs))
 
 
+def test_wgrad_winograd(emu):
+    errs = [pc.check_wgrad_winograd("cpu", 1, 8, 8, 64, 16),                    # one split, interior + border tiles
+            pc.check_wgrad_winograd("cpu", 2, 13, 9, 64, 32, seed=1),            # odd extents (half tiles), several images
+            pc.check_wgrad_winograd("cpu", 3, 6, 10, 128, 48, seed=2),           # two input-channel groups, ragged output group
+            pc.check_wgrad_winograd("cpu", 1, 25, 25, 64, 64, seed=3),           # several splits
+            pc.check_wgrad_winograd("cpu", 2, 5, 3, 64, 16, seed=4, pad_dy=16)]  # images smaller than a k-step, padded dy
+    print("winograd wgrad max err / sum|terms|", max(errs))
+
+
 def test_conv_heuristic_and_odd_shapes(emu):
     pc.check_conv("cpu", 1, 25, 25, 64, 128, 1)       # 5x25 tiles
     pc.check_conv("cpu", 3, 5, 3, 16, 16, 0)          # KC=16 fallback, image smaller than a tile

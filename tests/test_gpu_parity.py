@@ -637,3 +637,12 @@ def test_single_process_data_parallel_resnet_batchnorm_semantics():
         assert float((p.grad - ref).norm()) <= 1e-4 * max(float(ref.norm()), 1e-6 * gmax)
     # running statistics: replica 0's (the first chunk), as DataParallel keeps them
     assert torch.equal(dp.model.module.bn1.running_mean, halves[0][2].model.module.bn1.running_mean)
+
+
+# ---- Winograd-domain weight gradient -----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("b,h,w,cin,cout,pad", [(1, 8, 8, 64, 16, 0), (2, 13, 9, 64, 32, 0), (3, 6, 10, 128, 48, 0), (2, 5, 3, 64, 16, 16),
+                                                 (4, 400, 400, 64, 64, 0), (4, 100, 100, 256, 256, 0), (8, 25, 25, 512, 512, 0),
+                                                 (2, 133, 101, 128, 64, 0), (16, 13, 13, 512, 512, 0)])
+def test_wgrad_winograd(b, h, w, cin, cout, pad):
+    err = pc.check_wgrad_winograd(DEV, b, h, w, cin, cout, seed=h + cin, pad_dy=pad)
+    print("winograd wgrad %dx%dx%d %d->%d: err / sum|terms| %.2e" % (b, h, w, cin, cout, err))
