@@ -23,6 +23,12 @@
 //     per-load validity selects when every tile of the k-step lies inside the image;
 //   * loads of k-step s+1 are issued before the 32 MFMAs of step s; the negations of A dY A^T are folded into the final
 //     transform (signs of dU positions), so the operand transforms are 12 + 32 additions per lane and k-step.
+// Measured (profiles/r02_microbench_wgrad_wino_b128.txt): 1.15-1.67x the direct kernel on the layers it is used for, 0.50-0.55 of
+// the MFMA peak on its own multiplications.  What bounds it (knock-out builds, profiles/r02_wgw_diag.txt): with the loads
+// removed the same loop runs at 0.79-0.93, with the transforms removed nothing changes -- the 24 scalar loads per 32 MFMAs
+// (64-byte segments, 256 B per wave instruction) saturate the texture-address path; variants with less address arithmetic,
+// loads two steps ahead or loads spread between the MFMAs were all slower.  The fix is structural (share the loaded patch
+// across the workgroup through LDS, float4 loads: ~0.1 load instructions per MFMA instead of 0.75) and is the next version.
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"

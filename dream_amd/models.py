@@ -407,8 +407,8 @@ class DreamHourglass(nn.Module):
                 g = None
                 continue
             def leaf(pi=pi, inp=inp, g=g, cout=cout, cin=cin, ups=flags & CONV_UPSAMPLE2X):
-                if (not ups and self.conv_algorithm == "winograd" and cin % 64 == 0 and cout % 16 == 0 and cout >= 32
-                        and int(inp.shape[3]) == cin):
+                if (not ups and self.conv_algorithm == "winograd" and int(inp.shape[3]) == cin
+                        and ops.wgrad_winograd_pays(int(g.shape[0]) * int(g.shape[1]) * int(g.shape[2]), cin, cout)):
                     grads[pi], grads[pi + 1] = ops.conv3x3_wgrad_winograd(inp, g, cout, cin)     # 16/36 of the multiplications
                 else:
                     grads[pi], grads[pi + 1] = ops.conv3x3_wgrad(inp, g, cout, cin, ups)
@@ -1091,7 +1091,7 @@ class ResnetSimple(nn.Module):
                 if rec["has_res"]:
                     block["g_idt"] = gm          # masked block-output gradient == gradient of the identity branch
                 def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"]):
-                    if self._wino_train(conv) and cin % 64 == 0:
+                    if self._wino_train(conv) and ops.wgrad_winograd_pays(int(dz.shape[0]) * int(dz.shape[1]) * int(dz.shape[2]), cin, cout):
                         grads[conv.weight] = ops.conv3x3_wgrad_winograd(x, dz, cout, cin, want_bias=False)[0]
                     else:
                         grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]

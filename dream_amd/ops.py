@@ -233,6 +233,13 @@ def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
     return dw, dbias[:cout].contiguous()
 
 
+def wgrad_winograd_pays(pixels, cin, cout):
+    """Where the Winograd-domain weight gradient beats the direct kernel (profiles/r02_microbench_wgrad_wino_b128.txt:
+    1.15-1.67x on the layers with >= 128 x 128 channel pairs or >= 4 M pixels; it loses on small 64-channel maps, whose
+    split-K partials and short loops dominate)."""
+    return cin % 64 == 0 and cout % 16 == 0 and cout >= 64 and (cin * cout >= 16384 or pixels >= 4000000)
+
+
 def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True):
     """Weight (+ bias) gradient of a 3x3 stride-1 conv in the Winograd F(2x2,3x3) domain -> (dW OIHW [cout,cin,3,3], dbias
     [cout] or None).  cin % 64 == 0, cout % 16 == 0; dy may carry padded channels (>= cout)."""

@@ -12,7 +12,11 @@ lib = _hip.lib()
 x = torch.randn(batch, res, res, cin, device="cuda")
 w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
 bias = torch.randn(cout, device="cuda")
-if kind == "wino":
+if kind == "wgwino":
+    dy = torch.randn(batch, res, res, cout, device="cuda")
+    for _ in range(reps):
+        ops.conv3x3_wgrad_winograd(x, dy, cout, cin, want_bias=False)
+elif kind == "wino":
     u, _ = ops.pack_weight_winograd(w, 0)
     lib.dream_conv3x3_winograd_set_variant(variant)
     for _ in range(reps):
