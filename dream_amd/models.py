@@ -7,13 +7,14 @@ Mirrors /root/reference/dream/models.py:
   * ``ResnetSimple``    (models.py:17-155)   -- torchvision ResNet-101 trunk + ConvTranspose/BN decoder, evaluation
     (BatchNorm folded) and training (batch statistics) on the same kernels; identical ``state_dict()``.
   * ``DreamHourglassMultiStage`` (models.py:350-553) -- 1..6 hourglasses, each fed the image and the previous maps.
-  * ``DreamDataParallel`` stands in for ``torch.nn.DataParallel`` (dream/network.py:244-256): it only
-    contributes the ``module.`` key prefix; data parallelism is one process per GPU with an RCCL
-    all-reduce of the flat gradient buffer (see ``_HourglassFunction.backward``).
+  * ``DreamDataParallel`` (dream_amd/data_parallel.py) stands in for ``torch.nn.DataParallel`` (dream/network.py:244-256):
+    the ``module.`` key prefix, and persistent single-process replicas on the GPUs listed in ``gpu_ids``; under torchrun it is
+    a pass-through and the gradient exchange is the bucketed RCCL all-reduce in ``_HourglassFunction.backward`` below.
 
 ``nn.Conv2d`` objects are used purely as parameter containers (OIHW, as the reference stores them);
 their ATen forward is never called.  ``forward`` executes a static list of C-ABI calls on NHWC
-activations: first conv (NCHW image -> NHWC, VALU), MFMA 3x3 convs with fused bias/ReLU/upsample/max-pool,
+activations: first conv (NCHW image -> NHWC, VALU), 3x3 convs on the fp32 matrix cores (Winograd F(2x2,3x3) where it
+applies, direct implicit GEMM elsewhere) with fused bias/ReLU/upsample/max-pool,
 skip-connection adds, and an NCHW store in the last head conv; ``backward`` walks the same list in reverse.  If the HIP library or a GPU is missing the
 call raises -- there is no CPU path in this package.
 """

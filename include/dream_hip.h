@@ -17,8 +17,8 @@
  *   - activations inside the network are NHWC fp32 ("pixel-major": one pixel's channels are
  *     contiguous, so a wavefront's 64 lanes read/write whole 128-256 B lines); the boundary
  *     tensors of the reference API (network input, belief maps, targets) stay NCHW fp32.
- *   - all arithmetic is IEEE fp32 (MFMA v_mfma_f32_32x32x2_f32 == an fmaf chain); the peak
- *     path accumulates in fp64 exactly like scipy/NumPy do.
+ *   - all arithmetic is IEEE fp32 (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 == fmaf chains; the Winograd entry
+ *     points add and subtract in fp32 around them); the peak path accumulates in fp64 exactly like scipy/NumPy do.
  */
 #ifndef DREAM_HIP_H
 #define DREAM_HIP_H
