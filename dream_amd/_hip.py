@@ -70,6 +70,7 @@ _SIGNATURES = {
     "dream_conv3x3_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_winograd_weight_floats": (_SZ, [_I, _I]),
     "dream_conv3x3_winograd_set_variant": (_I, [_I]),
+    "dream_conv3x3_winograd_set_max_workgroups": (_I, [_I]),
     "dream_pack_conv3x3_winograd_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "dream_conv3x3_winograd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_upsample_conv3x3_weight_as_convT4x4": (_I, [_P, _P, _I, _I, _P]),

@@ -30,6 +30,7 @@
 //     bounds check (offset BUFFER_OOB), no 64-bit address arithmetic; tile -> (image, row, column) by magic multiplication;
 //   * the instruction order of the main loop is pinned (sched_barrier per pair of MFMAs): one patch load per pair, MFMA
 //     operands read one position ahead into the register set of the other parity, alternating accumulators.
+#include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
@@ -54,6 +55,7 @@ struct WinoParams {
     int B, H, W, Cin, Cout, CoutPad;
     int TY, TX;              // 2x2 tiles per image
     int ntiles;              // B * TY * TX  (< 2^24)
+    int nblk, blk_per_xcd;   // blocks of 32 tiles; each XCD's workgroups walk over a contiguous range of them
     unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX): tile -> (image, row, column) without divides
     int flags;
 };
@@ -73,7 +75,10 @@ constexpr int B_AHEAD = 6;   // positions the weight stream runs ahead of the MF
 // physical float4 slot of logical slot q (k = 4q .. 4q+3) in row t of a V plane
 DREAM_DEVICE int v_slot(int q, int t) { return q ^ ((t >> 2) & 2); }
 
-template <int NW>
+// MODE: what the epilogue does besides scale / shift / ReLU -- 0 nothing, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask
+// (data gradient through a ReLU: zero where the forward activation was).  Compile-time: the epilogue of a persistent
+// workgroup sits between two blocks' MFMA phases and must be straight-line code (exact s_waitcnt counts, loads batched).
+template <int NW, int MODE>
 __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams p) {
     constexpr int NT = 64 * NW;                        // threads
     constexpr int ITEMS = 512 / NT;                    // (tile, quad, row) items per thread and chunk: 2 (NW 4) or 1 (NW 8)
@@ -84,26 +89,35 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     const int lane = tid & 63;
     const int wave = wave_index();
 
-    // XCD-aware placement (see conv_mfma.hip): each XCD gets a contiguous range of tile blocks
-    const int nblk = (p.ntiles + WT - 1) / WT;
-    const int tb = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (tb >= nblk) return;
-    const int tile0 = tb * WT;
+    // PERSISTENT workgroups: the grid is what the chip holds at once (host side); a workgroup walks over tile blocks
+    // tb, tb + J, tb + 2J .. of its XCD's contiguous range (XCD-aware placement, see conv_mfma.hip: workgroup g runs on XCD
+    // g % 8; the J workgroups of an XCD work on J neighbouring blocks at any time and meet in its L2).  What this buys: the
+    // first chunk of the NEXT block is loaded and transformed during the last chunk of the current one, so only the very
+    // first block of a workgroup pays the load latency of a prologue (~2.5 us of a 14-56 us block).
+    const int xcd = (int)(blockIdx.x & 7), J = (int)(gridDim.x >> 3);
+    const int blk_hi = (xcd + 1) * p.blk_per_xcd;
+    const int blk_end = blk_hi < p.nblk ? blk_hi : p.nblk;
+    int tb = xcd * p.blk_per_xcd + (int)(blockIdx.x >> 3);
+    if (tb >= blk_end) return;
     const int n0 = blockIdx.y * (16 * NW);
     const int tiles_per_img = p.TY * p.TX;
+    const size_t img_floats = (size_t)p.H * p.W * p.Cin;
 
     // ---- input-transform plan: thread -> ITEMS items (tile t, channel quad q, patch row r); r = the lane's index in its quad
     // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, column) relative to the first image
-    // this workgroup touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare / select
-    // per load), the chunk's channel offset in the scalar operand.  The offsets are parked in LDS ([ITEMS][NT] uint4,
-    // conflict-free b128 access) and re-read per chunk: VGPRs that accumulators + weight ring + patch cannot spare.
-    const int b0 = div_magic40(tile0, p.magic_tpi);
-    const size_t img_floats = (size_t)p.H * p.W * p.Cin;
-    const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
+    // the BLOCK touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare / select per
+    // load), the chunk's channel offset in the scalar operand.  The offsets are parked in LDS ([ITEMS][NT] uint4, each entry
+    // private to its thread, conflict-free b128 access) and re-read per chunk: VGPRs that accumulators + weight ring + patch
+    // cannot spare.
     int soff[ITEMS];                                   // LDS float offset of V[p = 4r][t][slot q]; + j * 512 for p = 4r + j
     const int qr = lane & 3;                           // patch row of this lane's items (e & 3 with NT a multiple of 4)
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
+        const int e = tid + it * NT;
+        const int q = (e >> 2) & 3, t = (e >> 4) & 31;
+        soff[it] = v_plane(4 * qr) + t * WKC + 4 * v_slot(q, t);
+    }
+    auto plan_item = [&](int it, int tile0, int b0) -> u32x4 {
         const int e = tid + it * NT;
         const int q = (e >> 2) & 3, t = (e >> 4) & 31;
         const int tau = (DREAM_WINO_DIAG & 8) ? tile0 : tile0 + t;
@@ -111,15 +125,23 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         const int b = div_magic40(tau, p.magic_tpi), rem = tau - b * tiles_per_img;
         const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         const int gy = 2 * ty - 1 + qr, x0 = 2 * tx - 1;
-        const bool rok = tv && gy >= 0 && gy < p.H;
-        const int row = ((b - b0) * p.H + gy) * p.W;
+        const bool rok = tv & ((unsigned)gy < (unsigned)p.H);          // bitwise: no short-circuit branches inside a chunk
+        const unsigned off0 = (unsigned)(((((b - b0) * p.H + gy) * p.W + x0) * p.Cin + 4 * q) * 4);   // column 0 (wraps when outside)
+        const unsigned px = (unsigned)(p.Cin * 4);
         u32x4 g;
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            g[c] = (rok && (x0 + c) >= 0 && (x0 + c) < p.W) ? (unsigned)(((row + x0 + c) * p.Cin + 4 * q) * 4) : BUFFER_OOB;
+        for (int c = 0; c < 4; ++c) {
+            const bool ok = rok & ((unsigned)(x0 + c) < (unsigned)p.W);
+            g[c] = ok ? off0 + (unsigned)c * px : BUFFER_OOB;
+        }
         sG[it * NT + tid] = g;
-        soff[it] = v_plane(4 * qr) + t * WKC + 4 * v_slot(q, t);
-    }
+        return g;
+    };
+    // first tile / first image / input descriptor of a block; a block past the end of the range reads nothing (all OOB)
+    auto block_tile0 = [&](int blk) { return blk < blk_end ? blk * WT : p.ntiles; };
+    auto block_xbuf = [&](int b0) {
+        return make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
+    };
     // column transform across the quad: row r of B^T (u_0..u_3) = u_r + sb * u_partner(r), partner = {2, 2, 1, 1}, for
     // r = 0, 1, 2; the lane of r = 3 computes u_3 - u_1 = MINUS row 3 -- the packed weights carry the matching sign in their
     // positions 12..15 (wino_pack_kernel), so the product is unchanged and every lane needs one fma per value.
@@ -140,31 +162,19 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * WKC, ((size_t)((p.Cin / WKC) * 16 + B_AHEAD) * p.CoutPad - (size_t)n0) * WKC * sizeof(float));
 
     f32x4 acc[16][2];
-#pragma unroll
-    for (int pp = 0; pp < 16; ++pp)
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) acc[pp][blk] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
     const int nchunks = p.Cin / WKC;
 
-    // weight stream: ring of B_RING operand registers, position s lives in bq[s % B_RING].  Unconditional: the packed
-    // tensor ends with B_AHEAD zero positions, and a loop body without branches lets the compiler count outstanding loads
-    // exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at every merge point).
+    // weight stream: ring of B_RING operand registers, position s lives in bq[s % B_RING] (16 positions per chunk: the
+    // register depends on the position inside the chunk only).  Unconditional and branch-free, so the compiler can count
+    // outstanding loads exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at merge points); in the last chunk of a block the
+    // stream wraps around to the first positions of the next block (same weights).
     f32x4 bq[B_RING];
 #pragma unroll
     for (int s = 0; s < B_AHEAD; ++s) bq[s] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
-    auto prefetch_b = [&](int pp, int s0) {
-        if (DREAM_WINO_DIAG & 2) return;
-        bq[(pp + B_AHEAD) % B_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)(s0 + pp + B_AHEAD) * u_pos_stride);
-    };
 
     // patch row of an item: its four loads / row transform, quad exchange, column transform, four V stores
     f32x4 d[ITEMS][4];
     u32x4 goff[ITEMS];
-    auto item_offsets = [&](int it) { goff[it] = sG[it * NT + tid]; };       // written by this thread: no barrier
-    auto item_load_one = [&](int it, int c, int chunk) {
-        d[it][c] = buffer_load_x4(xbuf, goff[it][c], (DREAM_WINO_DIAG & 16) ? 0u : (unsigned)(chunk * WKC * 4));
-    };
     auto item_store = [&](int it, float *vbuf) {
         // row transform (B^T d B = (B^T (d B))): u_j = sum_c d_c B[c][j]
         const f32x4 u[4] = {d[it][0] - d[it][2], d[it][1] + d[it][2], d[it][2] - d[it][1], d[it][1] - d[it][3]};
@@ -187,32 +197,34 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         a[set][0] = *(const f32x4 *)(vbuf + v_plane(pp) + a_off[0]);
         a[set][1] = *(const f32x4 *)(vbuf + v_plane(pp) + a_off[1]);
     };
-    auto mfma_pair = [&](int pp, int r) {
-        acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], acc[pp][0]);
-        acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp % B_RING][r], acc[pp][1]);
-        __builtin_amdgcn_sched_barrier(0);
-    };
 
-    // prologue: chunk 0 into buffer 0
+    // ---- first block of this workgroup: plan, chunk 0 into buffer 0 (the only exposed load latency of the workgroup) --------
+    int tile0 = block_tile0(tb);
+    int b0 = div_magic40(tile0, p.magic_tpi);
+    BufferRsrc xbuf = block_xbuf(b0);
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
-        item_offsets(it);
+        goff[it] = plan_item(it, tile0, b0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) item_load_one(it, c, 0);
+        for (int c = 0; c < 4; ++c) d[it][c] = buffer_load_x4(xbuf, goff[it][c], 0u);
     }
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) item_store(it, sV);
     __syncthreads();
+    int par = 0;                                       // V buffer holding the chunk about to be multiplied
 
-    // V double-buffered: the transform of chunk c + 1 rides inside the MFMA phase of chunk c, one barrier per chunk.  Patch
-    // loads: ONE per pair of MFMAs (a load touches 16 separate 64-byte segments and the texture-address unit takes tens of
-    // cycles to accept it; issued back to back they stall the wave's in-order instruction stream, MFMAs included); item it
-    // loads during position it, is transformed and stored ten positions later.  The last chunk re-transforms itself into
-    // the idle buffer rather than branching around the slices.
-    for (int c = 0; c < nchunks; ++c) {
-        const float *cur = sV + (c & 1) * VB;
-        float *nxt = sV + ((c & 1) ^ 1) * VB;
-        const int cn = (c + 1 < nchunks) ? c + 1 : c;
+    // One chunk: 16 positions x (2 tile blocks x 4 k-steps) MFMAs on V buffer `par`, while the NEXT chunk is loaded,
+    // transformed and stored into the other buffer.  Patch loads: ONE per pair of MFMAs (a load touches 16 separate 64-byte
+    // segments and the texture-address unit takes tens of cycles to accept it; issued back to back they stall the wave's
+    // in-order instruction stream, MFMAs included); item it loads during position it, is transformed and stored ten
+    // positions later.  FIRST: the block's first chunk starts the accumulators from zero (no clearing pass).  LAST: the
+    // next chunk is chunk 0 of the NEXT block -- its plan is computed here (a few dozen VALU instructions per item) and
+    // kept in the offset table, the weight stream wraps around.
+    auto chunk = [&](auto first_tag, auto last_tag, int c, const BufferRsrc &xnext, int tile0n, int b0n) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        const float *cur = sV + par * VB;
+        float *nxt = sV + (par ^ 1) * VB;
+        const unsigned coff = LAST ? 0u : (unsigned)((c + 1) * WKC * 4);
         read_a(0, 0, cur);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -220,87 +232,141 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
             const bool tf = !(DREAM_WINO_DIAG & 1);
             const int li = (pp < ITEMS) ? pp : -1;                          // item loaded during this position
             const int si = (pp >= 10 && pp < 10 + ITEMS) ? pp - 10 : -1;    // item stored during this position
-            prefetch_b(pp, c * 16);
-            if (tf && li >= 0) { item_offsets(li); item_load_one(li, 0, cn); }
-            mfma_pair(pp, 0);
+            if (!(DREAM_WINO_DIAG & 2)) {
+                const int s = (LAST && pp + B_AHEAD >= 16) ? pp + B_AHEAD - 16 : c * 16 + pp + B_AHEAD;
+                bq[(pp + B_AHEAD) % B_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
+            }
+            auto load_one = [&](int col) {
+                d[li][col] = buffer_load_x4(LAST ? xnext : xbuf, goff[li][col], (DREAM_WINO_DIAG & 16) ? 0u : coff);
+            };
+            auto pair = [&](int r) {
+                if (FIRST && r == 0) {
+                    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+                    acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], zero);
+                    acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp % B_RING][r], zero);
+                } else {
+                    acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], acc[pp][0]);
+                    acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp % B_RING][r], acc[pp][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if (tf && li >= 0) {
+                if (LAST) goff[li] = plan_item(li, tile0n, b0n);
+                else goff[li] = sG[li * NT + tid];                          // written by this thread: no barrier
+                load_one(0);
+            }
+            pair(0);
             if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
-            if (tf && li >= 0) item_load_one(li, 1, cn);
-            mfma_pair(pp, 1);
-            if (tf && li >= 0) item_load_one(li, 2, cn);
+            if (tf && li >= 0) load_one(1);
+            pair(1);
+            if (tf && li >= 0) load_one(2);
             if (tf && si >= 0) item_store(si, nxt);
-            mfma_pair(pp, 2);
-            if (tf && li >= 0) item_load_one(li, 3, cn);
-            mfma_pair(pp, 3);
+            pair(2);
+            if (tf && li >= 0) load_one(3);
+            pair(3);
         }
         if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
-    }
+        par ^= 1;
+    };
+    const std::true_type yes{};
+    const std::false_type no{};
 
     // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ----------------
-    // Output addresses are 32-bit byte offsets from the first image of the workgroup, BUFFER_OOB for everything that must
-    // not be written (tile beyond the batch, channel beyond Cout, odd-extent overhang): masked stores without branches.
+    // Output addresses are 32-bit byte offsets from the first image of the block, BUFFER_OOB for everything that must not be
+    // written (tile beyond the batch, channel beyond Cout, odd-extent overhang): masked stores without branches.
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
-    const bool pool = (p.flags & DREAM_CONV_POOL2) != 0;
-    const bool mask = (p.flags & DREAM_CONV_RELUMASK) != 0;
+    constexpr bool pool = MODE == 1, has_res = MODE >= 2, mask = MODE == 3;
     const int col = n0 + wave * 16 + lt;
     const bool cok = col < p.Cout;
     const float sc = (p.scale != nullptr && cok) ? p.scale[col] : 1.0f;
     const float sh = (p.shift != nullptr && cok) ? p.shift[col] : 0.0f;
     const int Ho = pool ? p.H / 2 : p.H, Wo = pool ? p.W / 2 : p.W;
     const size_t out_img = (size_t)Ho * Wo * p.Cout;
-    const BufferRsrc ybuf = make_buffer(p.y + (size_t)b0 * out_img, (size_t)(p.B - b0) * out_img * sizeof(float));
-    const BufferRsrc rbuf = make_buffer(p.residual != nullptr ? p.residual + (size_t)b0 * out_img : p.y,
-                                        p.residual != nullptr ? (size_t)(p.B - b0) * out_img * sizeof(float) : 0);
     const unsigned px_b = (unsigned)(p.Cout * 4), row_b = (unsigned)(Wo * p.Cout * 4);
+    auto epilogue = [&](int tile0e, int b0e) {
+        const BufferRsrc ybuf = make_buffer(p.y + (size_t)b0e * out_img, (size_t)(p.B - b0e) * out_img * sizeof(float));
+        const BufferRsrc rbuf = make_buffer(has_res ? p.residual + (size_t)b0e * out_img : p.y,
+                                            has_res ? (size_t)(p.B - b0e) * out_img * sizeof(float) : 0);
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        // the lane's four tiles of this block are consecutive: decompose the first, step the others
-        const int tau0 = tile0 + blk * 16 + lg * 4;                 // C/D layout: row = 4 (l >> 4) + reg, col = l & 15
-        int b = div_magic40(tau0, p.magic_tpi);
-        const int rem = tau0 - b * tiles_per_img;
-        int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
+        for (int blk = 0; blk < 2; ++blk) {
+            // the lane's four tiles of this block are consecutive: decompose the first, step the others
+            const int tau0 = tile0e + blk * 16 + lg * 4;                // C/D layout: row = 4 (l >> 4) + reg, col = l & 15
+            int b = div_magic40(tau0, p.magic_tpi);
+            const int rem = tau0 - b * tiles_per_img;
+            int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
+            unsigned off[4][4];                                         // [tile][2 i + jj]
+            float rv[4][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
+            for (int r = 0; r < 4; ++r) {
+                // pooled output (floor(H/2) x floor(W/2)): the window of a tile with ty < Ho, tx < Wo lies entirely inside the image
+                const bool tok = cok & ((tau0 + r) < p.ntiles) & (!pool | ((ty < Ho) & (tx < Wo)));
+                const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
+                const unsigned base = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * p.Cout + col) * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[0][j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
-                s[1][j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
-            }
-            float out[2][2];
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                out[i][0] = s[i][0] + s[i][1] + s[i][2];
-                out[i][1] = s[i][1] - s[i][2] - s[i][3];
-            }
-            // pooled output (floor(H/2) x floor(W/2)): the window of a tile with ty < Ho, tx < Wo lies entirely inside the image
-            const bool tok = cok && (tau0 + r) < p.ntiles && (!pool || (ty < Ho && tx < Wo));
-            const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
-            const unsigned base = (unsigned)(((((b - b0) * Ho + oy) * Wo + ox) * p.Cout + col) * 4);
-            float best = -__builtin_huge_valf();
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    float v = out[i][jj];
-                    if (p.scale != nullptr) v = v * sc;
-                    v = v + sh;
-                    const bool inb = tok && (pool || ((oy + i) < Ho && (ox + jj) < Wo));
-                    const unsigned off = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
-                    if (p.residual != nullptr) {
-                        const float rv = buffer_load_f32(rbuf, off, 0);
-                        v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const bool inb = tok & (pool | (((oy + i) < Ho) & ((ox + jj) < Wo)));
+                        off[r][2 * i + jj] = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
+                        if (has_res) rv[r][2 * i + jj] = buffer_load_f32(rbuf, off[r][2 * i + jj], 0);   // 16 loads in flight
                     }
-                    if (relu) v = fmaxf(v, 0.0f);
-                    if (pool) best = fmaxf(best, v);
-                    else buffer_store_f32(ybuf, v, off, 0);
+                if (pool) off[r][0] = tok ? base : BUFFER_OOB;
+                const bool wrap_x = (tx + 1 == p.TX);                   // next tile
+                const bool wrap_y = wrap_x & (ty + 1 == p.TY);
+                tx = wrap_x ? 0 : tx + 1;
+                ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
+                b += wrap_y ? 1 : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s[0][j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
+                    s[1][j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
                 }
-            if (pool) buffer_store_f32(ybuf, best, tok ? base : BUFFER_OOB, 0);
-            if (++tx == p.TX) {                                     // next tile
-                tx = 0;
-                if (++ty == p.TY) { ty = 0; ++b; }
+                float out[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    out[i][0] = s[i][0] + s[i][1] + s[i][2];
+                    out[i][1] = s[i][1] - s[i][2] - s[i][3];
+                }
+                float best = -__builtin_huge_valf();
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        float v = out[i][jj] * sc + sh;                 // sc = 1 / sh = 0 when absent (exact)
+                        if (has_res) v = mask ? (rv[r][2 * i + jj] > 0.0f ? v : 0.0f) : v + rv[r][2 * i + jj];
+                        const float vr = fmaxf(v, 0.0f);
+                        v = relu ? vr : v;
+                        if (pool) best = fmaxf(best, v);
+                        else buffer_store_f32(ybuf, v, off[r][2 * i + jj], 0);
+                    }
+                if (pool) buffer_store_f32(ybuf, best, off[r][0], 0);
             }
         }
-    }
+    };
+
+    // ---- the blocks of this workgroup -----------------------------------------------------------------------------------
+    // Written out twice (first block, then the loop): at a control-flow join hipcc takes the more pessimistic of the incoming
+    // s_waitcnt states, and the state after the prologue (a handful of loads in flight) differs from the one after an
+    // epilogue (its stores still in flight); joined, every block would start by waiting for the previous block's stores.
+    auto block = [&]() {
+        const int tile0n = block_tile0(tb + J);
+        const int b0n = div_magic40(tile0n, p.magic_tpi);
+        const BufferRsrc xnext = block_xbuf(b0n);
+        chunk(yes, no, 0, xnext, tile0n, b0n);                     // nchunks >= 2 (host side)
+        for (int c = 1; c < nchunks - 1; ++c) chunk(no, no, c, xnext, tile0n, b0n);
+        chunk(no, yes, nchunks - 1, xnext, tile0n, b0n);
+        epilogue(tile0, b0);
+        tb += J;
+        tile0 = tile0n;
+        b0 = b0n;
+        xbuf = xnext;
+    };
+    block();
+    while (tb < blk_end) block();
 }
 
 // OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1: rows = Cin_fwd, cols = Cout_fwd)
@@ -346,17 +412,26 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u
     }
 }
 
-template <int NW>
+constexpr int kCUs = 256;     // MI355X
+int g_max_workgroups = 0;     // test hook: cap on resident workgroups (0 = the chip's capacity)
+
+template <int NW, int MODE>
 int launch_wino(const WinoParams &p, void *stream) {
     static bool attr_set = false;
-    void (*kernel)(const WinoParams) = conv_wino_kernel<NW>;
+    void (*kernel)(const WinoParams) = conv_wino_kernel<NW, MODE>;
     const size_t lds = (size_t)2 * VB * sizeof(float) + (size_t)512 * 16;          // V buffers + the offset table
     if (!attr_set) {
         DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    const int nblk = (p.ntiles + WT - 1) / WT;
-    const dim3 grid((unsigned)((nblk + 7) / 8 * 8), (unsigned)((p.Cout + 16 * NW - 1) / (16 * NW)));
+    // persistent grid: as many workgroups as the 256 CUs hold at once (2 of the 4-wave, 1 of the 8-wave kind per CU), a
+    // multiple of 8 (XCDs), split over the output-channel blocks; fewer when there are fewer tile blocks than that
+    const int ny = (p.Cout + 16 * NW - 1) / (16 * NW);
+    int resident = g_max_workgroups > 0 ? g_max_workgroups : kCUs * (NW == 4 ? 2 : 1);
+    int gx = resident / ny / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > (p.nblk + 7) / 8 * 8) gx = (p.nblk + 7) / 8 * 8;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
     hipLaunchKernelGGL(kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
@@ -391,6 +466,14 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
 
 // Workgroup width: 0 (default) = by layer (128 output channels per workgroup when the layer has more than 64, else 64);
 // 4 / 8 force the 64- / 128-channel kernel.  Same results bit for bit.
+// Test hook: cap the number of co-resident workgroups the persistent grid is sized for (0 = the chip's 256 CUs), so that
+// small problems walk over several tile blocks per workgroup.  Same results bit for bit.
+extern "C" int dream_conv3x3_winograd_set_max_workgroups(int n) {
+    DREAM_REQUIRE(n >= 0, "winograd: max workgroups %d", n);
+    g_max_workgroups = n;
+    return 0;
+}
+
 extern "C" int dream_conv3x3_winograd_set_variant(int variant) {
     DREAM_REQUIRE(variant == 0 || variant == 4 || variant == 8, "winograd variant %d: 0 (by layer), 4 or 8 wavefronts", variant);
     g_variant = variant;
@@ -404,7 +487,7 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
                                                int flags, void *stream) {
     DREAM_REQUIRE(x && u_packed && y, "winograd conv: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
-    DREAM_REQUIRE(Cin % WKC == 0, "winograd conv: Cin=%d must be a multiple of %d", Cin, WKC);
+    DREAM_REQUIRE(Cin % WKC == 0 && Cin >= 2 * WKC, "winograd conv: Cin=%d must be a multiple of %d and at least %d", Cin, WKC, 2 * WKC);
     DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
     DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd conv: fused max-pool takes no residual");
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
@@ -420,9 +503,21 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     const long ntiles = (long)B * p.TY * p.TX;
     DREAM_REQUIRE(ntiles < ((long)1 << 24), "winograd conv: %ld tiles, the tile decomposition handles < 2^24", ntiles);
     p.ntiles = (int)ntiles;
+    p.nblk = (p.ntiles + WT - 1) / WT;
+    p.blk_per_xcd = (p.nblk + 7) / 8;
     p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(p.TY * p.TX) - 1) / (unsigned long long)(p.TY * p.TX);
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
     const int nw = g_variant ? g_variant : (Cout > 64 ? 8 : 4);
-    return nw == 8 ? launch_wino<8>(p, stream) : launch_wino<4>(p, stream);
+    const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
+    switch (mode + (nw == 8 ? 4 : 0)) {
+        case 0: return launch_wino<4, 0>(p, stream);
+        case 1: return launch_wino<4, 1>(p, stream);
+        case 2: return launch_wino<4, 2>(p, stream);
+        case 3: return launch_wino<4, 3>(p, stream);
+        case 4: return launch_wino<8, 0>(p, stream);
+        case 5: return launch_wino<8, 1>(p, stream);
+        case 6: return launch_wino<8, 2>(p, stream);
+        default: return launch_wino<8, 3>(p, stream);
+    }
 }

@@ -237,7 +237,7 @@ class DreamHourglass(nn.Module):
             if self.conv_algorithm != "direct":
                 raise ValueError("unknown conv_algorithm %r" % (self.conv_algorithm,))
             return False
-        return cin % 16 == 0 and cout >= 64 and not (flags & ~(CONV_RELU | CONV_POOL2 | ops.CONV_RELUMASK))
+        return cin % 16 == 0 and cin >= 32 and cout >= 64 and not (flags & ~(CONV_RELU | CONV_POOL2 | ops.CONV_RELUMASK))
 
     @staticmethod
     def _join(a, b):

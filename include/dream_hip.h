@@ -96,9 +96,10 @@ int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *b
  * (dream_conv3x3_winograd_weight_floats(rows, cols) floats; mode 0: forward, rows = Cout, cols = Cin; mode 1: the
  * data-gradient operator, rows = Cin, cols = Cout); y = conv * scale[c] + shift[c] (+ residual, or masked by
  * residual > 0 with DREAM_CONV_RELUMASK) (ReLU) (2x2 max-pool); flags: DREAM_CONV_RELU | DREAM_CONV_POOL2 |
- * DREAM_CONV_RELUMASK; scale / shift / residual may be NULL. */
+ * DREAM_CONV_RELUMASK; scale / shift / residual may be NULL.  Cin: a multiple of 16, at least 32. */
 size_t dream_conv3x3_winograd_weight_floats(int rows, int cols);
 int dream_conv3x3_winograd_set_variant(int variant);   /* workgroup width: 0 = by layer (default), 4 / 8 wavefronts = 64 / 128 channels */
+int dream_conv3x3_winograd_set_max_workgroups(int n);  /* test hook: size the persistent grid for n co-resident workgroups (0 = the chip) */
 int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u_packed, int Cout, int Cin, int mode, void *stream);
 int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,

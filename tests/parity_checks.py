@@ -57,7 +57,7 @@ def check_conv(dev, B, H, W, Cin, Cout, flags, seed=0):
     return err
 
 
-def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=None):
+def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=None, max_workgroups=(8, 24)):
     """Winograd F(2x2,3x3) conv vs an fp64 direct convolution: error relative to the output maximum at fp32 round-off level
     (<= 2e-6; measured ~3e-7, the direct fp32 kernel ~1.5e-7)."""
     g = torch.Generator().manual_seed(seed)
@@ -75,8 +75,18 @@ def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_s
     res = None
     if residual is not None:
         res = torch.randn(B, Cout, H, W, generator=g)
-    y = ops.conv3x3_winograd(to(dev, _nhwc(x)), packed, Cout, to(dev, scale) if with_scale else None, to(dev, bias),
-                             to(dev, _nhwc(res)) if res is not None else None, flags).cpu().permute(0, 3, 1, 2)
+    args = (to(dev, _nhwc(x)), packed, Cout, to(dev, scale) if with_scale else None, to(dev, bias),
+            to(dev, _nhwc(res)) if res is not None else None, flags)
+    y = ops.conv3x3_winograd(*args).cpu().permute(0, 3, 1, 2)
+    # the persistent grid sized for fewer resident workgroups (each walks over several tile blocks, prefetching the next
+    # block's first chunk during the last chunk of the current one): same kernels, same order of operations per output
+    for cap in max_workgroups:
+        _hip.lib().dream_conv3x3_winograd_set_max_workgroups(cap)
+        try:
+            y_cap = ops.conv3x3_winograd(*args).cpu().permute(0, 3, 1, 2)
+        finally:
+            _hip.lib().dream_conv3x3_winograd_set_max_workgroups(0)
+        assert torch.equal(y, y_cap), ("persistent grid", cap, float((y - y_cap).abs().max()))
     ref = F.conv2d(x.double(), w.double(), None, padding=1)
     if with_scale:
         ref = ref * scale.double().view(1, -1, 1, 1)

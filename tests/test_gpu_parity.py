@@ -553,12 +553,13 @@ def test_checkpoint_save_load_identical_inference(arch, tmp_path):
 
 # ---- Winograd F(2x2,3x3) conv kernel ---------------------------------------------------------------------------------------
 WINO_CASES = [
-    (1, 8, 8, 16, 16, 0, {}), (2, 13, 25, 32, 64, 1, {}), (1, 25, 25, 48, 96, 1, {}), (3, 5, 3, 16, 7, 0, {}),
-    (2, 12, 20, 32, 80, 1 | 16, {}), (2, 13, 9, 16, 64, 1 | 16, {}), (1, 399, 201, 64, 64, 1 | 16, {}), (1, 10, 14, 64, 32, 1, {"with_scale": True, "residual": "add"}),
+    (1, 8, 8, 32, 16, 0, {}), (2, 13, 25, 32, 64, 1, {}), (1, 25, 25, 48, 96, 1, {}), (3, 5, 3, 32, 7, 0, {}),
+    (2, 12, 20, 32, 80, 1 | 16, {}), (2, 13, 9, 32, 64, 1 | 16, {}), (1, 399, 201, 64, 64, 1 | 16, {}), (1, 10, 14, 64, 32, 1, {"with_scale": True, "residual": "add"}),
     (1, 9, 11, 32, 48, 32, {"residual": "mask"}), (2, 7, 9, 32, 64, 0, {"mode": 1}),
     (2, 400, 400, 64, 64, 1 | 16, {}), (2, 200, 200, 128, 128, 1, {}), (4, 100, 100, 256, 256, 1, {}),
     (4, 50, 50, 512, 512, 1, {}), (8, 25, 25, 512, 512, 1, {}), (3, 13, 13, 512, 512, 1, {"with_scale": True}),
-    (2, 133, 101, 64, 128, 1, {}),
+    (2, 133, 101, 64, 128, 1, {}), (2, 200, 200, 128, 128, 32, {"residual": "mask", "mode": 1}),
+    (3, 100, 100, 256, 64, 1, {"with_scale": True, "residual": "add"}), (2, 101, 99, 48, 80, 1 | 16, {}),
 ]
 
 
