@@ -29,7 +29,13 @@
 //   * all global traffic goes through buffer descriptors: 32-bit offsets, zero padding and store masking by the hardware's
 //     bounds check (offset BUFFER_OOB), no 64-bit address arithmetic; tile -> (image, row, column) by magic multiplication;
 //   * the instruction order of the main loop is pinned (sched_barrier per pair of MFMAs): one patch load per pair, MFMA
-//     operands read one position ahead into the register set of the other parity, alternating accumulators.
+//     operands read one position ahead into the register set of the other parity, alternating accumulators;
+//   * workgroups are PERSISTENT: the grid is what the chip holds at once, each workgroup walks over the tile blocks of its
+//     XCD's range and loads + transforms the first chunk of its next block during the last chunk of the current one, so the
+//     load latency of a prologue is paid once per workgroup, not once per block (measured: +5 .. +30 % per layer, most on
+//     the layers with few input channels); the epilogue variant (plain / fused pool / residual / ReLU mask) is a template
+//     parameter, so the code between two blocks' MFMA phases is straight-line (exact s_waitcnt counts, its 16 mask or
+//     residual loads per tile group in flight together).
 #include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
@@ -37,7 +43,8 @@
 
 // Timing diagnostics only (tools/wino_diag.py builds separate libraries with -DDREAM_WINO_DIAG=k; never the product
 // library): bit 0 skips the input transform (loads + V stores), bit 1 the weight stream, bit 2 the per-chunk barrier,
-// bit 3 makes all 32 tiles read the first tile's patch, bit 4 makes every chunk read the first chunk's channels.
+// bit 3 makes all 32 tiles read the first tile's patch, bit 4 makes every chunk read the first chunk's channels, bit 6 swaps
+// the two instruction orders of the main loop (results stay correct).
 // Results are then wrong by construction; the point is what each part costs.
 #ifndef DREAM_WINO_DIAG
 #define DREAM_WINO_DIAG 0
@@ -175,17 +182,19 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     // patch row of an item: its four loads / row transform, quad exchange, column transform, four V stores
     f32x4 d[ITEMS][4];
     u32x4 goff[ITEMS];
+    // piece j (0..3) of an item's transform: column j of the row transform u = d B (B^T d B = B^T (d B)), the quad exchange
+    // for the column transform, one b128 store -- ~8 VALU instructions, placed after ONE pair of MFMAs each, so that the
+    // wave's next MFMA is never more than the other wave's MFMA time away
+    auto item_piece = [&](int it, int j, float *vbuf) {
+        const f32x4 u = j == 0 ? d[it][0] - d[it][2] : j == 1 ? d[it][1] + d[it][2] : j == 2 ? d[it][2] - d[it][1] : d[it][1] - d[it][3];
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(sb, quad_perm_2211(u[k]), u[k]);     // exact: sb = +-1
+        *(f32x4 *)(vbuf + soff[it] + j * (WT * WKC)) = v;
+    };
     auto item_store = [&](int it, float *vbuf) {
-        // row transform (B^T d B = (B^T (d B))): u_j = sum_c d_c B[c][j]
-        const f32x4 u[4] = {d[it][0] - d[it][2], d[it][1] + d[it][2], d[it][2] - d[it][1], d[it][1] - d[it][3]};
-        float *dst = vbuf + soff[it];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(sb, quad_perm_2211(u[j][k]), u[j][k]);     // exact: sb = +-1
-            *(f32x4 *)(dst + j * (WT * WKC)) = v;
-        }
+        for (int j = 0; j < 4; ++j) item_piece(it, j, vbuf);
     };
 
     // MFMA operands of position pp from V buffer vbuf: read one position ahead of their use into the register set of the
@@ -231,11 +240,13 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         for (int pp = 0; pp < 16; ++pp) {
             const bool tf = !(DREAM_WINO_DIAG & 1);
             const int li = (pp < ITEMS) ? pp : -1;                          // item loaded during this position
-            const int si = (pp >= 10 && pp < 10 + ITEMS) ? pp - 10 : -1;    // item stored during this position
-            if (!(DREAM_WINO_DIAG & 2)) {
+            constexpr int SP = 10;                                          // item it is transformed during position SP + it
+            const int si = (pp >= SP && pp < SP + ITEMS) ? pp - SP : -1;
+            auto load_b = [&]() {
+                if (DREAM_WINO_DIAG & 2) return;
                 const int s = (LAST && pp + B_AHEAD >= 16) ? pp + B_AHEAD - 16 : c * 16 + pp + B_AHEAD;
                 bq[(pp + B_AHEAD) % B_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
-            }
+            };
             auto load_one = [&](int col) {
                 d[li][col] = buffer_load_x4(LAST ? xnext : xbuf, goff[li][col], (DREAM_WINO_DIAG & 16) ? 0u : coff);
             };
@@ -250,20 +261,49 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
-            if (tf && li >= 0) {
-                if (LAST) goff[li] = plan_item(li, tile0n, b0n);
-                else goff[li] = sG[li * NT + tid];                          // written by this thread: no barrier
-                load_one(0);
+            // Two instruction orders, chosen by measurement (profiles/r02_wino_diag.txt; DIAG bit 6 swaps them): the 4-wave
+            // kernel (two items per thread, two workgroups per CU) is ~3 % faster with its loads ahead of the position's first
+            // MFMAs and the transform in one piece, the 8-wave kernel ~2 % faster the other way round.
+            if ((NW == 4) != ((DREAM_WINO_DIAG & 64) != 0)) {
+                load_b();
+                if (tf && li >= 0) {
+                    if (LAST) goff[li] = plan_item(li, tile0n, b0n);
+                    else goff[li] = sG[li * NT + tid];
+                    load_one(0);
+                }
+                pair(0);
+                if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
+                if (tf && li >= 0) load_one(1);
+                pair(1);
+                if (tf && li >= 0) load_one(2);
+                if (tf && si >= 0) item_store(si, nxt);
+                pair(2);
+                if (tf && li >= 0) load_one(3);
+                pair(3);
+            } else {
+                // every position STARTS with MFMAs (operands were read during the previous position); everything else --
+                // the weight load, the operand reads of the next position, one patch load or one transform piece -- follows
+                // a pair, never more than one memory instruction and ~8 VALU instructions between two pairs
+                pair(0);
+                load_b();
+                if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
+                if (tf && li >= 0) {
+                    if (LAST) goff[li] = plan_item(li, tile0n, b0n);
+                    else goff[li] = sG[li * NT + tid];                      // written by this thread: no barrier
+                    load_one(0);
+                }
+                if (tf && si >= 0) item_piece(si, 0, nxt);
+                pair(1);
+                if (tf && li >= 0) load_one(1);
+                if (tf && si >= 0) item_piece(si, 1, nxt);
+                pair(2);
+                if (tf && li >= 0) load_one(2);
+                if (tf && si >= 0) item_piece(si, 2, nxt);
+                pair(3);
+                if (tf && li >= 0) load_one(3);
+                if (tf && si >= 0) item_piece(si, 3, nxt);
+                if (pp == 15) __builtin_amdgcn_sched_barrier(0);
             }
-            pair(0);
-            if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
-            if (tf && li >= 0) load_one(1);
-            pair(1);
-            if (tf && li >= 0) load_one(2);
-            if (tf && si >= 0) item_store(si, nxt);
-            pair(2);
-            if (tf && li >= 0) load_one(3);
-            pair(3);
         }
         if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
         par ^= 1;
@@ -294,31 +334,42 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
             int b = div_magic40(tau0, p.magic_tpi);
             const int rem = tau0 - b * tiles_per_img;
             int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
-            unsigned off[4][4];                                         // [tile][2 i + jj]
-            float rv[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            // per tile: the byte offsets of its 2x2 outputs (or of its pooled output), BUFFER_OOB where nothing may be written
+            auto tile_offsets = [&](int r, unsigned *o) {
                 // pooled output (floor(H/2) x floor(W/2)): the window of a tile with ty < Ho, tx < Wo lies entirely inside the image
                 const bool tok = cok & ((tau0 + r) < p.ntiles) & (!pool | ((ty < Ho) & (tx < Wo)));
                 const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
                 const unsigned base = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * p.Cout + col) * 4);
+                if (pool) {
+                    o[0] = tok ? base : BUFFER_OOB;
+                } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const bool inb = tok & (pool | (((oy + i) < Ho) & ((ox + jj) < Wo)));
-                        off[r][2 * i + jj] = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
-                        if (has_res) rv[r][2 * i + jj] = buffer_load_f32(rbuf, off[r][2 * i + jj], 0);   // 16 loads in flight
-                    }
-                if (pool) off[r][0] = tok ? base : BUFFER_OOB;
-                const bool wrap_x = (tx + 1 == p.TX);                   // next tile
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const bool inb = tok & ((oy + i) < Ho) & ((ox + jj) < Wo);
+                            o[2 * i + jj] = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
+                        }
+                }
+                const bool wrap_x = (tx + 1 == p.TX);                   // step to the next tile
                 const bool wrap_y = wrap_x & (ty + 1 == p.TY);
                 tx = wrap_x ? 0 : tx + 1;
                 ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
                 b += wrap_y ? 1 : 0;
+            };
+            unsigned off[4][4];                                         // [tile][2 i + jj]
+            float rv[4][4];
+            if (has_res) {                                              // all 16 mask / residual loads of the block in flight
+#pragma unroll                                                          // before the first inverse transform
+                for (int r = 0; r < 4; ++r) {
+                    tile_offsets(r, off[r]);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) rv[r][e] = buffer_load_f32(rbuf, off[r][e], 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+                if (!has_res) tile_offsets(r, off[r]);
                 float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

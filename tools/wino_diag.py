@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [1, 100]              # 100: the product source built with -fno-slp-vectorize (no packed-f32 VALU)
+KS = [64, 1, 2]
 OUT = os.path.join(ROOT, "build", "diag")
 
 
@@ -37,8 +37,8 @@ def run(batch):
         libs[k] = h
     names = {0: "product", 1: "no transform", 2: "no weight stream", 4: "no barrier", 3: "no transform, no weights",
              7: "MFMAs + operand reads only", 8: "all tiles read one patch", 16: "all chunks read chunk 0",
-             18: "chunk 0 only, no weight stream", 100: "product, -fno-slp-vectorize"}
-    for (res, cin, cout) in [(400, 64, 64), (100, 256, 256), (50, 512, 512)]:
+             18: "chunk 0 only, no weight stream", 64: "the other instruction order (see the kernel)", 100: "product, -fno-slp-vectorize"}
+    for (res, cin, cout) in [(400, 64, 64), (200, 128, 128), (100, 256, 256), (50, 512, 512)]:
         x = torch.randn(batch, res, res, cin, device="cuda")
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         u, _ = ops.pack_weight_winograd(w, 0)
