@@ -67,6 +67,11 @@ DREAM_DEVICE float quad_perm_2211(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
 
+// DPP quad_perm [1,0,3,2]: the two lanes of every pair swap
+DREAM_DEVICE float quad_perm_1032(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
 // wave index within the workgroup as a provably wave-uniform (SGPR) value
 DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 

@@ -29,9 +29,16 @@
 // (64-byte segments, 256 B per wave instruction) saturate the texture-address path; variants with less address arithmetic,
 // loads two steps ahead or loads spread between the MFMAs were all slower.  The fix is structural (share the loaded patch
 // across the workgroup through LDS, float4 loads: ~0.1 load instructions per MFMA instead of 0.75) and is the next version.
+#include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
+
+// Timing diagnostics of the LDS version only (tools/wgw_diag.py builds separate libraries with -DDREAM_WGW_DIAG=k; never the
+// product): bit 0 no global loads, bit 1 no transform pieces, bit 2 no per-stage barrier.  Bits 0-2 make the results wrong by construction.
+#ifndef DREAM_WGW_DIAG
+#define DREAM_WGW_DIAG 0
+#endif
 
 namespace {
 
@@ -47,6 +54,7 @@ struct WgWinoParams {
 };
 
 constexpr int NCO = 2;       // 16-channel blocks of output channels per wave
+int g_wgw_version = 0;       // 0 = by shape (the LDS version where it applies), 1 = force the register-only version (tests, A/B)
 
 __global__ void __launch_bounds__(256, 2) wgrad_wino_kernel(const WgWinoParams p) {
     const int lane = threadIdx.x & 63;
@@ -207,6 +215,253 @@ __global__ void __launch_bounds__(256) wgrad_wino_reduce_kernel(const float *par
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Version 2: the transformed operands are SHARED by the workgroup through LDS.
+//
+//   workgroup = 8 waves = 64 output x 64 input channels x all 16 positions; wave w owns positions 2w and 2w+1 for the whole
+//   64 x 64 block: 2 x 16 accumulators of v_mfma_f32_16x16x4_f32 = 128 registers, two waves per SIMD.
+//   K runs over tiles in stages of 8 (tile = wave index for the producers): per stage the 512 threads load the 8 tiles' input
+//   patches (64 channels) and dy tiles (64 channels) with float4 loads -- a thread owns (tile, channel quad, patch row): 256
+//   contiguous bytes per patch row and wave -- transform them in registers (row transform lane-local, column transform
+//   through a DPP exchange inside the quad / pair, as in conv_wino.hip) and store V = B^T d B and dM = A dY A^T to LDS as
+//   [position][tile][channel].  The MFMA operands come back as ONE b128 read per operand, position and k-step: lane l reads
+//   channels 4 (l & 15) .. +3 of tile (l >> 4) and uses component m for the MFMA whose 16 rows (columns) are the channels
+//   4 i + m -- two LDS reads feed sixteen MFMAs.  Global loads per MFMA: 6 float4 per 64 (v1: 24 scalar loads per 32).
+//   Software pipeline: stage s multiplies LDS buffer s & 1 while the raw data of stage s+1 (loaded during stage s-1) is
+//   transformed into the other buffer and the loads of stage s+2 are issued; every piece of that work is a few instructions
+//   placed after one MFMA (pinned with sched_barrier).  (A third register set -- loads two stages ahead -- changed nothing.)
+//   Signs: the minus signs of A dY A^T and the negated fourth row of V (see conv_wino.hip) cancel except on the positions of
+//   the fourth COLUMN; they are applied by the reduction kernel, which also sums the split-K partials in a fixed order and
+//   applies dg = G^T dU G.
+constexpr int LT = 8;                         // tiles per stage
+constexpr int LPS = LT * 64;                  // floats per position plane: [tile][64 channels]
+// plane offsets, skewed so that the b128 transform stores of eight consecutive lanes cover the 32 banks ds_write_b128 sees
+// exactly once: V -- a quad's four lanes write rows 0..3 (8 floats apart), two quads side by side; dM -- the four lanes
+DREAM_DEVICE constexpr int l_plane_v(int p) { return p * LPS + 8 * (p >> 2); }
+// (dy row, column half) write rows {0,1} / {3,2} x columns {0,1} / {2,3}: 8 floats per column half, 16 per row half -- plus
+// 32 (a full turn of the banks) per row, so that the skews grow with p and no plane runs into the next one
+DREAM_DEVICE constexpr int l_plane_y(int p) { return p * LPS + 8 * ((p & 3) >> 1) + 16 * (p >> 3) + 32 * (p >> 2); }
+constexpr int LOPS = 16 * LPS + 128;          // floats per operand and buffer
+constexpr size_t L_LDS_BYTES = (size_t)4 * LOPS * sizeof(float);     // 2 buffers x (dM, V)
+
+struct WgWinoLdsParams {
+    const float *x;          // [B,H,W,Cin]
+    const float *dy;         // [B,H,W,Cdy]
+    float *partial;          // [nsplit][16][Cout][Cin]
+    int B, H, W, Cin, Cout, Cdy;
+    int TY, TX, ntiles;
+    unsigned long long magic_tpi, magic_tx;
+    int tiles_per_split;     // multiple of 16 (two stages)
+    int ncog;                // groups of 64 output channels
+};
+
+__global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsParams p) {
+    DREAM_DYNAMIC_LDS(float, smem);
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    const int cog = (int)blockIdx.x % p.ncog, cig = (int)blockIdx.x / p.ncog;
+    const int co0 = cog * 64, ci0 = cig * 64;
+    const int split = blockIdx.y;
+    const int k_begin = split * p.tiles_per_split;
+    const int k_end = (k_begin + p.tiles_per_split < p.ntiles) ? k_begin + p.tiles_per_split : p.ntiles;
+    const int nstages = ((k_end - k_begin + 2 * LT - 1) / (2 * LT)) * 2;      // even: the stage loop is unrolled by two
+    const int tiles_per_img = p.TY * p.TX;
+
+    // buffers relative to the first image of this split's tile range (32-bit offsets)
+    const int b0 = div_magic40(k_begin, p.magic_tpi);
+    const size_t ximg = (size_t)p.H * p.W * p.Cin, yimg = (size_t)p.H * p.W * p.Cdy;
+    const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * ximg, (size_t)(p.B - b0) * ximg * sizeof(float));
+    const BufferRsrc ybuf = make_buffer(p.dy + (size_t)b0 * yimg, (size_t)(p.B - b0) * yimg * sizeof(float));
+
+    // ---- producer roles: the wave's tile of a stage is (stage tile + wave); its decomposition is scalar work ----------------
+    // V: patch row vr = lane & 3, channel quad vq = lane >> 2.  dM: dy row yr2 = lane & 1, column half yh = (lane >> 1) & 1
+    // (the lane stores transformed columns 2 yh and 2 yh + 1), channel quad yq = lane >> 2.
+    const int vr = lane & 3, vq = lane >> 2;
+    const int yr2 = lane & 1, yh = (lane >> 1) & 1, yq = lane >> 2;
+    const float vsb = (vr == 1) ? 1.0f : -1.0f;             // column transform of V: u_r + vsb * u_partner (conv_wino.hip)
+    const float ysg = (yr2 == 0) ? 1.0f : -1.0f;            // mixed dM row: partner + ysg * own
+    const int v_store = l_plane_v(4 * vr) + wave * 64 + 4 * vq;              // V[4 vr + j]: + j * LPS
+    // dM rows of this lane: row A = its own values (row 0 for the upper dy row, row 3 for the lower one), row B = the mixed
+    // one (row 1 = upper + lower, row 2 = upper - lower); columns 2 yh + jj
+    const int y_store_a = l_plane_y((yr2 == 0 ? 0 : 12) + 2 * yh) + wave * 64 + 4 * yq;
+    const int y_store_b = l_plane_y((yr2 == 0 ? 4 : 8) + 2 * yh) + wave * 64 + 4 * yq;
+
+    f32x4 xr[2][4];                                          // [register set][column]
+    f32x4 yr[2][2];                                          // [register set][column]
+
+    // one load of stage st into register set `set`: n = 0..3 the patch row's columns, 4..5 the dy row's columns.
+    // VALU instructions share the SIMD's issue slots with the MFMAs (measured: every VALU instruction in this loop shows up
+    // in the run time), so the address is split: everything that depends on the tile is wave-uniform and computed on the
+    // scalar unit (offset of the tile's first output pixel + column), the lane adds its constant (patch row, channel quad)
+    // with one v_add and sets bit 31 where the pixel is outside the image (beyond any buffer: the hardware returns zeros).
+    const int lane_dx = (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);     // patch row vr - 1 relative to the tile's first output row
+    const int lane_dy = (int)(((yr2 * p.W) * p.Cdy + 4 * yq) * 4);
+    const int x_px = p.Cin * 4, y_px = p.Cdy * 4;
+    auto issue_load = [&](int set, int st, int n) {
+        const int tau = k_begin + st * LT + wave;                               // wave-uniform from here ...
+        const bool tv = tau < k_end;
+        const int b = div_magic40(tau, p.magic_tpi), rem = tau - b * tiles_per_img;
+        const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
+        const int pix = ((b - b0) * p.H + 2 * ty) * p.W + 2 * tx;               // the tile's first output pixel
+        if (n < 4) {
+            const int s_off = (pix * p.Cin + ci0) * 4 + (n - 1) * x_px;         // ... to here
+            const bool col_ok = tv & ((unsigned)(2 * tx - 1 + n) < (unsigned)p.W);
+            const bool ok = col_ok & ((unsigned)(2 * ty - 1 + vr) < (unsigned)p.H);
+            xr[set][n] = buffer_load_x4(xbuf, (unsigned)(s_off + lane_dx) | ((unsigned)!ok << 31), 0);     // bit 31: out of range
+        } else {
+            const int s_off = (pix * p.Cdy + co0) * 4 + (n - 4) * y_px;
+            const bool col_ok = tv & ((2 * tx + (n - 4)) < p.W);
+            const bool ok = col_ok & ((2 * ty + yr2) < p.H);
+            yr[set][n - 4] = buffer_load_x4(ybuf, (unsigned)(s_off + lane_dy) | ((unsigned)!ok << 31), 0);
+        }
+    };
+    // piece k = 0..3 of the V transform (transformed column j = k), 4..5 of the dM transform (column 2 yh + k - 4)
+    auto transform_piece = [&](int set, float *buf, int k) {
+        if (k < 4) {
+            const f32x4 *d = xr[set];
+            const f32x4 u = k == 0 ? d[0] - d[2] : k == 1 ? d[1] + d[2] : k == 2 ? d[2] - d[1] : d[1] - d[3];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(vsb, quad_perm_2211(u[e]), u[e]);
+            *(f32x4 *)(buf + LOPS + v_store + k * LPS) = v;
+        } else {
+            // along the dy row: (y0, y1) -> y0, y0 + y1, y0 - y1, y1 (the minus sign of the fourth column is applied at the end)
+            const int jj = k - 4;
+            const f32x4 y0 = yr[set][0], y1 = yr[set][1];
+            f32x4 m, mixed;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                m[e] = jj == 0 ? (yh ? y0[e] - y1[e] : y0[e]) : (yh ? y1[e] : y0[e] + y1[e]);
+                mixed[e] = __builtin_fmaf(ysg, m[e], quad_perm_1032(m[e]));     // upper lane: own + partner; lower: partner - own
+            }
+            *(f32x4 *)(buf + y_store_a + jj * LPS) = m;
+            *(f32x4 *)(buf + y_store_b + jj * LPS) = mixed;
+        }
+    };
+
+    // ---- consumer: MFMA operands ---------------------------------------------------------------------------------------------
+    const int li = lane & 15, lg = lane >> 4;
+    const int a_lane = lg * 64 + 4 * li;                     // + plane + k-step * 256
+    f32x4 acc[2][4][4];                                      // [position of this wave][m: co = 4 i + m][n: ci = 4 j + n]
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[pl][m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    // planes of positions 2 wave + pl (pl = 0, 1): same row (wave >> 1), columns 2 (wave & 1) + pl
+    const int py_base = (2 * wave) * LPS + 8 * (wave & 1) + 16 * (wave >> 2) + 32 * (wave >> 1);
+    const int pv_base = (2 * wave) * LPS + 8 * (wave >> 1);
+    f32x4 oy[2], ov[2];
+    auto read_ops = [&](int set, const float *buf, int grp) {   // grp = k-step * 2 + position
+        const int ks = grp >> 1, pl = grp & 1;
+        oy[set] = *(const f32x4 *)(buf + py_base + pl * LPS + ks * 256 + a_lane);
+        ov[set] = *(const f32x4 *)(buf + LOPS + pv_base + pl * LPS + ks * 256 + a_lane);
+    };
+
+    // one stage: 4 groups (2 k-steps x 2 positions) of 16 MFMAs on LDS buffer P; after MFMA number n of the stage one small
+    // piece of the producer work: transform pieces of stage st + 1 (register set 1 - P -> LDS buffer 1 - P), then the loads
+    // of stage st + 2 (-> register set P, free since the previous stage), operand reads of the next group.
+    auto stage = [&](auto parity, int st) {
+        constexpr int P = decltype(parity)::value;
+        const float *cur = smem + P * 2 * LOPS;
+        float *nxt = smem + (1 - P) * 2 * LOPS;
+        read_ops(0, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            const int pl = grp & 1;
+#pragma unroll
+            for (int mn = 0; mn < 16; ++mn) {
+                const int m = mn >> 2, n4 = mn & 3, n = grp * 16 + mn;
+                acc[pl][m][n4] = mfma_f32_16x16x4(oy[grp & 1][m], ov[grp & 1][n4], acc[pl][m][n4]);
+                if (mn == 4 && grp < 3) read_ops((grp + 1) & 1, cur, grp + 1);
+                if (!(DREAM_WGW_DIAG & 1) && n >= 1 && n < 13 && (n & 1) == 1) issue_load(P, st + 2, (n - 1) >> 1);        // 6 loads, every other MFMA
+                if (!(DREAM_WGW_DIAG & 2) && n >= 16 && n < 64 && (n & 7) == 0) transform_piece(1 - P, nxt, (n - 16) >> 3);  // 6 pieces, every 8th MFMA
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(DREAM_WGW_DIAG & 4)) __syncthreads();
+    };
+
+    // ---- prologue: stage 0 into buffer 0, loads of stage 1 in flight ----------------------------------------------------------
+#pragma unroll
+    for (int n = 0; n < 6; ++n) issue_load(0, 0, n);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) transform_piece(0, smem, k);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) issue_load(1, 1, n);
+    __syncthreads();
+    for (int st = 0; st < nstages; st += 2) {
+        stage(std::integral_constant<int, 0>{}, st);
+        stage(std::integral_constant<int, 1>{}, st + 1);
+    }
+
+    // ---- partial dU: lane holds rows i = 4 (l >> 4) + r, column j = l & 15 of every 16 x 16 block (m, n) -----------------------
+    float *out = p.partial + (size_t)split * 16 * p.Cout * p.Cin;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + 4 * (4 * lg + r) + m;
+                const f32x4 v = {acc[pl][m][0][r], acc[pl][m][1][r], acc[pl][m][2][r], acc[pl][m][3][r]};
+                *(f32x4 *)(out + ((size_t)(2 * wave + pl) * p.Cout + co) * p.Cin + ci0 + 4 * li) = v;
+            }
+}
+
+// dw_oihw[co][ci][3][3] = G^T (sum over splits, fixed order, of dU) G with the deferred signs (fourth column of the positions)
+__global__ void __launch_bounds__(256) wgrad_wino_lds_reduce_kernel(const float *partial, float *dw, int nsplit, int Cout, int Cin) {
+    const size_t n = (size_t)Cout * Cin;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float u[16];
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            float s = 0.0f;
+            for (int k = 0; k < nsplit; ++k) s += partial[((size_t)k * 16 + pp) * n + i];
+            u[pp] = ((pp & 3) == 3) ? -s : s;
+        }
+        float t[3][4];                              // G^T dU, G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float hs = 0.5f * (u[4 + j] + u[8 + j]), hd = 0.5f * (u[4 + j] - u[8 + j]);
+            t[0][j] = u[j] + hs;
+            t[1][j] = hd;
+            t[2][j] = hs + u[12 + j];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float hs = 0.5f * (t[a][1] + t[a][2]), hd = 0.5f * (t[a][1] - t[a][2]);
+            dw[i * 9 + a * 3 + 0] = t[a][0] + hs;
+            dw[i * 9 + a * 3 + 1] = hd;
+            dw[i * 9 + a * 3 + 2] = hs + t[a][3];
+        }
+    }
+}
+
+struct PlanLds { int nsplit, tiles_per_split, ntiles, TY, TX; };
+
+// one workgroup per CU (131 KB of LDS): the grid is (channel blocks) x (splits) ~ 256 workgroups of equal work
+PlanLds make_plan_lds(int B, int H, int W, int Cin, int Cout) {
+    PlanLds pl;
+    pl.TY = (H + 1) / 2; pl.TX = (W + 1) / 2;
+    pl.ntiles = B * pl.TY * pl.TX;
+    const int blocks = (Cout / 64) * (Cin / 64);
+    int want = (256 + blocks / 2) / blocks;
+    const int max_by_work = (pl.ntiles + 16 * LT - 1) / (16 * LT);          // at least 16 stages per split
+    if (want > max_by_work) want = max_by_work;
+    if (want < 1) want = 1;
+    const size_t img_bytes = (size_t)H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4;
+    const long tiles_per_img = (long)pl.TY * pl.TX;
+    while (((size_t)((pl.ntiles + want - 1) / want / tiles_per_img) + 2) * img_bytes >= ((size_t)1 << 30) && want < pl.ntiles) want *= 2;
+    pl.tiles_per_split = ((pl.ntiles + want - 1) / want + 2 * LT - 1) / (2 * LT) * (2 * LT);
+    pl.nsplit = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    return pl;
+}
+
+bool use_lds_version(int Cin, int Cout, int Cdy) { return g_wgw_version != 1 && Cin % 64 == 0 && Cout % 64 == 0 && Cdy % 4 == 0; }
+
 struct Plan { int nsplit, tiles_per_split, ntiles, TY, TX; };
 
 Plan make_plan(int B, int H, int W, int Cin, int Cout) {
@@ -232,7 +487,20 @@ Plan make_plan(int B, int H, int W, int Cin, int Cout) {
 extern "C" size_t dream_conv3x3_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0) return 0;
     const Plan pl = make_plan(B, H, W, Cin, Cout);
-    return (size_t)pl.nsplit * 9 * Cout * Cin * sizeof(float);
+    size_t bytes = (size_t)pl.nsplit * 9 * Cout * Cin * sizeof(float);
+    if (Cout % 64 == 0) {                               // the LDS version keeps all 16 positions per split
+        const PlanLds pl2 = make_plan_lds(B, H, W, Cin, Cout);
+        const size_t b2 = (size_t)pl2.nsplit * 16 * Cout * Cin * sizeof(float);
+        if (b2 > bytes) bytes = b2;
+    }
+    return bytes;
+}
+
+// Test / A-B hook: 0 = choose by shape (default), 1 = always the register-only version.
+extern "C" int dream_conv3x3_wgrad_winograd_set_version(int version) {
+    DREAM_REQUIRE(version == 0 || version == 1, "winograd wgrad: version %d", version);
+    g_wgw_version = version;
+    return 0;
 }
 
 // x [B,H,W,Cin], dy [B,H,W,Cdy] (Cdy >= Cout) NHWC -> dw_oihw [Cout,Cin,3,3] (overwritten).  Cin % 64 == 0, Cout % 16 == 0.
@@ -242,6 +510,32 @@ extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float
     DREAM_REQUIRE(x && dy && dw_oihw && workspace, "winograd wgrad: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cdy >= Cout, "winograd wgrad: bad shape");
     DREAM_REQUIRE(Cin % 64 == 0 && Cout % 16 == 0 && Cdy % 16 == 0, "winograd wgrad: Cin %% 64, Cout %% 16, Cdy %% 16 (got %d, %d, %d)", Cin, Cout, Cdy);
+    if (use_lds_version(Cin, Cout, Cdy)) {
+        const PlanLds pl = make_plan_lds(B, H, W, Cin, Cout);
+        DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd wgrad: too many tiles");
+        WgWinoLdsParams p;
+        p.x = x; p.dy = dy; p.partial = (float *)workspace;
+        p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Cdy = Cdy;
+        p.TY = pl.TY; p.TX = pl.TX; p.ntiles = pl.ntiles;
+        p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(pl.TY * pl.TX) - 1) / (unsigned long long)(pl.TY * pl.TX);
+        p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)pl.TX - 1) / (unsigned long long)pl.TX;
+        p.tiles_per_split = pl.tiles_per_split;
+        p.ncog = Cout / 64;
+        static bool attr_set = false;
+        if (!attr_set) {
+            DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_wino_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+        const dim3 grid((unsigned)(p.ncog * (Cin / 64)), (unsigned)pl.nsplit);
+        hipLaunchKernelGGL(wgrad_wino_lds_kernel, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
+        DREAM_LAUNCH_OK();
+        size_t rgrid = ((size_t)Cout * Cin + 255) / 256;
+        if (rgrid > 2048) rgrid = 2048;
+        hipLaunchKernelGGL(wgrad_wino_lds_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)workspace, dw_oihw, pl.nsplit, Cout, Cin);
+        DREAM_LAUNCH_OK();
+        return 0;
+    }
     const Plan pl = make_plan(B, H, W, Cin, Cout);
     DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd wgrad: too many tiles");
     WgWinoParams p;

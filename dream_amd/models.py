@@ -418,7 +418,11 @@ class DreamHourglass(nn.Module):
             if int(g.shape[3]) != cols_pad:
                 raise RuntimeError("internal: gradient has %d channels, packed weights expect %d" % (g.shape[3], cols_pad))
             if flags & CONV_UPSAMPLE2X:                    # the mask lives at half resolution: after upsample2_bwd
-                g = ops.upsample2_bwd(ops.conv3x3(g, packed_t, None, rows, 0))
+                if self._use_winograd(int(g.shape[3]), cin, 0) and int(g.shape[3]) == cout:
+                    u_t, rows_t = self._packed.get(mod.weight, "wino1")
+                    g = ops.upsample2_bwd(ops.conv3x3_winograd(g, u_t, rows_t, None, None, None, 0))
+                else:
+                    g = ops.upsample2_bwd(ops.conv3x3(g, packed_t, None, rows, 0))
             elif self._use_winograd(int(g.shape[3]), cin, ops.CONV_RELUMASK if fuse else 0) and int(g.shape[3]) == cout:
                 u_t, rows_t = self._packed.get(mod.weight, "wino1")       # data gradient = conv with the transposed, flipped taps
                 g = ops.conv3x3_winograd(g, u_t, rows_t, None, None, inp if fuse else None, ops.CONV_RELUMASK if fuse else 0)

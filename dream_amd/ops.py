@@ -235,9 +235,9 @@ def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
 
 def wgrad_winograd_pays(pixels, cin, cout):
     """Where the Winograd-domain weight gradient beats the direct kernel (profiles/r02_microbench_wgrad_wino_b128.txt:
-    1.15-1.67x on the layers with >= 128 x 128 channel pairs or >= 4 M pixels; it loses on small 64-channel maps, whose
+    1.2-2.1x on the layers with >= 128 x 64 channel pairs or >= 4 M pixels; it loses on small 64 x 64-channel maps, whose
     split-K partials and short loops dominate)."""
-    return cin % 64 == 0 and cout % 16 == 0 and cout >= 64 and (cin * cout >= 16384 or pixels >= 4000000)
+    return cin % 64 == 0 and cout % 16 == 0 and cout >= 64 and (cin * cout >= 8192 or pixels >= 4000000)
 
 
 def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True):

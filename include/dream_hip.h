@@ -280,6 +280,7 @@ int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_pack
 size_t dream_conv3x3_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout);
 int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
                                           int W, int Cin, int Cout, int Cdy, void *stream);
+int dream_conv3x3_wgrad_winograd_set_version(int version);   /* test / A-B hook: 0 = by shape (default), 1 = register-only kernel */
 /* general forms for the ResNet path (1x1 / 3x3, stride 1 / 2) and the 4x4 transposed conv */
 size_t dream_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad, int ksize, int stride);
 int dream_conv2d_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, float *dbias, void *workspace,

@@ -95,6 +95,7 @@ inline float quad_perm_2211(float v) {
     const int l = emu::lane(), src = (l & ~3) | ((l & 3) < 2 ? 2 : 1);
     return emu_exchange(v, src);
 }
+inline float quad_perm_1032(float v) { return emu_exchange(v, emu::lane() ^ 1); }
 inline int wave_index() { return emu::wave(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }

@@ -55,7 +55,12 @@ def test_wgrad_winograd(emu):
             pc.check_wgrad_winograd("cpu", 2, 13, 9, 64, 32, seed=1),            # odd extents (half tiles), several images
             pc.check_wgrad_winograd("cpu", 3, 6, 10, 128, 48, seed=2),           # two input-channel groups, ragged output group
             pc.check_wgrad_winograd("cpu", 1, 25, 25, 64, 64, seed=3),           # several splits
-            pc.check_wgrad_winograd("cpu", 2, 5, 3, 64, 16, seed=4, pad_dy=16)]  # images smaller than a k-step, padded dy
+            pc.check_wgrad_winograd("cpu", 2, 5, 3, 64, 16, seed=4, pad_dy=16),  # images smaller than a k-step, padded dy
+            # 64-multiples of output channels: the LDS-staged kernel (stages of 8 tiles, operands shared by the workgroup)
+            pc.check_wgrad_winograd("cpu", 2, 13, 9, 64, 64, seed=5),            # odd extents, several stages
+            pc.check_wgrad_winograd("cpu", 3, 6, 10, 128, 64, seed=6),           # two input-channel blocks
+            pc.check_wgrad_winograd("cpu", 1, 25, 25, 64, 128, seed=7),          # two output-channel blocks, several splits
+            pc.check_wgrad_winograd("cpu", 2, 5, 3, 64, 64, seed=8, pad_dy=16)]  # fewer tiles than a stage, padded dy
     print("winograd wgrad max err / sum|terms|", max(errs))
 
 

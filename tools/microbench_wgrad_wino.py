@@ -8,7 +8,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
-from dream_amd import ops  # noqa: E402
+from dream_amd import _hip, ops  # noqa: E402
 
 LAYERS = [(400, 64, 64, 1), (200, 64, 128, 1), (200, 128, 128, 1), (100, 128, 256, 1), (100, 256, 256, 3), (50, 256, 512, 1),
           (50, 512, 512, 3), (25, 512, 512, 4), (50, 256, 256, 1), (100, 128, 64, 1), (100, 64, 64, 1), (100, 64, 32, 1)]
@@ -43,12 +43,16 @@ def main():
         diff = float((a - w).abs().max()) / float(a.abs().max())
         ms_d = timeit(lambda: ops.conv3x3_wgrad(x, dy, cout, cin), args.reps)
         ms_w = timeit(lambda: ops.conv3x3_wgrad_winograd(x, dy, cout, cin), args.reps)
+        _hip.lib().dream_conv3x3_wgrad_winograd_set_version(1)          # the register-only kernel, for comparison
+        ms_w1 = timeit(lambda: ops.conv3x3_wgrad_winograd(x, dy, cout, cin), args.reps)
+        _hip.lib().dream_conv3x3_wgrad_winograd_set_version(0)
         flops = 2.0 * b * res * res * cin * cout * 9
         td += count * ms_d
         tw += count * ms_w
         print("%4d %4d->%4d x%d  direct %8.3f ms %6.1f TF | winograd %8.3f ms %6.1f TF-equiv (%.2f of peak on its own MACs) "
-              "speedup %.2f  rel diff %.1e" % (res, cin, cout, count, ms_d, flops / ms_d / 1e9, ms_w, flops / ms_w / 1e9,
-                                               flops / 2.25 / ms_w / 1e9 / 157.3, ms_d / ms_w, diff), flush=True)
+              "speedup %.2f  rel diff %.1e | register-only version %8.3f ms" % (
+                  res, cin, cout, count, ms_d, flops / ms_d / 1e9, ms_w, flops / ms_w / 1e9,
+                  flops / 2.25 / ms_w / 1e9 / 157.3, ms_d / ms_w, diff, ms_w1), flush=True)
         del x, dy, a, w
     print("sum over the vgg_q layers (b=%d): direct %.2f ms, winograd %.2f ms, speedup %.2f" % (args.batch, td, tw, td / tw))
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""Knock-out timing of the Winograd weight-gradient kernel (bit 0: no loads, bit 1: no operand transforms; results wrong by
-construction).  python tools/wgw_diag.py build | run"""
+"""Knock-out timing of the LDS-staged Winograd weight-gradient kernel (bit 0: no global loads, bit 1: no transform pieces,
+bit 2: no per-stage barrier -- results wrong by construction; bit 3: no stagger of the transform pieces between the two waves of a SIMD).
+python tools/wgw_diag.py build | run"""
 import ctypes
 import os
 import subprocess
@@ -8,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [1, 2, 3]
+KS = [1, 2, 4]
 OUT = os.path.join(ROOT, "build", "diag")
 
 
@@ -28,7 +29,7 @@ def run():
     libs = {0: _hip.lib()}
     for k in KS:
         libs[k] = ctypes.CDLL(os.path.join(OUT, "libwgw_diag_%d.so" % k))
-    names = {0: "product", 1: "no loads", 2: "no transforms", 3: "MFMAs only"}
+    names = {0: "product", 1: "no loads", 2: "no transforms", 3: "MFMAs + operand reads only", 4: "no barrier", 8: "producer work of both halves at the same MFMA numbers"}
     for (b, res, cin, cout) in [(128, 400, 64, 64), (128, 100, 256, 256), (128, 50, 512, 512)]:
         x = torch.randn(b, res, res, cin, device="cuda")
         dy = torch.randn(b, res, res, cout, device="cuda")
