@@ -12,3 +12,6 @@ cp $O/pmc_mfma.json profiles/r02_pmc_mfma.json
 for n in default train resnet_h_train16 resnet_h_train128 resnet_f_b32 resnet_h_b128 vgg_f_b32 vgg_f_train32; do tail -1 $O/bench_$n.log > profiles/r02_bench_${n}_line.json; done
 grep -h '^{"metric' $O/rocprof_default.log > profiles/r02_bench_default_under_rocprof_line.json
 tail -3 $O/pytest_gpu.log > profiles/r02_pytest_gpu_tail.txt
+for f in $O/layer_profile_*.txt; do cp $f profiles/r02_$(basename $f); done
+cp $O/microbench_wino_b128.txt profiles/r02_microbench_wino_b128.txt
+cp $O/microbench_wgrad_wino_b128.txt profiles/r02_microbench_wgrad_wino_b128.txt

@@ -31,7 +31,7 @@ rm -rf $O/pmc_sq_1 $O/pmc_sq_2
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_rt_$C" -o pmc -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 --no-cpu-baseline > "$R/$O/pmc_rt_$C.log" 2>&1); echo "resnet train pmc $C rc=$?"
 done
-python tools/pmc_traffic.py $(ls $O/pmc_rt_FETCH_SIZE/*/*.db $O/pmc_rt_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_rt_WRITE_SIZE/*/*.db $O/pmc_rt_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic_resnet_train.json "bn_,mfma_kernel,wino_kernel,wgrad_kernel,adam,pack" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 | head -40
+python tools/pmc_traffic.py $(ls $O/pmc_rt_FETCH_SIZE/*/*.db $O/pmc_rt_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_rt_WRITE_SIZE/*/*.db $O/pmc_rt_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic_resnet_train.json "bn_,conv_mfma_kernel,conv_wino_kernel,wgrad_kernel<,wgrad_wino,adam,pack" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 | head -40
 rm -rf $O/pmc_rt_FETCH_SIZE $O/pmc_rt_WRITE_SIZE
 line() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | cut -c1-160; }
 line train --mode train --steps 4 --warmup 1
@@ -45,4 +45,10 @@ echo "== rocprof train"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stat
 summ $O/prof_train $O/bench_train
 echo "== rocprof resnet_h train16"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
 summ $O/prof_rtrain $O/bench_resnet_h_train16
+echo "== layer profiles"
+for cfg in "resnet_h train 16" "vgg_q train 128" "vgg_q infer 128"; do set -- $cfg
+  timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-200
+done
+echo "== microbenches"; timeout 300 python tools/microbench_wino.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino_b128.txt; tail -1 $O/microbench_wino_b128.txt
+timeout 300 python tools/microbench_wgrad_wino.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wgrad_wino_b128.txt; tail -1 $O/microbench_wgrad_wino_b128.txt
 ls -la $O | head -60; du -sh $O

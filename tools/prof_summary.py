@@ -17,12 +17,12 @@ def main():
         for name, n, tot, avg, mn, mx in rows:
             f.write('"%s",%d,%.3f,%.1f,%.1f,%.1f,%.2f\n' % (name, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
         # template families (what bench.py's roofline.avg_launch_ms averages over)
-        for fam in ("conv_wino_kernel", "conv_mfma_kernel", "conv_f16x3_kernel", "wgrad_kernel", "bn_"):
-            sel = [r for r in rows if fam + "<" in r[0] or (fam.endswith("_") and fam in r[0])]
+        for fam in ("conv_wino_kernel<", "conv_mfma_kernel<", "conv_f16x3_kernel<", "wgrad_kernel<", "wgrad_wino", "bn_"):
+            sel = [r for r in rows if fam in r[0]]
             if sel:
                 n = sum(r[1] for r in sel)
                 tot = sum(r[2] for r in sel)
-                f.write('"%s<*> (all instantiations)",%d,%.3f,%.1f,%.1f,%.1f,%.2f\n' % (
+                f.write('"%s* (all of the family)",%d,%.3f,%.1f,%.1f,%.1f,%.2f\n' % (
                     fam, n, tot / 1e6, tot / n / 1e3, min(r[4] for r in sel) / 1e3, max(r[5] for r in sel) / 1e3, 100.0 * tot / total))
     print(open(out + "_kernel_stats.csv").read())
     # per-dispatch list of the dominant kernel family, with launch geometry
