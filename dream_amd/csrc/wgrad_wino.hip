@@ -11,24 +11,21 @@
 // i.e. 16 multiplications, all in fp32 (the transforms only add and subtract; G^T . G has factors 1/2, exact in binary).
 //
 // GEMM view per position: M = output channels, N = input channels, K = tiles (image, tile row, tile column flattened: up to
-// 5.1 M for 128 x 400 x 400).  v_mfma_f32_16x16x4_f32: lane l supplies A[co = l & 15][k = l >> 4] and B[k = l >> 4][ci = l & 15],
-// so a lane owns ONE tile and ONE channel of each operand per k-step: it loads the tile's 2x2 dy values (one channel) and
-// its 4x4 input patch (one channel) as scalars -- NHWC makes the 16 lanes of a channel group read one contiguous 64-byte
-// segment per pixel -- and transforms them IN REGISTERS into the 16 + 16 operands of the 16 positions' MFMAs.  No LDS at all.
-//   * wave tile = 32 output channels x 16 input channels x 16 positions (2 x 16 accumulators, 128 VGPRs); workgroup = 4 waves
-//     = 32 output x 64 input channels; the four waves load the same dy (L1 hits) and their own input channels;
-//   * split-K over tile ranges, partial 3x3 gradients (the linear map G^T . G applied per workgroup) to a workspace,
-//     summed in a fixed order by a second kernel: deterministic, no fp32 atomics;
-//   * buffer loads with hardware bounds masking (zero padding, odd extents, range tails); an interior fast path skips the
-//     per-load validity selects when every tile of the k-step lies inside the image;
-//   * loads of k-step s+1 are issued before the 32 MFMAs of step s; the negations of A dY A^T are folded into the final
-//     transform (signs of dU positions), so the operand transforms are 12 + 32 additions per lane and k-step.
-// Measured (profiles/r02_microbench_wgrad_wino_b128.txt): 1.15-1.67x the direct kernel on the layers it is used for, 0.50-0.55 of
-// the MFMA peak on its own multiplications.  What bounds it (knock-out builds, profiles/r02_wgw_diag.txt): with the loads
-// removed the same loop runs at 0.79-0.93, with the transforms removed nothing changes -- the 24 scalar loads per 32 MFMAs
-// (64-byte segments, 256 B per wave instruction) saturate the texture-address path; variants with less address arithmetic,
-// loads two steps ahead or loads spread between the MFMAs were all slower.  The fix is structural (share the loaded patch
-// across the workgroup through LDS, float4 loads: ~0.1 load instructions per MFMA instead of 0.75) and is the next version.
+// 5.1 M for 128 x 400 x 400), split over tile ranges ("split-K"); partial results go to a workspace and are summed in a FIXED
+// order by a second kernel: deterministic, no fp32 atomics.  All global loads go through buffer descriptors with hardware
+// bounds masking (zero padding, odd extents, range tails).
+//
+// Two kernels:
+//   * version 2 (wgrad_wino_lds_kernel, below): output channels a multiple of 64 -- every layer of the DREAM networks this
+//     path is used for.  The transformed operands are shared by the workgroup through LDS; 0.60-0.69 of the MFMA peak on its
+//     own multiplications, 1.8-2.1x the direct kernel (profiles/r02_microbench_wgrad_wino_b128.txt).
+//   * version 1 (wgrad_wino_kernel, next): registers only, any multiple of 16 output channels.  v_mfma_f32_16x16x4_f32:
+//     lane l supplies A[co = l & 15][k = l >> 4] and B[k = l >> 4][ci = l & 15], so a lane owns ONE tile and ONE channel of each
+//     operand per k-step: it loads the tile's 2x2 dy values and its 4x4 input patch (one channel each) as scalars and
+//     transforms them in registers into the 16 + 16 operands of the 16 positions' MFMAs.  Wave tile = 32 output x 16 input
+//     channels x 16 positions, workgroup = 4 waves; the linear map G^T . G is applied per workgroup (partials hold 3x3 taps).
+//     0.50-0.55 of the MFMA peak: its 24 scalar loads per 32 MFMAs are what bounds it (knock-out timing: 0.79-0.93 without
+//     the loads, unchanged without the transforms) -- the reason version 2 exists.
 #include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
