@@ -1,0 +1,227 @@
+// 1x1 stride-1 convolution = plain GEMM  Y[pos][cout] = sum_cin X[pos][cin] W[cout][cin]  on NHWC fp32 tensors, on the
+// CDNA4 fp32 matrix cores, WITHOUT LDS and without barriers.
+//
+// Replaces torch.nn.Conv2d(k=1) of the ResNet-101 bottlenecks behind /root/reference/dream/models.py:22-32 (conv1 / conv3 /
+// the stride-1 downsample of layer1) in evaluation (folded BatchNorm scale / shift, residual add, ReLU in the epilogue) and
+// training, and -- on mode-1 packed weights -- their data gradients (+ the sum with the other branch's gradient).
+// 37 % of a ResNet training step at 16 frames per GPU are such GEMMs of ~10 000 x 1024 x 256: 33 us at the roofline, of which
+// the LDS-staged direct kernel (conv_mfma.hip: patch staging, barriers per chunk, 128 x 128 workgroup tiles) needs 65-80.
+//
+//   * both operands are contiguous along K (input channels of a pixel; a packed weight row), so a lane feeds
+//     v_mfma_f32_16x16x4_f32 straight from one 16-byte load: lane l = (row i = l & 15, k group g = l >> 4) loads
+//     k = 16 t + 4 g .. +3 of its row and uses component e in k-step e -- the same assignment on both operands, so the MFMA
+//     contracts matching k's (the order of a sum does not matter to the algebra, and is fixed);
+//   * wave tile = 64 positions x 64 output channels: 4 + 4 loads feed 64 MFMAs per 16 k's; 64 accumulator registers, ~130
+//     VGPRs: three waves per SIMD hide the load latency, register double-buffering of the operands does the rest;
+//   * waves are independent in the K loop (no LDS, no barrier): a workgroup is four consecutive wave tiles, or -- when the
+//     problem has too few tiles to give every SIMD two or three waves (25 x 25 and 13 x 13 maps at 16 frames) -- two / one
+//     tile(s) whose K range is split over the waves, summed through LDS in a fixed order before the epilogue;
+//   * weights are packed [K/16][channel rows][16] with the rows permuted so that MFMA column block n, lane column j holds
+//     output channel 4 j + n: the four accumulator blocks of a lane are then four CONSECUTIVE channels of one position and
+//     the epilogue loads scale / shift / residual and stores the result as float4 (256 contiguous bytes per 16 lanes);
+//   * buffer descriptors: fixed per-lane offsets, the chunk offset in the scalar operand (no address arithmetic in the loop),
+//     rows beyond the end read zeros and are not stored.
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+namespace {
+
+struct GemmParams {
+    const float *x;          // [M][x_stride] (first K columns used)
+    const float *w;          // packed [K/16][NPad][16]
+    const float *scale;      // [N] or null
+    const float *shift;      // [N] or null
+    const float *residual;   // [M][N] or null
+    float *y;                // [M][N]
+    int M, K, N, NPad, x_stride;
+    int nrb, ncb;            // 64-row / 64-column blocks
+    int flags;               // DREAM_CONV_RELU
+};
+
+template <int KS>
+__global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
+    __shared__ float s_part[KS > 1 ? 4 * 64 * 64 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    // XCD-aware placement: workgroup b runs on XCD b % 8; give each XCD a contiguous range of wave tiles (column blocks of
+    // one row block are neighbours: they re-read the same input rows and meet in that XCD's L2)
+    const int nwg = (int)gridDim.x;
+    const int wg = (int)(blockIdx.x & 7) * (nwg >> 3) + (int)(blockIdx.x >> 3);
+    const int tile = wg * (4 / KS) + wave / KS;            // KS waves share a tile, each with 1 / KS of the K range
+    const int kpart = wave % KS;
+    const bool live = tile < p.nrb * p.ncb;
+    if (KS == 1 && !live) return;
+    const int cb = tile % p.ncb, rb = tile / p.ncb;
+    const int li = lane & 15, lg = lane >> 4;
+
+    const BufferRsrc xbuf = make_buffer(p.x, (size_t)p.M * p.x_stride * sizeof(float));
+    const BufferRsrc wbuf = make_buffer(p.w, (size_t)(p.K / 16) * p.NPad * 16 * sizeof(float));
+    unsigned a_off[4], b_off[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int row = rb * 64 + 16 * m + li;
+        a_off[m] = row < p.M ? (unsigned)((row * p.x_stride + 4 * lg) * 4) : BUFFER_OOB;
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) b_off[n] = (unsigned)(((cb * 64 + 16 * n + li) * 16 + 4 * lg) * 4);
+    const unsigned b_chunk = (unsigned)(p.NPad * 16 * 4);        // bytes between k chunks of the packed weights
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    f32x4 xa[2][4], xb[2][4];
+    auto load = [&](int set, int t) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) xa[set][m] = buffer_load_x4(xbuf, a_off[m], (unsigned)t * 64u);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xb[set][n] = buffer_load_x4(wbuf, b_off[n], (unsigned)t * b_chunk);
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(xa[set][m][e], xb[set][n][e], acc[m][n]);
+    };
+    const int nchunks = p.K / 16 / KS;               // even (host side); this wave's chunks start at t0
+    const int t0 = kpart * nchunks;
+    if (live) {
+        load(0, t0);
+        for (int t = 0; t < nchunks; t += 2) {
+            load(1, t0 + t + 1);
+            multiply(0);
+            load(0, t0 + (t + 2 < nchunks ? t + 2 : t));     // the last pair re-reads a chunk rather than branching
+            multiply(1);
+        }
+    }
+    // split K: partial tiles through LDS; wave kpart then owns row blocks m = kpart, kpart + KS, .. (fixed summation order)
+    if (KS > 1) {
+        f32x4 *sp = (f32x4 *)s_part;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) sp[((wave * 4 + m) * 4 + n) * 64 + lane] = acc[m][n];
+        __syncthreads();
+        const int w0 = wave - kpart;                 // first wave of this tile
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (m % KS == kpart) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    f32x4 v = sp[(((w0 + 0) * 4 + m) * 4 + n) * 64 + lane];
+#pragma unroll
+                    for (int k = 1; k < KS; ++k) v = v + sp[(((w0 + k) * 4 + m) * 4 + n) * 64 + lane];
+                    acc[m][n] = v;
+                }
+            }
+        if (!live) return;
+    }
+
+    // ---- epilogue: lane holds rows 4 (l >> 4) + r, column j = l & 15 of every block (m, n) = channels 4 j .. 4 j + 3 ----------
+    const int c0 = cb * 64 + 4 * li;
+    const bool cok = c0 < p.N;                       // N % 4 == 0
+    f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (p.scale != nullptr && cok) sc = *(const f32x4 *)(p.scale + c0);
+    if (p.shift != nullptr && cok) sh = *(const f32x4 *)(p.shift + c0);
+    const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rb * 64 + 16 * m + 4 * lg + r;
+            if ((KS == 1 || m % KS == kpart) && row < p.M && cok) {
+                f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+                v = v * sc + sh;
+                const size_t o = (size_t)row * p.N + c0;
+                if (p.residual != nullptr) v = v + *(const f32x4 *)(p.residual + o);
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                }
+                *(f32x4 *)(p.y + o) = v;
+            }
+        }
+}
+
+// w [Cout][Cin] (mode 0: rows = Cout, k = Cin) or, for the data gradient, the same tensor read as [k = Cout][rows = Cin]
+// (mode 1) -> packed [K/16][RowsPad][16] with physical row 64 c + 16 n + j = logical row 64 c + 4 j + n
+__global__ void __launch_bounds__(256) gemm1x1_pack_kernel(const float *w, float *packed, int Cout, int Cin, int rows, int K,
+                                                            int RowsPad, int mode) {
+    const size_t total = (size_t)(K / 16) * RowsPad * 16;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int e = (int)(i & 15);
+        const size_t rest = i >> 4;
+        const int prow = (int)(rest % RowsPad), t = (int)(rest / RowsPad);
+        const int blk = prow >> 6, n = (prow >> 4) & 3, j = prow & 15;
+        const int row = blk * 64 + 4 * j + n, k = 16 * t + e;
+        float v = 0.0f;
+        if (row < rows) v = mode == 0 ? w[(size_t)row * Cin + k] : w[(size_t)k * Cin + row];
+        packed[i] = v;
+    }
+}
+
+int g_conv1x1_ksplit = 0;     // test hook: 0 = by shape, 1 / 2 / 4 = force
+
+}  // namespace
+
+// Test hook: force the K split (0 = by problem size).  The result depends on it only through the summation order.
+extern "C" int dream_conv1x1_set_ksplit(int ks) {
+    DREAM_REQUIRE(ks == 0 || ks == 1 || ks == 2 || ks == 4, "conv1x1: K split %d", ks);
+    g_conv1x1_ksplit = ks;
+    return 0;
+}
+
+extern "C" size_t dream_conv1x1_weight_floats(int rows, int K) {
+    return (size_t)(K / 16) * (size_t)((rows + 63) / 64 * 64) * 16;
+}
+
+// w_oihw [Cout][Cin][1][1]; mode 0: forward operator (rows = Cout, K = Cin); mode 1: data-gradient operator (rows = Cin, K = Cout)
+extern "C" int dream_pack_conv1x1_weight(const float *w_oihw, float *packed, int Cout, int Cin, int mode, void *stream) {
+    DREAM_REQUIRE(w_oihw && packed && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "conv1x1 pack: bad arguments");
+    const int rows = mode == 0 ? Cout : Cin, K = mode == 0 ? Cin : Cout;
+    DREAM_REQUIRE(K % 32 == 0, "conv1x1 pack: contraction length %d must be a multiple of 32", K);
+    const int rows_pad = (rows + 63) / 64 * 64;
+    const size_t total = (size_t)(K / 16) * rows_pad * 16;
+    size_t grid = (total + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(gemm1x1_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin, rows,
+                       K, rows_pad, mode);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// y[M][N] = x[M][:K] . w^T * scale + shift (+ residual) (ReLU): M = B*H*W positions of an NHWC tensor with x_stride channels
+// per pixel (>= K: padded tensors), N = output channels (a multiple of 4), K a multiple of 32.  flags: DREAM_CONV_RELU.
+extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift,
+                                      const float *residual, float *y, long M, int K, int N, int x_stride, int flags, void *stream) {
+    DREAM_REQUIRE(x && w_packed && y, "conv1x1: null pointer");
+    DREAM_REQUIRE(M > 0 && K > 0 && N > 0 && x_stride >= K, "conv1x1: bad shape M=%ld K=%d N=%d stride=%d", M, K, N, x_stride);
+    DREAM_REQUIRE(K % 32 == 0 && N % 4 == 0 && x_stride % 4 == 0, "conv1x1: K %% 32, N %% 4, stride %% 4 (got %d, %d, %d)", K, N, x_stride);
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "conv1x1: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE((size_t)M * (size_t)x_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
+                  "conv1x1: tensor too large for 32-bit offsets");
+    GemmParams p;
+    p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.M = (int)M; p.K = K; p.N = N; p.NPad = (N + 63) / 64 * 64; p.x_stride = x_stride;
+    p.nrb = (int)((M + 63) / 64); p.ncb = p.NPad / 64;
+    p.flags = flags;
+    const long tiles = (long)p.nrb * p.ncb;
+    // the chip holds 3072 waves of this kernel (256 CUs x 4 SIMDs x 3): split K until the tiles give ~2 waves per SIMD
+    int ks = 1;
+    if (g_conv1x1_ksplit > 0) ks = g_conv1x1_ksplit;
+    else if (tiles < 768 && K % 128 == 0) ks = 4;
+    else if (tiles < 1536 && K % 64 == 0) ks = 2;
+    DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
+    const int per_wg = 4 / ks;
+    const unsigned grid = (unsigned)(((tiles + per_wg - 1) / per_wg + 7) / 8 * 8);
+    if (ks == 1) hipLaunchKernelGGL(gemm1x1_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (ks == 2) hipLaunchKernelGGL(gemm1x1_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(gemm1x1_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}

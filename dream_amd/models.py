@@ -810,6 +810,8 @@ class ResnetSimple(nn.Module):
         self._cache = {}
         self.precision = "fp32"        # "fp16x3": evaluation-mode forward on the split-precision conv kernel
         self.conv_algorithm = os.environ.get("DREAM_CONV_ALGORITHM", "winograd")   # see DreamHourglass.conv_algorithm
+        # stride-1 1x1 convs (forward and data gradient): "gemm" = the LDS-free GEMM kernel (gemm1x1.hip), "direct" = conv_mfma
+        self.conv1x1_algorithm = os.environ.get("DREAM_CONV1X1_ALGORITHM", "gemm")
         # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
@@ -880,8 +882,17 @@ class ResnetSimple(nn.Module):
             # the stride-1 3x3 convs of the bottlenecks: Winograd F(2x2,3x3) with the folded BatchNorm in the epilogue
             u, rows = self._cached(("wino", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 0))
             return ops.conv3x3_winograd(x, u, rows, scale, shift, residual, CONV_RELU if relu else 0)
+        if self._gemm1x1(conv, x):
+            # the 1x1 convs of the bottlenecks: a plain GEMM without LDS (gemm1x1.hip), folded BatchNorm / residual / ReLU fused
+            packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
+            return ops.conv1x1(x, packed, rows, scale, shift, residual, CONV_RELU if relu else 0)
         packed, rows, _ = self._cached(("w", name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), 0))
         return ops.conv2d(x, packed, rows, k, stride, scale, shift, residual, CONV_RELU if relu else 0)
+
+    def _gemm1x1(self, conv, x):
+        """Stride-1 1x1 convs with channel counts the LDS-free GEMM kernel takes (all of ResNet-101's: multiples of 64)."""
+        return (self.conv1x1_algorithm == "gemm" and int(conv.kernel_size[0]) == 1 and int(conv.stride[0]) == 1
+                and int(conv.weight.shape[1]) == int(x.shape[3]) and ops.conv1x1_applies(x, int(conv.weight.shape[0])))
 
     # ---- inference on the split-precision conv kernel (strided convs stay on the fp32 kernel) ------------------
     def _conv_bn16(self, name, x, amax, conv, bn, relu, residual=None):
@@ -985,6 +996,9 @@ class ResnetSimple(nn.Module):
         if self._wino_train(conv):
             u, rows = self._cached(("wino", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 0))
             z = ops.conv3x3_winograd(x, u, rows, None, bias, None, 0)
+        elif self._gemm1x1(conv, x):
+            packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
+            z = ops.conv1x1(x, packed, rows, None, bias, None, 0)
         else:
             packed, rows, _ = self._packed_w(name, conv, 0)
             z = ops.conv2d(x, packed, rows, k, stride, None, bias, None, 0)
@@ -1003,6 +1017,10 @@ class ResnetSimple(nn.Module):
         if self._wino_train(conv):
             u_t, rows = self._cached(("wino1", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 1))
             return ops.conv3x3_winograd(dz, u_t, rows, None, None, residual, 0)
+        if (self.conv1x1_algorithm == "gemm" and k == 1 and stride == 1 and int(dz.shape[3]) == int(conv.weight.shape[0])
+                and ops.conv1x1_applies(dz, cin)):
+            packed_t, rows = self._cached(("g1", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 1))
+            return ops.conv1x1(dz, packed_t, rows, None, None, residual, 0)
         packed_t, rows, _ = self._packed_w(name, conv, 1)
         return ops.conv2d_bwd_data(dz, packed_t, cin, k, stride, in_hw, residual=residual)
 

@@ -340,6 +340,35 @@ def conv2d(x_nhwc, packed, cout, ksize, stride=1, scale=None, shift=None, residu
     return y
 
 
+def pack_conv1x1_weight(w_oihw, mode=0):
+    """[Cout,Cin,1,1] -> the LDS-free GEMM kernel's operand layout; mode 1: the data-gradient operator.  Returns (packed, rows)."""
+    w = _f32(w_oihw)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    rows, k = (cout, cin) if mode == 0 else (cin, cout)
+    n = int(_hip.lib().dream_conv1x1_weight_floats(rows, k))
+    packed = torch.empty(n, dtype=torch.float32, device=w.device)
+    call("dream_pack_conv1x1_weight", ptr(w), ptr(packed), cout, cin, mode, stream())
+    return packed, rows
+
+
+def conv1x1_applies(x_nhwc, cout):
+    """The LDS-free GEMM kernel takes stride-1 1x1 convs with K % 32 == 0, N % 4 == 0 and tensors below 2 GB."""
+    k = int(x_nhwc.shape[3])
+    return k % 32 == 0 and cout % 4 == 0 and x_nhwc.numel() * 4 < (1 << 31)
+
+
+def conv1x1(x_nhwc, packed, cout, scale=None, shift=None, residual=None, flags=0):
+    """1x1 stride-1 conv, y = conv*scale + shift (+residual) (ReLU), NHWC."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    if residual is not None and tuple(residual.shape) != tuple(y.shape):
+        raise RuntimeError("conv1x1: residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    call("dream_conv1x1_nhwc_f32", ptr(x), ptr(packed), ptr(scale), ptr(shift), ptr(residual), ptr(y), b * h * w, cin, cout, cin,
+         flags, stream())
+    return y
+
+
 def conv_transpose4x4s2(x_nhwc, packed, cout, scale=None, shift=None, flags=0, direct_taps=16):
     """direct_taps: multiply-adds per (input pixel, cin, cout) of the direct algorithm this launch stands for -- 16 for a
     4x4 transposed conv, 36 when it replaces upsample + conv3x3; only used by bench.py's FLOP accounting."""

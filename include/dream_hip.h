@@ -97,6 +97,14 @@ int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *b
  * data-gradient operator, rows = Cin, cols = Cout); y = conv * scale[c] + shift[c] (+ residual, or masked by
  * residual > 0 with DREAM_CONV_RELUMASK) (ReLU) (2x2 max-pool); flags: DREAM_CONV_RELU | DREAM_CONV_POOL2 |
  * DREAM_CONV_RELUMASK; scale / shift / residual may be NULL.  Cin: a multiple of 16, at least 32. */
+/* 1x1 stride-1 conv as a plain GEMM without LDS (gemm1x1.hip): the ResNet-101 bottleneck convs behind dream/models.py:22-32
+ * and, on mode-1 packed weights, their data gradients.  y[M][N] = x[M][:K] . w^T * scale + shift (+ residual) (ReLU); M = B*H*W
+ * positions of an NHWC tensor with x_stride (>= K) channels per pixel; K % 32 == 0, N % 4 == 0; flags: DREAM_CONV_RELU. */
+size_t dream_conv1x1_weight_floats(int rows, int K);
+int dream_conv1x1_set_ksplit(int ks);   /* test hook: 0 = K split by problem size (default), 1 / 2 / 4 = forced */
+int dream_pack_conv1x1_weight(const float *w_oihw, float *packed, int Cout, int Cin, int mode, void *stream);
+int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift, const float *residual,
+                           float *y, long M, int K, int N, int x_stride, int flags, void *stream);
 size_t dream_conv3x3_winograd_weight_floats(int rows, int cols);
 int dream_conv3x3_winograd_set_variant(int variant);   /* workgroup width: 0 = by layer (default), 4 / 8 wavefronts = 64 / 128 channels */
 int dream_conv3x3_winograd_set_max_workgroups(int n);  /* test hook: size the persistent grid for n co-resident workgroups (0 = the chip) */

@@ -103,6 +103,47 @@ def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_s
     return err
 
 
+def check_conv1x1(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=False, ksplits=(0, 1, 2, 4)):
+    """LDS-free GEMM kernel for stride-1 1x1 convs vs an fp64 evaluation: error relative to the output maximum at fp32 round-off
+    level, for every K split the shape admits (the split only changes the order of the sum)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5 if with_scale else None
+    if mode == 1:                                        # data-gradient operator of conv(w'): w' is [Cin, Cout] here
+        wsrc = torch.randn(Cin, Cout, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
+        w = wsrc.permute(1, 0, 2, 3).contiguous()
+        packed, rows = ops.pack_conv1x1_weight(to(dev, wsrc), 1)
+    else:
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5
+        packed, rows = ops.pack_conv1x1_weight(to(dev, w), 0)
+    assert rows == Cout
+    res = torch.randn(B, Cout, H, W, generator=g) if residual else None
+    ref = F.conv2d(x.double(), w.double(), None)
+    if with_scale:
+        ref = ref * scale.double().view(1, -1, 1, 1)
+    ref = ref + bias.double().view(1, -1, 1, 1)
+    if res is not None:
+        ref = ref + res.double()
+    if flags & ops.CONV_RELU:
+        ref = ref.relu()
+    worst = 0.0
+    for ks in ksplits:
+        if ks and Cin % (32 * ks):
+            continue
+        _hip.lib().dream_conv1x1_set_ksplit(ks)
+        try:
+            y = ops.conv1x1(to(dev, _nhwc(x)), packed, Cout, to(dev, scale) if with_scale else None, to(dev, bias),
+                            to(dev, _nhwc(res)) if res is not None else None, flags).cpu().permute(0, 3, 1, 2)
+        finally:
+            _hip.lib().dream_conv1x1_set_ksplit(0)
+        assert y.shape == ref.shape, (tuple(y.shape), tuple(ref.shape))
+        err = float((y.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+        assert err <= 2e-6, (B, H, W, Cin, Cout, flags, ks, err)
+        worst = max(worst, err)
+    return worst
+
+
 def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0):
     """Winograd-domain weight gradient vs an fp64 evaluation of the direct sums: error relative to sum |terms| at fp32
     round-off level (the direct MFMA kernel is checked the same way)."""

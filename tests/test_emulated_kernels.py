@@ -50,6 +50,15 @@ def test_conv_winograd(emu, variant):
     print("winograd max rel err", max(errs))
 
 
+def test_conv1x1_gemm(emu):
+    errs = [pc.check_conv1x1("cpu", 1, 8, 8, 64, 64),                                             # one tile
+            pc.check_conv1x1("cpu", 2, 5, 7, 128, 36, ops.CONV_RELU, seed=1, with_scale=True),    # ragged rows and channels
+            pc.check_conv1x1("cpu", 1, 13, 13, 256, 192, ops.CONV_RELU, seed=2, residual=True),   # several tiles, K split 4
+            pc.check_conv1x1("cpu", 3, 4, 3, 64, 128, 0, seed=3, mode=1, residual=True),          # data-gradient operator
+            pc.check_conv1x1("cpu", 1, 9, 9, 160, 64, ops.CONV_RELU, seed=4)]                     # K = 160 (the stem's im2col)
+    print("conv1x1 gemm max rel err", max(errs))
+
+
 def test_wgrad_winograd(emu):
     errs = [pc.check_wgrad_winograd("cpu", 1, 8, 8, 64, 16),                    # one split, interior + border tiles
             pc.check_wgrad_winograd("cpu", 2, 13, 9, 64, 32, seed=1),            # odd extents (half tiles), several images

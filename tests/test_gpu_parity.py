@@ -570,6 +570,56 @@ def test_conv_winograd(b, h, w, cin, cout, flags, kw):
 
 
 # ---- single-process data parallelism behind gpu_ids (dream_amd/data_parallel.py; reference network.py:244-256) ------------
+@pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
+    (1, 8, 8, 64, 64, 0, {}), (2, 5, 7, 128, 36, 1, {"with_scale": True}), (1, 13, 13, 256, 192, 1, {"residual": True}),
+    (3, 4, 3, 64, 128, 0, {"mode": 1, "residual": True}), (1, 9, 9, 160, 64, 1, {}),
+    (16, 100, 100, 64, 256, 1, {"with_scale": True, "residual": True}), (16, 100, 100, 256, 64, 1, {"with_scale": True}),
+    (16, 25, 25, 1024, 256, 0, {}), (16, 25, 25, 256, 1024, 0, {"mode": 1, "residual": True}), (16, 13, 13, 2048, 512, 1, {}),
+    (128, 50, 50, 512, 128, 1, {"with_scale": True})])
+def test_conv1x1_gemm(b, h, w, cin, cout, flags, kw):
+    err = pc.check_conv1x1(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw)
+    print("conv1x1 gemm %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
+
+
+def test_resnet_conv1x1_algorithms_agree():
+    """ResnetSimple with the 1x1 convs on the GEMM kernel vs on the direct conv kernel: evaluation maps agree to fp32
+    round-off; one training step's gradient agrees in direction (cosine >= 0.99) -- the two kernels sum in different orders;
+    the gradients of the biases that feed a BatchNorm are pure round-off (exactly zero in exact arithmetic) and are excluded."""
+    k = 7
+    wts = om.recipe_weights(om.build_model("resnet_h", k).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    x = torch.from_numpy(cases.image_batch(4, 256, 320, seed=5)).to(DEV)
+    outs, grads = [], []
+    for alg in ("gemm", "direct"):
+        net = pc.build_network("resnet_h", DEV, weights=wts, optimizer="sgd", lr=1e-5, in_res=(320, 256))
+        net.model.module.conv1x1_algorithm = alg
+        net.enable_evaluation()
+        with torch.no_grad():
+            outs.append(net.inference(x)[0].clone())
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(4, k, (ow, oh), in_wh=(320, 256), seed=5)).to(DEV)
+        net.optimizer.zero_grad()
+        net.loss([x], t).backward()
+        grads.append({n: p.grad.detach().double().clone() for n, p in net.model.named_parameters()})
+    scale = max(1.0, float(outs[1].abs().max()))
+    map_err = float((outs[0] - outs[1]).abs().max()) / scale
+    names = [n for n in grads[0] if not (n.startswith("module.upsample") and n.endswith(".bias") and grads[1][n].dim() == 1
+                                         and n.split(".")[-2] in ("0", "3", "6", "9", "12") and n != "module.upsample.12.bias")]
+    total = sum(float(grads[1][n].pow(2).sum()) for n in names) ** 0.5
+    diff = sum(float((grads[0][n] - grads[1][n]).pow(2).sum()) for n in names) ** 0.5
+    rel = {n: float((grads[0][n] - grads[1][n]).norm()) / max(float(grads[1][n].norm()), 1e-30) for n in names if n.endswith("weight")}
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:3]
+    print("gemm vs direct 1x1 convs: maps differ by %.2e of the maximum; whole gradient by %.2e (relative L2); weight tensors: worst %s, "
+          "median %.2e" % (map_err, diff / total, ", ".join("%s %.1e" % kv for kv in worst), float(np.median(list(rel.values())))))
+    assert map_err <= 2e-5
+    # train-mode BatchNorm of a randomly initialised 101-layer trunk is ill-conditioned: two correct fp32 implementations
+    # differ by percents in every gradient tensor (parity_checks.check_resnet_train_step measures both kernels against the fp64
+    # oracle); what a wiring error would break is the DIRECTION of the gradient
+    dot = sum(float((grads[0][n] * grads[1][n]).sum()) for n in names)
+    norm0 = sum(float(grads[0][n].pow(2).sum()) for n in names) ** 0.5
+    assert dot / (norm0 * total) >= 0.99 and diff / total <= 0.15, (dot / (norm0 * total), diff / total)
+
+
 def _dp_network(arch, gpu_ids, optimizer="adam", lr=1e-5, in_res=(96, 64), weights=None):
     import contextlib
     import io
