@@ -70,6 +70,8 @@ _SIGNATURES = {
     "dream_conv3x3_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv1x1_weight_floats": (_SZ, [_I, _I]),
     "dream_conv1x1_set_ksplit": (_I, [_I]),
+    "dream_conv1x1_wgrad_workspace": (_SZ, [_c.c_long, _I, _I]),
+    "dream_conv1x1_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P]),
     "dream_pack_conv1x1_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "dream_conv1x1_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _I, _I, _I, _P]),
     "dream_conv3x3_winograd_weight_floats": (_SZ, [_I, _I]),

@@ -165,6 +165,125 @@ __global__ void __launch_bounds__(256) gemm1x1_pack_kernel(const float *w, float
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 1x1 stride-1 conv:  dW[co][ci] = sum_pos dY[pos][co] X[pos][ci]  -- a GEMM whose contraction runs over
+// POSITIONS, i.e. over the slow axis of both NHWC operands.  v_mfma_f32_16x16x4_f32 wants A[row][k] / B[k][col] with lane
+// l = (row / col i = l & 15, k = l >> 4): a lane loads the 16 bytes dY[pos 4 s + (l >> 4)][4 i .. 4 i + 3] and uses component m as
+// the A operand of the MFMA whose 16 rows are the channels 4 i + m (the same for X and the columns): ONE load per operand and
+// k-step feeds a 4 x 4 block of MFMAs = 64 x 64 channel pairs, each load instruction reads 4 x 256 contiguous bytes, and
+// nothing is staged or transformed.  The four waves of a workgroup take a quarter each of the workgroup's position range
+// for one 64 x 64 tile, sum through LDS (fixed order) and write ONE partial tile per workgroup; a second kernel sums the
+// workgroups' partials in a fixed order (deterministic, no atomics).
+// Replaces ATen's conv backward-weight for the 1x1 convs of ResNet-101 (dream/models.py:22-32 via network.py:335).
+struct Wgrad1x1Params {
+    const float *x;          // [M][Cin]
+    const float *dy;         // [M][Cdy]
+    float *partial;          // [nsplit][Cout][Cin]
+    int M, Cin, Cout, Cdy;
+    int ncob, ncib;          // 64-channel blocks
+    int chunks_per_wave;     // chunks of 16 positions each wave sums (even)
+};
+
+__global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const Wgrad1x1Params p) {
+    __shared__ float s_part[4 * 64 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = wave_index();
+    const int tile = (int)blockIdx.x % (p.ncob * p.ncib), split = (int)blockIdx.x / (p.ncob * p.ncib);
+    const int cob = tile % p.ncob, cib = tile / p.ncob;
+    const int li = lane & 15, lg = lane >> 4;
+    const BufferRsrc xbuf = make_buffer(p.x, (size_t)p.M * p.Cin * sizeof(float));
+    const BufferRsrc ybuf = make_buffer(p.dy, (size_t)p.M * p.Cdy * sizeof(float));
+    const long pos0 = ((long)split * 4 + wave) * p.chunks_per_wave * 16;          // first position of this wave
+    // lane offset: position pos0 + (l >> 4), channels 4 i ..; beyond the tensor the hardware returns zeros
+    const bool any = pos0 < p.M;
+    const unsigned y_off = any ? (unsigned)(((pos0 + lg) * p.Cdy + cob * 64 + 4 * li) * 4) : BUFFER_OOB;
+    const unsigned x_off = any ? (unsigned)(((pos0 + lg) * p.Cin + cib * 64 + 4 * li) * 4) : BUFFER_OOB;
+    const unsigned y_step = (unsigned)(4 * p.Cdy * 4), x_step = (unsigned)(4 * p.Cin * 4);      // bytes per k-step (4 positions)
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 ya[2][4], xa[2][4];                        // [register set][k-step of the chunk]
+    auto load = [&](int set, int c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            // the whole offset in the VECTOR operand: the hardware's bounds check (zeros beyond the last position) does not
+            // see the scalar offset
+            ya[set][s] = buffer_load_x4(ybuf, y_off + (unsigned)(4 * c + s) * y_step, 0);
+            xa[set][s] = buffer_load_x4(xbuf, x_off + (unsigned)(4 * c + s) * x_step, 0);
+        }
+    };
+    auto multiply = [&](int set) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(ya[set][s][m], xa[set][s][n], acc[m][n]);
+    };
+    const int nchunks = p.chunks_per_wave;
+    load(0, 0);
+    for (int c = 0; c < nchunks; c += 2) {
+        load(1, c + 1);
+        multiply(0);
+        load(0, c + 2 < nchunks ? c + 2 : c);
+        multiply(1);
+    }
+    // the workgroup's four partial tiles through LDS; wave w then owns row block m = w
+    f32x4 *sp = (f32x4 *)s_part;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) sp[((wave * 4 + m) * 4 + n) * 64 + lane] = acc[m][n];
+    __syncthreads();
+    float *out = p.partial + (size_t)split * p.Cout * p.Cin;
+    const int ci = cib * 64 + 4 * li;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        if (m == wave) {
+            f32x4 v[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                v[n] = sp[((0 * 4 + m) * 4 + n) * 64 + lane];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) v[n] = v[n] + sp[((k * 4 + m) * 4 + n) * 64 + lane];
+            }
+            // lane holds rows i = 4 (l >> 4) + r of block m (channel co = 4 i + m), column j = l & 15 (channels ci = 4 j + n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = cob * 64 + 4 * (4 * lg + r) + m;
+                if (co < p.Cout) *(f32x4 *)(out + (size_t)co * p.Cin + ci) = f32x4{v[0][r], v[1][r], v[2][r], v[3][r]};
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) wgrad1x1_reduce_kernel(const float *partial, float *dw, int nsplit, size_t n) {
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
+        f32x4 s = *(const f32x4 *)(partial + i);
+        for (int k = 1; k < nsplit; ++k) s = s + *(const f32x4 *)(partial + (size_t)k * n + i);
+        *(f32x4 *)(dw + i) = s;
+    }
+}
+
+struct Wgrad1x1Plan { int nsplit, chunks_per_wave; };
+
+Wgrad1x1Plan wgrad1x1_plan(long M, int Cin, int Cout) {
+    const int tiles = ((Cout + 63) / 64) * (Cin / 64);
+    const long chunks = (M + 15) / 16;
+    long nsplit = (768 + tiles - 1) / tiles;                       // ~3 workgroups per CU in total
+    const long max_by_work = (chunks + 31) / 32;                   // at least 8 chunks per wave
+    if (nsplit > max_by_work) nsplit = max_by_work;
+    if (nsplit < 1) nsplit = 1;
+    long cpw = (chunks + nsplit * 4 - 1) / (nsplit * 4);
+    cpw = (cpw + 1) / 2 * 2;
+    Wgrad1x1Plan pl;
+    pl.chunks_per_wave = (int)cpw;
+    pl.nsplit = (int)((chunks + cpw * 4 - 1) / (cpw * 4));
+    return pl;
+}
+
 int g_conv1x1_ksplit = 0;     // test hook: 0 = by shape, 1 / 2 / 4 = force
 
 }  // namespace
@@ -222,6 +341,37 @@ extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, con
     if (ks == 1) hipLaunchKernelGGL(gemm1x1_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else if (ks == 2) hipLaunchKernelGGL(gemm1x1_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(gemm1x1_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+extern "C" size_t dream_conv1x1_wgrad_workspace(long M, int Cin, int Cout) {
+    if (M <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 != 0) return 0;
+    const Wgrad1x1Plan pl = wgrad1x1_plan(M, Cin, Cout);
+    return (size_t)pl.nsplit * Cout * Cin * sizeof(float);
+}
+
+// x [M][Cin], dy [M][Cdy] (Cdy >= Cout: gradient tensors may carry padded channels) -> dw [Cout][Cin] (= OIHW with 1x1 taps),
+// overwritten.  Cin % 64 == 0, Cout % 4 == 0, Cdy % 4 == 0; workspace: dream_conv1x1_wgrad_workspace() bytes.
+extern "C" int dream_conv1x1_wgrad_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout,
+                                            int Cdy, void *stream) {
+    DREAM_REQUIRE(x && dy && dw && workspace, "conv1x1 wgrad: null pointer");
+    DREAM_REQUIRE(M > 0 && Cin > 0 && Cout > 0 && Cdy >= Cout, "conv1x1 wgrad: bad shape");
+    DREAM_REQUIRE(Cin % 64 == 0 && Cout % 4 == 0 && Cdy % 4 == 0, "conv1x1 wgrad: Cin %% 64, Cout %% 4, Cdy %% 4 (got %d, %d, %d)", Cin, Cout, Cdy);
+    DREAM_REQUIRE((size_t)(M + 64) * (size_t)(Cin > Cdy ? Cin : Cdy) * 4 < ((size_t)1 << 31), "conv1x1 wgrad: tensor too large for 32-bit offsets");
+    const Wgrad1x1Plan pl = wgrad1x1_plan(M, Cin, Cout);
+    Wgrad1x1Params p;
+    p.x = x; p.dy = dy; p.partial = (float *)workspace;
+    p.M = (int)M; p.Cin = Cin; p.Cout = Cout; p.Cdy = Cdy;
+    p.ncob = (Cout + 63) / 64; p.ncib = Cin / 64;
+    p.chunks_per_wave = pl.chunks_per_wave;
+    hipLaunchKernelGGL(wgrad1x1_kernel, dim3((unsigned)(p.ncob * p.ncib * pl.nsplit)), dim3(256), 0, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    const size_t n = (size_t)Cout * Cin;
+    size_t rgrid = (n / 4 + 255) / 256;
+    if (rgrid > 1024) rgrid = 1024;
+    hipLaunchKernelGGL(wgrad1x1_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, (hipStream_t)stream, (const float *)workspace, dw,
+                       pl.nsplit, n);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -1117,7 +1117,10 @@ class ResnetSimple(nn.Module):
                     if self._wino_train(conv) and ops.wgrad_winograd_pays(int(dz.shape[0]) * int(dz.shape[1]) * int(dz.shape[2]), cin, cout):
                         grads[conv.weight] = ops.conv3x3_wgrad_winograd(x, dz, cout, cin, want_bias=False)[0]
                     else:
-                        grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
+                        if self.conv1x1_algorithm == "gemm" and k == 1 and stride == 1 and ops.conv1x1_wgrad_applies(x, dz, cout):
+                            grads[conv.weight] = ops.conv1x1_wgrad(x, dz, cout, cin)
+                        else:
+                            grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
                 _on_side(side, leaf, rec["x"], dz)
                 in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
                 if is_ds:

@@ -369,6 +369,24 @@ def conv1x1(x_nhwc, packed, cout, scale=None, shift=None, residual=None, flags=0
     return y
 
 
+def conv1x1_wgrad_applies(x_nhwc, dy_nhwc, cout):
+    cin, cdy = int(x_nhwc.shape[3]), int(dy_nhwc.shape[3])
+    # (measured: 1.2-1.8x the direct weight-gradient kernel from 64 x 256 channel pairs on, 0.74x at 64 x 64)
+    return (cin % 64 == 0 and cout % 4 == 0 and cdy % 4 == 0 and cin * cout >= 8192 and tuple(x_nhwc.shape[:3]) == tuple(dy_nhwc.shape[:3])
+            and (x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] + 64) * max(cin, cdy) * 4 < (1 << 31))
+
+
+def conv1x1_wgrad(x_nhwc, dy_nhwc, cout, cin):
+    """Weight gradient of a stride-1 1x1 conv -> dW [cout, cin, 1, 1] (the GEMM over positions of gemm1x1.hip)."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    m = int(x.shape[0]) * int(x.shape[1]) * int(x.shape[2])
+    nbytes = int(_hip.lib().dream_conv1x1_wgrad_workspace(m, cin, cout))
+    ws = _workspace(nbytes, x.device)
+    dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
+    call("dream_conv1x1_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), m, cin, cout, int(dy.shape[3]), stream())
+    return dw
+
+
 def conv_transpose4x4s2(x_nhwc, packed, cout, scale=None, shift=None, flags=0, direct_taps=16):
     """direct_taps: multiply-adds per (input pixel, cin, cout) of the direct algorithm this launch stands for -- 16 for a
     4x4 transposed conv, 36 when it replaces upsample + conv3x3; only used by bench.py's FLOP accounting."""

@@ -105,6 +105,11 @@ int dream_conv1x1_set_ksplit(int ks);   /* test hook: 0 = K split by problem siz
 int dream_pack_conv1x1_weight(const float *w_oihw, float *packed, int Cout, int Cin, int mode, void *stream);
 int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift, const float *residual,
                            float *y, long M, int K, int N, int x_stride, int flags, void *stream);
+/* Weight gradient of the same conv (gemm1x1.hip): x [M][Cin], dy [M][Cdy >= Cout] -> dw [Cout][Cin], overwritten; Cin % 64 == 0,
+ * Cout % 4 == 0, Cdy % 4 == 0; deterministic split over positions (fixed-order sums). */
+size_t dream_conv1x1_wgrad_workspace(long M, int Cin, int Cout);
+int dream_conv1x1_wgrad_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout, int Cdy,
+                                 void *stream);
 size_t dream_conv3x3_winograd_weight_floats(int rows, int cols);
 int dream_conv3x3_winograd_set_variant(int variant);   /* workgroup width: 0 = by layer (default), 4 / 8 wavefronts = 64 / 128 channels */
 int dream_conv3x3_winograd_set_max_workgroups(int n);  /* test hook: size the persistent grid for n co-resident workgroups (0 = the chip) */

@@ -144,6 +144,21 @@ def check_conv1x1(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=F
     return worst
 
 
+def check_conv1x1_wgrad(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0):
+    """GEMM weight gradient of the stride-1 1x1 conv vs an fp64 evaluation: error relative to sum |terms| at fp32 round-off level."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    dy = torch.randn(B, H, W, Cout, generator=g)
+    ref = torch.einsum("bhwo,bhwi->oi", dy.double(), x.double())
+    aref = torch.einsum("bhwo,bhwi->oi", dy.double().abs(), x.double().abs())
+    dyn = torch.cat([dy, torch.randn(B, H, W, pad_dy, generator=g)], dim=3).contiguous() if pad_dy else dy
+    dw = ops.conv1x1_wgrad(to(dev, x), to(dev, dyn), Cout, Cin)
+    assert tuple(dw.shape) == (Cout, Cin, 1, 1)
+    err = float(((dw.cpu().double().view(Cout, Cin) - ref).abs() / aref).max())
+    assert err <= 3e-6, (B, H, W, Cin, Cout, err)
+    return err
+
+
 def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0):
     """Winograd-domain weight gradient vs an fp64 evaluation of the direct sums: error relative to sum |terms| at fp32
     round-off level (the direct MFMA kernel is checked the same way)."""

@@ -57,6 +57,11 @@ def test_conv1x1_gemm(emu):
             pc.check_conv1x1("cpu", 3, 4, 3, 64, 128, 0, seed=3, mode=1, residual=True),          # data-gradient operator
             pc.check_conv1x1("cpu", 1, 9, 9, 160, 64, ops.CONV_RELU, seed=4)]                     # K = 160 (the stem's im2col)
     print("conv1x1 gemm max rel err", max(errs))
+    werrs = [pc.check_conv1x1_wgrad("cpu", 1, 8, 8, 64, 64),                     # one tile, one split
+             pc.check_conv1x1_wgrad("cpu", 2, 5, 7, 128, 36, seed=1),            # ragged position count and output channels
+             pc.check_conv1x1_wgrad("cpu", 1, 33, 31, 64, 128, seed=2),          # several splits, tail beyond the last position
+             pc.check_conv1x1_wgrad("cpu", 3, 4, 3, 192, 64, seed=3, pad_dy=16)] # padded gradient tensor
+    print("conv1x1 wgrad max err / sum|terms|", max(werrs))
 
 
 def test_wgrad_winograd(emu):

@@ -581,6 +581,14 @@ def test_conv1x1_gemm(b, h, w, cin, cout, flags, kw):
     print("conv1x1 gemm %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,pad", [(1, 8, 8, 64, 64, 0), (2, 5, 7, 128, 36, 0), (1, 33, 31, 64, 128, 0), (3, 4, 3, 192, 64, 16),
+                                                (16, 100, 100, 64, 256, 0), (16, 25, 25, 1024, 256, 0), (16, 13, 13, 512, 2048, 0),
+                                                (128, 25, 25, 256, 1024, 0)])
+def test_conv1x1_wgrad_gemm(b, h, w, cin, cout, pad):
+    err = pc.check_conv1x1_wgrad(DEV, b, h, w, cin, cout, seed=h + cin, pad_dy=pad)
+    print("conv1x1 wgrad %dx%dx%d %d->%d: err / sum|terms| %.2e" % (b, h, w, cin, cout, err))
+
+
 def test_resnet_conv1x1_algorithms_agree():
     """ResnetSimple with the 1x1 convs on the GEMM kernel vs on the direct conv kernel: evaluation maps agree to fp32
     round-off; one training step's gradient agrees in direction (cosine >= 0.99) -- the two kernels sum in different orders;

@@ -33,7 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     a = ap.parse_args()
-    td = tg = 0.0
+    td = tg = twd = twg = 0.0
     for (res, cin, cout, count) in LAYERS:
         x = torch.randn(a.batch, res, res, cin, device="cuda")
         w = torch.randn(cout, cin, 1, 1, device="cuda") * 0.05
@@ -46,13 +46,24 @@ def main():
         diff = float((yd - yg).abs().max()) / float(yd.abs().max())
         ms_d = timeit(lambda: ops.conv2d(x, pd, cout, 1, 1, sc, sh, res_t, ops.CONV_RELU))
         ms_g = timeit(lambda: ops.conv1x1(x, pg, cout, sc, sh, res_t, ops.CONV_RELU))
+        dy = torch.randn(a.batch, res, res, cout, device="cuda")
+        wd = ops.conv2d_wgrad(x, dy, cout, cin, 1, 1)[0]
+        wg = ops.conv1x1_wgrad(x, dy, cout, cin)
+        wdiff = float((wd - wg).abs().max()) / float(wd.abs().max())
+        ms_wd = timeit(lambda: ops.conv2d_wgrad(x, dy, cout, cin, 1, 1))
+        ms_wg = timeit(lambda: ops.conv1x1_wgrad(x, dy, cout, cin))
+        twd += count * ms_wd
+        twg += count * ms_wg
         flops = 2.0 * a.batch * res * res * cin * cout
+        wline = " || wgrad direct %7.1f us %5.1f TF | gemm %7.1f us %5.1f TF speedup %.2f rel diff %.1e" % (
+            ms_wd * 1e3, flops / ms_wd / 1e9, ms_wg * 1e3, flops / ms_wg / 1e9, ms_wd / ms_wg, wdiff)
         td += count * ms_d
         tg += count * ms_g
         print("%4d %5d->%5d x%-2d direct %7.1f us %6.1f TF | gemm %7.1f us %6.1f TF (%.2f of peak) speedup %.2f  rel diff %.1e" % (
             res, cin, cout, count, ms_d * 1e3, flops / ms_d / 1e9, ms_g * 1e3, flops / ms_g / 1e9, flops / ms_g / 1e9 / 157.3,
-            ms_d / ms_g, diff), flush=True)
-    print("sum over the ResNet-101 1x1 layers (b=%d): direct %.2f ms, gemm %.2f ms, speedup %.2f" % (a.batch, td, tg, td / tg))
+            ms_d / ms_g, diff) + wline, flush=True)
+    print("sum over the ResNet-101 1x1 layers (b=%d): direct %.2f ms, gemm %.2f ms, speedup %.2f; weight gradients: direct %.2f ms, "
+          "gemm %.2f ms, speedup %.2f" % (a.batch, td, tg, td / tg, twd, twg, twd / twg))
 
 
 if __name__ == "__main__":
