@@ -35,15 +35,14 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float *x, const fl
         f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1};
         if (MODE == 1) { mu = ((const f32x4 *)mean)[c0]; is = ((const f32x4 *)invstd)[c0]; }
         if (prow < rows_per_block) {
-            for (size_t p = (size_t)blockIdx.x * rows_per_block + prow; p < npix; p += (size_t)gridDim.x * rows_per_block) {
-                const f32x4 v = ((const f32x4 *)x)[p * C4 + c0];
+            // one pixel's terms, added in pixel order (the summation order -- hence the result, bit for bit -- does not depend
+            // on how many loads are in flight)
+            auto add = [&](const f32x4 v, f32x4 g, const f32x4 ya) {
                 if (MODE == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { a0[k] += (double)v[k]; a1[k] += (double)v[k] * (double)v[k]; }
                 } else {
-                    f32x4 g = ((const f32x4 *)dy)[p * C4 + c0];
                     if (relu) {
-                        const f32x4 ya = ((const f32x4 *)y_act)[p * C4 + c0];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.0f ? g[k] : 0.0f;
                     }
@@ -54,6 +53,27 @@ __global__ void __launch_bounds__(256) bn_reduce_kernel(const float *x, const fl
                         a1[k] += (double)g[k] * (double)xh;
                     }
                 }
+            };
+            const size_t stride = (size_t)gridDim.x * rows_per_block;
+            size_t p = (size_t)blockIdx.x * rows_per_block + prow;
+            // four pixels per trip: a workgroup has one load per thread and trip in flight otherwise, and 2 workgroups per CU
+            // cover only ~1 TB/s of the memory latency
+            for (; p + 3 * stride < npix; p += 4 * stride) {
+                f32x4 v[4], g[4], ya[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t i = (p + u * stride) * C4 + c0;
+                    v[u] = ((const f32x4 *)x)[i];
+                    g[u] = MODE == 1 ? ((const f32x4 *)dy)[i] : v[u];
+                    ya[u] = (MODE == 1 && relu) ? ((const f32x4 *)y_act)[i] : v[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) add(v[u], g[u], ya[u]);
+            }
+            for (; p < npix; p += stride) {
+                const size_t i = p * C4 + c0;
+                const f32x4 v = ((const f32x4 *)x)[i];
+                add(v, MODE == 1 ? ((const f32x4 *)dy)[i] : v, (MODE == 1 && relu) ? ((const f32x4 *)y_act)[i] : v);
             }
         }
         // reduce the rows_per_block rows of this workgroup
