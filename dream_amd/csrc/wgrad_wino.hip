@@ -258,6 +258,9 @@ struct WgWinoLdsParams {
     int ncog;                // groups of 64 output channels
 };
 
+// UPS: x is stored at half resolution and the conv ran on its nearest x2 upsample (compile-time: the run-time form of the few
+// extra selects cost 19 spilled registers)
+template <bool UPS>
 __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsParams p) {
     DREAM_DYNAMIC_LDS(float, smem);
     const int lane = threadIdx.x & 63;
@@ -272,7 +275,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
 
     // buffers relative to the first image of this split's tile range (32-bit offsets)
     const int b0 = div_magic40(k_begin, p.magic_tpi);
-    const size_t ximg = (size_t)p.H * p.W * p.Cin, yimg = (size_t)p.H * p.W * p.Cdy;
+    const int Hs = UPS ? p.H / 2 : p.H, Ws = UPS ? p.W / 2 : p.W;               // stored extent of x
+    const size_t ximg = (size_t)Hs * Ws * p.Cin, yimg = (size_t)p.H * p.W * p.Cdy;
     const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * ximg, (size_t)(p.B - b0) * ximg * sizeof(float));
     const BufferRsrc ybuf = make_buffer(p.dy + (size_t)b0 * yimg, (size_t)(p.B - b0) * yimg * sizeof(float));
 
@@ -297,7 +301,9 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
     // in the run time), so the address is split: everything that depends on the tile is wave-uniform and computed on the
     // scalar unit (offset of the tile's first output pixel + column), the lane adds its constant (patch row, channel quad)
     // with one v_add and sets bit 31 where the pixel is outside the image (beyond any buffer: the hardware returns zeros).
-    const int lane_dx = (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);     // patch row vr - 1 relative to the tile's first output row
+    // patch row vr - 1 relative to the tile's first output row; with the fused upsample the tile's 4 x 4 patch of the upsampled
+    // image is rows / columns {-1, 0, 0, +1} of the stored one around the tile's source pixel ((2 t - 1 + r) >> 1 = t + ((r - 1) >> 1))
+    const int lane_dx = UPS ? (int)(((((vr - 1) >> 1) * Ws) * p.Cin + 4 * vq) * 4) : (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);
     const int lane_dy = (int)(((yr2 * p.W) * p.Cdy + 4 * yq) * 4);
     const int x_px = p.Cin * 4, y_px = p.Cdy * 4;
     auto issue_load = [&](int set, int st, int n) {
@@ -307,7 +313,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
         const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         const int pix = ((b - b0) * p.H + 2 * ty) * p.W + 2 * tx;               // the tile's first output pixel
         if (n < 4) {
-            const int s_off = (pix * p.Cin + ci0) * 4 + (n - 1) * x_px;         // ... to here
+            const int s_off = UPS ? ((((b - b0) * Hs + ty) * Ws + tx) * p.Cin + ci0) * 4 + ((n - 1) >> 1) * x_px
+                                    : (pix * p.Cin + ci0) * 4 + (n - 1) * x_px;  // ... to here
             const bool col_ok = tv & ((unsigned)(2 * tx - 1 + n) < (unsigned)p.W);
             const bool ok = col_ok & ((unsigned)(2 * ty - 1 + vr) < (unsigned)p.H);
             xr[set][n] = buffer_load_x4(xbuf, (unsigned)(s_off + lane_dx) | ((unsigned)!ok << 31), 0);     // bit 31: out of range
@@ -506,13 +513,18 @@ extern "C" int dream_conv3x3_wgrad_winograd_set_version(int version) {
     return 0;
 }
 
-// x [B,H,W,Cin], dy [B,H,W,Cdy] (Cdy >= Cout) NHWC -> dw_oihw [Cout,Cin,3,3] (overwritten).  Cin % 64 == 0, Cout % 16 == 0.
+// x [B,H,W,Cin] (or [B,H/2,W/2,Cin] with DREAM_CONV_UPSAMPLE2X: the conv that follows nn.Upsample(2)), dy [B,H,W,Cdy]
+// (Cdy >= Cout) NHWC -> dw_oihw [Cout,Cin,3,3] (overwritten).  Cin % 64 == 0, Cout % 16 == 0.
 // workspace: dream_conv3x3_wgrad_winograd_workspace() bytes.  (The bias gradient is dream_channel_sum_nhwc_f32(dy).)
 extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
-                                                     int W, int Cin, int Cout, int Cdy, void *stream) {
+                                                     int W, int Cin, int Cout, int Cdy, int flags, void *stream) {
     DREAM_REQUIRE(x && dy && dw_oihw && workspace, "winograd wgrad: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cdy >= Cout, "winograd wgrad: bad shape");
     DREAM_REQUIRE(Cin % 64 == 0 && Cout % 16 == 0 && Cdy % 16 == 0, "winograd wgrad: Cin %% 64, Cout %% 16, Cdy %% 16 (got %d, %d, %d)", Cin, Cout, Cdy);
+    DREAM_REQUIRE((flags & ~DREAM_CONV_UPSAMPLE2X) == 0, "winograd wgrad: unsupported flags 0x%x", flags);
+    const bool ups = (flags & DREAM_CONV_UPSAMPLE2X) != 0;      // x is [B,H/2,W/2,Cin], the conv ran on its nearest x2 upsample
+    DREAM_REQUIRE(!ups || (H % 2 == 0 && W % 2 == 0 && Cin % 64 == 0 && Cout % 64 == 0 && g_wgw_version != 1),
+                  "winograd wgrad: the fused upsample needs even extents and the LDS kernel (channels a multiple of 64)");
     if (use_lds_version(Cin, Cout, Cdy)) {
         const PlanLds pl = make_plan_lds(B, H, W, Cin, Cout);
         DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd wgrad: too many tiles");
@@ -526,11 +538,13 @@ extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float
         p.ncog = Cout / 64;
         static bool attr_set = false;
         if (!attr_set) {
-            DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_wino_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_wino_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_wino_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set = true;
         }
         const dim3 grid((unsigned)(p.ncog * (Cin / 64)), (unsigned)pl.nsplit);
-        hipLaunchKernelGGL(wgrad_wino_lds_kernel, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
+        if (ups) hipLaunchKernelGGL(wgrad_wino_lds_kernel<true>, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(wgrad_wino_lds_kernel<false>, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
         DREAM_LAUNCH_OK();
         size_t rgrid = ((size_t)Cout * Cin + 255) / 256;
         if (rgrid > 2048) rgrid = 2048;

@@ -408,9 +408,11 @@ class DreamHourglass(nn.Module):
                 g = None
                 continue
             def leaf(pi=pi, inp=inp, g=g, cout=cout, cin=cin, ups=flags & CONV_UPSAMPLE2X):
-                if (not ups and self.conv_algorithm == "winograd" and int(inp.shape[3]) == cin
-                        and ops.wgrad_winograd_pays(int(g.shape[0]) * int(g.shape[1]) * int(g.shape[2]), cin, cout)):
-                    grads[pi], grads[pi + 1] = ops.conv3x3_wgrad_winograd(inp, g, cout, cin)     # 16/36 of the multiplications
+                if (self.conv_algorithm == "winograd" and int(inp.shape[3]) == cin
+                        and ops.wgrad_winograd_pays(int(g.shape[0]) * int(g.shape[1]) * int(g.shape[2]), cin, cout)
+                        and (not ups or (cin % 64 == 0 and cout % 64 == 0 and g.shape[1] % 2 == 0 and g.shape[2] % 2 == 0))):
+                    # 16/36 of the multiplications; the nearest x2 upsample in front of the conv is fused into the patch load
+                    grads[pi], grads[pi + 1] = ops.conv3x3_wgrad_winograd(inp, g, cout, cin, flags=CONV_UPSAMPLE2X if ups else 0)
                 else:
                     grads[pi], grads[pi + 1] = ops.conv3x3_wgrad(inp, g, cout, cin, ups)
             _on_side(side, leaf, inp, g)

@@ -240,9 +240,10 @@ def wgrad_winograd_pays(pixels, cin, cout):
     return cin % 64 == 0 and cout % 16 == 0 and cout >= 64 and (cin * cout >= 8192 or pixels >= 4000000)
 
 
-def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True):
+def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True, flags=0):
     """Weight (+ bias) gradient of a 3x3 stride-1 conv in the Winograd F(2x2,3x3) domain -> (dW OIHW [cout,cin,3,3], dbias
-    [cout] or None).  cin % 64 == 0, cout % 16 == 0; dy may carry padded channels (>= cout)."""
+    [cout] or None).  cin % 64 == 0, cout % 16 == 0; dy may carry padded channels (>= cout).  flags: CONV_UPSAMPLE2X when x is
+    the half-resolution input of a conv that followed a nearest x2 upsample (channels a multiple of 64)."""
     x, dy = _f32(x_nhwc), _f32(dy_nhwc)
     b, h, w, cdy = (int(v) for v in dy.shape)
     if int(x.shape[3]) != cin:
@@ -250,7 +251,7 @@ def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True):
     nbytes = int(_hip.lib().dream_conv3x3_wgrad_winograd_workspace(b, h, w, cin, cout))
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    call("dream_conv3x3_wgrad_winograd_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), b, h, w, cin, cout, cdy, stream())
+    call("dream_conv3x3_wgrad_winograd_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), b, h, w, cin, cout, cdy, flags, stream())
     db = channel_sum(dy)[:cout].contiguous() if want_bias else None
     return dw, db
 

@@ -292,7 +292,9 @@ int dream_conv3x3_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_pack
  * loss.backward() (dream/network.py:335) for the stride-1 3x3 convs of dream/models.py:598-615,695-710,736-747,22-32. */
 size_t dream_conv3x3_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout);
 int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
-                                          int W, int Cin, int Cout, int Cdy, void *stream);
+                                          int W, int Cin, int Cout, int Cdy, int flags, void *stream);
+/* flags: 0 or DREAM_CONV_UPSAMPLE2X (x is [B,H/2,W/2,Cin]: weight gradient of the conv that follows nn.Upsample(2),
+ * dream/models.py:691-710; channels a multiple of 64) */
 int dream_conv3x3_wgrad_winograd_set_version(int version);   /* test / A-B hook: 0 = by shape (default), 1 = register-only kernel */
 /* general forms for the ResNet path (1x1 / 3x3, stride 1 / 2) and the 4x4 transposed conv */
 size_t dream_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad, int ksize, int stride);

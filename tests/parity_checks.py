@@ -159,20 +159,22 @@ def check_conv1x1_wgrad(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0):
     return err
 
 
-def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0):
+def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0, ups=False):
     """Winograd-domain weight gradient vs an fp64 evaluation of the direct sums: error relative to sum |terms| at fp32
-    round-off level (the direct MFMA kernel is checked the same way)."""
+    round-off level (the direct MFMA kernel is checked the same way).  ups: the conv ran on the nearest x2 upsample of x
+    (x is [B,Cin,H/2,W/2]); the upsample is fused into the kernel's patch loads."""
     g = torch.Generator().manual_seed(seed)
-    x = torch.randn(B, Cin, H, W, generator=g)
+    x = torch.randn(B, Cin, H // 2, W // 2, generator=g) if ups else torch.randn(B, Cin, H, W, generator=g)
+    xl = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
     dy = torch.randn(B, Cout, H, W, generator=g)
     wref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x.double(), wref, None, padding=1).backward(dy.double())
+    F.conv2d(xl.double(), wref, None, padding=1).backward(dy.double())
     aref = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)      # sum |terms|: the error scale
-    F.conv2d(x.double().abs(), aref, None, padding=1).backward(dy.double().abs())
+    F.conv2d(xl.double().abs(), aref, None, padding=1).backward(dy.double().abs())
     dyn = _nhwc(dy)
     if pad_dy:
         dyn = torch.cat([dyn, torch.zeros(B, H, W, pad_dy)], dim=3).contiguous()
-    dw, db = ops.conv3x3_wgrad_winograd(to(dev, _nhwc(x)), to(dev, dyn), Cout, Cin)
+    dw, db = ops.conv3x3_wgrad_winograd(to(dev, _nhwc(x)), to(dev, dyn), Cout, Cin, flags=ops.CONV_UPSAMPLE2X if ups else 0)
     err = float(((dw.cpu().double() - wref.grad).abs() / aref.grad).max())
     assert dw.shape == (Cout, Cin, 3, 3) and err <= 3e-6, (B, H, W, Cin, Cout, err)
     assert float((db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())

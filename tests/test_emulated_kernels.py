@@ -74,7 +74,9 @@ def test_wgrad_winograd(emu):
             pc.check_wgrad_winograd("cpu", 2, 13, 9, 64, 64, seed=5),            # odd extents, several stages
             pc.check_wgrad_winograd("cpu", 3, 6, 10, 128, 64, seed=6),           # two input-channel blocks
             pc.check_wgrad_winograd("cpu", 1, 25, 25, 64, 128, seed=7),          # two output-channel blocks, several splits
-            pc.check_wgrad_winograd("cpu", 2, 5, 3, 64, 64, seed=8, pad_dy=16)]  # fewer tiles than a stage, padded dy
+            pc.check_wgrad_winograd("cpu", 2, 5, 3, 64, 64, seed=8, pad_dy=16),  # fewer tiles than a stage, padded dy
+            pc.check_wgrad_winograd("cpu", 2, 12, 10, 64, 64, seed=9, ups=True),  # conv after a nearest x2 upsample (fused)
+            pc.check_wgrad_winograd("cpu", 1, 26, 26, 128, 64, seed=10, ups=True)]
     print("winograd wgrad max err / sum|terms|", max(errs))
 
 

@@ -705,3 +705,10 @@ def test_single_process_data_parallel_resnet_batchnorm_semantics():
 def test_wgrad_winograd(b, h, w, cin, cout, pad):
     err = pc.check_wgrad_winograd(DEV, b, h, w, cin, cout, seed=h + cin, pad_dy=pad)
     print("winograd wgrad %dx%dx%d %d->%d: err / sum|terms| %.2e" % (b, h, w, cin, cout, err))
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 12, 10, 64, 64), (1, 26, 26, 128, 64), (8, 100, 100, 256, 128), (16, 50, 50, 512, 256)])
+def test_wgrad_winograd_fused_upsample(b, h, w, cin, cout):
+    """The decoder convs that follow nn.Upsample(2) (dream/models.py:691-710): x at half resolution, upsample fused into the loads."""
+    err = pc.check_wgrad_winograd(DEV, b, h, w, cin, cout, seed=h + cin, ups=True)
+    print("winograd wgrad after upsample %dx%dx%d %d->%d: err / sum|terms| %.2e" % (b, h, w, cin, cout, err))

@@ -43,7 +43,7 @@ def run():
             fn.restype, fn.argtypes = _hip._SIGNATURES["dream_conv3x3_wgrad_winograd_nhwc_f32"]
 
             def call():
-                assert fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, res, res, cin, cout, cout,
+                assert fn(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), b, res, res, cin, cout, cout, 0,
                           torch.cuda.current_stream().cuda_stream) == 0
             call()
             torch.cuda.synchronize()
