@@ -15,3 +15,8 @@ tail -3 $O/pytest_gpu.log > profiles/r02_pytest_gpu_tail.txt
 for f in $O/layer_profile_*.txt; do cp $f profiles/r02_$(basename $f); done
 cp $O/microbench_wino_b128.txt profiles/r02_microbench_wino_b128.txt
 cp $O/microbench_wgrad_wino_b128.txt profiles/r02_microbench_wgrad_wino_b128.txt
+for b in 16 128; do cp $O/microbench_conv1x1_b$b.txt profiles/r02_microbench_conv1x1_b$b.txt; done
+tail -1 $O/rehearsal_2ranks_infer.log > profiles/r02_rehearsal_2ranks_gloo_infer_line.json
+tail -1 $O/rehearsal_2ranks_train.log > profiles/r02_rehearsal_2ranks_gloo_train_line.json
+tail -1 $O/rehearsal_single_process_train.log > profiles/r02_rehearsal_single_process_2replicas_train_line.json
+tail -3 $O/smoke.log > profiles/r02_smoke_tail.txt

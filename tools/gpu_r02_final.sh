@@ -7,7 +7,12 @@ mkdir -p $O
 export TMPDIR=/tmp
 R="$PWD"
 echo "== pytest gpu (all)"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-200
 echo "== default bench"; timeout 900 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
+echo "== two ranks on this one GPU over gloo (rehearsal of the torchrun path; the numbers mean nothing)"
+DREAM_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 2 --warmup 1 --batch 16 --no-cpu-baseline --no-split-leg > $O/rehearsal_2ranks_infer.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_2ranks_infer.log | cut -c1-160
+DREAM_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 2 --arch resnet_h --mode train --steps 2 --warmup 1 --global-batch 16 --no-cpu-baseline > $O/rehearsal_2ranks_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_2ranks_train.log | cut -c1-160
+DREAM_BENCH_GPU_IDS=0,0 timeout 600 python bench.py --gpus 2 --single-process --arch resnet_h --mode train --steps 2 --warmup 1 --global-batch 16 --no-cpu-baseline > $O/rehearsal_single_process_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_train.log | cut -c1-160
 # raw rocprofv3 databases stay on the box (gpurun copies back at most 64 MiB): summarised here, then removed
 summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" > /dev/null 2>&1; echo "summary $2 rc=$?"; rm -rf "$1"; }
 echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; grep -h '^{"metric' $O/rocprof_default.log | cut -c1-200
@@ -51,4 +56,5 @@ for cfg in "resnet_h train 16" "vgg_q train 128" "vgg_q infer 128"; do set -- $c
 done
 echo "== microbenches"; timeout 300 python tools/microbench_wino.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino_b128.txt; tail -1 $O/microbench_wino_b128.txt
 timeout 300 python tools/microbench_wgrad_wino.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wgrad_wino_b128.txt; tail -1 $O/microbench_wgrad_wino_b128.txt
+for b in 16 128; do timeout 300 python tools/microbench_conv1x1.py --batch $b 2>&1 | grep -v amdgpu.ids > $O/microbench_conv1x1_b$b.txt; tail -1 $O/microbench_conv1x1_b$b.txt; done
 ls -la $O | head -60; du -sh $O
