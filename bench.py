@@ -227,6 +227,7 @@ def main():
                        2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
     ops.conv3x3_winograd = timed(ops.conv3x3_winograd, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
                                  2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=16.0 / 36.0)
+    ops.conv1x1 = timed(ops.conv1x1, lambda y, x, packed, cout, *a, **k: 2.0 * y.numel() * x.shape[3])
     ops.conv_transpose3x3s2 = timed(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9,
                                     kernel_launches=4)        # the sub-pixel ops are four kernel launches each
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
@@ -318,11 +319,13 @@ def main():
                                       if args.arch == "vgg_q" else ""),
                        "batch_per_gpu": args.batch, "resolution": [args.res, args.res],
                        "parallelism": "dp%d%s" % (n_dev, " (single process, gpu_ids)" if single else ""),
-                       "conv_algorithm": ("winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 64 output channels, direct "
-                                          "implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else "direct implicit GEMM")},
+                       "conv_algorithm": (("winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 64 output channels, direct "
+                                           "implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else "direct implicit GEMM")
+                                          + ("; stride-1 1x1 convs as LDS-free GEMMs" if args.arch.startswith("resnet") else ""))},
             "roofline": {
                 "bound": "mfma",
-                "kernel": ("conv_wino_kernel + conv_mfma_kernel" if args.conv_algorithm == "winograd" else "conv_mfma_kernel")
+                "kernel": (("conv_wino_kernel + conv_mfma_kernel" if args.conv_algorithm == "winograd" else "conv_mfma_kernel")
+                           + (" + gemm1x1_kernel" if args.arch.startswith("resnet") else ""))
                 if args.precision == "fp32" or args.mode == "train" else "conv_f16x3_kernel",
                 "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                 "peak": peak, "unit": "TFLOP/s",
