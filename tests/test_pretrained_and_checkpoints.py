@@ -7,7 +7,6 @@ import sys
 import types
 import warnings
 
-import numpy as np
 import pytest
 import torch
 
