@@ -63,6 +63,8 @@ struct WinoParams {
     int TY, TX;              // 2x2 tiles per image
     int ntiles;              // B * TY * TX  (< 2^24)
     int nblk, blk_per_xcd;   // blocks of 32 tiles; each XCD's workgroups walk over a contiguous range of them
+    int out_scale, out_oy, out_ox;   // output pixel of conv position (y, x): (out_scale y + out_oy, out_scale x + out_ox) -- (1,0,0)
+                                     // for a conv, (2, a, b) for phase (a, b) of a stride-2 transposed conv
     unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX): tile -> (image, row, column) without divides
     int flags;
 };
@@ -85,9 +87,30 @@ DREAM_DEVICE int v_slot(int q, int t) { return q ^ ((t >> 2) & 2); }
 // MODE: what the epilogue does besides scale / shift / ReLU -- 0 nothing, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask
 // (data gradient through a ReLU: zero where the forward activation was).  Compile-time: the epilogue of a persistent
 // workgroup sits between two blocks' MFMA phases and must be straight-line code (exact s_waitcnt counts, loads batched).
-template <int NW, int MODE>
+// PAT: which of the 16 positions carry non-zero transformed weights.  0: all (3x3 conv).  1 + 2 a + b: phase (a, b) of
+// nn.ConvTranspose2d(k4, s2, p1) written as a 3x3 conv whose kernel has only 2 x 2 non-zero taps (rows {0,1} for a = 0, {1,2} for
+// a = 1; columns likewise): G g G^T then vanishes on row 3 (a = 0) / row 0 (a = 1) of the 4 x 4 domain, and likewise on a
+// column -- nine positions are left, their MFMAs are the F(2x2,2x2) minimal-filtering count (9 instead of 16 per 2 x 2
+// outputs of a phase), and the other seven are never loaded or multiplied.
+DREAM_DEVICE constexpr bool pat_row_active(int pat, int i) { return pat == 0 || (((pat - 1) >> 1) == 0 ? i <= 2 : i >= 1); }
+DREAM_DEVICE constexpr bool pat_col_active(int pat, int j) { return pat == 0 || (((pat - 1) & 1) == 0 ? j <= 2 : j >= 1); }
+DREAM_DEVICE constexpr bool pat_active(int pat, int pp) { return pat_row_active(pat, pp >> 2) && pat_col_active(pat, pp & 3); }
+DREAM_DEVICE constexpr int pat_count(int pat) { return pat == 0 ? 16 : 9; }
+DREAM_DEVICE constexpr int pat_pos(int pat, int k) {          // k-th active position
+    int n = 0;
+    for (int pp = 0; pp < 16; ++pp)
+        if (pat_active(pat, pp)) {
+            if (n == k) return pp;
+            ++n;
+        }
+    return 0;
+}
+
+template <int NW, int MODE, int PAT>
 __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams p) {
     constexpr int NT = 64 * NW;                        // threads
+    constexpr int NPOS = pat_count(PAT);               // positions this kernel multiplies
+    constexpr int RING = NPOS == 16 ? B_RING : NPOS;   // operand ring of the weight stream: a divisor of NPOS (slots carry over chunks)
     constexpr int ITEMS = 512 / NT;                    // (tile, quad, row) items per thread and chunk: 2 (NW 4) or 1 (NW 8)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer (16 skewed planes of [32 tiles][16 channels]), then the offset table
@@ -175,9 +198,9 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     // register depends on the position inside the chunk only).  Unconditional and branch-free, so the compiler can count
     // outstanding loads exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at merge points); in the last chunk of a block the
     // stream wraps around to the first positions of the next block (same weights).
-    f32x4 bq[B_RING];
+    f32x4 bq[RING];
 #pragma unroll
-    for (int s = 0; s < B_AHEAD; ++s) bq[s] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
+    for (int k = 0; k < B_AHEAD; ++k) bq[k] = buffer_load_x4(ubuf, b_lane, (unsigned)pat_pos(PAT, k) * u_pos_stride);
 
     // patch row of an item: its four loads / row transform, quad exchange, column transform, four V stores
     f32x4 d[ITEMS][4];
@@ -234,18 +257,20 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         const float *cur = sV + par * VB;
         float *nxt = sV + (par ^ 1) * VB;
         const unsigned coff = LAST ? 0u : (unsigned)((c + 1) * WKC * 4);
-        read_a(0, 0, cur);
+        read_a(0, pat_pos(PAT, 0), cur);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
+        for (int k = 0; k < NPOS; ++k) {                                    // k-th active position pp
+            constexpr int SP = NPOS == 16 ? 10 : 5;                         // item it is transformed during slot SP + it
+            const int pp = pat_pos(PAT, k);
             const bool tf = !(DREAM_WINO_DIAG & 1);
-            const int li = (pp < ITEMS) ? pp : -1;                          // item loaded during this position
-            constexpr int SP = 10;                                          // item it is transformed during position SP + it
-            const int si = (pp >= SP && pp < SP + ITEMS) ? pp - SP : -1;
+            const int li = (k < ITEMS) ? k : -1;                            // item loaded during this slot
+            const int si = (k >= SP && k < SP + ITEMS) ? k - SP : -1;
             auto load_b = [&]() {
                 if (DREAM_WINO_DIAG & 2) return;
-                const int s = (LAST && pp + B_AHEAD >= 16) ? pp + B_AHEAD - 16 : c * 16 + pp + B_AHEAD;
-                bq[(pp + B_AHEAD) % B_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
+                const int kn = k + B_AHEAD;                                 // slot the load is for: this chunk's, or the next one's
+                const int s = kn >= NPOS ? (LAST ? 0 : (c + 1) * 16) + pat_pos(PAT, kn - NPOS) : c * 16 + pat_pos(PAT, kn);
+                bq[kn % RING] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
             };
             auto load_one = [&](int col) {
                 d[li][col] = buffer_load_x4(LAST ? xnext : xbuf, goff[li][col], (DREAM_WINO_DIAG & 16) ? 0u : coff);
@@ -253,11 +278,11 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
             auto pair = [&](int r) {
                 if (FIRST && r == 0) {
                     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                    acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], zero);
-                    acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp % B_RING][r], zero);
+                    acc[pp][0] = mfma_f32_16x16x4(a[k & 1][0][r], bq[k % RING][r], zero);
+                    acc[pp][1] = mfma_f32_16x16x4(a[k & 1][1][r], bq[k % RING][r], zero);
                 } else {
-                    acc[pp][0] = mfma_f32_16x16x4(a[pp & 1][0][r], bq[pp % B_RING][r], acc[pp][0]);
-                    acc[pp][1] = mfma_f32_16x16x4(a[pp & 1][1][r], bq[pp % B_RING][r], acc[pp][1]);
+                    acc[pp][0] = mfma_f32_16x16x4(a[k & 1][0][r], bq[k % RING][r], acc[pp][0]);
+                    acc[pp][1] = mfma_f32_16x16x4(a[k & 1][1][r], bq[k % RING][r], acc[pp][1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -272,7 +297,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                     load_one(0);
                 }
                 pair(0);
-                if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
+                if (k + 1 < NPOS) read_a((k + 1) & 1, pat_pos(PAT, k + 1), cur);
                 if (tf && li >= 0) load_one(1);
                 pair(1);
                 if (tf && li >= 0) load_one(2);
@@ -286,7 +311,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                 // a pair, never more than one memory instruction and ~8 VALU instructions between two pairs
                 pair(0);
                 load_b();
-                if (pp < 15) read_a((pp + 1) & 1, pp + 1, cur);
+                if (k + 1 < NPOS) read_a((k + 1) & 1, pat_pos(PAT, k + 1), cur);
                 if (tf && li >= 0) {
                     if (LAST) goff[li] = plan_item(li, tile0n, b0n);
                     else goff[li] = sG[li * NT + tid];                      // written by this thread: no barrier
@@ -302,7 +327,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                 pair(3);
                 if (tf && li >= 0) load_one(3);
                 if (tf && si >= 0) item_piece(si, 3, nxt);
-                if (pp == 15) __builtin_amdgcn_sched_barrier(0);
+                if (k == NPOS - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
@@ -320,9 +345,12 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     const bool cok = col < p.Cout;
     const float sc = (p.scale != nullptr && cok) ? p.scale[col] : 1.0f;
     const float sh = (p.shift != nullptr && cok) ? p.shift[col] : 0.0f;
-    const int Ho = pool ? p.H / 2 : p.H, Wo = pool ? p.W / 2 : p.W;
-    const size_t out_img = (size_t)Ho * Wo * p.Cout;
-    const unsigned px_b = (unsigned)(p.Cout * 4), row_b = (unsigned)(Wo * p.Cout * 4);
+    const int Ho = pool ? p.H / 2 : p.H, Wo = pool ? p.W / 2 : p.W;           // grid of conv positions that are stored
+    const int S = pool ? 1 : p.out_scale;                                     // conv position -> output pixel (see WinoParams)
+    const int Wy = S * Wo;
+    const size_t out_img = (size_t)(S * Ho) * Wy * p.Cout;
+    const unsigned px_b = (unsigned)(S * p.Cout * 4), row_b = (unsigned)(S * Wy * p.Cout * 4);
+    const unsigned phase_b = pool ? 0u : (unsigned)((p.out_oy * Wy + p.out_ox) * p.Cout * 4);
     auto epilogue = [&](int tile0e, int b0e) {
         const BufferRsrc ybuf = make_buffer(p.y + (size_t)b0e * out_img, (size_t)(p.B - b0e) * out_img * sizeof(float));
         const BufferRsrc rbuf = make_buffer(has_res ? p.residual + (size_t)b0e * out_img : p.y,
@@ -339,7 +367,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
                 // pooled output (floor(H/2) x floor(W/2)): the window of a tile with ty < Ho, tx < Wo lies entirely inside the image
                 const bool tok = cok & ((tau0 + r) < p.ntiles) & (!pool | ((ty < Ho) & (tx < Wo)));
                 const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
-                const unsigned base = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * p.Cout + col) * 4);
+                const unsigned base = (unsigned)(((((b - b0e) * (S * Ho) + S * oy) * Wy + S * ox) * p.Cout + col) * 4) + phase_b;
                 if (pool) {
                     o[0] = tok ? base : BUFFER_OOB;
                 } else {
@@ -370,11 +398,13 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (!has_res) tile_offsets(r, off[r]);
+                // positions without weights (PAT) were never multiplied: they are zeros of the sums
+                auto M = [&](int pp) { return pat_active(PAT, pp) ? acc[pp][blk][r] : 0.0f; };
                 float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s[0][j] = acc[j][blk][r] + acc[4 + j][blk][r] + acc[8 + j][blk][r];
-                    s[1][j] = acc[4 + j][blk][r] - acc[8 + j][blk][r] - acc[12 + j][blk][r];
+                    s[0][j] = M(j) + M(4 + j) + M(8 + j);
+                    s[1][j] = M(4 + j) - M(8 + j) - M(12 + j);
                 }
                 float out[2][2];
 #pragma unroll
@@ -466,10 +496,10 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u
 constexpr int kCUs = 256;     // MI355X
 int g_max_workgroups = 0;     // test hook: cap on resident workgroups (0 = the chip's capacity)
 
-template <int NW, int MODE>
+template <int NW, int MODE, int PAT = 0>
 int launch_wino(const WinoParams &p, void *stream) {
     static bool attr_set = false;
-    void (*kernel)(const WinoParams) = conv_wino_kernel<NW, MODE>;
+    void (*kernel)(const WinoParams) = conv_wino_kernel<NW, MODE, PAT>;
     const size_t lds = (size_t)2 * VB * sizeof(float) + (size_t)512 * 16;          // V buffers + the offset table
     if (!attr_set) {
         DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -531,21 +561,19 @@ extern "C" int dream_conv3x3_winograd_set_variant(int variant) {
     return 0;
 }
 
-// y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32.
-// Supported flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor), DREAM_CONV_RELUMASK (residual = mask source).
-extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
-                                               const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
-                                               int flags, void *stream) {
+namespace {
+
+// geometry shared by the conv and the transposed-conv entry points
+int wino_setup(WinoParams &p, const float *x, const float *u_packed, const float *scale, const float *shift, const float *residual,
+               float *y, int B, int H, int W, int Cin, int Cout, int flags, int out_scale) {
     DREAM_REQUIRE(x && u_packed && y, "winograd conv: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
     DREAM_REQUIRE(Cin % WKC == 0 && Cin >= 2 * WKC, "winograd conv: Cin=%d must be a multiple of %d and at least %d", Cin, WKC, 2 * WKC);
-    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
-    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd conv: fused max-pool takes no residual");
-    DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
     // 32-bit byte offsets relative to the first image a workgroup touches: its 32 tiles span at most this many images
     const size_t span_imgs = (size_t)WT / ((size_t)((H + 1) / 2) * ((W + 1) / 2)) + 2;
-    DREAM_REQUIRE(span_imgs * H * W * (size_t)(Cin > Cout ? Cin : Cout) * sizeof(float) < ((size_t)1 << 31), "winograd conv: image too large for 32-bit offsets");
-    WinoParams p;
+    const size_t out_px = (size_t)out_scale * out_scale * H * W;
+    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) && span_imgs * out_px * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
+                  "winograd conv: image too large for 32-bit offsets");
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.CoutPad = (Cout + WPAD - 1) / WPAD * WPAD;
@@ -559,6 +587,40 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(p.TY * p.TX) - 1) / (unsigned long long)(p.TY * p.TX);
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
+    p.out_scale = out_scale; p.out_oy = 0; p.out_ox = 0;
+    return 0;
+}
+
+// [Cin][Cout][4][4] ConvTranspose2d(k4, s2, p1) weight -> four OIHW [Cout][Cin][3][3] conv kernels, one per output phase
+// (a, b): output (2 i + a, 2 j + b) = sum over the 2 x 2 inputs (i + dy, j + dx), dy in {-1, 0} (a = 0) or {0, +1} (a = 1), of
+// x * wT[a + 1 - 2 dy][b + 1 - 2 dx]; as a pad-1 3x3 correlation the tap (dy, dx) sits at [dy + 1][dx + 1], the rest is zero.
+__global__ void __launch_bounds__(256) convT4x4_phase_kernels(const float *wT, float *w3, int Cin, int Cout) {
+    const size_t per_phase = (size_t)Cout * Cin * 9, total = 4 * per_phase;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int tap = (int)(i % 9);
+        size_t rest = i / 9;
+        const int ci = (int)(rest % Cin);
+        rest /= Cin;
+        const int co = (int)(rest % Cout), phase = (int)(rest / Cout);
+        const int a = phase >> 1, b = phase & 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const int ky = a + 1 - 2 * dy, kx = b + 1 - 2 * dx;
+        const bool used = (a == 0 ? dy <= 0 : dy >= 0) && (b == 0 ? dx <= 0 : dx >= 0);
+        w3[i] = used ? wT[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.0f;
+    }
+}
+
+}  // namespace
+
+// y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32.
+// Supported flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor), DREAM_CONV_RELUMASK (residual = mask source).
+extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                               const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
+                                               int flags, void *stream) {
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd conv: fused max-pool takes no residual");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
+    WinoParams p;
+    if (int rc = wino_setup(p, x, u_packed, scale, shift, residual, y, B, H, W, Cin, Cout, flags, 1)) return rc;
     const int nw = g_variant ? g_variant : (Cout > 64 ? 8 : 4);
     const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
     switch (mode + (nw == 8 ? 4 : 0)) {
@@ -571,4 +633,48 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
         case 6: return launch_wino<8, 2>(p, stream);
         default: return launch_wino<8, 3>(p, stream);
     }
+}
+
+// nn.ConvTranspose2d(k4, s2, p1) (+ folded BatchNorm / bias, ReLU) of the ResNet decoder (dream/models.py:37-136) by minimal
+// filtering: every output phase (a, b) is a 2 x 2-tap stride-1 conv of x; written as a 3x3 conv with a zero-padded kernel its
+// Winograd-transformed weights vanish on seven of the 16 positions, so the Winograd kernel runs it with 9 multiplications per
+// 2 x 2 outputs of the phase instead of the 16 of the direct sub-pixel form (dream_conv_transpose4x4s2_nhwc_f32) -- 1.78x fewer,
+// same fp32 arithmetic.  x [B,H,W,Cin] -> y [B,2H,2W,Cout]; four launches (one per phase) sharing nothing but x.
+//   u4: dream_pack_convT4x4_winograd_weight(): 4 x dream_conv3x3_winograd_weight_floats(Cout, Cin) floats.  flags: DREAM_CONV_RELU.
+extern "C" size_t dream_convT4x4_winograd_weight_floats(int Cout, int Cin) { return 4 * dream_conv3x3_winograd_weight_floats(Cout, Cin); }
+
+// wT [Cin][Cout][4][4] -> u4; scratch: 4 * Cout * Cin * 9 floats (the four zero-padded 3x3 kernels)
+extern "C" int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream) {
+    DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0, "winograd convT pack: bad arguments");
+    const size_t total = (size_t)4 * Cout * Cin * 9;
+    size_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(convT4x4_phase_kernels, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wT, scratch, Cin, Cout);
+    DREAM_LAUNCH_OK();
+    const size_t per_u = dream_conv3x3_winograd_weight_floats(Cout, Cin);
+    for (int ph = 0; ph < 4; ++ph)
+        if (int rc = dream_pack_conv3x3_winograd_weight(scratch + (size_t)ph * Cout * Cin * 9, u4 + ph * per_u, Cout, Cin, 0, stream)) return rc;
+    return 0;
+}
+
+extern "C" int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift,
+                                                           float *y, int B, int H, int W, int Cin, int Cout, int flags, void *stream) {
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "winograd convT: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(Cout > 64, "winograd convT: needs more than 64 output channels (the 8-wave kernel), got %d", Cout);
+    WinoParams p;
+    if (int rc = wino_setup(p, x, u4, scale, shift, nullptr, y, B, H, W, Cin, Cout, flags, 2)) return rc;
+    const size_t per_u = dream_conv3x3_winograd_weight_floats(Cout, Cin);
+    for (int ph = 0; ph < 4; ++ph) {
+        p.u = u4 + ph * per_u;
+        p.out_oy = ph >> 1; p.out_ox = ph & 1;
+        int rc;
+        switch (ph) {
+            case 0: rc = launch_wino<8, 0, 1>(p, stream); break;
+            case 1: rc = launch_wino<8, 0, 2>(p, stream); break;
+            case 2: rc = launch_wino<8, 0, 3>(p, stream); break;
+            default: rc = launch_wino<8, 0, 4>(p, stream); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
 }

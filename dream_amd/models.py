@@ -814,6 +814,9 @@ class ResnetSimple(nn.Module):
         self.conv_algorithm = os.environ.get("DREAM_CONV_ALGORITHM", "winograd")   # see DreamHourglass.conv_algorithm
         # stride-1 1x1 convs (forward and data gradient): "gemm" = the LDS-free GEMM kernel (gemm1x1.hip), "direct" = conv_mfma
         self.conv1x1_algorithm = os.environ.get("DREAM_CONV1X1_ALGORITHM", "gemm")
+        # decoder ConvTranspose2d(k4,s2,p1) forward: "winograd" = minimal filtering on the Winograd kernel (9/16 of the direct
+        # multiplications, conv_wino.hip), "direct" = sub-pixel phases on conv_mfma
+        self.convT_algorithm = os.environ.get("DREAM_CONVT_ALGORITHM", "winograd")
         # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
@@ -977,9 +980,13 @@ class ResnetSimple(nn.Module):
                 name = "%s.%d" % (sname, i)
                 if isinstance(m, nn.ConvTranspose2d):
                     bn = mods[i + 1]
-                    packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
                     scale, shift = self._fold(name, bn, m.bias)
-                    y = ops.conv_transpose4x4s2(y, packed, cout, scale, shift, CONV_RELU)
+                    if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
+                        u4, cout = self._cached(("wu4", name), [m.weight], lambda m=m: ops.pack_convT4x4_winograd_weight(m.weight.detach()))
+                        y = ops.conv_transpose4x4s2_winograd(y, u4, cout, scale, shift, CONV_RELU)
+                    else:
+                        packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
+                        y = ops.conv_transpose4x4s2(y, packed, cout, scale, shift, CONV_RELU)
                     i += 3                                  # ConvTranspose2d, BatchNorm2d, ReLU
                 else:                                       # final 1x1 conv -> K belief maps, NCHW
                     packed, rows, _ = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_conv_weight(m.weight.detach(), 0))
@@ -1057,8 +1064,12 @@ class ResnetSimple(nn.Module):
                 name = "%s.%d" % (sname, i)
                 if isinstance(m, nn.ConvTranspose2d):
                     bn = mods[i + 1]
-                    packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
-                    z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)
+                    if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
+                        u4, cout = self._cached(("wu4", name), [m.weight], lambda m=m: ops.pack_convT4x4_winograd_weight(m.weight.detach()))
+                        z = ops.conv_transpose4x4s2_winograd(y, u4, cout, None, m.bias.detach(), 0)
+                    else:
+                        packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
+                        z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)
                     y2, mean, invstd = ops.bn_train_fwd(z, bn, None, True)
                     tape.append(dict(kind="convT", name=name, conv=m, bn=bn, relu=True, x=y, z=z, y=y2, mean=mean, invstd=invstd))
                     y = y2

@@ -77,6 +77,31 @@ def conv3x3_winograd(x_nhwc, packed_u, cout, scale=None, shift=None, residual=No
     return y
 
 
+def pack_convT4x4_winograd_weight(wT):
+    """[Cin,Cout,4,4] ConvTranspose2d(k4,s2,p1) weight -> the four phases' Winograd-transformed 3x3 kernels; returns (u4, cout)."""
+    w = _f32(wT)
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    n = int(_hip.lib().dream_convT4x4_winograd_weight_floats(cout, cin))
+    u4 = torch.empty(n, dtype=torch.float32, device=w.device)
+    scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
+    call("dream_pack_convT4x4_winograd_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, stream())
+    return u4, cout
+
+
+def convT4x4_winograd_applies(x_nhwc, cout):
+    cin = int(x_nhwc.shape[3])
+    return cin % 16 == 0 and cin >= 32 and cout > 64
+
+
+def conv_transpose4x4s2_winograd(x_nhwc, u4, cout, scale=None, shift=None, flags=0):
+    """ConvTranspose2d(k4,s2,p1) * scale + shift (ReLU) by minimal filtering (9/16 of the direct multiplications), NHWC."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv_transpose4x4s2_winograd_nhwc_f32", ptr(x), ptr(u4), ptr(scale), ptr(shift), ptr(y), b, h, w, cin, cout, flags, stream())
+    return y
+
+
 def conv3x3_first(x_nchw, w_oihw, bias, relu=True):
     x, w = _f32(x_nchw), _f32(w_oihw)
     b, cin, h, wd = (int(v) for v in x.shape)

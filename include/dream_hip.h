@@ -117,6 +117,15 @@ int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u_packed, int
 int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                     void *stream);
+/* nn.ConvTranspose2d(k4,s2,p1) (+ folded BatchNorm / bias, ReLU) of the ResNet decoder (dream/models.py:37-136) by minimal
+ * filtering on the Winograd kernel: each output phase is a 2x2-tap conv = a 3x3 conv whose transformed weights vanish on 7 of
+ * the 16 positions: 9 multiplications per 2x2 outputs of a phase instead of 16, same fp32 arithmetic.  x [B,H,W,Cin] ->
+ * y [B,2H,2W,Cout]; Cin % 16 == 0, Cin >= 32, Cout > 64; wT [Cin][Cout][4][4]; u4: dream_convT4x4_winograd_weight_floats()
+ * floats; scratch: 4*Cout*Cin*9 floats; flags: DREAM_CONV_RELU. */
+size_t dream_convT4x4_winograd_weight_floats(int Cout, int Cin);
+int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream);
+int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift, float *y,
+                                                int B, int H, int W, int Cin, int Cout, int flags, void *stream);
 /* nn.ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) of the deconv decoder (dream/models.py:621-686) by sub-pixel
  * decomposition: four stride-1 launches with 1/2/2/4 taps, no multiplications by zero (the DREAM_CONV_ZEROSTUFF2X form
  * of dream_conv3x3_nhwc_f32 computes the same result with 4x the MACs).  x [B,H,W,Cin] -> y [B,2H,2W,Cout];

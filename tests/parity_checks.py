@@ -103,6 +103,37 @@ def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_s
     return err
 
 
+def check_convT4x4_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, with_scale=False, max_workgroups=(8,)):
+    """ConvTranspose2d(k4,s2,p1) by minimal filtering on the Winograd kernel vs an fp64 conv_transpose2d: error relative to the
+    output maximum at fp32 round-off level."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    wT = torch.randn(Cin, Cout, 4, 4, generator=g) * (2.0 / (4 * Cin)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    scale = torch.rand(Cout, generator=g) + 0.5 if with_scale else None
+    u4, rows = ops.pack_convT4x4_winograd_weight(to(dev, wT))
+    assert rows == Cout
+    ref = F.conv_transpose2d(x.double(), wT.double(), None, stride=2, padding=1)
+    if with_scale:
+        ref = ref * scale.double().view(1, -1, 1, 1)
+    ref = ref + bias.double().view(1, -1, 1, 1)
+    if flags & ops.CONV_RELU:
+        ref = ref.relu()
+    args = (to(dev, _nhwc(x)), u4, Cout, to(dev, scale) if with_scale else None, to(dev, bias), flags)
+    y = ops.conv_transpose4x4s2_winograd(*args).cpu().permute(0, 3, 1, 2)
+    assert y.shape == ref.shape, (tuple(y.shape), tuple(ref.shape))
+    err = float((y.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+    assert err <= 2e-6, (B, H, W, Cin, Cout, flags, err)
+    for cap in max_workgroups:                          # persistent grid sized for fewer workgroups: same result, bit for bit
+        _hip.lib().dream_conv3x3_winograd_set_max_workgroups(cap)
+        try:
+            y_cap = ops.conv_transpose4x4s2_winograd(*args).cpu().permute(0, 3, 1, 2)
+        finally:
+            _hip.lib().dream_conv3x3_winograd_set_max_workgroups(0)
+        assert torch.equal(y, y_cap), ("persistent grid", cap)
+    return err
+
+
 def check_conv1x1(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=False, ksplits=(0, 1, 2, 4)):
     """LDS-free GEMM kernel for stride-1 1x1 convs vs an fp64 evaluation: error relative to the output maximum at fp32 round-off
     level, for every K split the shape admits (the split only changes the order of the sum)."""

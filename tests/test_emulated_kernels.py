@@ -50,6 +50,13 @@ def test_conv_winograd(emu, variant):
     print("winograd max rel err", max(errs))
 
 
+def test_conv_transpose4x4_winograd(emu):
+    errs = [pc.check_convT4x4_winograd("cpu", 1, 6, 6, 32, 128, max_workgroups=()),                        # one block per phase
+            pc.check_convT4x4_winograd("cpu", 2, 13, 9, 48, 96, ops.CONV_RELU, seed=1, with_scale=True),    # odd extents, 3 chunks, ragged cout
+            pc.check_convT4x4_winograd("cpu", 1, 26, 26, 32, 256, ops.CONV_RELU, seed=2)]                   # two channel blocks, several tile blocks per workgroup
+    print("convT4x4 winograd max rel err", max(errs))
+
+
 def test_conv1x1_gemm(emu):
     errs = [pc.check_conv1x1("cpu", 1, 8, 8, 64, 64),                                             # one tile
             pc.check_conv1x1("cpu", 2, 5, 7, 128, 36, ops.CONV_RELU, seed=1, with_scale=True),    # ragged rows and channels

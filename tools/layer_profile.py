@@ -36,7 +36,7 @@ def flops_of(name, args, out):
             o = out[0] if isinstance(out, tuple) else out
             return 2.0 * o.shape[0] * o.shape[1] * o.shape[2] * cout * x.shape[3] * k * k if o.dim() == 4 and o.shape[3] >= cout \
                 else 2.0 * o.numel() * x.shape[3] * k * k
-        if name == "conv_transpose4x4s2":
+        if name in ("conv_transpose4x4s2", "conv_transpose4x4s2_winograd"):
             x = t[0]
             return 2.0 * x.numel() * ints[0] * 16
         if name == "conv4x4s2":
