@@ -65,6 +65,8 @@ struct WinoParams {
     int nblk, blk_per_xcd;   // blocks of 32 tiles; each XCD's workgroups walk over a contiguous range of them
     int out_scale, out_oy, out_ox;   // output pixel of conv position (y, x): (out_scale y + out_oy, out_scale x + out_ox) -- (1,0,0)
                                      // for a conv, (2, a, b) for phase (a, b) of a stride-2 transposed conv
+    int in_scale, in_oy, in_ox;      // stored input pixel of conv position (y, x), likewise: (2, a, b) for the phase views of the
+                                     // gradient in the transposed conv's data gradient; the stored tensor is in_scale H x in_scale W
     unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX): tile -> (image, row, column) without divides
     int flags;
 };
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     if (tb >= blk_end) return;
     const int n0 = blockIdx.y * (16 * NW);
     const int tiles_per_img = p.TY * p.TX;
-    const size_t img_floats = (size_t)p.H * p.W * p.Cin;
+    const size_t img_floats = (size_t)(p.in_scale * p.H) * (p.in_scale * p.W) * p.Cin;     // stored input image
 
     // ---- input-transform plan: thread -> ITEMS items (tile t, channel quad q, patch row r); r = the lane's index in its quad
     // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, column) relative to the first image
@@ -156,8 +158,9 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
         const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         const int gy = 2 * ty - 1 + qr, x0 = 2 * tx - 1;
         const bool rok = tv & ((unsigned)gy < (unsigned)p.H);          // bitwise: no short-circuit branches inside a chunk
-        const unsigned off0 = (unsigned)(((((b - b0) * p.H + gy) * p.W + x0) * p.Cin + 4 * q) * 4);   // column 0 (wraps when outside)
-        const unsigned px = (unsigned)(p.Cin * 4);
+        const int Si = p.in_scale;                                    // conv position -> stored pixel (WinoParams)
+        const unsigned off0 = (unsigned)(((((b - b0) * (Si * p.H) + Si * gy + p.in_oy) * (Si * p.W) + Si * x0 + p.in_ox) * p.Cin + 4 * q) * 4);   // column 0 (wraps when outside)
+        const unsigned px = (unsigned)(Si * p.Cin * 4);
         u32x4 g;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -565,14 +568,14 @@ namespace {
 
 // geometry shared by the conv and the transposed-conv entry points
 int wino_setup(WinoParams &p, const float *x, const float *u_packed, const float *scale, const float *shift, const float *residual,
-               float *y, int B, int H, int W, int Cin, int Cout, int flags, int out_scale) {
+               float *y, int B, int H, int W, int Cin, int Cout, int flags, int out_scale, int in_scale = 1) {
     DREAM_REQUIRE(x && u_packed && y, "winograd conv: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
     DREAM_REQUIRE(Cin % WKC == 0 && Cin >= 2 * WKC, "winograd conv: Cin=%d must be a multiple of %d and at least %d", Cin, WKC, 2 * WKC);
     // 32-bit byte offsets relative to the first image a workgroup touches: its 32 tiles span at most this many images
     const size_t span_imgs = (size_t)WT / ((size_t)((H + 1) / 2) * ((W + 1) / 2)) + 2;
     const size_t out_px = (size_t)out_scale * out_scale * H * W;
-    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) && span_imgs * out_px * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
+    DREAM_REQUIRE(span_imgs * in_scale * in_scale * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) && span_imgs * out_px * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
                   "winograd conv: image too large for 32-bit offsets");
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -588,23 +591,37 @@ int wino_setup(WinoParams &p, const float *x, const float *u_packed, const float
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
     p.out_scale = out_scale; p.out_oy = 0; p.out_ox = 0;
+    p.in_scale = in_scale; p.in_oy = 0; p.in_ox = 0;
     return 0;
 }
 
 // [Cin][Cout][4][4] ConvTranspose2d(k4, s2, p1) weight -> four OIHW [Cout][Cin][3][3] conv kernels, one per output phase
 // (a, b): output (2 i + a, 2 j + b) = sum over the 2 x 2 inputs (i + dy, j + dx), dy in {-1, 0} (a = 0) or {0, +1} (a = 1), of
 // x * wT[a + 1 - 2 dy][b + 1 - 2 dx]; as a pad-1 3x3 correlation the tap (dy, dx) sits at [dy + 1][dx + 1], the rest is zero.
-__global__ void __launch_bounds__(256) convT4x4_phase_kernels(const float *wT, float *w3, int Cin, int Cout) {
+// bwd = 1: the kernels of the DATA GRADIENT instead -- dx(i, j) = sum over phases of a 2 x 2-tap correlation of the phase view
+// P_ab(i, j) = dY(2 i + a, 2 j + b): dx(i) += P(i - dy) wT[a + 1 - 2 dy], i.e. tap r = 1 - dy of a pad-1 3x3 correlation carries
+// wT[a - 1 + 2 r] (rows {1,2} for a = 0, {0,1} for a = 1); output channels = Cin of the transposed conv, input channels = Cout:
+// w3[phase][ci][co][3][3].
+__global__ void __launch_bounds__(256) convT4x4_phase_kernels(const float *wT, float *w3, int Cin, int Cout, int bwd) {
     const size_t per_phase = (size_t)Cout * Cin * 9, total = 4 * per_phase;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int tap = (int)(i % 9);
         size_t rest = i / 9;
-        const int ci = (int)(rest % Cin);
-        rest /= Cin;
-        const int co = (int)(rest % Cout), phase = (int)(rest / Cout);
-        const int a = phase >> 1, b = phase & 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const int ky = a + 1 - 2 * dy, kx = b + 1 - 2 * dx;
-        const bool used = (a == 0 ? dy <= 0 : dy >= 0) && (b == 0 ? dx <= 0 : dx >= 0);
+        const int inner = (int)(rest % (bwd ? Cout : Cin));
+        rest /= (bwd ? Cout : Cin);
+        const int outer = (int)(rest % (bwd ? Cin : Cout)), phase = (int)(rest / (bwd ? Cin : Cout));
+        const int ci = bwd ? outer : inner, co = bwd ? inner : outer;
+        const int a = phase >> 1, b = phase & 1, r = tap / 3, c = tap % 3;
+        int ky, kx;
+        bool used;
+        if (!bwd) {
+            const int dy = r - 1, dx = c - 1;
+            ky = a + 1 - 2 * dy; kx = b + 1 - 2 * dx;
+            used = (a == 0 ? dy <= 0 : dy >= 0) && (b == 0 ? dx <= 0 : dx >= 0);
+        } else {
+            ky = a - 1 + 2 * r; kx = b - 1 + 2 * c;
+            used = (a == 0 ? r >= 1 : r <= 1) && (b == 0 ? c >= 1 : c <= 1);
+        }
         w3[i] = used ? wT[(((size_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.0f;
     }
 }
@@ -644,16 +661,45 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
 extern "C" size_t dream_convT4x4_winograd_weight_floats(int Cout, int Cin) { return 4 * dream_conv3x3_winograd_weight_floats(Cout, Cin); }
 
 // wT [Cin][Cout][4][4] -> u4; scratch: 4 * Cout * Cin * 9 floats (the four zero-padded 3x3 kernels)
-extern "C" int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream) {
-    DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0, "winograd convT pack: bad arguments");
+// mode 0: forward operator (u4: 4 x dream_conv3x3_winograd_weight_floats(Cout, Cin)); mode 1: data-gradient operator
+// (dream_conv4x4s2_winograd_nhwc_f32; u4: 4 x dream_conv3x3_winograd_weight_floats(Cin, Cout))
+extern "C" int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, int mode, void *stream) {
+    DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "winograd convT pack: bad arguments");
     const size_t total = (size_t)4 * Cout * Cin * 9;
     size_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(convT4x4_phase_kernels, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wT, scratch, Cin, Cout);
+    hipLaunchKernelGGL(convT4x4_phase_kernels, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wT, scratch, Cin, Cout, mode);
     DREAM_LAUNCH_OK();
-    const size_t per_u = dream_conv3x3_winograd_weight_floats(Cout, Cin);
+    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;       // conv output / input channels
+    const size_t per_u = dream_conv3x3_winograd_weight_floats(rows, cols);
     for (int ph = 0; ph < 4; ++ph)
-        if (int rc = dream_pack_conv3x3_winograd_weight(scratch + (size_t)ph * Cout * Cin * 9, u4 + ph * per_u, Cout, Cin, 0, stream)) return rc;
+        if (int rc = dream_pack_conv3x3_winograd_weight(scratch + (size_t)ph * Cout * Cin * 9, u4 + ph * per_u, rows, cols, 0, stream)) return rc;
+    return 0;
+}
+
+// Data gradient of the transposed conv = a 4x4 stride-2 pad-1 conv of dY [B,2H,2W,Cout] -> dX [B,H,W,Cin], as the sum over the
+// four output phases of a 2 x 2-tap conv on the phase's stride-2 view of dY: the same nine-position scheme (patterns mirrored),
+// the phases accumulate into dX through the residual input of the epilogue.  u4: dream_pack_convT4x4_winograd_weight(mode 1).
+extern "C" int dream_conv4x4s2_winograd_nhwc_f32(const float *dy, const float *u4, float *dx, int B, int H, int W, int Cout, int Cin,
+                                                 void *stream) {
+    DREAM_REQUIRE(Cin > 64, "winograd conv4x4s2: needs more than 64 output channels (the 8-wave kernel), got %d", Cin);
+    WinoParams p;
+    if (int rc = wino_setup(p, dy, u4, nullptr, nullptr, nullptr, dx, B, H, W, Cout, Cin, 0, 1, 2)) return rc;
+    const size_t per_u = dream_conv3x3_winograd_weight_floats(Cin, Cout);
+    for (int ph = 0; ph < 4; ++ph) {
+        p.u = u4 + ph * per_u;
+        p.in_oy = ph >> 1; p.in_ox = ph & 1;
+        p.residual = ph == 0 ? nullptr : dx;         // phases 1..3 add to what is there (same thread reads and writes an element)
+        int rc;
+        // the data gradient's kernels have their taps in the opposite corner: pattern of phase (1 - a, 1 - b)
+        switch (ph) {
+            case 0: rc = launch_wino<8, 0, 4>(p, stream); break;
+            case 1: rc = launch_wino<8, 2, 3>(p, stream); break;
+            case 2: rc = launch_wino<8, 2, 2>(p, stream); break;
+            default: rc = launch_wino<8, 2, 1>(p, stream); break;
+        }
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -1112,8 +1112,14 @@ class ResnetSimple(nn.Module):
                     grads[m.weight] = ops.convT4x4_wgrad(x, dz)
                     grads[m.bias] = ops.channel_sum(dz)
                 _on_side(side, leaf, rec["x"], dz)
-                pk, rows = self._cached(("wTb", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_bwd_weight(m.weight.detach()))
-                g = ops.conv4x4s2(dz, pk, rows)
+                cin_t, cout_t = int(m.weight.shape[0]), int(m.weight.shape[1])
+                if (self.convT_algorithm == "winograd" and cout_t % 16 == 0 and cout_t >= 32 and cin_t > 64
+                        and int(dz.shape[3]) == cout_t and dz.shape[1] % 2 == 0 and dz.shape[2] % 2 == 0):
+                    u4b, rows = self._cached(("wu4b", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_winograd_weight(m.weight.detach(), 1))
+                    g = ops.conv4x4s2_winograd(dz, u4b, rows)
+                else:
+                    pk, rows = self._cached(("wTb", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_bwd_weight(m.weight.detach()))
+                    g = ops.conv4x4s2(dz, pk, rows)
             elif kind == "block_end":
                 block = dict(g_out=g, g_idt=None, g_ds=None)
             elif kind == "conv":

@@ -77,15 +77,26 @@ def conv3x3_winograd(x_nhwc, packed_u, cout, scale=None, shift=None, residual=No
     return y
 
 
-def pack_convT4x4_winograd_weight(wT):
-    """[Cin,Cout,4,4] ConvTranspose2d(k4,s2,p1) weight -> the four phases' Winograd-transformed 3x3 kernels; returns (u4, cout)."""
+def pack_convT4x4_winograd_weight(wT, mode=0):
+    """[Cin,Cout,4,4] ConvTranspose2d(k4,s2,p1) weight -> the four phases' Winograd-transformed 3x3 kernels of the forward
+    operator (mode 0; returns (u4, cout)) or of the data-gradient operator (mode 1; returns (u4, cin))."""
     w = _f32(wT)
     cin, cout = int(w.shape[0]), int(w.shape[1])
-    n = int(_hip.lib().dream_convT4x4_winograd_weight_floats(cout, cin))
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    n = int(_hip.lib().dream_convT4x4_winograd_weight_floats(rows, cols))
     u4 = torch.empty(n, dtype=torch.float32, device=w.device)
     scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
-    call("dream_pack_convT4x4_winograd_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, stream())
-    return u4, cout
+    call("dream_pack_convT4x4_winograd_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, mode, stream())
+    return u4, rows
+
+
+def conv4x4s2_winograd(dy_nhwc, u4_mode1, cin):
+    """Data gradient of ConvTranspose2d(k4,s2,p1): dy [B,2H,2W,Cout] -> dx [B,H,W,cin] (the four phase convs, summed)."""
+    dy = _f32(dy_nhwc)
+    b, h2, w2, cout = (int(v) for v in dy.shape)
+    dx = torch.empty((b, h2 // 2, w2 // 2, cin), dtype=torch.float32, device=dy.device)
+    call("dream_conv4x4s2_winograd_nhwc_f32", ptr(dy), ptr(u4_mode1), ptr(dx), b, h2 // 2, w2 // 2, cout, cin, stream())
+    return dx
 
 
 def convT4x4_winograd_applies(x_nhwc, cout):

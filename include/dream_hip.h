@@ -123,7 +123,12 @@ int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const
  * y [B,2H,2W,Cout]; Cin % 16 == 0, Cin >= 32, Cout > 64; wT [Cin][Cout][4][4]; u4: dream_convT4x4_winograd_weight_floats()
  * floats; scratch: 4*Cout*Cin*9 floats; flags: DREAM_CONV_RELU. */
 size_t dream_convT4x4_winograd_weight_floats(int Cout, int Cin);
-int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream);
+/* mode 0: forward operator; mode 1: data-gradient operator (u4: dream_convT4x4_winograd_weight_floats(Cin, Cout) floats) */
+int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, int mode, void *stream);
+/* data gradient of that transposed conv (= a 4x4 stride-2 pad-1 conv): dy [B,2H,2W,Cout] -> dx [B,H,W,Cin], Cin > 64, the four
+ * phases of dy summed; same nine-position scheme */
+int dream_conv4x4s2_winograd_nhwc_f32(const float *dy, const float *u4_mode1, float *dx, int B, int H, int W, int Cout, int Cin,
+                                      void *stream);
 int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift, float *y,
                                                 int B, int H, int W, int Cin, int Cout, int flags, void *stream);
 /* nn.ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) of the deconv decoder (dream/models.py:621-686) by sub-pixel

@@ -134,6 +134,23 @@ def check_convT4x4_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, with_scale
     return err
 
 
+def check_conv4x4s2_winograd(dev, B, H, W, Cin, Cout, seed=0):
+    """Data gradient of ConvTranspose2d(k4,s2,p1) (x [B,Cin,H,W] -> y [B,Cout,2H,2W]) by the four phase convs on the Winograd
+    kernel vs fp64 autograd: error relative to the maximum of the result at fp32 round-off level."""
+    g = torch.Generator().manual_seed(seed)
+    wT = torch.randn(Cin, Cout, 4, 4, generator=g) * (2.0 / (4 * Cout)) ** 0.5
+    dy = torch.randn(B, Cout, 2 * H, 2 * W, generator=g)
+    xref = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(xref, wT.double(), None, stride=2, padding=1).backward(dy.double())
+    u4, rows = ops.pack_convT4x4_winograd_weight(to(dev, wT), 1)
+    assert rows == Cin
+    dx = ops.conv4x4s2_winograd(to(dev, _nhwc(dy)), u4, Cin).cpu().permute(0, 3, 1, 2)
+    assert dx.shape == xref.grad.shape
+    err = float((dx.double() - xref.grad).abs().max()) / max(1.0, float(xref.grad.abs().max()))
+    assert err <= 2e-6, (B, H, W, Cin, Cout, err)
+    return err
+
+
 def check_conv1x1(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=False, ksplits=(0, 1, 2, 4)):
     """LDS-free GEMM kernel for stride-1 1x1 convs vs an fp64 evaluation: error relative to the output maximum at fp32 round-off
     level, for every K split the shape admits (the split only changes the order of the sum)."""

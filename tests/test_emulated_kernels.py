@@ -55,6 +55,10 @@ def test_conv_transpose4x4_winograd(emu):
             pc.check_convT4x4_winograd("cpu", 2, 13, 9, 48, 96, ops.CONV_RELU, seed=1, with_scale=True),    # odd extents, 3 chunks, ragged cout
             pc.check_convT4x4_winograd("cpu", 1, 26, 26, 32, 256, ops.CONV_RELU, seed=2)]                   # two channel blocks, several tile blocks per workgroup
     print("convT4x4 winograd max rel err", max(errs))
+    berrs = [pc.check_conv4x4s2_winograd("cpu", 1, 6, 6, 128, 32),                 # data gradient: one block per phase
+             pc.check_conv4x4s2_winograd("cpu", 2, 13, 9, 96, 48, seed=1),          # odd extents, 3 chunks, ragged channels
+             pc.check_conv4x4s2_winograd("cpu", 1, 20, 22, 256, 32, seed=2)]        # two channel blocks
+    print("conv4x4s2 (convT data gradient) winograd max rel err", max(berrs))
 
 
 def test_conv1x1_gemm(emu):

@@ -570,6 +570,14 @@ def test_conv_winograd(b, h, w, cin, cout, flags, kw):
 
 
 # ---- single-process data parallelism behind gpu_ids (dream_amd/data_parallel.py; reference network.py:244-256) ------------
+@pytest.mark.parametrize("b,h,w,cin,cout", [(1, 6, 6, 128, 32), (2, 13, 9, 96, 48), (1, 20, 22, 256, 32), (4, 13, 13, 2048, 256),
+                                            (4, 104, 104, 256, 256)])
+def test_conv4x4s2_winograd(b, h, w, cin, cout):
+    """Data gradient of the decoder's transposed convs on the Winograd kernel (four phase convs on stride-2 views, summed)."""
+    err = pc.check_conv4x4s2_winograd(DEV, b, h, w, cin, cout, seed=h + cin)
+    print("conv4x4s2 winograd %dx%dx%d %d<-%d: rel err %.2e" % (b, h, w, cin, cout, err))
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
     (1, 6, 6, 32, 128, 0, {}), (2, 13, 9, 48, 96, 1, {"with_scale": True}), (1, 26, 26, 32, 256, 1, {}),
     (4, 13, 13, 2048, 256, 1, {"with_scale": True}), (4, 104, 104, 256, 256, 1, {"with_scale": True}), (2, 208, 208, 256, 256, 1, {})])

@@ -33,7 +33,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     a = ap.parse_args()
-    td = tw = 0.0
+    td = tw = tbd = tbw = 0.0
     for (res, cin, cout) in LAYERS:
         if res == 208 and a.batch > 32:
             continue
@@ -47,14 +47,27 @@ def main():
         diff = float((yd - yw).abs().max()) / float(yd.abs().max())
         ms_d = timeit(lambda: ops.conv_transpose4x4s2(x, pd, cout, sc, sh, ops.CONV_RELU))
         ms_w = timeit(lambda: ops.conv_transpose4x4s2_winograd(x, u4, cout, sc, sh, ops.CONV_RELU))
+        dy = torch.randn(a.batch, 2 * res, 2 * res, cout, device="cuda")
+        pb, rows_b = ops.pack_convT4x4_bwd_weight(wT)
+        u4b, _ = ops.pack_convT4x4_winograd_weight(wT, 1)
+        gd = ops.conv4x4s2(dy, pb, rows_b)
+        gw = ops.conv4x4s2_winograd(dy, u4b, cin)
+        bdiff = float((gd[..., :cin] - gw).abs().max()) / float(gd.abs().max())
+        ms_bd = timeit(lambda: ops.conv4x4s2(dy, pb, rows_b))
+        ms_bw = timeit(lambda: ops.conv4x4s2_winograd(dy, u4b, cin))
+        tbd += ms_bd
+        tbw += ms_bw
         flops = 2.0 * a.batch * res * res * cin * cout * 16
+        bline = " || data gradient: direct %8.3f ms | winograd %8.3f ms speedup %.2f rel diff %.1e" % (ms_bd, ms_bw, ms_bd / ms_bw, bdiff)
+        del dy, gd, gw
         td += ms_d
         tw += ms_w
         print("%4d -> %4d  %5d->%4d  direct %8.3f ms %6.1f TF | winograd %8.3f ms %6.1f TF-equiv (%.2f of peak on its own MACs) "
               "speedup %.2f  rel diff %.1e" % (res, 2 * res, cin, cout, ms_d, flops / ms_d / 1e9, ms_w, flops / ms_w / 1e9,
-                                               flops * 9 / 16 / ms_w / 1e9 / 157.3, ms_d / ms_w, diff), flush=True)
+                                               flops * 9 / 16 / ms_w / 1e9 / 157.3, ms_d / ms_w, diff) + bline, flush=True)
         del x, yd, yw
-    print("sum over the decoder layers (b=%d): direct %.2f ms, winograd %.2f ms, speedup %.2f" % (a.batch, td, tw, td / tw))
+    print("sum over the decoder layers (b=%d): direct %.2f ms, winograd %.2f ms, speedup %.2f; data gradient: direct %.2f ms, "
+          "winograd %.2f ms, speedup %.2f" % (a.batch, td, tw, td / tw, tbd, tbw, tbd / tbw))
 
 
 if __name__ == "__main__":
