@@ -232,8 +232,8 @@ def main():
                                     kernel_launches=4)        # the sub-pixel ops are four kernel launches each
     ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
                                     kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
-    ops.conv_transpose4x4s2_winograd = timed(ops.conv_transpose4x4s2_winograd, lambda y, x, u4, cout, *a, **k: 2.0 * x.numel() * cout * 16,
-                                             kernel_launches=4, executed=9.0 / 16.0)     # minimal filtering: 9 of 16 multiplications
+    ops.conv_transpose4x4s2_winograd = timed(ops.conv_transpose4x4s2_winograd, lambda y, x, u4, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
+                                             kernel_launches=4, executed=lambda k: 9.0 / k.get("direct_taps", 16))     # minimal filtering: 9 multiplications
     ops.conv4x4s2_winograd = timed(ops.conv4x4s2_winograd, lambda y, dy, u4, cin: 2.0 * y.numel() * dy.shape[3] * 16,
                                    kernel_launches=4, executed=9.0 / 16.0)
     ops.conv_transpose3x3s2_f16x3 = timed(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9,

@@ -65,6 +65,8 @@ class _PackedCache:
                 elif mode == "ups":
                     wt4 = ops.upsample_conv_weight(weight.detach())
                     packed = ops.pack_convT4x4_weight_f16x3(wt4) if f16x3 else ops.pack_convT4x4_weight(wt4)
+                elif mode in ("ups_wino0", "ups_wino1"):          # the same transposed conv by minimal filtering (fwd / data gradient)
+                    packed = ops.pack_convT4x4_winograd_weight(ops.upsample_conv_weight(weight.detach()), int(mode[-1]))
                 else:
                     packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
                 hit = (tag, packed)
@@ -239,6 +241,10 @@ class DreamHourglass(nn.Module):
             return False
         return cin % 16 == 0 and cin >= 32 and cout >= 64 and not (flags & ~(CONV_RELU | CONV_POOL2 | ops.CONV_RELUMASK))
 
+    def _ups_winograd(self, cin, cout):
+        """The convs that follow nn.Upsample(2), as 4x4 stride-2 transposed convs on the Winograd kernel (conv_wino.hip, PAT)."""
+        return self.conv_algorithm == "winograd" and cin % 16 == 0 and cin >= 32 and cout > 64
+
     @staticmethod
     def _join(a, b):
         if a.shape != b.shape:        # what the reference's `+` raises for resolutions the pools do not divide
@@ -321,8 +327,13 @@ class DreamHourglass(nn.Module):
                     if kind == "wide" and not x_is_nhwc:
                         inp = ops.nchw_to_nhwc(inp, cpad=self.input_channel_pad())
                     if flags & CONV_UPSAMPLE2X:              # upsample + conv == a 4x4 transposed conv: 4 MACs / output, not 9
-                        pk4, cout4 = self._packed.get(mod.weight, "ups")
-                        act = ops.conv_transpose4x4s2(inp, pk4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
+                        if self._ups_winograd(int(inp.shape[3]), int(mod.weight.shape[0])):
+                            # ... and that transposed conv by minimal filtering on the Winograd kernel: 9/16 of those again
+                            u4, cout4 = self._packed.get(mod.weight, "ups_wino0")
+                            act = ops.conv_transpose4x4s2_winograd(inp, u4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
+                        else:
+                            pk4, cout4 = self._packed.get(mod.weight, "ups")
+                            act = ops.conv_transpose4x4s2(inp, pk4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
                     elif kind == "deconv":                   # ConvTranspose weight [Cin,Cout,3,3], mode-1 packing; sub-pixel
                         packed, rows, _, _ = self._packed.get(mod.weight, 1)   # phases: a quarter of the zero-stuffed MACs
                         act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
@@ -420,7 +431,13 @@ class DreamHourglass(nn.Module):
             if int(g.shape[3]) != cols_pad:
                 raise RuntimeError("internal: gradient has %d channels, packed weights expect %d" % (g.shape[3], cols_pad))
             if flags & CONV_UPSAMPLE2X:                    # the mask lives at half resolution: after upsample2_bwd
-                if self._use_winograd(int(g.shape[3]), cin, 0) and int(g.shape[3]) == cout:
+                if (self._ups_winograd(cin, cout) and cin > 64 and int(g.shape[3]) == cout
+                        and g.shape[1] % 2 == 0 and g.shape[2] % 2 == 0):
+                    # data gradient of the equivalent transposed conv, straight at half resolution (no full-resolution
+                    # intermediate, no upsample2_bwd pass): four phase convs of nine positions each
+                    u4b, rows_b = self._packed.get(mod.weight, "ups_wino1")
+                    g = ops.conv4x4s2_winograd(g, u4b, rows_b)
+                elif self._use_winograd(int(g.shape[3]), cin, 0) and int(g.shape[3]) == cout:
                     u_t, rows_t = self._packed.get(mod.weight, "wino1")
                     g = ops.upsample2_bwd(ops.conv3x3_winograd(g, u_t, rows_t, None, None, None, 0))
                 else:

@@ -104,7 +104,7 @@ def convT4x4_winograd_applies(x_nhwc, cout):
     return cin % 16 == 0 and cin >= 32 and cout > 64
 
 
-def conv_transpose4x4s2_winograd(x_nhwc, u4, cout, scale=None, shift=None, flags=0):
+def conv_transpose4x4s2_winograd(x_nhwc, u4, cout, scale=None, shift=None, flags=0, direct_taps=16):
     """ConvTranspose2d(k4,s2,p1) * scale + shift (ReLU) by minimal filtering (9/16 of the direct multiplications), NHWC."""
     x = _f32(x_nhwc)
     b, h, w, cin = (int(v) for v in x.shape)
