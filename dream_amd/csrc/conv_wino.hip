@@ -3,6 +3,11 @@
 // the direct algorithm's 36, i.e. 2.25x fewer MFMA cycles for the same fp32 result up to round-off (every product and sum is
 // IEEE fp32; the transforms only add / subtract, the weight transform is done once, in fp64, at pack time).
 //
+// The same kernel runs nn.ConvTranspose2d(k4,s2,p1) (the ResNet decoder, /root/reference/dream/models.py:37-136, and -- with
+// the equivalent weights -- the convs that follow nn.Upsample(2) in the VGG decoder, :691-710) and its data gradient by minimal
+// filtering: an output phase is a 3x3 conv with only 2 x 2 non-zero taps, whose transformed weights vanish on seven of the 16
+// positions (template parameter PAT below): 9 multiplications per 2 x 2 outputs of a phase instead of 16.
+//
 // Replaces torch.nn.Conv2d(k=3,s=1,p=1) (+ReLU, + the following MaxPool2d(2)) at /root/reference/dream/models.py:598-615
 // (VGG19 encoder), :695-710 (upsample decoder, the convs not preceded by an upsample), :736-747 (head), the 3x3 stride-1
 // convs of the ResNet-101 bottlenecks behind :22-32 in evaluation mode (folded BatchNorm), and -- on mode-1 packed
