@@ -4,20 +4,32 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): DREAM-vgg-Q inference, batch 128 of synthetic 400x400 frames
-already resident in HBM, one "step" = DreamNetwork.inference(x) = CNN forward + peak extraction,
-result = [B,K,2] float32 keypoints on the host (the reference's return contract).  With N ranks each
-rank processes its own batch of 128 (embarrassingly parallel, no data-path collective): weak scaling.
+Main workload (BASELINE.json configs[1]): DREAM-vgg-Q inference, batch 128 of synthetic 400x400 frames already resident in
+HBM, one "step" = DreamNetwork.inference(x) = CNN forward + peak extraction, result = [B,K,2] float32 keypoints on the host
+(the reference's return contract).  With N ranks each rank processes its own batch of 128 (embarrassingly parallel, no
+data-path collective): weak scaling.
 
-One JSON line on rank 0.  `roofline` is measured live: every launch of the dominant kernel
-(conv_mfma_kernel, 22 launches per step for vgg_q) is bracketed by HIP events on the launch stream inside
-the timed region; achieved = algorithmic FLOPs of those launches / their summed duration.
-`cpu_baseline` times the CPU oracle (torch-CPU restatement of the reference + NumPy peak path) on a
-bounded sample of the same workload on this host's cores (rank 0, N=1 only).
+`--gpus N` with N > 1 and no launcher environment (WORLD_SIZE unset) re-executes this file under
+`python -m torch.distributed.run --nproc-per-node N` -- one process per GPU over RCCL -- and rank 0 prints the line:
+`n_gpus` = N, `rccl_ranks` = the world size of the nccl (= RCCL) process group.  (`--single-process` instead drives the N GPUs
+from ONE process through training.platform.gpu_ids, the reference's nn.DataParallel contract.)
+
+One JSON line on rank 0.  `roofline` is measured live: every launch of the conv kernels is bracketed by HIP events on the
+launch stream inside the timed region; achieved = algorithmic FLOPs of those launches / their summed duration.
+  * N == 1: `secondary` = the other single-GPU configurations of BASELINE.json under the same clock: configs[2] (vgg_q
+    training b=128) and one GPU's share of configs[3] (resnet_h training, 16 frames) and configs[4] (resnet_f inference, 32
+    frames), two timed steps each, every one with its executed-multiplication roofline fraction; `cpu_baseline` times the CPU
+    oracle (torch-CPU restatement of the reference + NumPy peak path) on a bounded sample of the main workload.
+  * N > 1: `scale` = the sharded configurations BASELINE.json names: configs[3] (resnet_h training, 128 frames split over the
+    N GPUs, RCCL all-reduce of the gradients every step) and configs[4] (resnet_f inference, 256 frames split over the N
+    GPUs), each with whole-job and per-GPU frames/s (strong scaling), next to the weak-scaling vgg_q metric in `value`.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,7 +52,7 @@ def parse():
     ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process through training.platform.gpu_ids "
                     "(the reference's nn.DataParallel contract, dream_amd/data_parallel.py) instead of one process per GPU")
     ap.add_argument("--conv-algorithm", choices=["winograd", "direct"], default="winograd",
-                    help="fp32 3x3 stride-1 convs: Winograd F(2x2,3x3) on the fp32 MFMA (default) or the direct implicit GEMM")
+                    help="fp32 3x3 stride-1 convs: Winograd on the fp32 MFMA (default) or the direct implicit GEMM")
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--mode", choices=["inference", "train"], default="inference")
     ap.add_argument("--precision", choices=["fp32", "fp16x3"], default="fp32",
@@ -50,29 +62,32 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="inference through DreamNetwork.hip_graph (hipGraph replay; "
                     "per-launch HIP events are not recorded then)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the informational fp16x3 leg")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` (N = 1) / `scale` (N > 1) blocks")
+    ap.add_argument("--secondary-steps", type=int, default=2)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE, separate runs of this same command, FETCH_SIZE doubled per the gfx950 note in
-    MI355X_MICROARCH.md and calibrated on the max-pool kernel).  Counters cannot be read from inside the
-    process, so the latest committed profile summary is reported; null for any other workload."""
-    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path):
-            break
-    else:
+def bench_sha():
+    with open(os.path.abspath(__file__), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def pmc_traffic(spec):
+    """HBM bytes per launch of the conv kernels from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs
+    of this same command, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md and calibrated on the max-pool
+    kernel).  Counters cannot be read from inside the process, so the committed summary of the newest round is reported -- but
+    only when it was taken with THIS bench.py (the summary records the file's hash) on this workload; null otherwise."""
+    if (spec["arch"], spec["mode"], spec["batch"], spec["res"], spec["conv_algorithm"]) != ("vgg_q", "inference", 128, 400, "winograd"):
         return None
-    if args.arch != "vgg_q" or args.mode != "inference" or args.batch != 128 or args.res != 400:
-        return None
-    with open(path) as f:
-        d = json.load(f)
-    key = "conv_kernels" if "conv_kernels" in d else "conv_mfma_kernel"
-    if args.conv_algorithm == "direct" and key == "conv_kernels":
-        return None
-    return d[key]["traffic_gb_per_launch"] * 1e9
+    names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json") and n[0] == "r"),
+                   reverse=True)
+    for name in names:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+        if d.get("bench_py_sha") == bench_sha() and "conv_kernels" in d:
+            return d["conv_kernels"]["traffic_gb_per_launch"] * 1e9
+    return None
 
 
 ARCH_K = {"vgg_q": (7, "panda"), "vgg_f": (7, "panda"), "resnet_h": (7, "panda"), "resnet_f": (17, "baxter")}
@@ -141,148 +156,262 @@ def cpu_baseline(arch, res, seconds):
                       "extraction, %.1f s" % (n, res, res, bs, arch, dt)}
 
 
-def main():
-    args = parse()
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1, no launcher environment): one process per GPU under torch.distributed.run, RCCL."""
     import torch
-    import torch.distributed as dist
-    import cases
-    import dream_amd
-    from dream_amd import ops
+    n_visible = torch.cuda.device_count()
+    if n_visible < args.gpus and not os.environ.get("DREAM_BENCH_BACKEND"):
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_visible))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    single = args.single_process and world == 1 and args.gpus > 1
-    n_dev = args.gpus if single else world
-    if args.global_batch:
-        assert args.global_batch % max(n_dev, 1) == 0, "--global-batch must divide evenly over the GPUs"
-        args.batch = args.global_batch // max(n_dev, 1)
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    # One process per GPU over RCCL.  (Rehearsal of the N > 1 path on a single-GPU box: DREAM_BENCH_BACKEND=gloo lets
-    # the ranks share device 0 -- RCCL refuses two ranks on one device; numbers from such a run mean nothing.)
-    backend = os.environ.get("DREAM_BENCH_BACKEND", "nccl")
-    device_index = local_rank % torch.cuda.device_count()   # == local_rank unless the launcher exposes one device per rank
-    torch.cuda.set_device(device_index)
-    if world == 1 and os.environ.get("DREAM_FORCE_REDUCER"):      # rehearsal: exercise the gradient exchange with one rank
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29555")
-        dist.init_process_group("gloo", rank=0, world_size=1)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
-    total_batch = args.batch * (n_dev if single else 1)            # frames this PROCESS handles per step
 
-    n_kp, manip = ARCH_K[args.arch]
-    cfg = dream_amd.default_network_config(args.arch, manip, batch_size=args.batch)
-    cfg["training"]["config"]["net_input_resolution"] = [args.res, args.res]
-    if single:                                      # DREAM_BENCH_GPU_IDS=0,0: rehearsal of the N-replica path on a one-GPU box
-        ids = os.environ.get("DREAM_BENCH_GPU_IDS")
-        cfg["training"]["platform"]["gpu_ids"] = [int(v) for v in ids.split(",")] if ids else list(range(args.gpus))
-    import io
-    import contextlib
-    with contextlib.redirect_stdout(io.StringIO()):
-        net = dream_amd.create_network_from_config_data(cfg)
-    net.model.load_state_dict(synthetic_weights(net.model.state_dict()))
-    net.model.module.conv_algorithm = args.conv_algorithm
+class ConvTimer:
+    """Per-launch timing of the conv kernels (HIP events on the launch stream): wraps the dream_amd.ops conv entry points once;
+    while `recording`, every call is bracketed by two events and its algorithmic / executed FLOPs are noted."""
 
-    x = torch.from_numpy(cases.image_batch(total_batch, args.res, args.res, seed=rank)).cuda()
-    if args.mode == "train":
-        net.enable_training()
-        ow, oh = net.trained_net_output_resolution()
-        tgt = torch.from_numpy(cases.target_batch(total_batch, n_kp, (ow, oh), in_wh=(args.res, args.res), seed=rank)).cuda()
-    else:
-        net.enable_evaluation()
-        net.hip_graph = bool(args.graph)
-        if args.precision != "fp32":
-            net.model.module.precision = args.precision
+    def __init__(self, ops, torch):
+        self.events, self.recording, self.torch = [], False, torch
+        C = ops.CONV_POOL2
 
-    # ---- per-launch timing of the dominant kernel (HIP events on the launch stream) ------------------
-    conv_events = []          # (start, end, flops)
-    recording = [False]
+        def pooled(flags):                    # a fused 2x2 max-pool stores 1/4 of the conv outputs it computed
+            return 4.0 if flags & C else 1.0
 
-    def timed(orig, flops_of, kernel_launches=1, executed=1.0):
-        """executed: executed MACs / direct-algorithm MACs of this operator (Winograd: 16 / 36), or a callable of the kwargs."""
+        w = self.wrap
+        # algorithmic FLOPs of one launch = 2 * outputs * (input channels * taps); y is NHWC or NCHW [B,...]
+        ops.conv3x3 = w(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0, relu_mask=None: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
+        ops.conv2d = w(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
+                       2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
+        ops.conv3x3_winograd = w(ops.conv3x3_winograd, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
+                                 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=16.0 / 36.0)
+        if hasattr(ops, "conv3x3_winograd4"):
+            ops.conv3x3_winograd4 = w(ops.conv3x3_winograd4, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
+                                      2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=36.0 / 144.0)
+        ops.conv1x1 = w(ops.conv1x1, lambda y, x, packed, cout, *a, **k: 2.0 * y.numel() * x.shape[3])
+        ops.conv_transpose3x3s2 = w(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9,
+                                    kernel_launches=4)        # the sub-pixel ops are four kernel launches each
+        ops.conv_transpose4x4s2 = w(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
+                                    kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
+        ops.conv_transpose4x4s2_winograd = w(ops.conv_transpose4x4s2_winograd, lambda y, x, u4, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
+                                             kernel_launches=4, executed=lambda k: 9.0 / k.get("direct_taps", 16))     # minimal filtering: 9 multiplications
+        ops.conv4x4s2_winograd = w(ops.conv4x4s2_winograd, lambda y, dy, u4, cin: 2.0 * y.numel() * dy.shape[3] * 16,
+                                   kernel_launches=4, executed=9.0 / 16.0)
+        ops.conv_transpose3x3s2_f16x3 = w(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9,
+                                          kernel_launches=4)
+        ops.conv_transpose4x4s2_f16x3 = w(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
+                                          kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
+        ops.conv2d_amax = w(ops.conv2d_amax, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
+        ops.conv2d_f16x3 = w(ops.conv2d_f16x3,
+                             lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
+                             2.0 * y[0].numel() * pooled(flags) * x.shape[3] * ksize * ksize)
+
+    def wrap(self, orig, flops_of, kernel_launches=1, executed=1.0):
+        """executed: executed MACs / direct-algorithm MACs of this operator (Winograd F(2x2): 16 / 36), or a callable of the kwargs."""
         def wrapper(*a, **k):
-            if not recording[0] or k.get("relu_mask") is not None:     # conv3x3(relu_mask=..) forwards to conv2d: timed there
+            if not self.recording or k.get("relu_mask") is not None:     # conv3x3(relu_mask=..) forwards to conv2d: timed there
                 return orig(*a, **k)
-            s_ev = torch.cuda.Event(enable_timing=True)
-            e_ev = torch.cuda.Event(enable_timing=True)
+            s_ev = self.torch.cuda.Event(enable_timing=True)
+            e_ev = self.torch.cuda.Event(enable_timing=True)
             s_ev.record()
             y = orig(*a, **k)
             e_ev.record()
             fl = flops_of(y, *a, **k)
-            conv_events.append((s_ev, e_ev, fl, kernel_launches, fl * (executed(k) if callable(executed) else executed)))
+            self.events.append((s_ev, e_ev, fl, kernel_launches, fl * (executed(k) if callable(executed) else executed)))
             return y
         return wrapper
 
-    # algorithmic FLOPs of one launch = 2 * outputs * (input channels * taps); y is NHWC or NCHW [B,...]
-    def pooled(flags):                    # a fused 2x2 max-pool stores 1/4 of the conv outputs it computed
-        return 4.0 if flags & ops.CONV_POOL2 else 1.0
+    def summary(self):
+        ms = sum(ev[0].elapsed_time(ev[1]) for ev in self.events)
+        return {"ms": ms, "flops": sum(ev[2] for ev in self.events), "launches": sum(ev[3] for ev in self.events),
+                "executed": sum(ev[4] for ev in self.events)}
 
-    ops.conv3x3 = timed(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0, relu_mask=None: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
-    ops.conv2d = timed(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
-                       2.0 * y.numel() * pooled(flags) * x.shape[3] * ksize * ksize)
-    ops.conv3x3_winograd = timed(ops.conv3x3_winograd, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
-                                 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=16.0 / 36.0)
-    ops.conv1x1 = timed(ops.conv1x1, lambda y, x, packed, cout, *a, **k: 2.0 * y.numel() * x.shape[3])
-    ops.conv_transpose3x3s2 = timed(ops.conv_transpose3x3s2, lambda y, x, packed, bias, cout, *a, **k: 2.0 * x.numel() * cout * 9,
-                                    kernel_launches=4)        # the sub-pixel ops are four kernel launches each
-    ops.conv_transpose4x4s2 = timed(ops.conv_transpose4x4s2, lambda y, x, packed, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
-                                    kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
-    ops.conv_transpose4x4s2_winograd = timed(ops.conv_transpose4x4s2_winograd, lambda y, x, u4, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
-                                             kernel_launches=4, executed=lambda k: 9.0 / k.get("direct_taps", 16))     # minimal filtering: 9 multiplications
-    ops.conv4x4s2_winograd = timed(ops.conv4x4s2_winograd, lambda y, dy, u4, cin: 2.0 * y.numel() * dy.shape[3] * 16,
-                                   kernel_launches=4, executed=9.0 / 16.0)
-    ops.conv_transpose3x3s2_f16x3 = timed(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9,
-                                          kernel_launches=4)
-    ops.conv_transpose4x4s2_f16x3 = timed(ops.conv_transpose4x4s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
-                                          kernel_launches=4, executed=lambda k: 16.0 / k.get("direct_taps", 16))
-    ops.conv2d_amax = timed(ops.conv2d_amax, lambda y, x, packed, cout, ksize, *a, **k: 2.0 * y[0].numel() * x.shape[3] * ksize * ksize)
-    ops.conv2d_f16x3 = timed(ops.conv2d_f16x3,
-                             lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
-                             2.0 * y[0].numel() * pooled(flags) * x.shape[3] * ksize * ksize)
+
+class Context:
+    pass
+
+
+def build_network(ctx, spec):
+    import io
+    import contextlib
+    import torch
+    import cases
+    import dream_amd
+    n_kp, manip = ARCH_K[spec["arch"]]
+    cfg = dream_amd.default_network_config(spec["arch"], manip, batch_size=spec["batch"])
+    cfg["training"]["config"]["net_input_resolution"] = [spec["res"], spec["res"]]
+    # an empty gpu_ids list means "every visible GPU" in one process (the reference's DataParallel contract); this process
+    # drives exactly the device(s) it was given
+    cfg["training"]["platform"]["gpu_ids"] = list(ctx.single_ids) if ctx.single else [ctx.device_index]
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = dream_amd.create_network_from_config_data(cfg)
+    net.model.load_state_dict(synthetic_weights(net.model.state_dict()))
+    net.model.module.conv_algorithm = spec["conv_algorithm"]
+    frames = spec["batch"] * (len(ctx.single_ids) if ctx.single else 1)               # frames this PROCESS handles per step
+    x = torch.from_numpy(cases.image_batch(frames, spec["res"], spec["res"], seed=ctx.rank)).cuda()
+    tgt = None
+    if spec["mode"] == "train":
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        tgt = torch.from_numpy(cases.target_batch(frames, n_kp, (ow, oh), in_wh=(spec["res"], spec["res"]), seed=ctx.rank)).cuda()
+    else:
+        net.enable_evaluation()
+        net.hip_graph = bool(spec.get("graph"))
+        if spec.get("precision", "fp32") != "fp32":
+            net.model.module.precision = spec["precision"]
+    n_dev = len(net.model.devices())
+    assert n_dev == (len(ctx.single_ids) if ctx.single else 1), "network spreads over %d devices" % n_dev
+    return net, x, tgt, frames
+
+
+def timed_region(ctx, net, x, tgt, spec):
+    """W warm-up steps, then exactly K steps between barrier+synchronize pairs; max over ranks.
+    -> (seconds, conv timer summary, output of the last step)."""
+    import torch
+    import torch.distributed as dist
+    timer = ctx.timer
 
     def step():
-        if args.mode == "train":
+        if spec["mode"] == "train":
             return net.train([x], tgt)
         with torch.no_grad():
             return net.inference(x)
 
+    def sync():
+        if ctx.single:
+            for i in set(ctx.single_ids):
+                torch.cuda.synchronize(i)
+        else:
+            torch.cuda.synchronize()
+
     def barrier():
-        if world > 1:
+        if ctx.world > 1:
             dist.barrier()
 
-    def timed_region():
-        """W warm-up steps, then exactly K steps between barrier+synchronize pairs; max over ranks."""
-        del conv_events[:]
-        for _ in range(args.warmup):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        recording[0] = not args.graph          # events cannot be timed inside a captured graph
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        torch.cuda.synchronize()
-        barrier()
-        dt = time.perf_counter() - t0
-        recording[0] = False
-        if world > 1:
-            tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt = float(tmax.item())
-        ms = sum(ev[0].elapsed_time(ev[1]) for ev in conv_events)
-        fl = sum(ev[2] for ev in conv_events)
-        executed_flops[0] = sum(ev[4] for ev in conv_events)
-        return dt, ms, fl, sum(ev[3] for ev in conv_events), out
+    del timer.events[:]
+    for _ in range(spec["warmup"]):
+        step()
+    sync()
+    barrier()
+    timer.recording = not spec.get("graph") and not ctx.single        # events cannot be timed inside a captured graph
+    sync()
+    t0 = time.perf_counter()
+    out = None
+    for _ in range(spec["steps"]):
+        out = step()
+    sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.recording = False
+    if ctx.world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt, timer.summary(), out
 
-    executed_flops = [0.0]
-    dt, conv_ms, conv_flops, n_launch, out_main = timed_region()
-    conv_executed = executed_flops[0]
+
+def roofline_of(spec, conv, dt, peak):
+    ms, fl, ex = conv["ms"], conv["flops"], conv["executed"]
+    wino = spec["conv_algorithm"] == "winograd"
+    kernel = ("conv_wino_kernel + conv_mfma_kernel" if wino else "conv_mfma_kernel") + \
+             (" + gemm1x1_kernel" if spec["arch"].startswith("resnet") else "")
+    if spec.get("precision", "fp32") != "fp32" and spec["mode"] == "inference":
+        kernel = "conv_f16x3_kernel"
+    return {
+        "bound": "mfma", "kernel": kernel,
+        "achieved": fl / (ms * 1e-3) / 1e12 if ms > 0 else None, "peak": peak, "unit": "TFLOP/s",
+        "frac": (fl / (ms * 1e-3) / 1e12 / peak) if ms > 0 else None,
+        # frac above counts the DIRECT algorithm's FLOPs (SURVEY.md 8d); executed_frac counts the multiplications the kernels
+        # actually issue (Winograd F(2x2,3x3) 16/36 of direct, upsample + conv as a transposed conv by minimal filtering 9/36)
+        "executed_frac": (ex / (ms * 1e-3) / 1e12 / peak) if ms > 0 else None,
+        "executed_over_direct": ex / fl if fl > 0 else None,
+        "launches": conv["launches"], "avg_launch_ms": ms / max(conv["launches"], 1),
+        "algorithmic_gflop_per_launch": fl / max(conv["launches"], 1) / 1e9,
+        "share_of_step_time": ms * 1e-3 / dt if dt > 0 else None,
+    }
+
+
+def workload_text(spec, n_kp, manip, baseline_index=None):
+    what = ("forward + MSE belief-map loss + backward + Adam step (DreamNetwork.train)" if spec["mode"] == "train"
+            else "CNN forward + belief-map peak extraction (DreamNetwork.inference)")
+    return ("DREAM-%s (%s, %d keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames resident in HBM; %s%s"
+            % (spec["arch"], manip, n_kp, spec["mode"], spec["batch"], spec["res"], spec["res"], what,
+               " (BASELINE.json configs[%d])" % baseline_index if baseline_index is not None else ""))
+
+
+def run_side_workload(ctx, spec, label, baseline_index, sharded_total=None):
+    """One more configuration under the same clock -> a compact result block."""
+    import gc
+    import torch
+    net, x, tgt, frames = build_network(ctx, spec)
+    dt, conv, _ = timed_region(ctx, net, x, tgt, spec)
+    n_kp, manip = ARCH_K[spec["arch"]]
+    total = frames * spec["steps"] * ctx.world
+    roof = roofline_of(spec, conv, dt, PEAK_F32_MFMA_TFLOPS)
+    block = {"config": label, "workload": workload_text(spec, n_kp, manip, baseline_index),
+             "value": total / dt, "unit": "frames/s", "ms_per_step": dt / spec["steps"] * 1e3, "steps": spec["steps"],
+             "warmup": spec["warmup"], "batch_per_gpu": spec["batch"], "dtype": "f32",
+             "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "executed_frac", "share_of_step_time")}}
+    if sharded_total is not None:
+        n = ctx.n_gpus
+        block.update({"global_batch": sharded_total, "scaling": "strong", "per_gpu_frames_per_s": total / dt / n})
+    del net, x, tgt
+    gc.collect()
+    torch.cuda.empty_cache()
+    return block
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
+        self_launch(args)
+    import torch
+    import torch.distributed as dist
+    import dream_amd  # noqa: F401
+    from dream_amd import ops
+
+    ctx = Context()
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.single = bool(args.single_process and ctx.world == 1 and args.gpus > 1)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    assert ctx.world == args.gpus or ctx.single or (ctx.world == 1 and args.gpus == 1), \
+        "launched with %d ranks but --gpus %d" % (ctx.world, args.gpus)
+    # One process per GPU over RCCL.  (Rehearsal of the N > 1 path on a single-GPU box: DREAM_BENCH_BACKEND=gloo lets
+    # the ranks share device 0 -- RCCL refuses two ranks on one device; numbers from such a run mean nothing.)
+    backend = os.environ.get("DREAM_BENCH_BACKEND", "nccl")
+    ctx.device_index = local_rank % torch.cuda.device_count()   # == local_rank unless the launcher exposes one device per rank
+    torch.cuda.set_device(ctx.device_index)
+    ids = os.environ.get("DREAM_BENCH_GPU_IDS")                 # 0,0: rehearsal of the N-replica path on a one-GPU box
+    ctx.single_ids = ([int(v) for v in ids.split(",")] if ids else list(range(args.gpus))) if ctx.single else [ctx.device_index]
+    ctx.n_gpus = len(ctx.single_ids) if ctx.single else ctx.world
+    assert ctx.n_gpus == args.gpus, "running on %d GPUs but --gpus %d" % (ctx.n_gpus, args.gpus)
+    if ctx.world == 1 and os.environ.get("DREAM_FORCE_REDUCER"):      # rehearsal: exercise the gradient exchange with one rank
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    if ctx.world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device_index))
+        else:
+            dist.init_process_group(backend)
+    if args.global_batch:
+        assert args.global_batch % ctx.n_gpus == 0, "--global-batch must divide evenly over the GPUs"
+        args.batch = args.global_batch // ctx.n_gpus
+    ctx.timer = ConvTimer(ops, torch)
+
+    spec = {"arch": args.arch, "mode": args.mode, "batch": args.batch, "res": args.res, "steps": args.steps,
+            "warmup": args.warmup, "precision": args.precision, "conv_algorithm": args.conv_algorithm, "graph": args.graph}
+    n_kp, manip = ARCH_K[args.arch]
+    net, x, tgt, frames = build_network(ctx, spec)
+    dt, conv, out_main = timed_region(ctx, net, x, tgt, spec)
     # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
     # fp16 MFMA MACs, so its ceiling in ALGORITHMIC flops is the dense fp16 MFMA peak / 3
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" or args.mode == "train" else PEAK_F16_MFMA_TFLOPS / 3.0
@@ -290,66 +419,83 @@ def main():
     # second, informational leg: the same workload on the split-precision conv kernel (fp32 in/out, 3 fp16 MFMAs per
     # product).  The headline `value` stays the exact-fp32 path unless --precision fp16x3 is given explicitly.
     split = None
-    if args.mode == "inference" and args.precision == "fp32" and not args.no_split_leg:
+    if args.mode == "inference" and args.precision == "fp32" and not args.no_split_leg and not ctx.single:
         net.model.module.precision = "fp16x3"
-        dt2, ms2, fl2, n2, out2 = timed_region()
+        dt2, conv2, out2 = timed_region(ctx, net, x, tgt, spec)
         net.model.module.precision = "fp32"
         diff = float((out_main[0] - out2[0]).abs().max())
         scale = max(1.0, float(out_main[0].abs().max()))
         k32, k16 = out_main[1], out2[1]
         both = (k32 != -999.999) & (k16 != -999.999)
-        split = {"value": total_batch * args.steps * world / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
+        ach2 = conv2["flops"] / (conv2["ms"] * 1e-3) / 1e12 if conv2["ms"] > 0 else None
+        split = {"value": frames * args.steps * ctx.world / dt2, "unit": "frames/s", "ms_per_step": dt2 / args.steps * 1e3,
                  "dtype": "f32 in/out; products as 3 x f16 MFMA (hi*hi + hi*lo + lo*hi), f32 accumulate",
                  "roofline": {"bound": "mfma", "kernel": "conv_f16x3_kernel",
-                              "achieved": fl2 / (ms2 * 1e-3) / 1e12, "peak": PEAK_F16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s",
-                              "frac": fl2 / (ms2 * 1e-3) / 1e12 / (PEAK_F16_MFMA_TFLOPS / 3.0), "launches": n2,
+                              "achieved": ach2, "peak": PEAK_F16_MFMA_TFLOPS / 3.0, "unit": "TFLOP/s",
+                              "frac": ach2 / (PEAK_F16_MFMA_TFLOPS / 3.0) if ach2 else None, "launches": conv2["launches"],
                               "note": "algorithmic FLOPs; each costs 3 f16 MFMA MACs, so the ceiling is 2500/3 TFLOP/s"},
                  "max_abs_diff_vs_fp32_path": diff, "tolerance": 1e-4 * scale,
                  "max_keypoint_diff_px": float((k32 - k16).abs()[both].max()) if bool(both.any()) else 0.0,
                  "detections_agree": float(((k32 == -999.999) == (k16 == -999.999)).float().mean())}
+    del net, x, tgt, out_main
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
 
-    if rank == 0:
-        frames = total_batch * args.steps * world
+    # ---- the other BASELINE.json configurations under the same clock -------------------------------------------------------
+    side = None
+    default_main = (args.arch, args.mode, args.res, args.precision, args.conv_algorithm) == ("vgg_q", "inference", 400, "fp32", "winograd") \
+        and not args.global_batch and not args.graph
+    if default_main and not args.no_secondary:
+        base = {"res": 400, "steps": args.secondary_steps, "warmup": 1, "precision": "fp32", "conv_algorithm": "winograd"}
+        side = []
+        if ctx.n_gpus == 1:
+            side.append(run_side_workload(ctx, dict(base, arch="vgg_q", mode="train", batch=128), "configs[2]", 2))
+            side.append(run_side_workload(ctx, dict(base, arch="resnet_h", mode="train", batch=16),
+                                          "configs[3], one GPU's share (16 of 128 frames)", None))
+            side.append(run_side_workload(ctx, dict(base, arch="resnet_f", mode="inference", batch=32),
+                                          "configs[4], one GPU's share (32 of 256 frames)", None))
+        else:
+            n = ctx.n_gpus
+            if 128 % n == 0:
+                side.append(run_side_workload(ctx, dict(base, arch="resnet_h", mode="train", batch=128 // n), "configs[3]", 3,
+                                              sharded_total=128))
+            if 256 % n == 0:
+                side.append(run_side_workload(ctx, dict(base, arch="resnet_f", mode="inference", batch=256 // n), "configs[4]", 4,
+                                              sharded_total=256))
+
+    if ctx.rank == 0:
+        total = frames * args.steps * ctx.world
+        roof = roofline_of(spec, conv, dt, peak)
+        roof["traffic"] = pmc_traffic(spec)
+        roof["traffic_unit"] = "bytes/launch (PMC passes of this bench.py, profiles/rNN_pmc_traffic.json; null when none matches)"
         line = {
             "metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
-            "value": frames / dt, "unit": "frames/s", "n_gpus": n_dev, "steps": args.steps, "warmup": args.warmup,
+            "value": total / dt, "unit": "frames/s", "n_gpus": ctx.n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": "DREAM-%s (%s, %d keypoints) %s, batch %d per GPU, synthetic %dx%d RGB frames "
-                                   "resident in HBM; CNN forward + belief-map peak extraction%s"
-                                   % (args.arch, manip, n_kp, args.mode, args.batch, args.res, args.res,
-                                      " (BASELINE.json configs[%d])" % (2 if args.mode == "train" else 1)
-                                      if args.arch == "vgg_q" else ""),
+            "rccl_ranks": (dist.get_world_size() if ctx.world > 1 and backend == "nccl" else (1 if not ctx.single else 0)),
+            "per_gpu_frames_per_s": total / dt / ctx.n_gpus,
+            "config": {"workload": workload_text(spec, n_kp, manip, (2 if args.mode == "train" else 1)
+                                                 if (args.arch, args.batch, args.res) == ("vgg_q", 128, 400) else None),
                        "batch_per_gpu": args.batch, "resolution": [args.res, args.res],
-                       "parallelism": "dp%d%s" % (n_dev, " (single process, gpu_ids)" if single else ""),
-                       "conv_algorithm": (("winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 64 output channels, direct "
+                       "parallelism": "dp%d%s" % (ctx.n_gpus, " (single process, gpu_ids)" if ctx.single
+                                                  else (" (one process per GPU, %s)" % ("RCCL" if backend == "nccl" else backend)
+                                                        if ctx.world > 1 else "")),
+                       "conv_algorithm": (("winograd for the stride-1 3x3 convs with >= 64 output channels, direct "
                                            "implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else "direct implicit GEMM")
                                           + ("; stride-1 1x1 convs as LDS-free GEMMs" if args.arch.startswith("resnet") else ""))},
-            "roofline": {
-                "bound": "mfma",
-                "kernel": (("conv_wino_kernel + conv_mfma_kernel" if args.conv_algorithm == "winograd" else "conv_mfma_kernel")
-                           + (" + gemm1x1_kernel" if args.arch.startswith("resnet") else ""))
-                if args.precision == "fp32" or args.mode == "train" else "conv_f16x3_kernel",
-                "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
-                "peak": peak, "unit": "TFLOP/s",
-                "frac": (conv_flops / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
-                # frac above counts the DIRECT algorithm's FLOPs; executed_frac counts the multiplications the
-                # kernels actually issue (Winograd 16/36 of direct, upsample+conv as a 4x4 transposed conv 16/36)
-                "executed_frac": (conv_executed / (conv_ms * 1e-3) / 1e12 / peak) if conv_ms > 0 else None,
-                "executed_over_direct": conv_executed / conv_flops if conv_flops > 0 else None,
-                "traffic": pmc_traffic(args), "traffic_unit": "bytes/launch (PMC, profiles/r0N_pmc_traffic.json)",
-                "launches": n_launch, "avg_launch_ms": conv_ms / max(n_launch, 1),
-                "algorithmic_gflop_per_launch": conv_flops / max(n_launch, 1) / 1e9,
-                "share_of_step_time": conv_ms * 1e-3 / dt,
-            },
+            "roofline": roof,
         }
         if split is not None:
             line["split_precision"] = split
-        if world == 1 and not args.no_cpu_baseline and args.mode == "inference":
+        if side:
+            line["secondary" if ctx.n_gpus == 1 else "scale"] = side
+        if ctx.world == 1 and not ctx.single and not args.no_cpu_baseline and args.mode == "inference":
             line["cpu_baseline"] = cpu_baseline(args.arch, args.res, args.cpu_seconds)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

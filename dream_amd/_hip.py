@@ -52,6 +52,8 @@ _SIGNATURES = {
     "dream_channel_sum_nhwc_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
     "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
+    "dream_allreduce_sum_f32": (_I, [_I, _c.POINTER(_I), _c.POINTER(_P), _SZ, _c.POINTER(_P)]),
+    "dream_allreduce_uses_rccl": (_I, [_I, _c.POINTER(_I)]),
     "dream_add_f32": (_I, [_P, _P, _P, _SZ, _P, _P]),
     "dream_stage_input_nhwc_f32": (_I, [_P, _P, _P] + [_I] * 7 + [_P, _P]),
     "dream_stage_input_bwd_f32": (_I, [_P, _P] + [_I] * 8 + [_P]),
@@ -104,6 +106,7 @@ _SIGNATURES = {
     "dream_mse_fwd_bwd_f32": (_I, [_P, _P, _P, _P, _P, _SZ, _D, _P]),
     "dream_normalize_u8_hwc_to_chw_f32": (_I, [_P, _P, _I, _I, _I, _c.POINTER(_F), _c.POINTER(_F), _P]),
     "dream_create_belief_maps_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_create_belief_maps_f64kps_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_smoothl1_fwd_bwd_f32": (_I, [_P, _P, _P, _P, _P, _SZ, _D, _P]),
     "dream_relu_bwd_f32": (_I, [_P, _P, _P, _SZ, _P]),
     "dream_maxpool2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -159,7 +162,7 @@ def check_symbols():
     unbound = [n for n in declared if n not in _SIGNATURES]
     if missing or unbound:
         raise HipLibraryError("missing exports %s / unbound %s" % (missing, unbound))
-    if handle.dream_hip_abi_version() != 1:
+    if handle.dream_hip_abi_version() != 2:
         raise HipLibraryError("ABI version mismatch")
     return declared
 
@@ -198,6 +201,12 @@ def device_tensor(t):
 def stream():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def stream_on(device):
+    """HIP stream the calling thread currently uses on ``device`` (a torch.device of type cuda)."""
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def cout_pad(cout):

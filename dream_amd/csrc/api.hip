@@ -2,6 +2,9 @@
 #include "common.h"
 #include "../../include/dream_hip.h"
 #include <string.h>
+#include <mutex>
+#include <set>
+#include <utility>
 
 char *dream_err_buf() {
     static thread_local char buf[DREAM_ERR_LEN] = {0};
@@ -20,5 +23,17 @@ extern "C" int dream_hip_device_name(int dev, char *buf, size_t buflen) {
     hipDeviceProp_t prop;
     DREAM_HIP_OK(hipGetDeviceProperties(&prop, dev));
     snprintf(buf, buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return 0;
+}
+
+int dream_allow_full_lds(const void *kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    DREAM_HIP_OK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return 0;
+    DREAM_HIP_OK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({dev, kernel});
     return 0;
 }

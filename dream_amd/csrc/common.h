@@ -26,6 +26,10 @@ char *dream_err_buf();            // thread-local, 512 bytes
         }                                                                   \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize (the full 160 KB of LDS) is a property of (device, kernel): set once per pair,
+// from whichever host thread launches the kernel on that device first (api.hip).  0 = ok, else the error text is set.
+int dream_allow_full_lds(const void *kernel);
+
 #define DREAM_LAUNCH_OK() DREAM_HIP_OK(hipGetLastError())
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -343,7 +343,6 @@ const Variant16 kVariants16[] = {
     {"f16x3 m2n2w4x2 prio", 256, 128, 352, 512, conv_f16x3_kernel<2, 2, 4, 2, 352, true>},
 };
 constexpr int kNum16 = 8;
-bool g_attr16[kNum16] = {};
 int g_forced16 = -1;
 
 void choose_tile16(int H, int W, int BM, int np_max, int lane_stride, int kext, bool even, int *th_out, int *tw_out) {
@@ -456,10 +455,7 @@ int launch16(const float *x, const unsigned *amax_in, const void *w_hi, const vo
     p.flags = flags;
     const size_t lds = ((size_t)2 * p.PH * p.PW + (size_t)4 * var.BN) * S16 * sizeof(_Float16);
     DREAM_REQUIRE(lds <= 160 * 1024, "LDS request %zu too large", lds);
-    if (!g_attr16[v]) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attr16[v] = true;
-    }
+    if (dream_allow_full_lds((const void *)var.kernel)) return 2;
     const dim3 grid((unsigned)(ceil_div((int)((size_t)B * p.tiles_x * p.tiles_y), 8) * 8), (unsigned)ceil_div(Cout, var.BN));
     hipLaunchKernelGGL(var.kernel, grid, dim3(var.threads), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();

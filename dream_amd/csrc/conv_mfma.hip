@@ -339,7 +339,6 @@ constexpr int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 constexpr int kNumSelectable = 11;         // variants a caller may force (the big-patch one is picked automatically)
 constexpr int kBigPatchVariant = 11;
 int g_forced_variant = -1;
-bool g_attr_set[kNumVariants] = {};
 
 // pixel tile: maximise useful rows per workgroup, then minimise the staged patch
 void choose_tile(int H, int W, int BM, int np_max, int lane_stride, int kext, bool even, int *th_out, int *tw_out) {
@@ -442,10 +441,7 @@ int launch_conv(const float *x, const float *w, const float *scale, const float 
 
     const size_t lds = ((size_t)p.PH * p.PW + 2 * (size_t)var.BN) * S * sizeof(float);
     DREAM_REQUIRE(lds <= 160 * 1024, "LDS request %zu too large", lds);
-    if (!g_attr_set[v]) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        g_attr_set[v] = true;
-    }
+    if (dream_allow_full_lds((const void *)var.kernel)) return 2;
     const dim3 grid((unsigned)(ceil_div((int)((size_t)B * p.tiles_x * p.tiles_y), 8) * 8), (unsigned)ceil_div(Cout, var.BN));
     hipLaunchKernelGGL(var.kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();

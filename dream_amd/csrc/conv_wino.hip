@@ -506,13 +506,9 @@ int g_max_workgroups = 0;     // test hook: cap on resident workgroups (0 = the 
 
 template <int NW, int MODE, int PAT = 0>
 int launch_wino(const WinoParams &p, void *stream) {
-    static bool attr_set = false;
     void (*kernel)(const WinoParams) = conv_wino_kernel<NW, MODE, PAT>;
     const size_t lds = (size_t)2 * VB * sizeof(float) + (size_t)512 * 16;          // V buffers + the offset table
-    if (!attr_set) {
-        DREAM_HIP_OK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    if (dream_allow_full_lds((const void *)kernel)) return 2;
     // persistent grid: as many workgroups as the 256 CUs hold at once (2 of the 4-wave, 1 of the 8-wave kind per CU), a
     // multiple of 8 (XCDs), split over the output-channel blocks; fewer when there are fewer tile blocks than that
     const int ny = (p.Cout + 16 * NW - 1) / (16 * NW);

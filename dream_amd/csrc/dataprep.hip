@@ -88,8 +88,14 @@ extern "C" int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float
 }
 
 // kps: [N,2] (x, y) FLOAT64 device (the reference truncates the float64 coordinate); blob: [(2w+1)^2] fp32 device (host-computed, see above); out: [N,H,W]
-extern "C" int dream_create_belief_maps_f32(const double *kps, const float *blob, float *out, int N, int H, int W, int w,
-                                            void *stream) {
+extern "C" int dream_create_belief_maps_f32(const float *, const float *, float *, int, int, int, int, void *) {
+    DREAM_REQUIRE(false, "dream_create_belief_maps_f32 (fp32 keypoints, ABI 1) was withdrawn: pass float64 keypoints to "
+                         "dream_create_belief_maps_f64kps_f32");
+    return 1;
+}
+
+extern "C" int dream_create_belief_maps_f64kps_f32(const double *kps, const float *blob, float *out, int N, int H, int W, int w,
+                                                   void *stream) {
     DREAM_REQUIRE(kps && blob && out && N > 0 && H > 0 && W > 0 && w >= 0, "create_belief_maps: bad arguments");
     hipLaunchKernelGGL(belief_maps_kernel, dim3(sgrid((size_t)N * H * W)), dim3(256), 0, (hipStream_t)stream, kps, blob, out, N, H,
                        W, w);

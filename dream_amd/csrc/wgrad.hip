@@ -257,17 +257,16 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *part, fl
 struct WgradVariant {
     void (*kernel)(WgradParams);
     int RW, CW, NT, PIX;
-    bool attr_set;
 };
 // NT is the EXACT tap count of a launch (no runtime tap test inside the k-loop)
 WgradVariant g_wvariants[] = {
-    {wgrad_kernel<1, 1, 9, 128>, 64, 64, 9, 128, false},     // 0: 3x3 convs
-    {wgrad_kernel<2, 1, 4, 64>, 128, 64, 4, 64, false},      // 1: transposed-conv phase with 4 taps
-    {wgrad_kernel<2, 2, 1, 64>, 128, 128, 1, 64, false},     // 2: 1x1 convs / 1-tap phase, >= 128 x 128
-    {wgrad_kernel<1, 1, 4, 128>, 64, 64, 4, 128, false},     // 3: 4-tap phase, < 128 rows
-    {wgrad_kernel<2, 1, 2, 64>, 128, 64, 2, 64, false},      // 4: 2-tap phase (k = 3 transposed conv)
-    {wgrad_kernel<1, 1, 2, 128>, 64, 64, 2, 128, false},     // 5: 2-tap phase, < 128 rows
-    {wgrad_kernel<1, 1, 1, 128>, 64, 64, 1, 128, false},     // 6: 1 tap, small
+    {wgrad_kernel<1, 1, 9, 128>, 64, 64, 9, 128},     // 0: 3x3 convs
+    {wgrad_kernel<2, 1, 4, 64>, 128, 64, 4, 64},      // 1: transposed-conv phase with 4 taps
+    {wgrad_kernel<2, 2, 1, 64>, 128, 128, 1, 64},     // 2: 1x1 convs / 1-tap phase, >= 128 x 128
+    {wgrad_kernel<1, 1, 4, 128>, 64, 64, 4, 128},     // 3: 4-tap phase, < 128 rows
+    {wgrad_kernel<2, 1, 2, 64>, 128, 64, 2, 64},      // 4: 2-tap phase (k = 3 transposed conv)
+    {wgrad_kernel<1, 1, 2, 128>, 64, 64, 2, 128},     // 5: 2-tap phase, < 128 rows
+    {wgrad_kernel<1, 1, 1, 128>, 64, 64, 1, 128},     // 6: 1 tap, small
 };
 int g_wgrad_forced = -1;          // A/B switch (dream_wgrad_set_variant)
 
@@ -286,8 +285,8 @@ struct WgradGeom {
 };
 
 // Blocking for a launch of `ntaps` taps (exact): wide tiles when both dW dimensions fill them.
-int pick_wvariant(int ntaps, int Cp, int RowsPad) {
-    const bool rows128 = RowsPad >= 128 && g_wgrad_forced != 0;
+int pick_wvariant(int ntaps, int Cp, int RowsPad, int forced) {
+    const bool rows128 = RowsPad >= 128 && forced != 0;
     switch (ntaps) {
     case 9: return 0;
     case 4: return rows128 ? 1 : 3;
@@ -323,8 +322,8 @@ void choose_tile_w(const WgradGeom &g, int pix, int *th_out, int *tw_out) {
     *tw_out = btw;
 }
 
-int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
-    const int v = pick_wvariant(g.group[main_group(g)].ntaps, Cp, RowsPad);
+int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad, int forced) {
+    const int v = pick_wvariant(g.group[main_group(g)].ntaps, Cp, RowsPad, forced);
     if (v < 0) return 1;
     const WgradVariant &var = g_wvariants[v];
     int th, tw;
@@ -341,15 +340,13 @@ int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad) {
 }
 
 size_t wgrad_workspace_bytes(int B, const WgradGeom &g, int Cp, int RowsPad) {
-    // the A/B switch may change the split: size for the larger of the two
-    const int saved = g_wgrad_forced;
+    // the A/B switch may change the split: size for the larger of the two (the switch is passed down as an argument --
+    // replicas of the single-process data-parallel path call in here concurrently, nothing global may be touched)
     int sk = 0;
     for (int f = -1; f <= 0; ++f) {
-        g_wgrad_forced = f;
-        const int s = pick_splitk_g(B, g, Cp, RowsPad);
+        const int s = pick_splitk_g(B, g, Cp, RowsPad, f);
         sk = s > sk ? s : sk;
     }
-    g_wgrad_forced = saved;
     return ((size_t)sk * g.ntaps * RowsPad * Cp + (size_t)(sk + 1) * RowsPad) * sizeof(float);
 }
 
@@ -363,12 +360,13 @@ int launch_wgrad(const float *tile_t, const float *patch_t, float *dw_packed, fl
     p.Ct = Ct; p.Cp = Cp; p.RowsPad = RowsPad; p.flags = flags;
     p.in_scale = g.in_scale; p.in_step = g.in_step; p.lane_stride = g.lane_stride;
     p.ntaps_total = g.ntaps;
-    p.splitk = pick_splitk_g(B, g, Cp, RowsPad);       // one split for all groups: they share the partial buffer
+    const int forced = g_wgrad_forced;                  // read once: the A/B hook may flip it while a launch is being set up
+    p.splitk = pick_splitk_g(B, g, Cp, RowsPad, forced);   // one split for all groups: they share the partial buffer
     p.part = (float *)workspace;
     float *bias_part = p.part + (size_t)p.splitk * g.ntaps * RowsPad * Cp;
     for (int gi = 0; gi < g.ngroups; ++gi) {
         const TapGroup &tg = g.group[gi];
-        const int v = pick_wvariant(tg.ntaps, Cp, RowsPad);
+        const int v = pick_wvariant(tg.ntaps, Cp, RowsPad, forced);
         DREAM_REQUIRE(v >= 0, "wgrad: no blocking for a %d-tap launch", tg.ntaps);
         WgradVariant &var = g_wvariants[v];
         choose_tile_w(g, var.PIX, &p.TH, &p.TW);
@@ -379,10 +377,7 @@ int launch_wgrad(const float *tile_t, const float *patch_t, float *dw_packed, fl
         p.tiles_total = B * p.tiles_x * p.tiles_y;
         const size_t lds = ((size_t)var.PIX * var.RW + (size_t)p.PH * p.PW * var.CW) * sizeof(float);
         DREAM_REQUIRE(lds <= 160 * 1024, "wgrad: LDS request %zu too large", lds);
-        if (!var.attr_set) {
-            DREAM_HIP_OK(hipFuncSetAttribute((const void *)var.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            var.attr_set = true;
-        }
+        if (dream_allow_full_lds((const void *)var.kernel)) return 2;
         p.nrb = ceil_div(RowsPad, var.RW); p.ncb = ceil_div(Cp, var.CW);
         const dim3 grid((unsigned)(p.nrb * p.ncb * ceil_div(p.splitk, 8) * 8));
         p.pad_y = tg.pad_y; p.pad_x = tg.pad_x; p.ntaps = tg.ntaps;

@@ -536,12 +536,7 @@ extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float
         p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)pl.TX - 1) / (unsigned long long)pl.TX;
         p.tiles_per_split = pl.tiles_per_split;
         p.ncog = Cout / 64;
-        static bool attr_set = false;
-        if (!attr_set) {
-            DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_wino_lds_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            DREAM_HIP_OK(hipFuncSetAttribute((const void *)wgrad_wino_lds_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set = true;
-        }
+        if (dream_allow_full_lds((const void *)wgrad_wino_lds_kernel<false>) || dream_allow_full_lds((const void *)wgrad_wino_lds_kernel<true>)) return 2;
         const dim3 grid((unsigned)(p.ncog * (Cin / 64)), (unsigned)pl.nsplit);
         if (ups) hipLaunchKernelGGL(wgrad_wino_lds_kernel<true>, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(wgrad_wino_lds_kernel<false>, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);

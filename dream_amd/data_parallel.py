@@ -4,25 +4,32 @@ device_ids=gpu_ids).cuda()`` does for the reference (/root/reference/dream/netwo
 
   * PERSISTENT replicas.  nn.DataParallel re-broadcasts every parameter to every device on every forward (88.9 - 220 MB x 7
     peers) and re-creates the replica modules each call.  Here every listed device keeps its own copy of the
-    model; all parameters of a copy are views into ONE flat buffer, so a refresh after an optimizer step or a
-    ``load_state_dict`` is one device-to-device copy per replica over xGMI -- and it only happens when a parameter's version
-    counter moved.
+    model; all parameters of a copy are views into ONE flat buffer.
   * The batch is split into contiguous chunks of dim 0 (``Tensor.chunk``, as ``DataParallel.scatter`` does); every chunk
     runs forward (and backward) on its device from its own host thread; belief maps are concatenated on ``device_ids[0]``
     in the original order, keypoints of ``DreamNetwork.inference`` are extracted on each device and concatenated on the host.
   * Training: one autograd node for the whole data-parallel network.  Its backward scatters dL/d(maps), runs every replica's
-    backward plan, packs each replica's parameter gradients into the flat layout, moves the flat buffers to ``device_ids[0]``
-    (peer copies, one per replica, each on its own xGMI link), sums them there and hands views of the sum to autograd, so the
-    optimizer sees one contiguous gradient buffer (a single Adam launch, dream_amd/optim.py).  BatchNorm: per-replica batch
-    statistics, running statistics kept by replica 0 = the module whose ``state_dict()`` callers save -- as DataParallel.
+    backward plan, packs each replica's parameter gradients into that replica's flat gradient buffer (same layout as the flat
+    parameter buffer) and sums the buffers in place with ONE RCCL all-reduce over xGMI (ops.allreduce_sum_ ->
+    csrc/collective.hip: ncclCommInitAll group of the listed devices).  Autograd receives views of the master's (summed)
+    buffer, so the optimizer sees one contiguous gradient buffer: a single Adam launch on the master -- and, through
+    ``step_replicas``, the identical single launch on every replica with that replica's own copy of the summed gradients and
+    its own moment buffers.  No gather on GPU 0, no parameter copy after the step: the replicas stay identical because
+    they apply the same update to the same numbers.  (An optimizer that is not dream_amd's leaves the replicas stale; the
+    version stamp notices and they are refreshed by one flat peer copy each.)  BatchNorm: per-replica batch statistics,
+    running statistics kept by replica 0 = the module whose ``state_dict()`` callers save -- as DataParallel.
+  * The host is off the critical path: a replica's launch sequence for one input shape -- ~1 700 launches for a ResNet-101
+    training step, each a Python ``torch.empty`` + ctypes call under the GIL, 30 ms of host time per replica-step -- is
+    captured into hipGraphs the second time the shape is seen (forward graph, backward graph, one memory pool) and replayed
+    from then on: per replica and step the GIL is held for two graph launches and the input copies.  Weight packing runs inside
+    the training graphs (weights change every step), evaluation graphs are keyed on the parameter versions.
   * Under torchrun (LOCAL_RANK set, one process per GPU -- the path bench.py uses for N > 1) the wrapper is a pass-through and
     the gradient exchange is the bucketed RCCL all-reduce inside the model's own autograd node (dream_amd/models.py).
-
-The host side is Python threads: kernel launches go through ctypes, which releases the GIL for the duration of the call.
 """
 import copy
 import os
 import threading
+import weakref
 from concurrent.futures import ThreadPoolExecutor
 
 import torch
@@ -97,11 +104,43 @@ def flat_is_intact(module):
     return all(p.data_ptr() == base + 4 * o for p, o in zip(rec["param_list"], lay.offsets))
 
 
-def _version_stamp(module):
+def reset_weight_caches(module):
+    """Drop every packed / folded copy of the weights a model keeps for the kernels (they are rebuilt on first use)."""
+    from . import models
+    for m in module.modules():
+        if "_packed" in m.__dict__:
+            m._packed = models._PackedCache()
+        for name in ("_cache", "_aux"):
+            if name in m.__dict__:
+                setattr(m, name, {})
+
+
+def _param_stamp(module):
     rec = module._dream_flat
-    return (sum(p._version for p in rec["param_list"]),
-            sum(m._buffers[n]._version for m, n in rec["buffer_list"]),
-            rec["params"].data_ptr())
+    return (sum(p._version for p in rec["param_list"]), rec["params"].data_ptr())
+
+
+def _buffer_stamp(module):
+    rec = module._dream_flat
+    return sum(m._buffers[n]._version for m, n in rec["buffer_list"])
+
+
+def _settings(module):
+    return tuple(getattr(module, a, None) for a in ("precision", "conv_algorithm", "conv1x1_algorithm", "convT_algorithm"))
+
+
+class _Busy:
+    """Token of a captured training forward whose backward has not run yet (the saved activations live in the graph's pool:
+    a second forward of the same graph would overwrite them).  Released by the backward or when autograd drops the context."""
+
+    def __init__(self, entry):
+        self.entry = entry
+        entry["busy"] = True
+        weakref.finalize(self, _Busy._release, entry)
+
+    @staticmethod
+    def _release(entry):
+        entry["busy"] = False
 
 
 class _DataParallelFunction(torch.autograd.Function):
@@ -125,6 +164,8 @@ class DreamDataParallel(nn.Module):
     ``state_dict()`` keys, ``device_ids`` (None / empty = every visible device), input on ``device_ids[0]``, outputs gathered
     on ``device_ids[0]``."""
 
+    _capture_lock = threading.Lock()              # hipGraph captures are taken one at a time, process-wide
+
     def __init__(self, module, device_ids=None):
         super().__init__()
         self.module = module
@@ -132,8 +173,14 @@ class DreamDataParallel(nn.Module):
         object.__setattr__(self, "_replicas", [])         # modules for devices[1:] -- deliberately not registered
         object.__setattr__(self, "_devices", None)
         object.__setattr__(self, "_pool", None)
-        object.__setattr__(self, "_stamp", None)
+        object.__setattr__(self, "_pstamp", None)         # parameter / buffer versions of the master the replicas agree with
+        object.__setattr__(self, "_bstamp", None)
         object.__setattr__(self, "_lock", threading.Lock())
+        object.__setattr__(self, "_graphs", {})           # (replica index, key) -> captured launch sequence
+        object.__setattr__(self, "_reduced", 0)           # replicas whose flat gradient buffer holds this step's all-reduced sum
+        object.__setattr__(self, "_opt_state", {})        # replica index -> optimizer state buffers on that replica's device
+        # statistics of the last step (tests, bench): hipGraph replays / eager replica runs / captures
+        object.__setattr__(self, "stats", {"replays": 0, "eager": 0, "captures": 0, "param_copies": 0, "replica_steps": 0})
 
     # ---- devices ----------------------------------------------------------------------------------------------------------
     def devices(self):
@@ -157,6 +204,11 @@ class DreamDataParallel(nn.Module):
     def n_devices(self, batch):
         return max(1, min(len(self.devices()), int(batch)))
 
+    def use_graphs(self):
+        """Replica launch sequences as hipGraphs: real GPUs, more than one replica, not switched off (DREAM_DP_GRAPHS=0)."""
+        devs = self.devices()
+        return len(devs) > 1 and devs[0].type == "cuda" and os.environ.get("DREAM_DP_GRAPHS", "1") != "0"
+
     # ---- replicas ---------------------------------------------------------------------------------------------------------
     def flatten_parameters(self):
         """Called by DreamNetwork once the model sits on its device: parameters become views of one flat buffer."""
@@ -168,11 +220,17 @@ class DreamDataParallel(nn.Module):
     def _ensure_replicas(self, n):
         if not flat_is_intact(self.module):
             flatten_module_(self.module)
-            object.__setattr__(self, "_stamp", None)
+            self._invalidate()
         devs = self.devices()
         while len(self._replicas) < n - 1:
             dev = devs[len(self._replicas) + 1]
-            rep = copy.deepcopy(self.module)
+            # the master's packed weight copies and its flat record stay with the master: a replica builds its own on its device
+            memo = {id(v): None for m in self.module.modules()
+                    for v in (m.__dict__.get("_packed"), m.__dict__.get("_cache"), m.__dict__.get("_aux"), m.__dict__.get("_dream_flat"))
+                    if v is not None}
+            rep = copy.deepcopy(self.module, memo)
+            rep.__dict__.pop("_dream_flat", None)
+            reset_weight_caches(rep)
             if dev.type == "cuda":
                 with torch.cuda.device(dev):
                     rep = rep.to(dev)
@@ -180,32 +238,47 @@ class DreamDataParallel(nn.Module):
             for prm in rep.parameters():
                 prm.requires_grad_(False)
             self._replicas.append(rep)
-            object.__setattr__(self, "_stamp", None)
+            self._invalidate()
         if self._pool is None and n > 1 and devs[0].type == "cuda":
             object.__setattr__(self, "_pool", ThreadPoolExecutor(max_workers=len(devs) - 1, thread_name_prefix="dream-dp"))
 
+    def _invalidate(self):
+        object.__setattr__(self, "_pstamp", None)
+        object.__setattr__(self, "_bstamp", None)
+        self._graphs.clear()
+        self._opt_state.clear()
+
     def _sync_replicas(self, n):
-        """Refresh the replicas from the master when a parameter / buffer changed: one flat copy each."""
-        stamp = _version_stamp(self.module)
+        """Bring the replicas in line with the master where they are not: parameters by one flat peer copy each (only when
+        something other than dream_amd's optimizers changed them: load_state_dict, a foreign optimizer, manual edits);
+        BatchNorm running statistics by one small copy each, and only for evaluation (training uses batch statistics)."""
         for rep in self._replicas[:n - 1]:
             rep.train(self.module.training)
-            for attr in ("precision", "conv_algorithm"):
+            for attr in ("precision", "conv_algorithm", "conv1x1_algorithm", "convT_algorithm"):
                 if hasattr(self.module, attr) and getattr(rep, attr) != getattr(self.module, attr):
                     setattr(rep, attr, getattr(self.module, attr))
-        if stamp == self._stamp:
-            return
         src = self.module._dream_flat
-        with torch.no_grad():
-            for rep in self._replicas:
-                dst = rep._dream_flat
-                dst["params"].copy_(src["params"], non_blocking=True)
-                for prm in dst["param_list"]:
-                    ops.bump_version(prm)
-                if src["buffers"] is not None:
-                    dst["buffers"].copy_(src["buffers"], non_blocking=True)
-                    for m, name in dst["buffer_list"]:
-                        ops.bump_version(m._buffers[name])
-        object.__setattr__(self, "_stamp", stamp)
+        pstamp = _param_stamp(self.module)
+        if pstamp != self._pstamp:
+            with torch.no_grad():
+                for rep in self._replicas:
+                    dst = rep._dream_flat
+                    dst["params"].copy_(src["params"], non_blocking=True)
+                    for prm in dst["param_list"]:
+                        ops.bump_version(prm)
+            self.stats["param_copies"] += len(self._replicas)
+            self._opt_state.clear()                         # replica moments belong to the parameter history that just ended
+            object.__setattr__(self, "_pstamp", pstamp)
+        if src["buffers"] is not None and not self.module.training:
+            bstamp = _buffer_stamp(self.module)
+            if bstamp != self._bstamp:
+                with torch.no_grad():
+                    for rep in self._replicas:
+                        dst = rep._dream_flat
+                        dst["buffers"].copy_(src["buffers"], non_blocking=True)
+                        for m, name in dst["buffer_list"]:
+                            ops.bump_version(m._buffers[name])
+                object.__setattr__(self, "_bstamp", bstamp)
 
     def train(self, mode=True):
         super().train(mode)
@@ -234,21 +307,109 @@ class DreamDataParallel(nn.Module):
         chunks = x.chunk(n, dim=0)
         return [c.contiguous() if d == x.device else c.to(d, non_blocking=True) for c, d in zip(chunks, devs)]
 
-    def _forward_shards(self, x, save, post=None):
+    # ---- one replica's forward / backward, eager or as hipGraph replay ------------------------------------------------------
+    def _graph_key(self, x, save, post_key):
+        rep0 = self.module
+        key = (tuple(x.shape), bool(save), bool(rep0.training), _settings(rep0), post_key)
+        if not (rep0.training and save):
+            # evaluation-type graphs read packed weights that were built outside the graph: valid for these versions only
+            key += (_param_stamp(rep0), _buffer_stamp(rep0) if rep0._dream_flat["buffers"] is not None else 0)
+        return key
+
+    def _replica_forward(self, i, x, save, post, post_key):
+        """-> (outputs (+ post result), context for _replica_backward)."""
+        rep = self._replica(i)
+        if not self.use_graphs():
+            return self._eager_forward(rep, x, save, post)
+        key = self._graph_key(x, save, post_key)
+        entry = self._graphs.get((i, key))
+        if entry is None:
+            # evaluation graphs of older parameter versions can never be replayed again: drop them (and their memory pools)
+            for k in [k for k in self._graphs if k[0] == i and k[1][:5] == key[:5] and k[1] != key]:
+                del self._graphs[k]
+            entry = self._graphs[(i, key)] = {"seen": 0, "fwd": None, "bwd": None, "busy": False}
+        entry["seen"] += 1
+        if entry["fwd"] is None and (entry["seen"] < 2 or entry["busy"]):
+            self.stats["eager"] += 1
+            return self._eager_forward(rep, x, save, post)          # first sighting of this shape: run it as it comes
+        if entry["busy"]:
+            self.stats["eager"] += 1
+            return self._eager_forward(rep, x, save, post)          # its saved activations still await their backward
+        if entry["fwd"] is None:
+            self._capture_forward(entry, rep, x, save, post)
+        entry["x"].copy_(x, non_blocking=True)
+        entry["fwd"].replay()
+        for t in entry["bumps"]:
+            ops.bump_version(t)
+        self.stats["replays"] += 1
+        return entry["outs"], (("graph", entry, _Busy(entry)) if save else None)
+
+    @staticmethod
+    def _eager_forward(rep, x, save, post):
+        with torch.no_grad():
+            outs, c = rep.dp_forward(x, save)
+            return (outs + [post(outs)] if post is not None else outs), (("eager", c) if save else None)
+
+    def _capture_forward(self, entry, rep, x, save, post):
+        with DreamDataParallel._capture_lock, torch.no_grad():
+            if rep.training and save:
+                reset_weight_caches(rep)            # weights change every step: their packing belongs inside the graph
+            entry["x"] = x.clone()
+            torch.cuda.current_stream().synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with ops.log_bumps() as bumps, torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                outs, c = rep.dp_forward(entry["x"], save)
+                if post is not None:
+                    outs = outs + [post(outs)]
+            entry.update(fwd=graph, outs=outs, saved=c, bumps=list(bumps), pool=graph.pool())
+            self.stats["captures"] += 1
+
+    def _replica_backward(self, i, ctx, gos, gflat, offsets, numels):
+        """One replica's backward; its parameter gradients land in ``gflat`` (the replica's flat gradient buffer)."""
+        rep = self._replica(i)
+        with torch.no_grad():
+            if ctx[0] == "eager":
+                self._pack_grads(rep.dp_backward(ctx[1], gos), gflat, offsets, numels)
+                self.stats["eager"] += 1
+                return
+            entry = ctx[1]
+            if entry["bwd"] is None:
+                with DreamDataParallel._capture_lock:
+                    entry["gos"] = [None if g is None else g.clone() for g in gos]
+                    torch.cuda.current_stream().synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, pool=entry["pool"], capture_error_mode="thread_local"):
+                        self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels)
+                    entry.update(bwd=graph, gflat_ptr=gflat.data_ptr())
+                    self.stats["captures"] += 1
+            assert entry["gflat_ptr"] == gflat.data_ptr()
+            for s, g in zip(entry["gos"], gos):
+                if s is not None:
+                    s.copy_(g, non_blocking=True)
+            entry["bwd"].replay()
+            self.stats["replays"] += 1
+
+    @staticmethod
+    def _pack_grads(grads, gflat, offsets, numels):
+        views = [gflat[o:o + m].view_as(g) for o, m, g in zip(offsets, numels, grads)]
+        torch._foreach_copy_(views, [g.contiguous() for g in grads])
+
+    def _grad_buffer(self, i):
+        """Replica i's persistent flat gradient buffer (laid out like its flat parameter buffer; the padding stays zero)."""
+        rec = self._replica(i)._dream_flat
+        if rec.get("grads") is None or rec["grads"].device != rec["params"].device:
+            rec["grads"] = torch.zeros_like(rec["params"])
+        return rec["grads"]
+
+    # ---- the data-parallel step ---------------------------------------------------------------------------------------------
+    def _forward_shards(self, x, save, post=None, post_key=None):
         """-> (outs[i] = list of output tensors of replica i (+ post(outs) appended when given), ctxs, chunk sizes)."""
         with self._lock:
             n = self.n_devices(x.shape[0])
             self._ensure_replicas(n)
             self._sync_replicas(n)
             xs = self._scatter(x, n)
-
-            def job(i):
-                def run():
-                    with torch.no_grad():
-                        outs, c = self._replica(i).dp_forward(xs[i], save)
-                        return (outs + [post(outs)] if post is not None else outs), c
-                return run
-            res = self._run([job(i) for i in range(len(xs))])
+            res = self._run([(lambda i=i: self._replica_forward(i, xs[i], save, post, post_key)) for i in range(len(xs))])
         return [r[0] for r in res], [r[1] for r in res], [int(c.shape[0]) for c in xs]
 
     def _gather(self, outs, upto=None):
@@ -265,25 +426,63 @@ class DreamDataParallel(nn.Module):
         base = master_rec["params"].data_ptr()
         offsets = [(prm.data_ptr() - base) // 4 for prm in params]          # the gradient buffer mirrors the parameter buffer
         numels = [prm.numel() for prm in params]
-        total = master_rec["param_layout"].total
         splits = [g.split(sizes, dim=0) if g is not None else [None] * n for g in grad_outs]
+        flats = [self._grad_buffer(i) for i in range(n)]
 
         def job(i):
             def run():
-                with torch.no_grad():
-                    gos = [None if s[i] is None else (s[i].contiguous() if s[i].device == devs[i] else s[i].to(devs[i], non_blocking=True))
-                           for s in splits]
-                    grads = self._replica(i).dp_backward(ctxs[i], gos)
-                    flat = torch.zeros((total,), dtype=torch.float32, device=devs[i])
-                    views = [flat[o:o + m].view_as(g) for o, m, g in zip(offsets, numels, grads)]
-                    torch._foreach_copy_(views, [g.contiguous() for g in grads])
-                    return flat
+                gos = [None if s[i] is None else (s[i].contiguous() if s[i].device == devs[i] else s[i].to(devs[i], non_blocking=True))
+                       for s in splits]
+                self._replica_backward(i, ctxs[i], gos, flats[i], offsets, numels)
             return run
-        flats = self._run([job(i) for i in range(n)])
+        with self._lock:
+            self._run([job(i) for i in range(n)])
+            # ONE all-reduce(sum) over the replicas' flat gradient buffers, in place, ordered behind each replica's backward
+            # on that replica's stream (RCCL over xGMI for distinct GPUs; csrc/collective.hip)
+            if n > 1:
+                ops.allreduce_sum_(flats)
+            object.__setattr__(self, "_reduced", n)
         total_flat = flats[0]
-        for f in flats[1:]:                                                  # peer copy + add on device_ids[0]
-            ops.add_(total_flat, f if f.device == total_flat.device else f.to(total_flat.device, non_blocking=True))
         return [total_flat[o:o + m].view(prm.shape) for o, m, prm in zip(offsets, numels, params)]
+
+    # ---- optimizer hook: the identical update on every replica (dream_amd/optim.py) -------------------------------------------
+    def step_replicas(self, kind, flat_params, flat_grads, hyper, master_state):
+        """Called by HipAdam / HipSGD inside ``step()``, BEFORE the master's launch, with the slices of the master's flat
+        parameter / gradient buffers they are about to update: applies the same update -- one launch per replica on the
+        replica's device -- to the same slice of every replica's flat parameter buffer, with the replica's own copy of the
+        all-reduced gradients and its own moment buffers (created from the master's current moments).  -> True when every replica was
+        updated (the caller then confirms with ``mark_params_synced()`` after it bumped the master's versions)."""
+        n = self._reduced
+        object.__setattr__(self, "_reduced", 0)
+        mrec = self.module._dream_flat
+        if n <= 1 or n != len(self._replicas) + 1 or self._pstamp != _param_stamp(self.module) or mrec.get("grads") is None:
+            return False
+        lo, count = (flat_params.data_ptr() - mrec["params"].data_ptr()) // 4, int(flat_params.numel())
+        if not (0 <= lo and lo + count <= mrec["params"].numel() and flat_grads.data_ptr() == mrec["grads"].data_ptr() + 4 * lo
+                and int(flat_grads.numel()) == count):
+            return False                                    # the optimizer is not stepping on this network's flat buffers
+        devs = self.devices()
+        with torch.no_grad():
+            for i, rep in enumerate(self._replicas, 1):
+                rec = rep._dream_flat
+                p, g = rec["params"][lo:lo + count], rec["grads"][lo:lo + count]
+                dev = devs[i]
+                ctxm = torch.cuda.device(dev) if dev.type == "cuda" else _Null()
+                with ctxm:
+                    if kind == "adam":
+                        st = self._opt_state.get(i)
+                        if st is None or st[0].numel() != count:
+                            st = self._opt_state[i] = tuple(m.to(dev, copy=True) for m in master_state)
+                        ops.adam_step_(p, g, st[0], st[1], hyper["lr"], hyper["beta1"], hyper["beta2"], hyper["eps"], hyper["step"])
+                    else:
+                        ops.sgd_step_(p, g, hyper["lr"])
+                for prm in rec["param_list"]:
+                    ops.bump_version(prm)
+        self.stats["replica_steps"] += len(self._replicas)
+        return True
+
+    def mark_params_synced(self):
+        object.__setattr__(self, "_pstamp", _param_stamp(self.module))
 
     # ---- nn.Module interface ------------------------------------------------------------------------------------------------
     def forward(self, x, *args, **kwargs):
@@ -297,11 +496,20 @@ class DreamDataParallel(nn.Module):
             outs = self._gather(outs)
         return self.module.dp_finish(outs)
 
-    def inference_shards(self, x, post):
+    def inference_shards(self, x, post, post_key=None):
         """No-grad forward of every chunk on its device followed by ``post(outputs)`` on the same device (the peak
-        extraction of DreamNetwork.inference).  -> (outputs gathered on device_ids[0], [post result of each chunk])."""
-        outs, _, _ = self._forward_shards(x, save=False, post=post)
+        extraction of DreamNetwork.inference; ``post_key``: the settings ``post`` closes over, part of the hipGraph key).
+        -> (outputs gathered on device_ids[0], [post result of each chunk])."""
+        outs, _, _ = self._forward_shards(x, save=False, post=post, post_key=("post", post_key))
         return self._gather(outs, upto=len(outs[0]) - 1), [o[-1] for o in outs]
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def _distributed_world():

@@ -175,5 +175,5 @@ def create_belief_map_batch(image_resolution, keypoints_bk2, sigma=2):
     blob64 = np.exp(-((dx ** 2 + dy ** 2) / (2 * (sigma ** 2))))           # float64, as the reference computes it
     blob = torch.from_numpy(blob64.astype(np.float32)).to(kps.device)        # the .float() cast of the reference
     out = torch.empty((b, k, height, width), dtype=torch.float32, device=kps.device)
-    _hip.call("dream_create_belief_maps_f32", ops.ptr(kps), ops.ptr(blob), ops.ptr(out), b * k, height, width, w, ops.stream())
+    _hip.call("dream_create_belief_maps_f64kps_f32", ops.ptr(kps), ops.ptr(blob), ops.ptr(out), b * k, height, width, w, ops.stream())
     return out

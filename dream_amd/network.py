@@ -24,7 +24,7 @@ import torch
 from PIL import Image as PILImage
 
 from . import image_proc, models, ops
-from .optim import HipAdam, HipSGD, HipMSELoss, HipSmoothL1Loss
+from .optim import HipAdam, HipSGD, HipMSELoss, HipSmoothL1Loss, attach_data_parallel
 
 KNOWN_ARCHITECTURES = ["vgg", "resnet"]
 KNOWN_OPTIMIZERS = ["adam", "sgd"]
@@ -324,7 +324,8 @@ class DreamNetwork:
         if isinstance(dp, models.DreamDataParallel) and dp.n_devices(x.shape[0]) > 1 and not torch.is_grad_enabled():
             # embarrassingly parallel split: every GPU runs the CNN and the peak stage on its chunk; the maps are gathered
             # on device_ids[0] (the reference's return contract), the [b,K,2] keypoints meet on the host
-            heads, kps_chunks = dp.inference_shards(x, lambda outs: peaks(outs[-1]))
+            heads, kps_chunks = dp.inference_shards(x, lambda outs: peaks(outs[-1]), post_key=(
+                offset, bool(self.use_belief_peak_scores), float(self.belief_peak_next_best_score)))
             return heads[-1], torch.cat([k.cpu() for k in kps_chunks], dim=0)
         belief_maps_batch = self.model(x)[-1]
         return belief_maps_batch, peaks(belief_maps_batch)
@@ -392,6 +393,7 @@ class DreamNetwork:
                 assert "learning_rate" in tcfg["optimizer"], \
                     'Required key "learning_rate" in dictionary "optimizer" is missing to use the SGD optimizer.'
                 self.optimizer = HipSGD(params, lr=tcfg["optimizer"]["learning_rate"])
+            attach_data_parallel(self.optimizer, self.model)
         self.model.train()
 
     def enable_evaluation(self):

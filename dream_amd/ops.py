@@ -1,9 +1,12 @@
 """Thin functional layer over the C ABI: allocates outputs as torch tensors and forwards raw device
 pointers + the current HIP stream to libdream_hip.so.  No arithmetic happens in Python/ATen here."""
+import ctypes
+import threading
+
 import torch
 
 from . import _hip
-from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream
+from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream, stream_on
 
 CONV_ZEROSTUFF2X = 8
 CONV_POOL2 = 16
@@ -486,8 +489,27 @@ def bn_train_fwd(x_nhwc, bn, residual=None, relu=True):
     return y, mean, invstd
 
 
+_bump_log = threading.local()
+
+
+class log_bumps:
+    """Context manager: collects the tensors whose version is bumped inside it (a hipGraph capture of a training forward:
+    the replay writes BatchNorm's running statistics again, so the owner of the graph repeats the bumps after every replay)."""
+
+    def __enter__(self):
+        self.prev = getattr(_bump_log, "items", None)
+        _bump_log.items = []
+        return _bump_log.items
+
+    def __exit__(self, *exc):
+        _bump_log.items = self.prev
+
+
 def bump_version(t):
     """Tell autograd and the version-keyed caches that a kernel changed ``t`` in place through its raw pointer."""
+    log = getattr(_bump_log, "items", None)
+    if log is not None:
+        log.append(t)
     inc = getattr(torch.autograd.graph, "increment_version", None)
     if inc is not None:
         inc(t)
@@ -604,6 +626,27 @@ def maxpool3s2_bwd(dy, x):
 def add_(dst, src):
     call("dream_add_inplace_f32", ptr(dst), ptr(_f32(src)), dst.numel(), stream())
     return dst
+
+
+def allreduce_sum_(flats):
+    """In place: every tensor of ``flats`` -- one flat fp32 buffer per data-parallel replica, each on its replica's GPU, same
+    length -- becomes the element-wise sum of all of them (one RCCL all-reduce over xGMI for distinct GPUs, csrc/collective.hip).
+    Ordered on the stream the calling thread currently uses on each device."""
+    n = len(flats)
+    count = int(flats[0].numel())
+    for t in flats:
+        if t.dtype != torch.float32 or int(t.numel()) != count:
+            raise RuntimeError("allreduce_sum_: buffers must be float32 of equal length")
+    devs = (ctypes.c_int * n)(*[(t.device.index or 0) if t.is_cuda else 0 for t in flats])
+    bufs = (ctypes.c_void_p * n)(*[ptr(t) for t in flats])
+    streams = (ctypes.c_void_p * n)(*[stream_on(t.device) if t.is_cuda else None for t in flats])
+    call("dream_allreduce_sum_f32", n, devs, bufs, count, streams)
+    return flats
+
+
+def allreduce_uses_rccl(devices):
+    n = len(devices)
+    return bool(_hip.lib().dream_allreduce_uses_rccl(n, (ctypes.c_int * n)(*[int(d) for d in devices])))
 
 
 def add(a, b, want_amax=False):

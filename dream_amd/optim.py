@@ -69,6 +69,12 @@ def _flat_span(tensors):
     return flat, [o - lo for o in offs]
 
 
+def attach_data_parallel(optimizer, dp):
+    """DreamNetwork.enable_training: the optimizer of a single-process data-parallel network (dream_amd/data_parallel.py) applies
+    every step to the replicas as well (DreamDataParallel.step_replicas) instead of having them re-copied from the master."""
+    optimizer._dp = dp if hasattr(dp, "step_replicas") else None
+
+
 class _FlatStepMixin:
     """One kernel launch per optimizer step instead of one per tensor (46 for vgg_q, 318 for resnet_h): parameters that
     are views of one flat buffer are updated as that buffer; the gradients are used in place when they form the same layout
@@ -100,17 +106,40 @@ class HipAdam(_FlatStepMixin, torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
-    def _state_of(self, p, like_flat=None, off=0):
+    def _state_of(self, p):
         st = self.state[p]
         if not st:
             st["step"] = 0
-            if like_flat is None:
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            else:                                             # views of the flat moment buffers
-                st["exp_avg"] = like_flat[0][off:off + p.numel()].view(p.shape)
-                st["exp_avg_sq"] = like_flat[1][off:off + p.numel()].view(p.shape)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
         return st
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Optimizer.load_state_dict hands every parameter CLONES of the saved moments; the flat plan (whose
+        moment buffers are the source of truth of the one-launch step) is dropped so that the next step adopts them."""
+        super().load_state_dict(state_dict)
+        self._plan = None
+
+    def _adopt_moments(self, plan, params, offs):
+        """Build the flat moment buffers of ``plan``; per-parameter state that already exists (a resumed optimizer:
+        load_state_dict, or a re-plan after the parameters moved) is copied into them before the state is re-pointed at the
+        views.  -> False when the existing per-parameter step counts disagree (the per-tensor path keeps them apart)."""
+        flat = plan["span"][0]
+        steps = {int(self.state[p]["step"]) for p in params if self.state[p]}
+        if len(steps) > 1 or (steps and any(not self.state[p] for p in params)):
+            return False
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        for p, o in zip(params, offs):
+            st = self.state[p]
+            mv, vv = m[o:o + p.numel()].view(p.shape), v[o:o + p.numel()].view(p.shape)
+            if st:
+                mv.copy_(st["exp_avg"])
+                vv.copy_(st["exp_avg_sq"])
+            st["exp_avg"], st["exp_avg_sq"], st["flat"] = mv, vv, True
+            st.setdefault("step", 0)
+        plan["moments"] = (m, v)
+        plan["step"] = steps.pop() if steps else 0
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -119,25 +148,28 @@ class HipAdam(_FlatStepMixin, torch.optim.Optimizer):
             b1, b2 = group["betas"]
             params = group["params"]
             plan = self._flat_plan(params) if len(self.param_groups) == 1 and all(p.grad is not None for p in params) else None
-            if plan is not None and plan["span"] is not None and not any(self.state[p] and "flat" not in self.state[p] for p in params):
+            if plan is not None and plan["span"] is not None and "moments" not in plan and not plan.get("per_tensor"):
+                if not self._adopt_moments(plan, params, plan["span"][1]):
+                    plan["per_tensor"] = True
+            if plan is not None and plan["span"] is not None and "moments" in plan:
                 flat, offs = plan["span"]
-                if "moments" not in plan:
-                    plan["moments"] = (torch.zeros_like(flat), torch.zeros_like(flat))
-                    plan["step"] = 0
-                    for p, o in zip(params, offs):
-                        self._state_of(p, plan["moments"], o)["flat"] = True
                 plan["step"] += 1
-                ops.adam_step_(flat, self._flat_grad(plan, params), plan["moments"][0], plan["moments"][1], group["lr"], b1, b2,
-                               group["eps"], plan["step"])
+                grad = self._flat_grad(plan, params)
+                dp = getattr(self, "_dp", None)
+                replicas_stepped = dp is not None and grad is not plan["grad"] and dp.step_replicas(
+                    "adam", flat, grad, dict(lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], step=plan["step"]), plan["moments"])
+                ops.adam_step_(flat, grad, plan["moments"][0], plan["moments"][1], group["lr"], b1, b2, group["eps"], plan["step"])
                 for p in params:
                     self.state[p]["step"] = plan["step"]
                     _bump_version(p)
+                if replicas_stepped:
+                    dp.mark_params_synced()
                 continue
             for p in params:
                 if p.grad is None:
                     continue
                 st = self._state_of(p)
-                st["step"] += 1
+                st["step"] = int(st["step"]) + 1
                 ops.adam_step_(p.data, p.grad.contiguous(), st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2,
                                group["eps"], st["step"])
                 _bump_version(p)
@@ -155,9 +187,15 @@ class HipSGD(_FlatStepMixin, torch.optim.Optimizer):
             params = group["params"]
             plan = self._flat_plan(params) if len(self.param_groups) == 1 and all(p.grad is not None for p in params) else None
             if plan is not None and plan["span"] is not None:
-                ops.sgd_step_(plan["span"][0], self._flat_grad(plan, params), group["lr"])
+                grad = self._flat_grad(plan, params)
+                dp = getattr(self, "_dp", None)
+                replicas_stepped = dp is not None and grad is not plan["grad"] and dp.step_replicas(
+                    "sgd", plan["span"][0], grad, dict(lr=group["lr"]), None)
+                ops.sgd_step_(plan["span"][0], grad, group["lr"])
                 for p in params:
                     _bump_version(p)
+                if replicas_stepped:
+                    dp.mark_params_synced()
                 continue
             for p in params:
                 if p.grad is not None:

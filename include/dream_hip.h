@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DREAM_HIP_ABI_VERSION 1
+#define DREAM_HIP_ABI_VERSION 2
 
 /* conv flags */
 #define DREAM_CONV_RELU        1   /* fuse ReLU into the epilogue (reference: nn.ReLU(inplace) after the conv) */
@@ -259,7 +259,11 @@ int dream_softargmax_f32(const float *maps, const float *beta, float *scratch, f
  * blob = the (2w+1)^2 Gaussian window computed on the host exactly as the reference does, out [N,H,W]. */
 int dream_normalize_u8_hwc_to_chw_f32(const unsigned char *img, float *out, int B, int H, int W,
                                       const float *mean3, const float *stdev3, void *stream);
-int dream_create_belief_maps_f32(const double *kps, const float *blob, float *out, int N, int H, int W, int w,
+int dream_create_belief_maps_f64kps_f32(const double *kps, const float *blob, float *out, int N, int H, int W, int w,
+                                        void *stream);
+/* ABI 1 took fp32 keypoints under this name; fp32 cannot hold the reference's float64 coordinates (57.9999999 is pixel 57,
+ * its fp32 rounding pixel 58), so the entry point now FAILS with a message instead of reading fp32 data as float64. */
+int dream_create_belief_maps_f32(const float *kps, const float *blob, float *out, int N, int H, int W, int w,
                                  void *stream);
 /* Keypoint frames after peak extraction (dream/image_proc.py:135-147 convert_keypoints_to_netin_from_netout,
  * :215-260 convert_keypoints_to_raw_from_netin; call sites dream/network.py:480-488, dream/analysis.py:219-232):
@@ -344,6 +348,15 @@ int dream_channel_sum_nhwc_f32(const float *x, float *out, void *workspace, size
 int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
 /* dst += src (gradient accumulation where two branches meet) */
 int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream);
+
+/* ---- gradient exchange of the single-process data-parallel path (SURVEY.md 8b "allreduce_grads", 8e; what
+ * torch.nn.DataParallel's ReduceAddCoalesced + the next forward's parameter broadcast do for dream/network.py:244-256,335) ----
+ * bufs[i]: flat fp32 gradient buffer of replica i on GPU devices[i] (identical layout, `count` floats), streams[i]: the HIP
+ * stream replica i's backward was enqueued on.  Afterwards every buffer holds the element-wise sum, stream-ordered.  Distinct
+ * devices: ONE RCCL all-reduce over xGMI (ncclCommInitAll group, cached per device list).  A list that repeats one device
+ * (rehearsal of N replicas on one GPU) is summed locally.  dream_allreduce_uses_rccl: which of the two a list takes. */
+int dream_allreduce_sum_f32(int ndev, const int *devices, void *const *bufs, size_t count, void *const *streams);
+int dream_allreduce_uses_rccl(int ndev, const int *devices);
 /* out = a + b: the encoder skip tensors joining the decoder (`x_0_5 + x_0_4_d`, `y_0_5 + x_0_3_d`, ...,
  * dream/models.py:774-807).  amax_out (optional) receives the bit pattern of max|out| for the split-precision kernel. */
 int dream_add_f32(const float *a, const float *b, float *out, size_t n, unsigned *amax_out, void *stream);

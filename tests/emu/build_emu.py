@@ -22,7 +22,7 @@ def build(force=False):
            "-Wno-unused-value", "-Wno-psabi", "-Wno-gnu-anonymous-struct", "-Wno-vla-cxx-extension",
            "-I", HERE, "-I", csrc, os.path.join(HERE, "emu_runtime.cpp")]
     cmd += sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".hip"))   # each its own TU
-    cmd += ["-o", OUT]
+    cmd += ["-ldl", "-o", OUT]
     subprocess.check_call(cmd)
     return OUT
 

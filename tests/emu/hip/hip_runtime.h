@@ -89,6 +89,14 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char *hipGetErrorString(hipError_t) { return "emulator"; }
 inline hipError_t hipFuncSetAttribute(const void *, int, int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *c) { *c = 0; return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+typedef void *hipEvent_t;
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     strcpy(p->name, "SIMT emulator"); strcpy(p->gcnArchName, "host"); p->multiProcessorCount = 0; return hipSuccess;
 }

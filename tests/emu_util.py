@@ -24,7 +24,7 @@ def load_emulated_lib():
 def emulated_hip():
     from dream_amd import _hip, ops
     handle = load_emulated_lib()
-    saved = (_hip._lib, _hip.ptr, _hip.stream, ops.ptr, ops.stream, _hip.device_tensor)
+    saved = (_hip._lib, _hip.ptr, _hip.stream, ops.ptr, ops.stream, _hip.device_tensor, _hip.stream_on, ops.stream_on)
 
     def cpu_ptr(t):
         if t is None:
@@ -35,8 +35,9 @@ def emulated_hip():
     _hip._lib = handle
     _hip.ptr = ops.ptr = cpu_ptr
     _hip.stream = ops.stream = lambda: None
+    _hip.stream_on = ops.stream_on = lambda device: None
     _hip.device_tensor = lambda t: t
     try:
         yield handle
     finally:
-        _hip._lib, _hip.ptr, _hip.stream, ops.ptr, ops.stream, _hip.device_tensor = saved
+        _hip._lib, _hip.ptr, _hip.stream, ops.ptr, ops.stream, _hip.device_tensor, _hip.stream_on, ops.stream_on = saved

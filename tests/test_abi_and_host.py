@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     declared = _hip.check_symbols()
     assert len(declared) >= 30 and "dream_conv3x3_nhwc_f32" in declared
     assert set(declared) == set(_hip._SIGNATURES.keys())
-    assert _hip.lib().dream_hip_abi_version() == 1
+    assert _hip.lib().dream_hip_abi_version() == 2
     assert _hip.lib().dream_conv3x3_num_variants() == 11  # selectable; one more (big-patch) variant is automatic
 
 

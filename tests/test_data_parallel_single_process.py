@@ -2,7 +2,9 @@
 reference's torch.nn.DataParallel at dream/network.py:244-256) with two EMULATED devices -- replicas on CPU tensors, kernels
 under the SIMT emulator.  Checked: chunks are processed by different persistent replicas, inference results equal the
 single-device ones bit for bit and in order, a training step equals the single-device step on the whole batch, the replicas are
-refreshed after the optimizer step (one flat copy), the optimizer runs as ONE launch on the flat buffers."""
+kept identical by applying the optimizer's ONE flat launch on every replica to the all-reduced gradients (no parameter copy
+after a step), a foreign optimizer is noticed and repaired by one flat copy, HipAdam resumes from a saved state."""
+import copy
 import os
 
 import numpy as np
@@ -87,14 +89,18 @@ def test_training_step_equals_the_single_device_step(emu, two_devices, monkeypat
     base = grads[0].untyped_storage().data_ptr()
     assert all(g.untyped_storage().data_ptr() == base for g in grads)
     n_param = sum(p.numel() for p in net.model.parameters())
-    assert len(launches) == 1 and n_param <= launches[0] <= net.model.module._dream_flat["params"].numel()
-    # the replica was refreshed after each step
+    # one launch on the master and the identical launch on the replica
+    assert len(launches) == 2 and launches[0] == launches[1] and n_param <= launches[0] <= net.model.module._dream_flat["params"].numel()
+    # the replica applied the same update to the same (all-reduced) gradients: identical without any copy from the master
     rep = net.model._replicas[0]
+    copies = net.model.stats["param_copies"]
+    assert copies == 1 and net.model.stats["replica_steps"] == 1            # the one copy: creation of the replica
     for (k, a), (_, b) in zip(net.model.module.named_parameters(), rep.named_parameters()):
         assert a.data_ptr() != b.data_ptr()
-    net.model._sync_replicas(2)
-    for (k, a), (_, b) in zip(net.model.module.named_parameters(), rep.named_parameters()):
         assert torch.equal(a, b), k
+    assert torch.equal(net.model.module._dream_flat["grads"], rep._dream_flat["grads"])
+    net.model._sync_replicas(2)
+    assert net.model.stats["param_copies"] == copies
     os.environ["DREAM_DP_EMULATED_DEVICES"] = "0"
     del launches[:]
     single = _net("vgg_q", lr=1e-5, opt="adam")
@@ -129,3 +135,65 @@ def test_device_resolution_rules(monkeypatch):
     dp = models.DreamDataParallel(torch.nn.Linear(2, 2), device_ids=[3, 1])
     assert dp.device_ids == [3, 1]                                                  # kept as given (reference attribute)
     assert dp.n_devices(1) == 1
+
+
+def test_four_replicas_stay_identical_over_steps_and_match_one_device(emu, monkeypatch):
+    monkeypatch.setenv("DREAM_DP_EMULATED_DEVICES", "4")
+    x = torch.from_numpy(cases.image_batch(4, 32, 32, seed=5))
+    t = torch.from_numpy(cases.target_batch(4, 7, (8, 8), in_wh=(32, 32), seed=5))
+    net = _net("vgg_q", lr=1e-5, opt="adam")
+    net.enable_training()
+    reduced = []
+    real = ops.allreduce_sum_
+    monkeypatch.setattr(ops, "allreduce_sum_", lambda flats: (reduced.append(len(flats)), real(flats))[1])
+    losses = [net.train([x], t).item() for _ in range(2)]
+    dp = net.model
+    assert len(dp._replicas) == 3 and reduced == [4, 4]                 # ONE all-reduce over the four flat buffers per step
+    assert dp.stats["param_copies"] == 3 and dp.stats["replica_steps"] == 6
+    for rep in dp._replicas:
+        assert torch.equal(rep._dream_flat["params"], dp.module._dream_flat["params"])
+    os.environ["DREAM_DP_EMULATED_DEVICES"] = "0"
+    single = _net("vgg_q", lr=1e-5, opt="adam")
+    single.enable_training()
+    losses1 = [single.train([x], t).item() for _ in range(2)]
+    assert np.allclose(losses, losses1, rtol=2e-6), (losses, losses1)
+    for (k, a), (_, b) in zip(net.model.named_parameters(), single.model.named_parameters()):
+        assert float((a - b).abs().max()) <= 1e-7 + 2e-5 * float(b.abs().max()), k
+
+
+def test_foreign_optimizer_is_repaired_by_a_flat_copy(emu, two_devices):
+    x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=6))
+    t = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=6))
+    net = _net("vgg_q", lr=1e-6, opt="sgd")
+    net.enable_training()
+    net.optimizer = torch.optim.SGD(net.model.parameters(), lr=1e-6)       # not dream_amd's: knows nothing about replicas
+    net.train([x], t)
+    dp = net.model
+    rep = dp._replicas[0]
+    assert dp.stats["replica_steps"] == 0
+    assert not torch.equal(rep._dream_flat["params"], dp.module._dream_flat["params"])
+    before = dp.stats["param_copies"]
+    net.train([x], t)                                                    # the next forward notices the version stamp
+    assert dp.stats["param_copies"] == before + 1
+
+
+def test_adam_resumes_from_a_saved_state_bit_for_bit(emu):
+    """SURVEY.md 8f rank 4 (resume incl. optimizer state): two continuous steps == one step, optimizer.state_dict() ->
+    a fresh network + optimizer -> load_state_dict, one more step."""
+    x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=7))
+    t = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=7))
+    a = _net("vgg_q", lr=1e-3, opt="adam")
+    a.enable_training()
+    a.train([x], t)
+    model_sd = {k: v.clone() for k, v in a.model.state_dict().items()}
+    opt_sd = copy.deepcopy(a.optimizer.state_dict())
+    a.train([x], t)
+    b = _net("vgg_q", lr=1e-3, opt="adam")
+    b.model.load_state_dict(model_sd)
+    b.enable_training()
+    b.optimizer.load_state_dict(opt_sd)
+    b.train([x], t)
+    for (k, pa), (_, pb) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        assert torch.equal(pa, pb), k
+    st = b.optimizer.state[next(iter(b.model.parameters()))]
+    assert int(st["step"]) == 2 and st["exp_avg"].abs().sum() > 0

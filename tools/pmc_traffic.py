@@ -6,9 +6,17 @@ Usage: python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE/*.db gpurun_out/pmc
 gfx950 correction (MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE counts 128-B requests as 64 B, so the raw
 value is doubled; the max-pool kernel (pure streaming, algorithmic bytes known exactly) is reported beside it as the
 calibration of that rule on this run."""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+
+def bench_py_sha():
+    """bench.py reports roofline.traffic from this summary only when it was measured with the same bench.py."""
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
 
 B = 128
 # vgg_q at 400x400: (cin, cout, H) per MFMA conv launch, pooled = 2x2 max-pool fused into the store
@@ -54,7 +62,7 @@ def main():
     pool_alg = 4.0 * B * (100 * 100 * 256 + 50 * 50 * 512) * (npool / 2.0)
     if len(sys.argv) > 4:                                   # generic mode: just the per-family totals of another workload
         fams = sys.argv[4].split(",")
-        out_d = {"command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py " + " ".join(sys.argv[5:]),
+        out_d = {"bench_py_sha": bench_py_sha(), "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py " + " ".join(sys.argv[5:]),
                  "units": "GB per profiled run; FETCH_SIZE doubled per the gfx950 rule", "families": {}}
         for fam in fams:
             n1, b1 = family(fetch, fam)
@@ -66,8 +74,9 @@ def main():
         print(json.dumps(out_d["families"], indent=1))
         return
     res = {
+        "bench_py_sha": bench_py_sha(),
         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
-                   "--no-cpu-baseline --no-split-leg (one PMC counter per run)",
+                   "--no-cpu-baseline --no-split-leg --no-secondary (one PMC counter per run)",
         "workload": "DREAM-vgg-Q inference B=128 400x400",
         "units": "counters are KiB; FETCH_SIZE doubled per the gfx950 rule (see calibration)",
         "calibration_maxpool2_kernel": {"dispatches": npool, "fetch_gb_raw": pool_fetch / 1e9,
