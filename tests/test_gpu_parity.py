@@ -715,6 +715,73 @@ def test_single_process_data_parallel_resnet_batchnorm_semantics():
     assert torch.equal(dp.model.module.bn1.running_mean, halves[0][2].model.module.bn1.running_mean)
 
 
+def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch):
+    """gpu_ids = [0, 0, 0, 0]: from the second sighting of a shape every replica's forward and backward run as hipGraph
+    replays (dream_amd/data_parallel.py).  Three ResNet training steps (eager, capture + replay, replay) must equal the same
+    steps with DREAM_DP_GRAPHS=0 bit for bit -- same kernels, same order --, the replicas must stay identical to the master
+    without a parameter copy, and a replayed step must hold the host (the GIL) for a fraction of an eager step's enqueue time."""
+    import time
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(8, 64, 64, seed=41)).to(DEV)
+
+    def run(graphs):
+        monkeypatch.setenv("DREAM_DP_GRAPHS", "1" if graphs else "0")
+        net = _dp_network("resnet_h", [0, 0, 0, 0], optimizer="adam", lr=1e-5, in_res=(64, 64), weights=wts)
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(8, 7, (ow, oh), in_wh=(64, 64), seed=41)).to(DEV)
+        losses, host = [], []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = net.train([x], t)
+            host.append(time.perf_counter() - t0)          # enqueue time: nothing waits for the GPU inside train()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return net, losses, host
+
+    g, lg, hg = run(True)
+    e, le, he = run(False)
+    dp = g.model
+    assert len(dp._replicas) == 3 and dp.stats["captures"] == 8, dp.stats           # 4 replicas x (forward + backward)
+    assert dp.stats["replays"] == 4 * 2 * 3 and dp.stats["param_copies"] == 3 and dp.stats["replica_steps"] == 3 * 4
+    assert e.model.stats["replays"] == 0
+    assert lg == le, (lg, le)
+    for (k, a), (_, b) in zip(g.model.named_parameters(), e.model.named_parameters()):
+        assert torch.equal(a, b), k
+    for rep in dp._replicas:
+        assert torch.equal(rep._dream_flat["params"], dp.module._dream_flat["params"])
+    assert torch.equal(g.model.module.bn1.running_mean, e.model.module.bn1.running_mean)
+    print("host seconds per step: graphs %s, eager %s" % (["%.4f" % v for v in hg], ["%.4f" % v for v in he]))
+    assert hg[3] < 0.5 * he[3], (hg, he)
+    # evaluation after training: graphs are keyed on the parameter versions, results equal the eager path
+    g.enable_evaluation()
+    e.enable_evaluation()
+    with torch.no_grad():
+        outs = [g.inference(x) for _ in range(3)]
+        ref = e.inference(x)
+    for m, k in outs:
+        assert torch.equal(m, ref[0]) and torch.equal(k, ref[1])
+
+
+def test_allreduce_entry_point(monkeypatch):
+    """dream_allreduce_sum_f32: buffers that share the one GPU of this box are summed locally; with DREAM_FORCE_RCCL=1 a
+    one-device list goes through RCCL itself (dlopen, ncclCommInitAll, group call) -- the sequence an 8-GPU node runs."""
+    a = torch.arange(1000, dtype=torch.float32, device=DEV)
+    bufs = [a.clone(), 2 * a, 3 * a + 1]
+    assert not ops.allreduce_uses_rccl([0, 0, 0]) and ops.allreduce_uses_rccl([0, 1, 2])
+    ops.allreduce_sum_(bufs)
+    torch.cuda.synchronize()
+    for b in bufs:
+        assert torch.equal(b, 6 * a + 1)
+    monkeypatch.setenv("DREAM_FORCE_RCCL", "1")
+    assert ops.allreduce_uses_rccl([0])
+    one = [a.clone()]
+    ops.allreduce_sum_(one)
+    torch.cuda.synchronize()
+    assert torch.equal(one[0], a)
+
+
 # ---- Winograd-domain weight gradient -----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("b,h,w,cin,cout,pad", [(1, 8, 8, 64, 16, 0), (2, 13, 9, 64, 32, 0), (3, 6, 10, 128, 48, 0), (2, 5, 3, 64, 16, 16),
                                                  (4, 400, 400, 64, 64, 0), (4, 100, 100, 256, 256, 0), (8, 25, 25, 512, 512, 0),
