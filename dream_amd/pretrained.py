@@ -65,7 +65,10 @@ def _torchvision_state_dict(arch):
             net = ctor(pretrained=True)                     # the call the reference makes
     except Exception as e:                                   # no cache and no network
         return None, "torchvision could not provide the weights: %s" % (e,)
-    return net.state_dict(), None
+    try:
+        return net.state_dict(), None
+    except Exception as e:                                   # a stand-in torchvision (test harnesses) without real modules
+        return None, "torchvision.models.%s() did not return a module with a state_dict: %s" % (arch, e)
 
 
 def init_vgg19_encoder(hourglass):

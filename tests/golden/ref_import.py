@@ -33,6 +33,16 @@ def import_reference():
     """Returns the imported reference package ``dream`` (version 1.3.0)."""
     if "dream" in sys.modules and getattr(sys.modules["dream"], "__version__", None) == "1.3.0":
         return sys.modules["dream"]
+    register_stubs()
+    import dream
+    assert dream.__version__ == "1.3.0"
+    return dream
+
+
+def register_stubs():
+    """Stand-ins for the reference's absent third-party imports, ``.cuda()`` as the identity, /root/reference on sys.path --
+    everything import_reference() needs short of importing ``dream`` itself (tests/test_dropin.py imports it through
+    dream_amd.dropin instead)."""
     assert have_reference(), "reference checkout not present (expected on the GPU box)"
     import torch
     import yaml
@@ -77,10 +87,8 @@ def import_reference():
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
 
-    sys.path.insert(0, REFERENCE_ROOT)
-    import dream
-    assert dream.__version__ == "1.3.0"
-    return dream
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
 
 
 def network_config(arch, manip="panda", n_keypoints=None, lr=1e-4, optimizer="adam", overrides=None):
