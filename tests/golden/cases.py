@@ -129,10 +129,35 @@ def target_batch(b, k, out_wh, in_wh=(400, 400), seed=0):
 # (B, H, W), weight recipe, exact-zero background?).  vgg_q: the general recipe weights on uint8-quantised noisy frames;
 # resnet_h: oracle.models.structured_weights (no additive terms, bilinear transposed convs) on frames whose background is
 # exactly zero, so the maps are exactly zero away from the blobs.  The calibrated last layer is stored in the fixture.
+# Since round 3 keyed by CASE name: name -> (arch, manipulator, K, last layer, (B, H, W), recipe, zero background): the headline
+# shape (vgg_q at 2 x 400 x 400), the deconv decoder (vgg_f) and the full-resolution ResNet decoder (resnet_f, 17 keypoints).
 STRUCTURED_CASES = {
-    "vgg_q": ("heads_0.4", (2, 200, 200), "recipe", False),
-    "resnet_h": ("upsample.12", (2, 400, 400), "structured", True),
+    "vgg_q": ("vgg_q", "panda", 7, "heads_0.4", (2, 200, 200), "recipe", False),
+    "resnet_h": ("resnet_h", "panda", 7, "upsample.12", (2, 400, 400), "structured", True),
+    "vgg_q_400": ("vgg_q", "panda", 7, "heads_0.4", (2, 400, 400), "recipe", False),
+    "vgg_f": ("vgg_f", "panda", 7, "heads_0.4", (1, 160, 160), "recipe", False),
+    "resnet_f": ("resnet_f", "baxter", 17, "upsample2.3", (1, 200, 200), "structured", True),
 }
+
+# ResNet training golden (G12): name -> (arch, manipulator, K, (B, H, W), last-layer keys scaled by TRAIN_FINAL_SCALE)
+STRUCTURED_BLOBS = {}                      # blobs per frame where not the default 3
+# least fraction of (frame, keypoint) maps with a detection the generator accepts (default 0.25); at 400 x 400 the random
+# network gives most maps several comparable peaks, which the 0.25 rule rejects
+STRUCTURED_MIN_DETECTIONS = {"vgg_q_400": 0.12, "vgg_f": 0.12}
+
+
+def structured_input(case):
+    """Frames of a structured case -> (NCHW float32, blob centres)."""
+    _, _, _, _, (b, h, w), _, zero_bg = STRUCTURED_CASES[case]
+    return blob_image_batch(b, h, w, seed=91, n_blobs=STRUCTURED_BLOBS.get(case, 3), zero_background=zero_bg)
+
+
+RESNET_TRAIN_CASES = {
+    "resnet_h": ("resnet_h", "panda", 7, (2, 128, 128), ("upsample.12.weight", "upsample.12.bias")),
+    "resnet_f": ("resnet_f", "baxter", 17, (2, 64, 64), ("upsample2.3.weight", "upsample2.3.bias")),
+}
+RESNET_TRAIN_LR = 1e-6                     # SGD
+RESNET_DECODER_PREFIXES = ("upsample.", "upsample2.")
 
 
 def blob_image_batch(b, h, w, seed=0, n_blobs=3, zero_background=False):

@@ -178,55 +178,101 @@ def structured(dream):
     here on the reference's own activations and STORED in the fixture.  The fixture is certified decidable: the
     reference's own peak stage gives the same detections, and keypoints within 1e-3 px, on maps perturbed by +-1e-4."""
     from oracle import peaks as opeaks
-    for arch, (last, (b, h, wd), recipe, zero_bg) in cases.STRUCTURED_CASES.items():
-        cfg = ref_import.network_config(arch)
+    only = [a for a in sys.argv[1:] if a in cases.STRUCTURED_CASES]
+    for case, (arch, manip, n_kp, last, (b, h, wd), recipe, zero_bg) in cases.STRUCTURED_CASES.items():
+        if only and case not in only:
+            continue
+        cfg = ref_import.network_config(arch, manip)
         cfg["training"]["config"]["net_input_resolution"] = [wd, h]
         net = dream.create_network_from_config_data(cfg)
         sd = {key[len("module."):]: v for key, v in net.model.state_dict().items()}
         w = omodels.structured_weights(sd) if recipe == "structured" else omodels.recipe_weights(sd)
         wk, bk = last + ".weight", last + ".bias"
         k, cin, kh, kw = w[wk].shape
-        rs = np.random.RandomState(77)
-        mix = rs.uniform(-0.4 if zero_bg else 0.0, 1.0, (k, cin, 1, 1)) * (rs.uniform(0, 1, (k, cin, 1, 1)) < 0.35)
-        w[wk] = torch.as_tensor(np.broadcast_to(mix, (k, cin, kh, kw)) / (kh * kw), dtype=torch.float32).contiguous()
-        w[bk] = torch.zeros(k)
-        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
-        net.enable_evaluation()
-        x_np, centres = cases.blob_image_batch(b, h, wd, seed=91, zero_background=zero_bg)
+        x_np, centres = cases.structured_input(case)
         x = torch.from_numpy(x_np)
-        with torch.no_grad():
-            z = net.model(x)[0].double().numpy()                       # [B,K,Ho,Wo] un-calibrated responses
-        bg = np.zeros(k) if zero_bg else np.median(z.transpose(1, 0, 2, 3).reshape(k, -1), axis=1)
-        flat = (z - bg[None, :, None, None]).transpose(1, 0, 2, 3).reshape(k, -1)
-        ext = flat[np.arange(k), np.abs(flat).argmax(1)]                # strongest deviation, with its sign
-        scale = 1.0 / ext
-        w[wk] = (w[wk].double() * torch.as_tensor(scale).view(k, 1, 1, 1)).float()
-        w[bk] = torch.as_tensor(-bg * scale).float()
-        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
-        with torch.no_grad():
-            maps, kps = net.inference(x)
-            net.model.double()
-            maps64 = net.model(x.double())[0]
-            net.model.float()
-        maps, kps = maps.numpy(), kps.numpy()
-        det = kps[..., 0] > -999
-        print("structured", arch, maps.shape, "absmax %.3f" % np.abs(maps).max(), "detections", int(det.sum()), "/", det.size,
-              "fp32-vs-fp64 of the reference itself: %.2e" % float(np.abs(maps - maps64.numpy()).max()))
-        assert 0.25 <= det.mean() <= 0.95, "fixture should contain both detections and rejections"
-        off = opeaks.upsampling_offset(*net.trained_net_output_resolution())
-        prs = np.random.RandomState(3)
-        for trial in range(4):                                          # decidability at the tolerance the test demands
-            pert = maps + prs.uniform(-1e-4, 1e-4, maps.shape).astype(np.float32)
-            pk = opeaks.keypoints_from_belief_maps(pert, off)
-            assert np.array_equal(pk[..., 0] > -999, det), "a detection decision flips within 1e-4"
-            assert np.abs(pk - kps)[det].max() < 1e-3, np.abs(pk - kps)[det].max()
-        np.savez_compressed(os.path.join(HERE, "structured_%s.npz" % arch), maps=maps, keypoints=kps, centres=centres,
+        for mix_seed in range(77, 97):          # the first channel mix that gives both detections and rejections (stored below)
+            rs = np.random.RandomState(mix_seed)
+            mix = rs.uniform(-0.4 if zero_bg else 0.0, 1.0, (k, cin, 1, 1)) * (rs.uniform(0, 1, (k, cin, 1, 1)) < 0.35)
+            w[wk] = torch.as_tensor(np.broadcast_to(mix, (k, cin, kh, kw)) / (kh * kw), dtype=torch.float32).contiguous()
+            w[bk] = torch.zeros(k)
+            net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+            net.enable_evaluation()
+            with torch.no_grad():
+                z = net.model(x)[0].double().numpy()                       # [B,K,Ho,Wo] un-calibrated responses
+            bg = np.zeros(k) if zero_bg else np.median(z.transpose(1, 0, 2, 3).reshape(k, -1), axis=1)
+            flat = (z - bg[None, :, None, None]).transpose(1, 0, 2, 3).reshape(k, -1)
+            ext = flat[np.arange(k), np.abs(flat).argmax(1)]                # strongest deviation, with its sign
+            scale = 1.0 / ext
+            w[wk] = (w[wk].double() * torch.as_tensor(scale).view(k, 1, 1, 1)).float()
+            w[bk] = torch.as_tensor(-bg * scale).float()
+            net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+            with torch.no_grad():
+                maps, kps = net.inference(x)
+                net.model.double()
+                maps64 = net.model(x.double())[0]
+                net.model.float()
+            maps, kps = maps.numpy(), kps.numpy()
+            det = kps[..., 0] > -999
+            print("structured", case, maps.shape, "absmax %.3f" % np.abs(maps).max(), "detections", int(det.sum()), "/", det.size,
+                  "fp32-vs-fp64 of the reference itself: %.2e" % float(np.abs(maps - maps64.numpy()).max()))
+            if not (cases.STRUCTURED_MIN_DETECTIONS.get(case, 0.25) <= det.mean() <= 0.95):                            # both detections and rejections wanted
+                continue
+            off = opeaks.upsampling_offset(*net.trained_net_output_resolution())
+            prs = np.random.RandomState(3)
+            ok = True
+            for trial in range(4):                                          # decidability at the tolerance the test demands
+                pert = maps + prs.uniform(-1e-4, 1e-4, maps.shape).astype(np.float32)
+                pk = opeaks.keypoints_from_belief_maps(pert, off)
+                ok = ok and np.array_equal(pk[..., 0] > -999, det) and np.abs(pk - kps)[det].max() < 1e-3
+            if ok:
+                break
+        else:
+            raise AssertionError("no channel mix gave a balanced fixture whose decisions are stable under +-1e-4")
+        np.savez_compressed(os.path.join(HERE, "structured_%s.npz" % case), maps=maps, keypoints=kps, centres=centres,
                             final_weight=w[wk].numpy(), final_bias=w[bk].numpy())
+
+
+def grad_sample(t, n=64):
+    """Strided sample of a tensor (the same rule on both sides of the comparison)."""
+    f = t.detach().flatten()
+    return f[:: max(1, f.numel() // n)][:n].double().numpy().copy()
+
+
+def resnet_training(dream):
+    """G12: one DreamNetwork.train() step (dream/network.py:328-364) of the ResNet networks -- train-mode BatchNorm, the
+    transposed-conv decoder, SGD -- run by the reference: loss, every parameter's gradient norm and a strided gradient sample,
+    the updated parameters' samples and the BatchNorm running statistics after the step."""
+    for case, (arch, manip, n_kp, (b, h, wd), final_keys) in cases.RESNET_TRAIN_CASES.items():
+        cfg = ref_import.network_config(arch, manip, lr=cases.RESNET_TRAIN_LR, optimizer="sgd")
+        cfg["training"]["config"]["net_input_resolution"] = [wd, h]
+        net = dream.create_network_from_config_data(cfg)
+        sd = net.model.state_dict()
+        w = omodels.recipe_weights({key[len("module."):]: v for key, v in sd.items()}, final_keys=final_keys,
+                                   final_scale=cases.TRAIN_FINAL_SCALE)
+        net.model.load_state_dict({"module." + key: v for key, v in w.items()})
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        x = torch.from_numpy(cases.image_batch(b, h, wd, seed=17))
+        tgt = torch.from_numpy(cases.target_batch(b, n_kp, (ow, oh), in_wh=(wd, h), seed=17))
+        loss = net.train([x], tgt)
+        out = {"loss": np.array(loss.item(), np.float64)}
+        for key, p in net.model.named_parameters():
+            out["gradnorm/" + key] = np.array(float(p.grad.double().norm()))
+            out["gradsample/" + key] = grad_sample(p.grad)
+            out["param_sample/" + key] = grad_sample(p)
+        for key, buf in net.model.named_buffers():
+            if key.endswith("running_mean") or key.endswith("running_var"):
+                out["buffer_sample/" + key] = grad_sample(buf)
+        np.savez_compressed(os.path.join(HERE, "train_%s.npz" % case), **out)
+        print("train", case, (b, h, wd), "->", (ow, oh), "loss", loss.item(), "keys", len(out))
 
 
 def main():
     dream = ref_import.import_reference()
     torch.manual_seed(0)
+    if "--only-resnet-training" in sys.argv:
+        return resnet_training(dream)
     if "--only-peak-rules" in sys.argv:
         return peak_rules(dream)
     if "--only-structured" in sys.argv:
@@ -327,6 +373,7 @@ def main():
     belief_maps(dream)
     structured(dream)
     peak_rules(dream)
+    resnet_training(dream)
 
 
 if __name__ == "__main__":

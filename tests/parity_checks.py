@@ -472,9 +472,10 @@ def check_structured(dev, arch, precision="fp32"):
     """North-star bounds on the structured fixture (blob-like maps of magnitude 1, tests/golden/structured_<arch>.npz,
     generated by the reference): belief maps within an ABSOLUTE 1e-4, every detection / rejection decision identical,
     detected keypoints within 1e-3 px of the reference's."""
-    last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[arch]
-    g = np.load(os.path.join(GOLD, "structured_%s.npz" % arch))
-    sd = om.build_model(arch, 7).state_dict()
+    case = arch
+    arch, manip, k, last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[case]
+    g = np.load(os.path.join(GOLD, "structured_%s.npz" % case))
+    sd = om.build_model(arch, k).state_dict()
     weights = om.structured_weights(sd) if recipe == "structured" else om.recipe_weights(sd)
     weights[last + ".weight"] = torch.from_numpy(g["final_weight"])
     weights[last + ".bias"] = torch.from_numpy(g["final_bias"])
@@ -482,7 +483,7 @@ def check_structured(dev, arch, precision="fp32"):
     net.enable_evaluation()
     if precision != "fp32":
         net.model.module.precision = precision
-    x, _ = cases.blob_image_batch(b, h, w, seed=91, zero_background=zero_bg)
+    x, _ = cases.structured_input(case)
     with torch.no_grad():
         maps, kps = net.inference(to(dev, torch.from_numpy(x)))
     y, got_k, ref_k = maps.cpu().numpy(), kps.numpy(), g["keypoints"]
@@ -633,6 +634,76 @@ def check_resnet_train_step(dev, arch="resnet_h", shape=(2, 64, 64), steps=1):
         e32 = (b32.double() - b64.double()).abs().max().item() / scale
         ehip = (bm.detach().cpu().double() - b64.double()).abs().max().item() / scale
         assert ehip <= 3 * e32 + 1e-3, (name, ehip, e32)
+
+
+def grad_sample(t, n=64):
+    """The sampling rule of tests/golden/make_golden.py (G12)."""
+    f = t.detach().flatten()
+    return f[:: max(1, f.numel() // n)][:n].double().cpu().numpy().copy()
+
+
+def check_resnet_train_golden(dev, case):
+    """One DreamNetwork.train() step of a ResNet against the REFERENCE's own step (tests/golden/train_<case>.npz, generated by
+    make_golden.py G12 from dream/network.py:328-364 on dream/models.py:17-155).  The decoder -- 4 (5) x [ConvTranspose2d, BatchNorm,
+    ReLU] + the 1x1 head, well-conditioned -- is held to 1e-3: gradient norms, gradient samples, updated parameters, running
+    statistics.  The trunk's gradients pass through ~100 train-mode BatchNorms over 2 frames (ill-conditioned: two correct fp32
+    implementations differ by percents) and are held by direction: cosine of the sampled gradients >= 0.98 overall and per
+    stage, norms within 5 %.  -> dict of the measured figures."""
+    arch, manip, k, (b, h, w), final_keys = cases.RESNET_TRAIN_CASES[case]
+    g = np.load(os.path.join(GOLD, "train_%s.npz" % case))
+    wts = om.recipe_weights(om.build_model(arch, k).state_dict(), final_keys, cases.TRAIN_FINAL_SCALE)
+    net = build_network(arch, dev, weights=wts, optimizer="sgd", lr=cases.RESNET_TRAIN_LR, in_res=(w, h))
+    net.enable_training()
+    ow, oh = net.trained_net_output_resolution()
+    x = to(dev, torch.from_numpy(cases.image_batch(b, h, w, seed=17)))
+    t = to(dev, torch.from_numpy(cases.target_batch(b, k, (ow, oh), in_wh=(w, h), seed=17)))
+    loss = net.train([x], t).item()
+    ref_loss = float(g["loss"])
+    res = {"loss_rel": abs(loss - ref_loss) / abs(ref_loss)}
+    assert res["loss_rel"] <= 1e-4, (loss, ref_loss)
+    dec_norm, dec_sample, dec_param = 0.0, 0.0, 0.0
+    trunk = {}
+    for key, p in net.model.named_parameters():
+        name = key[len("module."):]
+        ref_n, ref_s = float(g["gradnorm/" + key]), g["gradsample/" + key]
+        got_n, got_s = float(p.grad.double().norm()), grad_sample(p.grad)
+        if name.startswith(cases.RESNET_DECODER_PREFIXES):
+            if ref_n < 1e-12:                        # conv bias in front of a BatchNorm: the true gradient is exactly zero
+                assert got_n <= 1e-6 * max(float(g["gradnorm/module." + name.replace(".bias", ".weight")]), 1e-12), key
+                continue
+            dec_norm = max(dec_norm, abs(got_n - ref_n) / ref_n)
+            dec_sample = max(dec_sample, float(np.abs(got_s - ref_s).max()) / max(float(np.abs(ref_s).max()), 1e-30))
+            ps, rs_ = grad_sample(p), g["param_sample/" + key]
+            dec_param = max(dec_param, float(np.abs(ps - rs_).max()) / max(float(np.abs(rs_).max()), 1e-30))
+        else:
+            stage = name.split(".")[0]
+            acc = trunk.setdefault(stage, [0.0, 0.0, 0.0, 0.0, 0.0])
+            acc[0] += float((got_s * ref_s).sum())
+            acc[1] += float((got_s * got_s).sum())
+            acc[2] += float((ref_s * ref_s).sum())
+            acc[3] += got_n ** 2
+            acc[4] += ref_n ** 2
+    res.update(decoder_gradnorm_rel=dec_norm, decoder_gradsample_rel=dec_sample, decoder_param_rel=dec_param)
+    assert dec_norm <= 1e-3 and dec_sample <= 1e-3 and dec_param <= 1e-6, res
+    tot = [sum(a[i] for a in trunk.values()) for i in range(5)]
+    res["trunk_cos"] = tot[0] / (tot[1] * tot[2]) ** 0.5
+    res["trunk_norm_rel"] = abs(tot[3] ** 0.5 - tot[4] ** 0.5) / tot[4] ** 0.5
+    res["trunk_stage_cos"] = {st: a[0] / max((a[1] * a[2]) ** 0.5, 1e-300) for st, a in trunk.items() if a[2] > 0}
+    assert res["trunk_cos"] >= 0.98 and res["trunk_norm_rel"] <= 0.05, res
+    assert min(res["trunk_stage_cos"].values()) >= 0.95, res
+    bn_dec, bn_trunk = 0.0, 0.0
+    for key, buf in net.model.named_buffers():
+        if not (key.endswith("running_mean") or key.endswith("running_var")):
+            continue
+        ref_s, got_s = g["buffer_sample/" + key], grad_sample(buf)
+        e = float(np.abs(got_s - ref_s).max()) / max(float(np.abs(ref_s).max()), 1e-30)
+        if key[len("module."):].startswith(cases.RESNET_DECODER_PREFIXES):
+            bn_dec = max(bn_dec, e)
+        else:
+            bn_trunk = max(bn_trunk, e)
+    res.update(decoder_bn_rel=bn_dec, trunk_bn_rel=bn_trunk)
+    assert bn_dec <= 1e-4 and bn_trunk <= 1e-3, res
+    return res
 
 
 def check_resnet_training_ops(dev):

@@ -151,6 +151,12 @@ def test_resnet_training_ops():
     pc.check_resnet_training_ops(DEV)
 
 
+@pytest.mark.parametrize("case", sorted(cases.RESNET_TRAIN_CASES))
+def test_resnet_train_step_reference_golden(case):
+    res = pc.check_resnet_train_golden(DEV, case)
+    print("resnet train golden", case, res)
+
+
 def test_resnet_h_train_step():
     pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
 
@@ -320,19 +326,19 @@ def test_hip_graph_inference_is_bit_identical(arch, shape):
 
 
 def test_full_size_resnet_f_properties():
-    """BASELINE.json configs[4] shape (resnet_f, 17 keypoints, 400x400 -> 416x416 maps; one GPU's share is 32 frames,
-    8 suffice for the property): batch-position independence, the CPU oracle on one frame, bit-exact peak stage."""
+    """BASELINE.json configs[4] at one GPU's share: resnet_f, 17 keypoints, 32 frames of 400x400 -> 416x416 maps:
+    batch-position independence, the CPU oracle on one frame, bit-exact peak stage."""
     net = pc.build_network("resnet_f", DEV)
     net.enable_evaluation()
     base = torch.from_numpy(cases.image_batch(2, 400, 400, seed=78))
-    x = base.repeat(4, 1, 1, 1).to(DEV)
+    x = base.repeat(16, 1, 1, 1).to(DEV)
     with torch.no_grad():
         maps, kps = net.inference(x)
         net.model.module.precision = "fp16x3"
         maps16, kps16 = net.inference(x)
     maps, maps16 = maps.cpu(), maps16.cpu()
-    assert maps.shape == (8, 17, 416, 416) and kps.shape == (8, 17, 2)
-    for r in range(1, 4):
+    assert maps.shape == (32, 17, 416, 416) and kps.shape == (32, 17, 2)
+    for r in range(1, 16):
         assert torch.equal(maps[2 * r:2 * r + 2], maps[:2]) and torch.equal(kps[2 * r:2 * r + 2], kps[:2])
         assert torch.equal(maps16[2 * r:2 * r + 2], maps16[:2])
     ref = om.build_model("resnet_f", 17)

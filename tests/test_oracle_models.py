@@ -61,14 +61,15 @@ def test_cnn_matches_reference_outputs(arch):
 def test_structured_fixture_regenerates_from_the_oracle(arch):
     """The structured (blob-like, magnitude-1) fixture: weights and frames regenerate from the committed recipes and the
     oracle reproduces the reference's maps / keypoints -- on any box, without the reference."""
-    last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[arch]
-    g = np.load(os.path.join(GOLD, "structured_%s.npz" % arch))
-    m = om.build_model(arch, 7)
+    case = arch
+    arch, manip, k, last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[case]
+    g = np.load(os.path.join(GOLD, "structured_%s.npz" % case))
+    m = om.build_model(arch, k)
     wts = om.structured_weights(m.state_dict()) if recipe == "structured" else om.recipe_weights(m.state_dict())
     wts[last + ".weight"], wts[last + ".bias"] = torch.from_numpy(g["final_weight"]), torch.from_numpy(g["final_bias"])
     m.load_state_dict(wts)
     m.eval()
-    x, centres = cases.blob_image_batch(b, h, w, seed=91, zero_background=zero_bg)
+    x, centres = cases.structured_input(case)
     assert np.array_equal(centres, g["centres"])
     with torch.no_grad():
         y = m(torch.from_numpy(x))[0].numpy()
@@ -163,3 +164,35 @@ def test_variant_hourglasses_match_reference(name):
                     ref = float(g["train/gradnorm/module." + key])
                     assert abs(float(p.grad.double().norm()) - ref) <= 1e-4 * max(ref, 1e-6), key
         assert np.allclose(losses, g["train/losses"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("case", sorted(cases.RESNET_TRAIN_CASES))
+def test_resnet_train_step_matches_reference(case):
+    """G12: the oracle's ResNet training step (train-mode BatchNorm, transposed-conv decoder, SGD) reproduces the reference's
+    DreamNetwork.train() step: loss, every gradient norm / sample, updated parameters, running statistics."""
+    arch, manip, k, (b, h, w), final_keys = cases.RESNET_TRAIN_CASES[case]
+    g = np.load(os.path.join(GOLD, "train_%s.npz" % case))
+    m = om.build_model(arch, k)
+    m.load_state_dict(om.recipe_weights(m.state_dict(), final_keys, cases.TRAIN_FINAL_SCALE))
+    m.train()
+    o = torch.optim.SGD(m.parameters(), lr=cases.RESNET_TRAIN_LR)
+    x = torch.from_numpy(cases.image_batch(b, h, w, seed=17))
+    out = m(x)[0]
+    t = torch.from_numpy(cases.target_batch(b, k, (out.shape[3], out.shape[2]), in_wh=(w, h), seed=17))
+    o.zero_grad()
+    loss = torch.nn.functional.mse_loss(out, t)
+    loss.backward()
+    o.step()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+
+    def sample(v):
+        f = v.detach().flatten()
+        return f[:: max(1, f.numel() // 64)][:64].double().numpy()
+    for key, p in m.named_parameters():
+        ref = float(g["gradnorm/module." + key])
+        assert abs(float(p.grad.double().norm()) - ref) <= 1e-5 * max(ref, 1e-12), key
+        assert np.abs(sample(p.grad) - g["gradsample/module." + key]).max() <= 1e-5 * max(np.abs(g["gradsample/module." + key]).max(), 1e-12), key
+        assert np.abs(sample(p) - g["param_sample/module." + key]).max() <= 1e-6 * max(np.abs(g["param_sample/module." + key]).max(), 1e-12), key
+    for key, buf in m.named_buffers():
+        if key.endswith("running_mean") or key.endswith("running_var"):
+            assert np.abs(sample(buf) - g["buffer_sample/module." + key]).max() <= 1e-6 * max(np.abs(g["buffer_sample/module." + key]).max(), 1e-12), key
