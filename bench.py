@@ -51,8 +51,9 @@ def parse():
                     "the GPUs (BASELINE configs[3]: 128 over 8, configs[4]: 256 over 8); overrides --batch")
     ap.add_argument("--single-process", action="store_true", help="N GPUs from ONE process through training.platform.gpu_ids "
                     "(the reference's nn.DataParallel contract, dream_amd/data_parallel.py) instead of one process per GPU")
-    ap.add_argument("--conv-algorithm", choices=["winograd", "direct"], default="winograd",
-                    help="fp32 3x3 stride-1 convs: Winograd on the fp32 MFMA (default) or the direct implicit GEMM")
+    ap.add_argument("--conv-algorithm", choices=["winograd", "winograd2", "direct"], default="winograd",
+                    help="fp32 3x3 stride-1 convs: Winograd on the fp32 MFMA (default: F(4x4,3x3) where it pays, F(2x2,3x3) elsewhere; "
+                         "winograd2: F(2x2,3x3) everywhere) or the direct implicit GEMM")
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--mode", choices=["inference", "train"], default="inference")
     ap.add_argument("--precision", choices=["fp32", "fp16x3"], default="fp32",
@@ -252,7 +253,9 @@ def build_network(ctx, spec):
     with contextlib.redirect_stdout(io.StringIO()):
         net = dream_amd.create_network_from_config_data(cfg)
     net.model.load_state_dict(synthetic_weights(net.model.state_dict()))
-    net.model.module.conv_algorithm = spec["conv_algorithm"]
+    from dream_amd import ops
+    net.model.module.conv_algorithm = "direct" if spec["conv_algorithm"] == "direct" else "winograd"
+    ops.set_winograd_tile(2 if spec["conv_algorithm"] == "winograd2" else 0)
     frames = spec["batch"] * (len(ctx.single_ids) if ctx.single else 1)               # frames this PROCESS handles per step
     x = torch.from_numpy(cases.image_batch(frames, spec["res"], spec["res"], seed=ctx.rank)).cuda()
     tgt = None
@@ -318,8 +321,8 @@ def timed_region(ctx, net, x, tgt, spec):
 
 def roofline_of(spec, conv, dt, peak):
     ms, fl, ex = conv["ms"], conv["flops"], conv["executed"]
-    wino = spec["conv_algorithm"] == "winograd"
-    kernel = ("conv_wino_kernel + conv_mfma_kernel" if wino else "conv_mfma_kernel") + \
+    wino = spec["conv_algorithm"] != "direct"
+    kernel = (("conv_wino4_kernel + " if spec["conv_algorithm"] == "winograd" else "") + "conv_wino_kernel + conv_mfma_kernel" if wino else "conv_mfma_kernel") + \
              (" + gemm1x1_kernel" if spec["arch"].startswith("resnet") else "")
     if spec.get("precision", "fp32") != "fp32" and spec["mode"] == "inference":
         kernel = "conv_f16x3_kernel"
@@ -483,8 +486,10 @@ def main():
                        "parallelism": "dp%d%s" % (ctx.n_gpus, " (single process, gpu_ids)" if ctx.single
                                                   else (" (one process per GPU, %s)" % ("RCCL" if backend == "nccl" else backend)
                                                         if ctx.world > 1 else "")),
-                       "conv_algorithm": (("winograd for the stride-1 3x3 convs with >= 64 output channels, direct "
-                                           "implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else "direct implicit GEMM")
+                       "conv_algorithm": (("winograd F(4x4,3x3) for the stride-1 3x3 convs with >= 128 output channels, F(2x2,3x3) for "
+                                           "those with 64, direct implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else
+                                           "winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 64 output channels, direct implicit GEMM "
+                                           "elsewhere" if args.conv_algorithm == "winograd2" else "direct implicit GEMM")
                                           + ("; stride-1 1x1 convs as LDS-free GEMMs" if args.arch.startswith("resnet") else ""))},
             "roofline": roof,
         }

@@ -1,0 +1,532 @@
+// 3x3 stride-1 pad-1 convolution on NHWC fp32 tensors by the Winograd minimal-filtering algorithm F(4x4, 3x3) on the CDNA4 fp32
+// matrix cores: 36 multiplications per 4x4 output tile and input channel -- 2.25 per output where F(2x2,3x3) (conv_wino.hip)
+// needs 4 and the direct algorithm 9.  Every product and sum is IEEE fp32; the weight transform runs once, in fp64, at pack time.
+//
+// Replaces torch.nn.Conv2d(k=3,s=1,p=1) (+ReLU, + the following MaxPool2d(2)) at /root/reference/dream/models.py:598-615 (VGG19
+// encoder), :695-710 (decoder convs not preceded by an upsample) for the layers with at least 128 output channels -- 78 % of a
+// DREAM-vgg-Q forward pass -- and, on mode-1 packed weights, their data gradients.
+//
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: 6x6 input patch, g: 3x3 filter, Y: 4x4 outputs
+//
+// Interpolation points (0, 1, -1, 1/2, -2, inf), NOT the usual (0, +-1, +-2, inf): measured against an fp64 direct convolution on
+// the vgg_q layer shapes (profiles/r03_f4_accuracy.txt) the error relative to the output maximum is 1.0e-6 .. 2.7e-6 (the usual
+// points: 2.5e-6 .. 1.2e-5; F(2x2,3x3): 2e-7 .. 5e-7; the direct fp32 kernel: 5e-7 .. 1.4e-6) -- mixing a small and a large
+// point keeps the entries of B^T, G and A^T within [1/8, 8] and the transformed operands well scaled.  With these points
+//
+//   B^T = [ 1 -1.5 -2    1.5  1    0 ]     A^T = [ 1  1  1  1     1  0 ]     G = [  1      0     0    ]
+//         [ 0 -1    0.5  2.5  1    0 ]           [ 0  1 -1  1/2  -2  0 ]         [  1/3    1/3   1/3  ]
+//         [ 0  1   -2.5  0.5  1    0 ]           [ 0  1  1  1/4   4  0 ]         [ -1/3    1/3  -1/3  ]
+//         [ 0 -2   -1    2    1    0 ]           [ 0  1 -1  1/8  -8  1 ]         [ -16/15 -8/15 -4/15 ]
+//         [ 0  0.5 -1   -0.5  1    0 ]                                           [  1/15  -2/15  4/15 ]
+//         [ 0  1   -1.5 -2    1.5  1 ]                                           [  0      0     1    ]
+//
+// GEMM view: for each of the 36 positions p of the transformed 6x6 domain,  M_p[tile][cout] = sum_cin V_p[tile][cin] U_p[cin][cout].
+//   * tiles are numbered over (image, tile row, tile column); a workgroup takes 16 consecutive ones (256 output pixels) and
+//     128 output channels; wavefront = 16 tiles x 16 channels x all 36 positions: 36 accumulators of v_mfma_f32_16x16x4_f32
+//     (144 VGPRs), so the inverse transform A^T M A is lane-local;
+//   * V = B^T d B is computed by the workgroup for one 16-channel chunk at a time, in two passes through LDS, WHILE the MFMAs of
+//     the previous chunk run: pass 1 -- a thread owns (tile, channel quad, patch ROW): six b128 loads, the transform along the
+//     row in registers, six b128 stores to a staging tile; pass 2 -- a thread owns (tile, channel quad, transformed COLUMN):
+//     six b128 reads down the column, the transform along it, six b128 stores into the V buffer the next chunk's MFMAs read
+//     (B^T has 4-5 non-zeros per row: the cross-lane exchange F(2x2)'s kernel does with one DPP move would take four here).
+//     384 items per pass on 512 threads: 48 per wavefront and pass, the same work on every wavefront between two barriers;
+//   * U (the transformed weights, packed [Cin/16][36][CoutPad][16]) never touches LDS: every wavefront streams its own 16-channel
+//     operand rows straight from L2 into a ring of registers, 1 KB coalesced per position, several positions ahead;
+//   * all global traffic through buffer descriptors (32-bit offsets, zero padding and store masking by the bounds check);
+//   * positions are multiplied in PAIRS with alternating accumulators (a dependent v_mfma_f32_16x16x4_f32 has 40 cycles of
+//     latency against 32 of issue), one memory instruction or transform piece behind each pair of MFMAs (pinned order);
+//   * persistent workgroups walking over the tile blocks of their XCD's range, the next block's first chunk transformed during
+//     the current block's last chunk -- as conv_wino.hip.
+#include <type_traits>
+#include <dream_cdna4.h>
+#include "common.h"
+#include "../../include/dream_hip.h"
+
+// Timing diagnostics only (tools/wino4_diag.py builds separate libraries with -DDREAM_W4_DIAG=k; never the product library; results
+// are then wrong by construction): bit 0 no patch loads, bit 1 no weight stream, bit 2 no barriers, bit 3 no pass 1 / pass 2, bit 4 patch loads out of range.
+#ifndef DREAM_W4_DIAG
+#define DREAM_W4_DIAG 0
+#endif
+
+namespace {
+
+struct Wino4Params {
+    const float *x;          // [B,H,W,Cin]
+    const float *u;          // [Cin/16][36][CoutPad][16] (+ W4_AHEAD zero positions)
+    const float *scale;      // per-channel multiplier (eval-mode BatchNorm fold) or null
+    const float *shift;      // per-channel addend (bias / BN shift) or null
+    const float *residual;   // ReLU mask source (DREAM_CONV_RELUMASK) or addend of the output's shape, or null
+    float *y;                // [B,H,W,Cout]  (or [B,H/2,W/2,Cout] with DREAM_CONV_POOL2)
+    int B, H, W, Cin, Cout, CoutPad;
+    int TY, TX;              // 4x4 tiles per image
+    int ntiles;              // B * TY * TX  (< 2^24)
+    int nblk, blk_per_xcd;   // blocks of 16 tiles; each XCD's workgroups walk over a contiguous range of them
+    unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX)
+    int flags;
+};
+
+constexpr int W4T = 16;       // tiles per workgroup
+constexpr int W4K = 16;       // input channels per chunk
+constexpr int W4NW = 8;       // wavefronts: 128 output channels
+constexpr int W4PAD = 128;    // output channels the packed weights are padded to
+constexpr int W4P = 36;       // positions
+// V plane p = 6 i + j: [16 tiles][16 channels] = 256 floats = exactly one wavefront-wide b128 read; planes 272 floats apart
+// (68 float4 slots = 4 mod 8), so that the pass-2 stores of the lanes (q = 0..3, j, j + 1) of a store group fall on all 32 banks
+// of the LDS store path
+constexpr int V4PS = W4T * W4K + 16;          // plane stride in floats
+DREAM_DEVICE constexpr int v4_plane(int p) { return p * V4PS; }
+constexpr int V4B = W4P * V4PS;               // floats per V buffer
+// staging tile of pass 1: float4 slot [(tile, row)][6 q + j], 25 slots per (tile, row): the 8 lanes of a store group
+// (q = 0..3 of two consecutive rows) write slots 6 q + j and 25 + 6 q + j -- eight different residues mod 8
+constexpr int S4ROW = 25;
+constexpr int S4B = W4T * 6 * S4ROW * 4;      // floats
+#ifndef DREAM_W4_RING
+#define DREAM_W4_RING 6
+#endif
+constexpr int W4_RING = DREAM_W4_RING;   // operand registers of the weight stream: position k of the chunk of parity PH lives in bq[(36 PH + k) % RING]
+                                         // (chunks run in pairs: 72 % 8 == 0 and 36 % 6 == 0, so RING may be 8 or 6)
+constexpr int W4_AHEAD = W4_RING - 2;    // positions the weight stream runs ahead of the MFMAs (two are in use)
+
+DREAM_DEVICE int v4_slot(int q, int t) { return q ^ ((t >> 2) & 2); }       // float4 slot of channel quad q in row t of a V plane
+
+DREAM_DEVICE f32x4 fma4(float c, f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = __builtin_fmaf(c, a[k], b[k]);
+    return r;
+}
+
+// row j of B^T applied to d[0..5] (see the header); 4 packed operations per float4 pair, nothing kept between rows.  Differences are
+// packed by hand (pk_sub4: v_pk_add_f32 with negated second operand): hipcc packs fma and add (v_pk_fma_f32, v_pk_add_f32: two
+// channels per instruction) but not sub.
+DREAM_DEVICE f32x4 sub4(f32x4 y, f32x4 x) { return pk_sub4(y, x); }
+DREAM_DEVICE f32x4 bt_row(int j, const f32x4 *d) {
+    switch (j) {
+        case 0: return fma4(-2.0f, d[2], fma4(1.5f, sub4(d[3], d[1]), d[0] + d[4]));
+        case 1: return fma4(2.5f, d[3], fma4(0.5f, d[2], sub4(d[4], d[1])));
+        case 2: return fma4(0.5f, d[3], fma4(-2.5f, d[2], d[4] + d[1]));
+        case 3: return fma4(2.0f, sub4(d[3], d[1]), sub4(d[4], d[2]));
+        case 4: return fma4(-0.5f, sub4(d[3], d[1]), sub4(d[4], d[2]));
+        default: return fma4(-2.0f, d[3], fma4(1.5f, sub4(d[4], d[2]), d[1] + d[5]));
+    }
+}
+
+// MODE: 0 plain, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask (conv_wino.hip)
+template <int MODE>
+__global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Params p) {
+    constexpr int NT = 64 * W4NW;
+    DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer, then the staging tile
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = wave_index();
+    // 384 items per pass on 512 threads: every wavefront takes 48 of each pass (lanes 48..63 repeat the items of lanes 32..47:
+    // same loads, same values to the same LDS addresses from a different store group -- no branch, no predication), so that all
+    // eight wavefronts carry the same work between two barriers and none of them idles at one.
+    const int item_id = wave * 48 + (lane < 48 ? lane : lane - 16);
+
+    const int xcd = (int)(blockIdx.x & 7), J = (int)(gridDim.x >> 3);
+    const int blk_hi = (xcd + 1) * p.blk_per_xcd;
+    const int blk_end = blk_hi < p.nblk ? blk_hi : p.nblk;
+    int tb = xcd * p.blk_per_xcd + (int)(blockIdx.x >> 3);
+    if (tb >= blk_end) return;
+    const int n0 = blockIdx.y * (16 * W4NW);
+    const int tiles_per_img = p.TY * p.TX;
+    const size_t img_floats = (size_t)p.H * p.W * p.Cin;
+
+    // ---- pass 1 item: (tile t1, channel quad q1, patch row r1)
+    const int q1 = item_id & 3, r1 = (item_id >> 2) % 6, t1 = (item_id >> 2) / 6;
+    const int s1_off = ((t1 * 6 + r1) * S4ROW + 6 * q1) * 4;                 // staging float offset of column j = 0
+    // ---- pass 2 item: (tile t2, channel quad q2, transformed column j2)
+    const int q2 = item_id & 3, j2 = (item_id >> 2) % 6, t2 = (item_id >> 2) / 6;
+    const int s2_off = ((t2 * 6) * S4ROW + 6 * q2 + j2) * 4;                  // staging float offset of row r = 0 (rows: + S4ROW * 4)
+    const int v2_off = v4_plane(j2) + t2 * W4K + 4 * v4_slot(q2, t2);         // V float offset of plane (i = 0, j2); plane 6 i + j2: + 6 i * V4PS
+
+    // offsets of the item's six loads: byte offset of column 0 relative to the first image of the block + a validity bit per
+    // column (BUFFER_OOB where the patch leaves the image: the hardware returns zeros).  Recomputed per block from the thread's
+    // packed (t1, r1, q1) -- `opaque` keeps the compiler from hoisting the unpacked values into registers it does not have.
+    unsigned goff0;
+    int item1 = t1 | (r1 << 8) | (q1 << 16);           // bits 24..29: validity of the six columns (plan_item)
+    auto plan_item = [&](int tile0, int b0) {
+        asm volatile("" : "+v"(item1));
+        const int t = item1 & 255, r = (item1 >> 8) & 255, q = (item1 >> 16) & 255;
+        const int tau = tile0 + t;
+        const bool tv = tau < p.ntiles;
+        const int b = div_magic40(tau, p.magic_tpi), rem = tau - b * tiles_per_img;
+        const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
+        const int gy = 4 * ty - 1 + r, x0 = 4 * tx - 1;
+        const bool rok = tv & ((unsigned)gy < (unsigned)p.H);
+        goff0 = (unsigned)(((((b - b0) * p.H + gy) * p.W + x0) * p.Cin + 4 * q) * 4);
+        item1 &= 0xffffff;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) item1 |= (rok & ((unsigned)(x0 + c) < (unsigned)p.W)) ? (1 << (24 + c)) : 0;
+    };
+    const unsigned px_in = (unsigned)(p.Cin * 4);
+    auto item_offset = [&](int c) {
+        if (DREAM_W4_DIAG & 16) {                      // diagnostics: the loads are issued but out of range (zeros, no memory traffic)
+            unsigned o = BUFFER_OOB;
+            asm volatile("" : "+v"(o));
+            return o;
+        }
+        return (item1 >> (24 + c)) & 1 ? goff0 + (unsigned)c * px_in : BUFFER_OOB;
+    };
+    auto block_tile0 = [&](int blk) { return blk < blk_end ? blk * W4T : p.ntiles; };
+    auto block_xbuf = [&](int b0) {
+        return make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
+    };
+
+    // ---- MFMA operand addresses: A lane l -> tile (l & 15), k = 4 (l >> 4) .. +3 (one float4 feeds the 4 MFMAs of a position)
+    const int lt = lane & 15, lg = lane >> 4;
+    const int a_off = lt * W4K + 4 * v4_slot(lg, lt);
+    const unsigned b_lane = (unsigned)(((wave * 16 + lt) * W4K + 4 * lg) * 4);
+    const unsigned u_pos_stride = (unsigned)(p.CoutPad * W4K * 4);
+    const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * W4K, ((size_t)((p.Cin / W4K) * W4P + W4_AHEAD) * p.CoutPad - (size_t)n0) * W4K * sizeof(float));
+
+    f32x4 acc[W4P];
+    const int nchunks = p.Cin / W4K;
+
+    // weight stream: the k-th position of the chunk sequence (k counted from the start of the block, 36 per chunk) lives in
+    // bq[k % 8]; the chunk loop is unrolled by two so that the ring index is a compile-time constant (72 % 8 == 0)
+    f32x4 bq[W4_RING];
+#pragma unroll
+    for (int k = 0; k < W4_AHEAD; ++k) bq[k] = buffer_load_x4(ubuf, b_lane, (unsigned)k * u_pos_stride);
+
+    // LDS addresses: one per-lane base register per (role, V buffer), everything else in the instructions' 16-bit immediate
+    // offsets (every plane / row offset below is < 64 KB from its base).  `opaque` keeps the compiler from folding the buffer
+    // offsets into per-access address registers (it would need one per plane beyond 64 KB).  The chunks of a block alternate
+    // between the two V buffers and their number is even, so chunk parity PH reads buffer PH and fills buffer 1 - PH.
+    // (offsets in float4 units, so that the accesses stay provably 16-byte aligned: b128 LDS instructions)
+    f32x4 *const sV4 = (f32x4 *)sV;
+    int vrd[2], vwr[2], s1p = (2 * V4B + s1_off) / 4, s2p = (2 * V4B + s2_off) / 4;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        vrd[h] = (h * V4B + a_off) / 4;
+        vwr[h] = (h * V4B + v2_off) / 4;
+        asm volatile("" : "+v"(vrd[h]), "+v"(vwr[h]));
+    }
+    asm volatile("" : "+v"(s1p), "+v"(s2p));
+    f32x4 d[6];                                        // pass 1: the patch row; pass 2: the staged column
+    auto pass1_piece = [&](int j) { sV4[s1p + j] = bt_row(j, d); };
+    auto pass2_read = [&](int r) { d[r] = sV4[s2p + r * S4ROW]; };
+    auto pass2_piece = [&](int i, int h) { sV4[vwr[h] + i * (6 * V4PS / 4)] = bt_row(i, d); };
+
+    f32x4 a[2][2];                                     // [set][position of the pair]
+    auto read_a = [&](int set, int pp, int h) {
+        a[set][0] = sV4[vrd[h] + v4_plane(pp) / 4];
+        a[set][1] = sV4[vrd[h] + v4_plane(pp + 1) / 4];
+    };
+
+    // ---- first block of this workgroup: plan, chunk 0 through both passes into buffer 0 ------------------------------------------
+    int tile0 = block_tile0(tb);
+    int b0 = div_magic40(tile0, p.magic_tpi);
+    BufferRsrc xbuf = block_xbuf(b0);
+    plan_item(tile0, b0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) d[c] = buffer_load_x4(xbuf, item_offset(c), 0u);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) pass1_piece(j);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 6; ++r) pass2_read(r);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pass2_piece(i, 0);
+    __syncthreads();
+
+    // One chunk: 18 slots of two positions x 4 k-steps on V buffer PH; meanwhile the NEXT chunk goes through the two passes:
+    // its six patch loads behind the first MFMA pairs, pass 1 in slots S1 .. S1 + 2 (two pieces per slot), a barrier, the six
+    // staging reads in slot S2, pass 2 in slots S2 + 1 .. S2 + 3, the end-of-chunk barrier.  PH: parity of the chunk inside
+    // the block (chunks run in pairs: the ring index of the weight stream is a compile-time constant, 72 % 8 == 0).  `last`
+    // (wave-uniform; only the odd chunk can be the last one): the next chunk is chunk 0 of the NEXT block -- its plan is
+    // computed here, the weight stream wraps around.  One instantiation per parity, one call site each: the loop below.
+    auto chunk = [&](auto ph_tag, bool last, int c, int tile0n, int b0n) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr int S1 = 10, S2 = 13;                   // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
+        const unsigned coff = last ? 0u : (unsigned)((c + 1) * W4K * 4);
+        const int cnext = last ? 0 : (c + 1) * W4P;                          // first position of the next chunk in the weight stream
+        if (PH == 1 && last) xbuf = block_xbuf(b0n);                        // this block's loads are all issued: from here on the next block's
+        read_a(0, 0, PH);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 18; ++s) {
+            const int pp = 2 * s;
+            auto load_b = [&](int half) {                                    // weight operands of position pp + half + AHEAD
+                if (DREAM_W4_DIAG & 2) return;
+                const int kn = pp + half + W4_AHEAD;
+                const int spos = kn >= W4P ? cnext + (kn - W4P) : c * W4P + kn;
+                bq[(PH * W4P + kn) % W4_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)spos * u_pos_stride);
+            };
+            auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), coff); };
+            auto pair = [&](int r) {
+                const int i0 = (PH * W4P + pp) % W4_RING, i1 = (PH * W4P + pp + 1) % W4_RING;
+                acc[pp] = mfma_f32_16x16x4(a[s & 1][0][r], bq[i0][r], acc[pp]);
+                acc[pp + 1] = mfma_f32_16x16x4(a[s & 1][1][r], bq[i1][r], acc[pp + 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            pair(0);
+            load_b(0);
+            if (s + 1 < 18) read_a((s + 1) & 1, pp + 2, PH);
+            if (PH == 1 && s == 0 && last) plan_item(tile0n, b0n);
+            if (s < 3) load_x(2 * s);
+            if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1));
+            if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(0); pass2_read(1); }
+            if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1), 1 - PH);
+            pair(1);
+            load_b(1);
+            if (s < 3) load_x(2 * s + 1);
+            if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(2); pass2_read(3); }
+            pair(2);
+            if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1) + 1);
+            if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(4); pass2_read(5); }
+            if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1) + 1, 1 - PH);
+            pair(3);
+            if (s == S1 + 2 && !(DREAM_W4_DIAG & 4)) {                       // pass 1 of the next chunk is staged
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(DREAM_W4_DIAG & 4)) __syncthreads();
+    };
+    const std::integral_constant<int, 0> ph0{};
+    const std::integral_constant<int, 1> ph1{};
+
+    // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ------------------------
+    constexpr bool pool = MODE == 1, has_res = MODE >= 2, mask = MODE == 3;
+    auto epilogue = [&](int tile0e, int b0e) {
+        // Everything the epilogue needs is read again from the kernel-argument segment (scalar loads, once per block): kept in
+        // SGPRs across the MFMA phases these values push the kernel past its scalar register file (spills through VGPR lanes).
+        const Wino4Params &e = *DREAM_KERNARG(p);
+        const bool relu = (e.flags & DREAM_CONV_RELU) != 0;
+        const int Ho = pool ? e.H / 2 : e.H, Wo = pool ? e.W / 2 : e.W;
+        const size_t out_img = (size_t)Ho * Wo * e.Cout;
+        const unsigned px_b = (unsigned)(e.Cout * 4), row_b = (unsigned)(Wo * e.Cout * 4);
+        const int ln = lane_id();                      // from the hardware (mbcnt), not from a register kept across the MFMA phases
+        const int lt = ln & 15, lg = ln >> 4;
+        const int col = n0 + wave * 16 + lt;
+        const bool cok = col < e.Cout;
+        const float sc = (e.scale != nullptr && cok) ? e.scale[col] : 1.0f;
+        const float sh = (e.shift != nullptr && cok) ? e.shift[col] : 0.0f;
+        const BufferRsrc ybuf = make_buffer(e.y + (size_t)b0e * out_img, (size_t)(e.B - b0e) * out_img * sizeof(float));
+        const BufferRsrc rbuf = make_buffer(has_res ? e.residual + (size_t)b0e * out_img : e.y,
+                                            has_res ? (size_t)(e.B - b0e) * out_img * sizeof(float) : 0);
+        // C/D layout: reg r of lane l is tile 4 (l >> 4) + r of the block: the lane's four tiles are consecutive
+        const int tau0 = tile0e + lg * 4;
+        int b = div_magic40(tau0, p.magic_tpi);
+        const int rem = tau0 - b * tiles_per_img;
+        int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool tok = cok & ((tau0 + r) < p.ntiles);
+            // stored positions of this tile: a 4x4 block of outputs, or its 2x2 block of pooled outputs
+            constexpr int NS = pool ? 2 : 4;
+            const int oy = NS * ty, ox = NS * tx;
+            const unsigned base = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * e.Cout + col) * 4);
+            // byte offset of stored position (i, jj) of this tile, BUFFER_OOB where nothing may be written -- computed where it is
+            // used (the accumulators leave no registers for a table)
+            auto out_off = [&](int i, int jj) {
+                const bool inb = tok & ((oy + i) < Ho) & ((ox + jj) < Wo);
+                return inb ? base + (unsigned)i * row_b + (unsigned)jj * px_b : BUFFER_OOB;
+            };
+            // A^T M A in two lane-local steps that shrink the live set: rows first (6 x 6 -> 6 x 4, in place of the
+            // accumulator values just read), then one output column at a time, stored as soon as it exists
+            float sA[6][4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const float m0 = acc[6 * i][r], m1 = acc[6 * i + 1][r], m2 = acc[6 * i + 2][r], m3 = acc[6 * i + 3][r],
+                            m4 = acc[6 * i + 4][r], m5 = acc[6 * i + 5][r];
+                const float t1 = m1 - m2, t2 = m1 + m2;
+                sA[i][0] = (m0 + t2) + (m3 + m4);
+                sA[i][1] = __builtin_fmaf(-2.0f, m4, __builtin_fmaf(0.5f, m3, t1));
+                sA[i][2] = __builtin_fmaf(4.0f, m4, __builtin_fmaf(0.25f, m3, t2));
+                sA[i][3] = __builtin_fmaf(-8.0f, m4, __builtin_fmaf(0.125f, m3, t1)) + m5;
+            }
+            auto finish = [&](float v, unsigned o) {                  // scale / shift, residual or mask, ReLU
+                v = v * sc + sh;
+                if (has_res) {
+                    const float rv = buffer_load_f32(rbuf, o, 0);
+                    v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
+                }
+                const float vr = fmaxf(v, 0.0f);
+                return relu ? vr : v;
+            };
+            float keep[4];                                            // pool: the even column's values wait for the odd one
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const float t1 = sA[1][jj] - sA[2][jj], t2 = sA[1][jj] + sA[2][jj];
+                float o4[4];
+                o4[0] = (sA[0][jj] + t2) + (sA[3][jj] + sA[4][jj]);
+                o4[1] = __builtin_fmaf(-2.0f, sA[4][jj], __builtin_fmaf(0.5f, sA[3][jj], t1));
+                o4[2] = __builtin_fmaf(4.0f, sA[4][jj], __builtin_fmaf(0.25f, sA[3][jj], t2));
+                o4[3] = __builtin_fmaf(-8.0f, sA[4][jj], __builtin_fmaf(0.125f, sA[3][jj], t1)) + sA[5][jj];
+                if (pool) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o4[i] = finish(o4[i], 0u);
+                    if ((jj & 1) == 0) {
+                        keep[0] = fmaxf(o4[0], o4[1]);
+                        keep[1] = fmaxf(o4[2], o4[3]);
+                    } else {
+                        buffer_store_f32(ybuf, fmaxf(keep[0], fmaxf(o4[0], o4[1])), out_off(0, jj >> 1), 0);
+                        buffer_store_f32(ybuf, fmaxf(keep[1], fmaxf(o4[2], o4[3])), out_off(1, jj >> 1), 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned o = out_off(i, jj);
+                        buffer_store_f32(ybuf, finish(o4[i], o), o, 0);
+                    }
+                }
+            }
+            const bool wrap_x = (tx + 1 == p.TX);
+            const bool wrap_y = wrap_x & (ty + 1 == p.TY);
+            tx = wrap_x ? 0 : tx + 1;
+            ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
+            b += wrap_y ? 1 : 0;
+        }
+    };
+
+    // ---- the blocks of this workgroup (chunks in pairs: nchunks is even, host side) ----------------------------------------------
+    while (true) {
+        const int tile0n = block_tile0(tb + J);
+        const int b0n = div_magic40(tile0n, p.magic_tpi);
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int pp = 0; pp < W4P; ++pp) acc[pp] = zero;
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk(ph0, false, c, tile0n, b0n);
+            chunk(ph1, c + 2 == nchunks, c + 1, tile0n, b0n);
+        }
+        epilogue(tile0, b0);
+        tb += J;
+        if (tb >= blk_end) break;
+        tile0 = tile0n;
+        b0 = b0n;
+    }
+}
+
+// OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1) -> U = G g G^T in fp64, rounded once to fp32,
+// laid out [cols/16][36 positions][RowsPad][16]
+__global__ void __launch_bounds__(256) wino4_pack_kernel(const float *w, float *u, int Cout, int Cin, int rows, int cols, int RowsPad,
+                                                          int mode) {
+    const double G[6][3] = {{1.0, 0.0, 0.0},
+                            {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
+                            {-1.0 / 3.0, 1.0 / 3.0, -1.0 / 3.0},
+                            {-16.0 / 15.0, -8.0 / 15.0, -4.0 / 15.0},
+                            {1.0 / 15.0, -2.0 / 15.0, 4.0 / 15.0},
+                            {0.0, 0.0, 1.0}};
+    const size_t total = (size_t)(cols / W4K) * RowsPad * W4K;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int kk = (int)(i % W4K);
+        const size_t rest = i / W4K;
+        const int n = (int)(rest % RowsPad);
+        const int ch = (int)(rest / RowsPad);
+        const int k = ch * W4K + kk;
+        double g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.0f;
+                if (n < rows) {
+                    v = (mode == 0) ? w[(((size_t)n * Cin + k) * 3 + a) * 3 + b]
+                                    : w[(((size_t)k * Cin + n) * 3 + (2 - a)) * 3 + (2 - b)];
+                }
+                g[a][b] = (double)v;
+            }
+        double t[6][3];                                             // G g
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * g[0][b] + G[a][1] * g[1][b] + G[a][2] * g[2][b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {                           // (G g) G^T
+                const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
+                u[(((size_t)ch * W4P + (a * 6 + b)) * RowsPad + n) * W4K + kk] = (float)v;
+            }
+    }
+}
+
+int g_max_workgroups4 = 0;     // test hook: cap on resident workgroups (0 = the chip's 256 CUs)
+
+template <int MODE>
+int launch_wino4(const Wino4Params &p, void *stream) {
+    void (*kernel)(const Wino4Params) = conv_wino4_kernel<MODE>;
+    const size_t lds = ((size_t)2 * V4B + S4B) * sizeof(float);
+    if (dream_allow_full_lds((const void *)kernel)) return 2;
+    const int ny = (p.Cout + 16 * W4NW - 1) / (16 * W4NW);
+    const int resident = g_max_workgroups4 > 0 ? g_max_workgroups4 : 256;
+    int gx = resident / ny / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > (p.nblk + 7) / 8 * 8) gx = (p.nblk + 7) / 8 * 8;
+    const dim3 grid((unsigned)gx, (unsigned)ny);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * W4NW), lds, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t dream_conv3x3_winograd4_weight_floats(int rows, int cols) {
+    const size_t rows_pad = (size_t)((rows + W4PAD - 1) / W4PAD) * W4PAD;
+    return ((size_t)(cols / W4K) * W4P + W4_AHEAD) * rows_pad * W4K;
+}
+
+extern "C" int dream_conv3x3_winograd4_set_max_workgroups(int n) {
+    DREAM_REQUIRE(n >= 0, "winograd F(4x4): max workgroups %d", n);
+    g_max_workgroups4 = n;
+    return 0;
+}
+
+// w: OIHW [Cout,Cin,3,3]; mode 0: forward operator (rows = Cout, cols = Cin); mode 1: data-gradient operator (rows = Cin,
+// cols = Cout, taps flipped).  u: dream_conv3x3_winograd4_weight_floats(rows, cols) floats.
+extern "C" int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u, int Cout, int Cin, int mode, void *stream) {
+    DREAM_REQUIRE(w_oihw && u && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "winograd F(4x4) pack: bad arguments");
+    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
+    DREAM_REQUIRE(cols % (2 * W4K) == 0, "winograd F(4x4) pack: %d input channels, must be a multiple of %d", cols, 2 * W4K);
+    const int rows_pad = (rows + W4PAD - 1) / W4PAD * W4PAD;
+    const size_t total = (size_t)(cols / W4K) * rows_pad * W4K;
+    size_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, rows, cols,
+                       rows_pad, mode);
+    DREAM_LAUNCH_OK();
+    DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / W4K) * W4P * rows_pad * W4K, 0, (size_t)W4_AHEAD * rows_pad * W4K * sizeof(float),
+                                (hipStream_t)stream));
+    return 0;
+}
+
+// y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32, by F(4x4,3x3).
+// Cin a multiple of 32; flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor), DREAM_CONV_RELUMASK.
+extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                                const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
+                                                void *stream) {
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd F(4x4) conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd F(4x4) conv: fused max-pool takes no residual");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd F(4x4) conv: ReLU mask without a mask tensor");
+    DREAM_REQUIRE(x && u_packed && y, "winograd F(4x4) conv: null pointer");
+    DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd F(4x4) conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
+    DREAM_REQUIRE(Cin % (2 * W4K) == 0, "winograd F(4x4) conv: Cin=%d must be a multiple of %d", Cin, 2 * W4K);
+    Wino4Params p;
+    const size_t span_imgs = (size_t)W4T / ((size_t)((H + 3) / 4) * ((W + 3) / 4)) + 2;
+    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) && span_imgs * H * W * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
+                  "winograd F(4x4) conv: image too large for 32-bit offsets");
+    p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    p.CoutPad = (Cout + W4PAD - 1) / W4PAD * W4PAD;
+    DREAM_REQUIRE(((size_t)(Cin / W4K) * W4P + W4_AHEAD) * (size_t)p.CoutPad * W4K * sizeof(float) < ((size_t)1 << 31), "winograd F(4x4) conv: weights too large");
+    p.TY = (H + 3) / 4; p.TX = (W + 3) / 4;
+    const long ntiles = (long)B * p.TY * p.TX;
+    DREAM_REQUIRE(ntiles < ((long)1 << 24), "winograd F(4x4) conv: %ld tiles, the tile decomposition handles < 2^24", ntiles);
+    p.ntiles = (int)ntiles;
+    p.nblk = (p.ntiles + W4T - 1) / W4T;
+    p.blk_per_xcd = (p.nblk + 7) / 8;
+    p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(p.TY * p.TX) - 1) / (unsigned long long)(p.TY * p.TX);
+    p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
+    p.flags = flags;
+    const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
+    switch (mode) {
+        case 0: return launch_wino4<0>(p, stream);
+        case 1: return launch_wino4<1>(p, stream);
+        case 2: return launch_wino4<2>(p, stream);
+        default: return launch_wino4<3>(p, stream);
+    }
+}

@@ -15,6 +15,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // all LDS of a kernel lives in ONE dynamic array whose base is 16-byte aligned (ds_read_b128)
 #define DREAM_DYNAMIC_LDS(type, var) extern __shared__ __attribute__((aligned(16))) type var[]
 
+// The kernel's own argument block, re-read from the kernarg segment (wave-uniform scalar loads) at the point of the call: for
+// values that are needed once per tile block and would otherwise sit in SGPRs across the main loop (the empty asm makes the
+// pointer opaque, so the loads cannot be merged with the kernel's initial argument loads and hoisted).  `arg` must be the
+// kernel's single by-value struct.
+template <class T>
+DREAM_DEVICE const T *kernarg_again(const T &) {
+    const T *kp = (const T *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+#define DREAM_KERNARG(arg) kernarg_again(arg)
+
 DREAM_DEVICE f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -34,6 +46,17 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 DREAM_DEVICE f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// y - x on four floats as two v_pk_add_f32 with the second operand negated (hipcc emits four v_sub_f32 for a vector subtraction)
+DREAM_DEVICE f32x4 pk_sub4(f32x4 y, f32x4 x) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    f32x2_ lo, hi;
+    const f32x2_ ylo = {y[0], y[1]}, yhi = {y[2], y[3]}, xlo = {x[0], x[1]}, xhi = {x[2], x[3]};
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(ylo), "v"(xlo));
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(yhi), "v"(xhi));
+    const f32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return r;
 }
 
 // Raw buffer loads (buffer_load_dwordx4 ... offen): 16 bytes per lane at base + voffset + soffset, voffset a 32-bit VGPR,
@@ -71,6 +94,10 @@ DREAM_DEVICE float quad_perm_2211(float v) {
 DREAM_DEVICE float quad_perm_1032(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
 }
+
+// lane index 0..63 recomputed from the hardware (v_mbcnt): for code that runs long after the kernel's entry and should not pin a
+// register with threadIdx.x until then
+DREAM_DEVICE int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // wave index within the workgroup as a provably wave-uniform (SGPR) value
 DREAM_DEVICE int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }

@@ -62,6 +62,8 @@ class _PackedCache:
             with torch.no_grad():
                 if mode in ("wino0", "wino1"):                    # Winograd F(2x2,3x3) transformed weights (fwd / data gradient)
                     packed = ops.pack_weight_winograd(weight.detach(), int(mode[-1]))
+                elif mode in ("wino4_0", "wino4_1"):              # Winograd F(4x4,3x3)
+                    packed = ops.pack_weight_winograd4(weight.detach(), int(mode[-1]))
                 elif mode == "ups":
                     wt4 = ops.upsample_conv_weight(weight.detach())
                     packed = ops.pack_convT4x4_weight_f16x3(wt4) if f16x3 else ops.pack_convT4x4_weight(wt4)
@@ -338,8 +340,9 @@ class DreamHourglass(nn.Module):
                         packed, rows, _, _ = self._packed.get(mod.weight, 1)   # phases: a quarter of the zero-stuffed MACs
                         act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
                     elif int(mod.weight.shape[1]) == int(inp.shape[3]) and self._use_winograd(int(inp.shape[3]), int(mod.weight.shape[0]), flags):
-                        u, rows = self._packed.get(mod.weight, "wino0")
-                        act = ops.conv3x3_winograd(inp, u, rows, None, bias, None, flags)
+                        tile = ops.winograd_tile(int(inp.shape[1]), int(inp.shape[2]), int(inp.shape[3]), int(mod.weight.shape[0]))
+                        u, rows = self._packed.get(mod.weight, "wino4_0" if tile == 4 else "wino0")
+                        act = ops.conv3x3_winograd_tile(tile, inp, u, rows, None, bias, None, flags)
                     else:
                         packed, rows, _, _ = self._packed.get(mod.weight, 0)
                         act = ops.conv3x3(inp, packed, bias, rows, flags)
@@ -438,13 +441,15 @@ class DreamHourglass(nn.Module):
                     u4b, rows_b = self._packed.get(mod.weight, "ups_wino1")
                     g = ops.conv4x4s2_winograd(g, u4b, rows_b)
                 elif self._use_winograd(int(g.shape[3]), cin, 0) and int(g.shape[3]) == cout:
-                    u_t, rows_t = self._packed.get(mod.weight, "wino1")
-                    g = ops.upsample2_bwd(ops.conv3x3_winograd(g, u_t, rows_t, None, None, None, 0))
+                    tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin)
+                    u_t, rows_t = self._packed.get(mod.weight, "wino4_1" if tile == 4 else "wino1")
+                    g = ops.upsample2_bwd(ops.conv3x3_winograd_tile(tile, g, u_t, rows_t, None, None, None, 0))
                 else:
                     g = ops.upsample2_bwd(ops.conv3x3(g, packed_t, None, rows, 0))
             elif self._use_winograd(int(g.shape[3]), cin, ops.CONV_RELUMASK if fuse else 0) and int(g.shape[3]) == cout:
-                u_t, rows_t = self._packed.get(mod.weight, "wino1")       # data gradient = conv with the transposed, flipped taps
-                g = ops.conv3x3_winograd(g, u_t, rows_t, None, None, inp if fuse else None, ops.CONV_RELUMASK if fuse else 0)
+                tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin)
+                u_t, rows_t = self._packed.get(mod.weight, "wino4_1" if tile == 4 else "wino1")   # data gradient = conv with the transposed, flipped taps
+                g = ops.conv3x3_winograd_tile(tile, g, u_t, rows_t, None, None, inp if fuse else None, ops.CONV_RELUMASK if fuse else 0)
                 masked = fuse
             else:
                 g = ops.conv3x3(g, packed_t, None, rows, 0, relu_mask=inp if fuse else None)
@@ -902,8 +907,9 @@ class ResnetSimple(nn.Module):
         cout, cin = int(conv.weight.shape[0]), int(conv.weight.shape[1])
         if k == 3 and stride == 1 and self.conv_algorithm == "winograd" and cin % 16 == 0 and cout >= 64:
             # the stride-1 3x3 convs of the bottlenecks: Winograd F(2x2,3x3) with the folded BatchNorm in the epilogue
-            u, rows = self._cached(("wino", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 0))
-            return ops.conv3x3_winograd(x, u, rows, scale, shift, residual, CONV_RELU if relu else 0)
+            tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), cin, cout)
+            u, rows = self._cached(("wino", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 0, tile))
+            return ops.conv3x3_winograd_tile(tile, x, u, rows, scale, shift, residual, CONV_RELU if relu else 0)
         if self._gemm1x1(conv, x):
             # the 1x1 convs of the bottlenecks: a plain GEMM without LDS (gemm1x1.hip), folded BatchNorm / residual / ReLU fused
             packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
@@ -1020,8 +1026,9 @@ class ResnetSimple(nn.Module):
         k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
         bias = conv.bias.detach() if conv.bias is not None else None
         if self._wino_train(conv):
-            u, rows = self._cached(("wino", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 0))
-            z = ops.conv3x3_winograd(x, u, rows, None, bias, None, 0)
+            tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), int(conv.weight.shape[1]), int(conv.weight.shape[0]))
+            u, rows = self._cached(("wino", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 0, tile))
+            z = ops.conv3x3_winograd_tile(tile, x, u, rows, None, bias, None, 0)
         elif self._gemm1x1(conv, x):
             packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
             z = ops.conv1x1(x, packed, rows, None, bias, None, 0)
@@ -1041,8 +1048,9 @@ class ResnetSimple(nn.Module):
 
     def _bwd_data(self, name, conv, dz, cin, k, stride, in_hw, residual=None):
         if self._wino_train(conv):
-            u_t, rows = self._cached(("wino1", name), [conv.weight], lambda: ops.pack_weight_winograd(conv.weight.detach(), 1))
-            return ops.conv3x3_winograd(dz, u_t, rows, None, None, residual, 0)
+            tile = ops.winograd_tile(int(dz.shape[1]), int(dz.shape[2]), int(conv.weight.shape[0]), int(conv.weight.shape[1]))
+            u_t, rows = self._cached(("wino1", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 1, tile))
+            return ops.conv3x3_winograd_tile(tile, dz, u_t, rows, None, None, residual, 0)
         if (self.conv1x1_algorithm == "gemm" and k == 1 and stride == 1 and int(dz.shape[3]) == int(conv.weight.shape[0])
                 and ops.conv1x1_applies(dz, cin)):
             packed_t, rows = self._cached(("g1", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 1))

@@ -80,6 +80,60 @@ def conv3x3_winograd(x_nhwc, packed_u, cout, scale=None, shift=None, residual=No
     return y
 
 
+def winograd_tile(h, w, cin, cout):
+    """Output tile of the Winograd kernel for a stride-1 3x3 conv on an h x w map: 4 = F(4x4,3x3) (csrc/conv_wino4.hip: 2.25
+    multiplications per output, measured 1.3-1.4x F(2x2,3x3) on its layers, profiles/r03_microbench_wino4_b128.txt) where its
+    workgroup shape applies (128 output channels per workgroup, Cin a multiple of 32 and >= 64) and rounding the map up to whole
+    4 x 4 tiles costs less than that gain; else 2 = F(2x2,3x3) (csrc/conv_wino.hip).  DREAM_WINOGRAD_TILE=2 forces F(2x2)."""
+    if _WINOGRAD_TILE_FORCED == 2 or cin % 32 != 0 or cin < 64 or cout < 128:
+        return 2
+    pad4 = ((h + 3) // 4) * ((w + 3) // 4) * 16
+    pad2 = ((h + 1) // 2) * ((w + 1) // 2) * 4
+    return 4 if pad4 < 1.25 * pad2 else 2
+
+
+import os as _os
+_WINOGRAD_TILE_FORCED = int(_os.environ.get("DREAM_WINOGRAD_TILE", "0"))
+
+
+def set_winograd_tile(tile):
+    """0: by layer (winograd_tile); 2: F(2x2,3x3) everywhere (A/B runs, bench.py --conv-algorithm winograd2)."""
+    global _WINOGRAD_TILE_FORCED
+    _WINOGRAD_TILE_FORCED = int(tile)
+
+
+def pack_weight_winograd_tile(w_oihw, mode, tile):
+    return pack_weight_winograd4(w_oihw, mode) if tile == 4 else pack_weight_winograd(w_oihw, mode)
+
+
+def conv3x3_winograd_tile(tile, x_nhwc, packed_u, cout, scale=None, shift=None, residual=None, flags=0):
+    fn = conv3x3_winograd4 if tile == 4 else conv3x3_winograd        # looked up at call time: bench.py wraps both
+    return fn(x_nhwc, packed_u, cout, scale, shift, residual, flags)
+
+
+def pack_weight_winograd4(w_oihw, mode=0):
+    """OIHW [Cout,Cin,3,3] -> the transformed weights of the Winograd F(4x4,3x3) kernel ([cols/16][36][rows_pad][16]); mode as
+    pack_weight_winograd.  Returns (packed, rows)."""
+    w = _f32(w_oihw)
+    cout, cin = int(w.shape[0]), int(w.shape[1])
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    n = int(_hip.lib().dream_conv3x3_winograd4_weight_floats(rows, cols))
+    packed = torch.empty((n,), dtype=torch.float32, device=w.device)
+    call("dream_pack_conv3x3_winograd4_weight", ptr(w), ptr(packed), cout, cin, mode, stream())
+    return packed, rows
+
+
+def conv3x3_winograd4(x_nhwc, packed_u, cout, scale=None, shift=None, residual=None, flags=0):
+    """3x3 stride-1 pad-1 conv by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): same contract as conv3x3_winograd; Cin % 32 == 0."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    shape = (b, h // 2, w // 2, cout) if flags & CONV_POOL2 else (b, h, w, cout)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_winograd4_nhwc_f32", ptr(x), ptr(packed_u), ptr(scale), ptr(shift), ptr(residual), ptr(y), b, h, w, cin,
+         cout, flags, stream())
+    return y
+
+
 def pack_convT4x4_winograd_weight(wT, mode=0):
     """[Cin,Cout,4,4] ConvTranspose2d(k4,s2,p1) weight -> the four phases' Winograd-transformed 3x3 kernels of the forward
     operator (mode 0; returns (u4, cout)) or of the data-gradient operator (mode 1; returns (u4, cin))."""

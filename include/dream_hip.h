@@ -117,6 +117,17 @@ int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u_packed, int
 int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                     void *stream);
+
+/* The same convolution by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): 36 multiplications per 4x4 outputs and input channel
+ * (2.25 per output; F(2x2,3x3): 4; direct: 9), interpolation points (0, 1, -1, 1/2, -2, inf), IEEE fp32 throughout, weights
+ * transformed in fp64 at pack time.  For the layers of dream/models.py:598-615,695-710 with >= 128 output channels.
+ * Cin a multiple of 32.  Packed weights: dream_conv3x3_winograd4_weight_floats(rows, cols) floats; mode / flags as above. */
+size_t dream_conv3x3_winograd4_weight_floats(int rows, int cols);
+int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u, int Cout, int Cin, int mode, void *stream);
+int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                     const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
+                                     void *stream);
+int dream_conv3x3_winograd4_set_max_workgroups(int n);     /* test hook, as dream_conv3x3_winograd_set_max_workgroups */
 /* nn.ConvTranspose2d(k4,s2,p1) (+ folded BatchNorm / bias, ReLU) of the ResNet decoder (dream/models.py:37-136) by minimal
  * filtering on the Winograd kernel: each output phase is a 2x2-tap conv = a 3x3 conv whose transformed weights vanish on 7 of
  * the 16 positions: 9 multiplications per 2x2 outputs of a phase instead of 16, same fp32 arithmetic.  x [B,H,W,Cin] ->

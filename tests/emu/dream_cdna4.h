@@ -9,6 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DREAM_DEVICE inline __attribute__((always_inline))
+#define DREAM_KERNARG(arg) (&(arg))
 #define DREAM_DYNAMIC_LDS(type, var) type *var = (type *)emu::tb->dyn_lds
 
 inline f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
@@ -68,6 +69,7 @@ inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
     }
     return c;
 }
+inline f32x4 pk_sub4(f32x4 y, f32x4 x) { return y - x; }
 // raw buffer loads: zeros for lanes whose voffset is outside the descriptor (see the product header)
 struct BufferRsrc { const char *base; unsigned bytes; };
 constexpr unsigned BUFFER_OOB = 0x80000000u;
@@ -97,6 +99,7 @@ inline float quad_perm_2211(float v) {
 }
 inline float quad_perm_1032(float v) { return emu_exchange(v, emu::lane() ^ 1); }
 inline int wave_index() { return emu::wave(); }
+inline int lane_id() { return emu::lane(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 inline double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 inline int lane_xor(int v, int m) { return __shfl_xor(v, m, 64); }

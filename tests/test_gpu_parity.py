@@ -575,6 +575,21 @@ def test_conv_winograd(b, h, w, cin, cout, flags, kw):
     print("winograd %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
+    (1, 8, 8, 32, 16, 0, {}), (2, 13, 25, 32, 64, ops.CONV_RELU, {}), (3, 5, 3, 64, 7, 0, {}),
+    (2, 12, 20, 32, 144, ops.CONV_RELU | ops.CONV_POOL2, {}), (2, 13, 9, 32, 64, ops.CONV_RELU | ops.CONV_POOL2, {}),
+    (1, 10, 14, 64, 32, ops.CONV_RELU, dict(with_scale=True, residual="add")), (1, 9, 11, 32, 48, ops.CONV_RELUMASK, dict(residual="mask")),
+    (2, 7, 9, 32, 64, 0, dict(mode=1)),
+    # the vgg_q layers F(4x4,3x3) serves (batch 2; the data gradients of the same layers through mode 1 / the mask)
+    (2, 200, 200, 64, 128, ops.CONV_RELU, {}), (2, 200, 200, 128, 128, ops.CONV_RELU | ops.CONV_POOL2, {}),
+    (2, 100, 100, 128, 256, ops.CONV_RELU, {}), (2, 100, 100, 256, 256, ops.CONV_RELU, {}), (4, 50, 50, 256, 512, ops.CONV_RELU, {}),
+    (4, 50, 50, 512, 512, ops.CONV_RELU, {}), (8, 25, 25, 512, 512, ops.CONV_RELU, {}), (4, 50, 50, 256, 256, 0, {}),
+    (2, 100, 100, 256, 128, ops.CONV_RELUMASK, dict(mode=1, residual="mask")), (16, 13, 13, 512, 512, 0, {})])
+def test_conv_winograd4(b, h, w, cin, cout, flags, kw):
+    err = pc.check_conv_winograd4(DEV, b, h, w, cin, cout, flags, seed=b + h, max_workgroups=(8, 24), **kw)
+    print("winograd F(4x4) %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
+
+
 # ---- single-process data parallelism behind gpu_ids (dream_amd/data_parallel.py; reference network.py:244-256) ------------
 @pytest.mark.parametrize("b,h,w,cin,cout", [(1, 6, 6, 128, 32), (2, 13, 9, 96, 48), (1, 20, 22, 256, 32), (4, 13, 13, 2048, 256),
                                             (4, 104, 104, 256, 256)])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Run one conv layer shape repeatedly on one kernel (for rocprofv3 --pmc passes).
-usage: one_layer.py <fp32|f16x3|wino> <variant> <res> <cin> <cout> <batch> [reps]"""
+usage: one_layer.py <fp32|f16x3|wino|wino4> <variant> <res> <cin> <cout> <batch> [reps]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,6 +16,10 @@ if kind == "wgwino":
     dy = torch.randn(batch, res, res, cout, device="cuda")
     for _ in range(reps):
         ops.conv3x3_wgrad_winograd(x, dy, cout, cin, want_bias=False)
+elif kind == "wino4":
+    u, _ = ops.pack_weight_winograd4(w, 0)
+    for _ in range(reps):
+        ops.conv3x3_winograd4(x, u, cout, None, bias, None, 1)
 elif kind == "wino":
     u, _ = ops.pack_weight_winograd(w, 0)
     lib.dream_conv3x3_winograd_set_variant(variant)

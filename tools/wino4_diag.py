@@ -1,0 +1,72 @@
+#!/usr/bin/env python
+"""Knock-out timing of the Winograd F(4x4,3x3) kernel: libraries built with -DDREAM_W4_DIAG=k (bit 0: no patch loads, bit 1: no
+weight stream, bit 2: no barriers, bit 3: no pass 1 / pass 2; results are wrong by construction) against the product library, same
+layer, same box.  `build` runs here (hipcc), `run` on the GPU box.   python tools/wino4_diag.py build | run [--batch 128]"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+KS = [16, 18, 2, 9, 11, 108]          # >= 100: product code with another weight-ring size (k - 100)
+OUT = os.path.join(ROOT, "dream_amd", "diag")       # travels with the snapshot (git-ignored *.so)
+NAMES = {0: "product", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
+         11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 108: "product, weight ring 8 (6 ahead)"}
+
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    csrc = os.path.join(ROOT, "dream_amd", "csrc")
+    procs = []
+    for k in KS:
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+               "-I", os.path.join(csrc, "include"), "-DDREAM_W4_DIAG=%d" % (k if k < 100 else 0)] + (
+                   ["-DDREAM_W4_RING=%d" % (k - 100)] if k >= 100 else []) + [os.path.join(csrc, "conv_wino4.hip"),
+               os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino4_diag_%d.so" % k)]
+        procs.append(subprocess.Popen(cmd))
+    assert all(p.wait() == 0 for p in procs)
+
+
+def run(batch):
+    import torch
+    from dream_amd import _hip, ops
+    libs = {0: _hip.lib()}
+    for k in KS:
+        h = ctypes.CDLL(os.path.join(OUT, "libwino4_diag_%d.so" % k))
+        fn = h.dream_conv3x3_winograd4_nhwc_f32
+        fn.restype, fn.argtypes = _hip._SIGNATURES["dream_conv3x3_winograd4_nhwc_f32"]
+        libs[k] = h
+    for (res, cin, cout) in [(200, 128, 128), (100, 256, 256), (50, 512, 512), (25, 512, 512)]:
+        x = torch.randn(batch, res, res, cin, device="cuda")
+        w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
+        u, _ = ops.pack_weight_winograd4(w, 0)
+        y = torch.empty(batch, res, res, cout, device="cuda")
+        flops = 2.0 * batch * res * res * cin * cout * 9 / 4.0
+        line = []
+        for k in [0] + KS:
+            fn = libs[k].dream_conv3x3_winograd4_nhwc_f32
+
+            def call():
+                rc = fn(x.data_ptr(), u.data_ptr(), None, None, None, y.data_ptr(), batch, res, res, cin, cout, 1,
+                        torch.cuda.current_stream().cuda_stream)
+                assert rc == 0
+            call()
+            torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(5):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                call()
+                e.record()
+                torch.cuda.synchronize()
+                best = min(best, s.elapsed_time(e))
+            line.append("%s %.3f ms (%.2f)" % (NAMES[k], best, flops / best / 1e9 / 157.3))
+        print("%d %d->%d b=%d: " % (res, cin, cout, batch) + " | ".join(line), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build()
+    else:
+        run(int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 128)
