@@ -340,7 +340,7 @@ class DreamHourglass(nn.Module):
                         packed, rows, _, _ = self._packed.get(mod.weight, 1)   # phases: a quarter of the zero-stuffed MACs
                         act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
                     elif int(mod.weight.shape[1]) == int(inp.shape[3]) and self._use_winograd(int(inp.shape[3]), int(mod.weight.shape[0]), flags):
-                        tile = ops.winograd_tile(int(inp.shape[1]), int(inp.shape[2]), int(inp.shape[3]), int(mod.weight.shape[0]))
+                        tile = ops.winograd_tile(int(inp.shape[1]), int(inp.shape[2]), int(inp.shape[3]), int(mod.weight.shape[0]), int(inp.shape[0]))
                         u, rows = self._packed.get(mod.weight, "wino4_0" if tile == 4 else "wino0")
                         act = ops.conv3x3_winograd_tile(tile, inp, u, rows, None, bias, None, flags)
                     else:
@@ -441,13 +441,13 @@ class DreamHourglass(nn.Module):
                     u4b, rows_b = self._packed.get(mod.weight, "ups_wino1")
                     g = ops.conv4x4s2_winograd(g, u4b, rows_b)
                 elif self._use_winograd(int(g.shape[3]), cin, 0) and int(g.shape[3]) == cout:
-                    tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin)
+                    tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin, int(g.shape[0]))
                     u_t, rows_t = self._packed.get(mod.weight, "wino4_1" if tile == 4 else "wino1")
                     g = ops.upsample2_bwd(ops.conv3x3_winograd_tile(tile, g, u_t, rows_t, None, None, None, 0))
                 else:
                     g = ops.upsample2_bwd(ops.conv3x3(g, packed_t, None, rows, 0))
             elif self._use_winograd(int(g.shape[3]), cin, ops.CONV_RELUMASK if fuse else 0) and int(g.shape[3]) == cout:
-                tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin)
+                tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin, int(g.shape[0]))
                 u_t, rows_t = self._packed.get(mod.weight, "wino4_1" if tile == 4 else "wino1")   # data gradient = conv with the transposed, flipped taps
                 g = ops.conv3x3_winograd_tile(tile, g, u_t, rows_t, None, None, inp if fuse else None, ops.CONV_RELUMASK if fuse else 0)
                 masked = fuse
@@ -907,7 +907,7 @@ class ResnetSimple(nn.Module):
         cout, cin = int(conv.weight.shape[0]), int(conv.weight.shape[1])
         if k == 3 and stride == 1 and self.conv_algorithm == "winograd" and cin % 16 == 0 and cout >= 64:
             # the stride-1 3x3 convs of the bottlenecks: Winograd F(2x2,3x3) with the folded BatchNorm in the epilogue
-            tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), cin, cout)
+            tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), cin, cout, int(x.shape[0]))
             u, rows = self._cached(("wino", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 0, tile))
             return ops.conv3x3_winograd_tile(tile, x, u, rows, scale, shift, residual, CONV_RELU if relu else 0)
         if self._gemm1x1(conv, x):
@@ -1026,7 +1026,7 @@ class ResnetSimple(nn.Module):
         k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
         bias = conv.bias.detach() if conv.bias is not None else None
         if self._wino_train(conv):
-            tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), int(conv.weight.shape[1]), int(conv.weight.shape[0]))
+            tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), int(conv.weight.shape[1]), int(conv.weight.shape[0]), int(x.shape[0]))
             u, rows = self._cached(("wino", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 0, tile))
             z = ops.conv3x3_winograd_tile(tile, x, u, rows, None, bias, None, 0)
         elif self._gemm1x1(conv, x):
@@ -1048,7 +1048,7 @@ class ResnetSimple(nn.Module):
 
     def _bwd_data(self, name, conv, dz, cin, k, stride, in_hw, residual=None):
         if self._wino_train(conv):
-            tile = ops.winograd_tile(int(dz.shape[1]), int(dz.shape[2]), int(conv.weight.shape[0]), int(conv.weight.shape[1]))
+            tile = ops.winograd_tile(int(dz.shape[1]), int(dz.shape[2]), int(conv.weight.shape[0]), int(conv.weight.shape[1]), int(dz.shape[0]))
             u_t, rows = self._cached(("wino1", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 1, tile))
             return ops.conv3x3_winograd_tile(tile, dz, u_t, rows, None, None, residual, 0)
         if (self.conv1x1_algorithm == "gemm" and k == 1 and stride == 1 and int(dz.shape[3]) == int(conv.weight.shape[0])

@@ -80,15 +80,20 @@ def conv3x3_winograd(x_nhwc, packed_u, cout, scale=None, shift=None, residual=No
     return y
 
 
-def winograd_tile(h, w, cin, cout):
+def winograd_tile(h, w, cin, cout, batch=None):
     """Output tile of the Winograd kernel for a stride-1 3x3 conv on an h x w map: 4 = F(4x4,3x3) (csrc/conv_wino4.hip: 2.25
     multiplications per output, measured 1.3-1.4x F(2x2,3x3) on its layers, profiles/r03_microbench_wino4_b128.txt) where its
-    workgroup shape applies (128 output channels per workgroup, Cin a multiple of 32 and >= 64) and rounding the map up to whole
-    4 x 4 tiles costs less than that gain; else 2 = F(2x2,3x3) (csrc/conv_wino.hip).  DREAM_WINOGRAD_TILE=2 forces F(2x2)."""
+    workgroup shape applies (128 output channels per workgroup, Cin a multiple of 32 and >= 64), rounding the map up to whole
+    4 x 4 tiles costs less than that gain, and the batch gives every CU at least two workgroups' worth of tiles; else 2 = F(2x2,3x3) (csrc/conv_wino.hip).  DREAM_WINOGRAD_TILE=2 forces F(2x2)."""
     if _WINOGRAD_TILE_FORCED == 2 or cin % 32 != 0 or cin < 64 or cout < 128:
         return 2
-    pad4 = ((h + 3) // 4) * ((w + 3) // 4) * 16
+    if _WINOGRAD_TILE_FORCED == 4:
+        return 4                       # tests: F(4x4) wherever the kernel applies, whatever the map and batch size
+    t4 = ((h + 3) // 4) * ((w + 3) // 4)
+    pad4 = t4 * 16
     pad2 = ((h + 1) // 2) * ((w + 1) // 2) * 4
+    if batch is not None and ((batch * t4 + 15) // 16) * ((cout + 127) // 128) < 2 * 256:
+        return 2                       # fewer than two 16-tile blocks per CU: the 32-tile F(2x2) blocks fill the chip better
     return 4 if pad4 < 1.25 * pad2 else 2
 
 
@@ -97,7 +102,8 @@ _WINOGRAD_TILE_FORCED = int(_os.environ.get("DREAM_WINOGRAD_TILE", "0"))
 
 
 def set_winograd_tile(tile):
-    """0: by layer (winograd_tile); 2: F(2x2,3x3) everywhere (A/B runs, bench.py --conv-algorithm winograd2)."""
+    """0: by layer (winograd_tile); 2: F(2x2,3x3) everywhere (A/B runs, bench.py --conv-algorithm winograd2); 4: F(4x4,3x3)
+    wherever the kernel applies (parity tests on small batches)."""
     global _WINOGRAD_TILE_FORCED
     _WINOGRAD_TILE_FORCED = int(tile)
 

@@ -441,6 +441,28 @@ def test_structured_fixture_absolute_tolerance(arch):
     print("structured %s fp32: max |map error| %.2e, max keypoint error %.2e px" % (arch, err, perr))
 
 
+@pytest.mark.parametrize("arch", ["vgg_q", "vgg_q_400", "vgg_f", "resnet_h"])
+def test_structured_fixture_absolute_tolerance_winograd4(arch):
+    """The same north-star bounds with Winograd F(4x4,3x3) on every layer the kernel takes (at batch 128 the default; at the
+    fixtures' 1-2 frames the layers would fall back to F(2x2,3x3) for lack of tiles)."""
+    ops.set_winograd_tile(4)
+    try:
+        err, perr = pc.check_structured(DEV, arch)
+    finally:
+        ops.set_winograd_tile(0)
+    print("structured %s fp32, F(4x4,3x3) forced: max |map error| %.2e, max keypoint error %.2e px" % (arch, err, perr))
+
+
+@pytest.mark.parametrize("opt", ["adam", "sgd"])
+def test_train_steps_golden_winograd4(opt):
+    ops.set_winograd_tile(4)
+    try:
+        res = pc.check_train_steps(DEV, opt, steps=3)
+    finally:
+        ops.set_winograd_tile(0)
+    print("train golden %s, F(4x4,3x3) forced: fraction of tight parameter samples %.4f, worst %.2e" % ((opt,) + tuple(res)))
+
+
 @pytest.mark.parametrize("arch", sorted(cases.STRUCTURED_CASES))
 def test_structured_fixture_absolute_tolerance_split_precision(arch):
     err, perr = pc.check_structured(DEV, arch, precision="fp16x3")
