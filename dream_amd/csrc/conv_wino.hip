@@ -44,6 +44,7 @@
 #include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
+#include "pack_device.h"
 #include "../../include/dream_hip.h"
 
 // Timing diagnostics only (tools/wino_diag.py builds separate libraries with -DDREAM_WINO_DIAG=k; never the product
@@ -459,46 +460,10 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
 }
 
 // OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1: rows = Cin_fwd, cols = Cout_fwd)
-// -> U = G g G^T in fp64, rounded once to fp32, laid out [cols/16][16 positions][RowsPad][16].
-__global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u, int Cout, int Cin, int rows, int cols,
-                                                         int RowsPad, int mode) {
-    const size_t total = (size_t)(cols / WKC) * RowsPad * WKC;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int kk = (int)(i % WKC);
-        const size_t rest = i / WKC;
-        const int n = (int)(rest % RowsPad);
-        const int ch = (int)(rest / RowsPad);
-        const int k = ch * WKC + kk;
-        double g[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float v = 0.0f;
-                if (n < rows) {
-                    v = (mode == 0) ? w[(((size_t)n * Cin + k) * 3 + a) * 3 + b]
-                                    : w[(((size_t)k * Cin + n) * 3 + (2 - a)) * 3 + (2 - b)];
-                }
-                g[a][b] = (double)v;
-            }
-        double t[4][3];                                             // G g
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            t[0][b] = g[0][b];
-            t[1][b] = 0.5 * (g[0][b] + g[1][b] + g[2][b]);
-            t[2][b] = 0.5 * (g[0][b] - g[1][b] + g[2][b]);
-            t[3][b] = g[2][b];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {                               // (G g) G^T
-            const double r0 = t[a][0], r1 = 0.5 * (t[a][0] + t[a][1] + t[a][2]), r2 = 0.5 * (t[a][0] - t[a][1] + t[a][2]),
-                         r3 = t[a][2];
-            const double rr[4] = {r0, r1, r2, r3};
-#pragma unroll
-            for (int b = 0; b < 4; ++b)                             // row 3 negated: the kernel computes -V[3][.] (see there)
-                u[(((size_t)ch * 16 + (a * 4 + b)) * RowsPad + n) * WKC + kk] = (float)(a == 3 ? -rr[b] : rr[b]);
-        }
-    }
+// -> U = G g G^T in fp64, rounded once to fp32, laid out [cols/16][16 positions][RowsPad][16]: pack_device.h (dream_pack::winograd2)
+static_assert(WKC == 16 && WPAD == 128, "pack_device.h assumes 16-channel chunks and rows padded to 128");
+__global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u, int Cout, int Cin, int mode) {
+    dream_pack::winograd2(w, u, Cout, Cin, mode, (int)blockIdx.x, (int)gridDim.x);
 }
 
 constexpr int kCUs = 256;     // MI355X
@@ -541,8 +506,7 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
     const size_t total = (size_t)(cols / WKC) * rows_pad * WKC;
     size_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, rows, cols,
-                       rows_pad, mode);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode);
     DREAM_LAUNCH_OK();
     DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / WKC) * 16 * rows_pad * WKC, 0, (size_t)B_AHEAD * rows_pad * WKC * sizeof(float),
                                 (hipStream_t)stream));

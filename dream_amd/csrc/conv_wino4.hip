@@ -40,6 +40,7 @@
 #include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
+#include "pack_device.h"
 #include "../../include/dream_hip.h"
 
 // Timing diagnostics only (tools/wino4_diag.py builds separate libraries with -DDREAM_W4_DIAG=k; never the product library; results
@@ -239,7 +240,13 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
     // computed here, the weight stream wraps around.  One instantiation per parity, one call site each: the loop below.
     auto chunk = [&](auto ph_tag, bool last, int c, int tile0n, int b0n) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
-        constexpr int S1 = 10, S2 = 13;                   // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
+#ifndef DREAM_W4_S1
+#define DREAM_W4_S1 10
+#define DREAM_W4_S2 13
+#define DREAM_W4_LX 3
+#endif
+        constexpr int S1 = DREAM_W4_S1, S2 = DREAM_W4_S2; // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
+        constexpr int LX = DREAM_W4_LX;                   // patch loads in slots 0 .. LX - 1 (6 / LX per slot)
         const unsigned coff = last ? 0u : (unsigned)((c + 1) * W4K * 4);
         const int cnext = last ? 0 : (c + 1) * W4P;                          // first position of the next chunk in the weight stream
         if (PH == 1 && last) xbuf = block_xbuf(b0n);                        // this block's loads are all issued: from here on the next block's
@@ -265,13 +272,13 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
             load_b(0);
             if (s + 1 < 18) read_a((s + 1) & 1, pp + 2, PH);
             if (PH == 1 && s == 0 && last) plan_item(tile0n, b0n);
-            if (s < 3) load_x(2 * s);
+            if (s < LX) { for (int c2 = 0; c2 < 3 / LX; ++c2) load_x((6 / LX) * s + c2); }
             if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1));
             if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(0); pass2_read(1); }
             if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1), 1 - PH);
             pair(1);
             load_b(1);
-            if (s < 3) load_x(2 * s + 1);
+            if (s < LX) { for (int c2 = 3 / LX; c2 < 6 / LX; ++c2) load_x((6 / LX) * s + c2); }
             if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(2); pass2_read(3); }
             pair(2);
             if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1) + 1);
@@ -402,47 +409,10 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
 }
 
 // OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1) -> U = G g G^T in fp64, rounded once to fp32,
-// laid out [cols/16][36 positions][RowsPad][16]
-__global__ void __launch_bounds__(256) wino4_pack_kernel(const float *w, float *u, int Cout, int Cin, int rows, int cols, int RowsPad,
-                                                          int mode) {
-    const double G[6][3] = {{1.0, 0.0, 0.0},
-                            {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
-                            {-1.0 / 3.0, 1.0 / 3.0, -1.0 / 3.0},
-                            {-16.0 / 15.0, -8.0 / 15.0, -4.0 / 15.0},
-                            {1.0 / 15.0, -2.0 / 15.0, 4.0 / 15.0},
-                            {0.0, 0.0, 1.0}};
-    const size_t total = (size_t)(cols / W4K) * RowsPad * W4K;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int kk = (int)(i % W4K);
-        const size_t rest = i / W4K;
-        const int n = (int)(rest % RowsPad);
-        const int ch = (int)(rest / RowsPad);
-        const int k = ch * W4K + kk;
-        double g[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float v = 0.0f;
-                if (n < rows) {
-                    v = (mode == 0) ? w[(((size_t)n * Cin + k) * 3 + a) * 3 + b]
-                                    : w[(((size_t)k * Cin + n) * 3 + (2 - a)) * 3 + (2 - b)];
-                }
-                g[a][b] = (double)v;
-            }
-        double t[6][3];                                             // G g
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) t[a][b] = G[a][0] * g[0][b] + G[a][1] * g[1][b] + G[a][2] * g[2][b];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {                           // (G g) G^T
-                const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
-                u[(((size_t)ch * W4P + (a * 6 + b)) * RowsPad + n) * W4K + kk] = (float)v;
-            }
-    }
+// laid out [cols/16][36 positions][RowsPad][16]: pack_device.h (dream_pack::winograd4)
+static_assert(W4K == 16 && W4PAD == 128 && W4P == 36, "pack_device.h assumes 16-channel chunks, 36 positions, rows padded to 128");
+__global__ void __launch_bounds__(256) wino4_pack_kernel(const float *w, float *u, int Cout, int Cin, int mode) {
+    dream_pack::winograd4(w, u, Cout, Cin, mode, (int)blockIdx.x, (int)gridDim.x);
 }
 
 int g_max_workgroups4 = 0;     // test hook: cap on resident workgroups (0 = the chip's 256 CUs)
@@ -486,8 +456,7 @@ extern "C" int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u
     const size_t total = (size_t)(cols / W4K) * rows_pad * W4K;
     size_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, rows, cols,
-                       rows_pad, mode);
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode);
     DREAM_LAUNCH_OK();
     DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / W4K) * W4P * rows_pad * W4K, 0, (size_t)W4_AHEAD * rows_pad * W4K * sizeof(float),
                                 (hipStream_t)stream));

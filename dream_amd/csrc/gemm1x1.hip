@@ -23,6 +23,7 @@
 //     rows beyond the end read zeros and are not stored.
 #include <dream_cdna4.h>
 #include "common.h"
+#include "pack_device.h"
 #include "../../include/dream_hip.h"
 
 namespace {
@@ -148,21 +149,9 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
         }
 }
 
-// w [Cout][Cin] (mode 0: rows = Cout, k = Cin) or, for the data gradient, the same tensor read as [k = Cout][rows = Cin]
-// (mode 1) -> packed [K/16][RowsPad][16] with physical row 64 c + 16 n + j = logical row 64 c + 4 j + n
-__global__ void __launch_bounds__(256) gemm1x1_pack_kernel(const float *w, float *packed, int Cout, int Cin, int rows, int K,
-                                                            int RowsPad, int mode) {
-    const size_t total = (size_t)(K / 16) * RowsPad * 16;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int e = (int)(i & 15);
-        const size_t rest = i >> 4;
-        const int prow = (int)(rest % RowsPad), t = (int)(rest / RowsPad);
-        const int blk = prow >> 6, n = (prow >> 4) & 3, j = prow & 15;
-        const int row = blk * 64 + 4 * j + n, k = 16 * t + e;
-        float v = 0.0f;
-        if (row < rows) v = mode == 0 ? w[(size_t)row * Cin + k] : w[(size_t)k * Cin + row];
-        packed[i] = v;
-    }
+// packed operand layout: pack_device.h (dream_pack::conv1x1)
+__global__ void __launch_bounds__(256) gemm1x1_pack_kernel(const float *w, float *packed, int Cout, int Cin, int mode) {
+    dream_pack::conv1x1(w, packed, Cout, Cin, mode, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -308,8 +297,7 @@ extern "C" int dream_pack_conv1x1_weight(const float *w_oihw, float *packed, int
     const size_t total = (size_t)(K / 16) * rows_pad * 16;
     size_t grid = (total + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(gemm1x1_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin, rows,
-                       K, rows_pad, mode);
+    hipLaunchKernelGGL(gemm1x1_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, packed, Cout, Cin, mode);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -887,6 +887,9 @@ class ResnetSimple(nn.Module):
 
     # ---- execution (eval-mode BatchNorm folded into the conv epilogues) ----------------------------------
     def _cached(self, key, tensors, build):
+        rec = self.__dict__.get("_pack_records")
+        if rec is not None and key[0] != "bn":
+            return self._cached_recording(key, tensors, build, rec)
         tag = tuple((t._version, t.data_ptr()) for t in tensors)
         hit = self._cache.get(key)
         if hit is None or hit[0] != tag:
@@ -894,6 +897,54 @@ class ResnetSimple(nn.Module):
                 hit = (tag, build())
             self._cache[key] = hit
         return hit[1]
+
+    # ---- training: all packed weight copies of a step refreshed by ONE launch ------------------------------------------------------
+    def _cached_recording(self, key, tensors, build, rec):
+        """_cached during the recording step of _repack_weights: also notes which batchable packs build() made."""
+        tag = tuple((t._version, t.data_ptr()) for t in tensors)
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != tag:
+            with torch.no_grad(), ops.record_packs() as descs:
+                out = build()
+            self._cache[key] = hit = (tag, out)
+            # batchable: everything build() launched was one of the table's kinds, reading the parameter itself (not a derived copy)
+            if descs and all(any(d[1].data_ptr() == t.data_ptr() for t in tensors) for d in descs):
+                rec[key] = (tensors, out, list(descs))
+        return hit[1]
+
+    def _repack_weights(self):
+        """A training step re-packs every conv weight (the optimizer changed them all): 216 launches of 2-10 us, 6.8 % of a
+        step at 16 frames (profiles/r02_layer_profile_resnet_h_train16.txt).  The first training step records which packed copies
+        it builds from which parameter; from the second step on ONE launch (dream_pack_weights_batched: a device-resident job
+        table, blockIdx.y = job) rewrites all of them in place at the start of the step and the cache entries are stamped with
+        the parameters' new versions.  The few packs the table does not cover (tap-major copies for the direct kernel, the
+        transposed convs' phase kernels) stay lazy.  Skipped while a hipGraph capture is under way (the data-parallel replicas
+        capture their whole step, packing included)."""
+        first = next(self.parameters())
+        if not first.is_cuda and not os.environ.get("DREAM_PACK_BATCHED_ON_CPU"):
+            return
+        if (first.is_cuda and torch.cuda.is_current_stream_capturing()) or os.environ.get("DREAM_PACK_BATCHED", "1") == "0":
+            object.__setattr__(self, "_pack_records", None)
+            return
+        st = self.__dict__.get("_pack_state")
+        stamp = first.data_ptr()
+        if st is None or st["stamp"] != stamp:
+            st = {"stamp": stamp, "table": None, "records": {}, "steps": 0}
+            object.__setattr__(self, "_pack_state", st)
+        if st["table"] is None:
+            st["steps"] += 1
+            if st["steps"] == 1 or not st["records"]:
+                object.__setattr__(self, "_pack_records", st["records"])          # record this step's packs
+                return
+            object.__setattr__(self, "_pack_records", None)
+            st["keys"] = list(st["records"].items())
+            descs = [d for _, (_, _, ds) in st["keys"] for d in ds]
+            st["table"], st["njobs"] = ops.pack_job_table(descs, first.device), len(descs)
+        tags = {key: tuple((t._version, t.data_ptr()) for t in tensors) for key, (tensors, _, _) in st["keys"]}
+        if any(self._cache.get(key, (None,))[0] != tag or self._cache[key][1] is not st["records"][key][1] for key, tag in tags.items()):
+            ops.pack_weights_batched(st["table"], st["njobs"])
+            for key, tag in tags.items():
+                self._cache[key] = (tag, st["records"][key][1])
 
     def _fold(self, name, bn, conv_bias=None):
         tensors = [bn.weight, bn.bias, bn.running_mean, bn.running_var] + ([conv_bias] if conv_bias is not None else [])
@@ -1059,6 +1110,7 @@ class ResnetSimple(nn.Module):
         return ops.conv2d_bwd_data(dz, packed_t, cin, k, stride, in_hw, residual=residual)
 
     def run_forward_train(self, x):
+        self._repack_weights()
         tape = []
         col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
         w1 = self._cached(("w", "conv1"), [self.conv1.weight],

@@ -23,6 +23,45 @@ def round_up(v, m):
     return (v + m - 1) // m * m
 
 
+_pack_log = threading.local()
+PACK_CONV1X1, PACK_WINOGRAD2, PACK_WINOGRAD4 = 0, 1, 2
+
+
+class record_packs:
+    """Context manager: collects (kind, weight, packed, cout, cin, mode) of the batchable weight packs made inside it (the first
+    training step of a model; dream_pack_weights_batched then refreshes all of them with one launch per step)."""
+
+    def __enter__(self):
+        self.prev = getattr(_pack_log, "items", None)
+        _pack_log.items = []
+        return _pack_log.items
+
+    def __exit__(self, *exc):
+        _pack_log.items = self.prev
+
+
+def _log_pack(kind, w, packed, cout, cin, mode):
+    log = getattr(_pack_log, "items", None)
+    if log is not None:
+        log.append((kind, w, packed, cout, cin, mode))
+
+
+def pack_job_table(descs, device):
+    """Device-resident dream_pack_job table (include/dream_hip.h) for pack_weights_batched."""
+    import numpy as np
+    dt = np.dtype([("src", np.uint64), ("dst", np.uint64), ("kind", np.int32), ("cout", np.int32), ("cin", np.int32), ("mode", np.int32)])
+    if int(_hip.lib().dream_pack_job_bytes()) != dt.itemsize:
+        raise RuntimeError("dream_pack_job layout mismatch")
+    arr = np.zeros(len(descs), dt)
+    for i, (kind, w, packed, cout, cin, mode) in enumerate(descs):
+        arr[i] = (ptr(w), ptr(packed), kind, cout, cin, mode)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device)
+
+
+def pack_weights_batched(table, njobs, workgroups_per_job=16):
+    call("dream_pack_weights_batched", ptr(table), int(njobs), int(workgroups_per_job), stream())
+
+
 def pack_weight(w_oihw, mode=0):
     """OIHW [Cout,Cin,3,3] -> tap-major packed tensor (see dream_pack_conv3x3_weight).
     Returns (packed, rows, rows_pad, cols_pad)."""
@@ -65,6 +104,7 @@ def pack_weight_winograd(w_oihw, mode=0):
     n = int(_hip.lib().dream_conv3x3_winograd_weight_floats(rows, cols))
     packed = torch.empty((n,), dtype=torch.float32, device=w.device)
     call("dream_pack_conv3x3_winograd_weight", ptr(w), ptr(packed), cout, cin, mode, stream())
+    _log_pack(PACK_WINOGRAD2, w, packed, cout, cin, mode)
     return packed, rows
 
 
@@ -126,6 +166,7 @@ def pack_weight_winograd4(w_oihw, mode=0):
     n = int(_hip.lib().dream_conv3x3_winograd4_weight_floats(rows, cols))
     packed = torch.empty((n,), dtype=torch.float32, device=w.device)
     call("dream_pack_conv3x3_winograd4_weight", ptr(w), ptr(packed), cout, cin, mode, stream())
+    _log_pack(PACK_WINOGRAD4, w, packed, cout, cin, mode)
     return packed, rows
 
 
@@ -448,6 +489,7 @@ def pack_conv1x1_weight(w_oihw, mode=0):
     n = int(_hip.lib().dream_conv1x1_weight_floats(rows, k))
     packed = torch.empty(n, dtype=torch.float32, device=w.device)
     call("dream_pack_conv1x1_weight", ptr(w), ptr(packed), cout, cin, mode, stream())
+    _log_pack(PACK_CONV1X1, w, packed, cout, cin, mode)
     return packed, rows
 
 

@@ -128,6 +128,19 @@ int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, cons
                                      const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                      void *stream);
 int dream_conv3x3_winograd4_set_max_workgroups(int n);     /* test hook, as dream_conv3x3_winograd_set_max_workgroups */
+
+/* ---- all packed weight copies of a network in one launch (training: every conv weight changes every step) ----------------------
+ * jobs: DEVICE array of njobs entries; src = the weight tensor as the reference stores it (OIHW), dst = the packed copy
+ * (dream_conv1x1_weight_floats / dream_conv3x3_winograd_weight_floats / dream_conv3x3_winograd4_weight_floats floats; the zero tail
+ * the Winograd kernels over-read is written by the one-tensor entry points and not touched here), mode as theirs. */
+enum { DREAM_PACK_CONV1X1 = 0, DREAM_PACK_WINOGRAD2 = 1, DREAM_PACK_WINOGRAD4 = 2 };
+typedef struct dream_pack_job {
+    const float *src;
+    float *dst;
+    int kind, cout, cin, mode;
+} dream_pack_job;
+size_t dream_pack_job_bytes(void);
+int dream_pack_weights_batched(const dream_pack_job *jobs_device, int njobs, int workgroups_per_job, void *stream);
 /* nn.ConvTranspose2d(k4,s2,p1) (+ folded BatchNorm / bias, ReLU) of the ResNet decoder (dream/models.py:37-136) by minimal
  * filtering on the Winograd kernel: each output phase is a 2x2-tap conv = a 3x3 conv whose transformed weights vanish on 7 of
  * the 16 positions: 9 multiplications per 2x2 outputs of a phase instead of 16, same fp32 arithmetic.  x [B,H,W,Cin] ->

@@ -269,3 +269,27 @@ def test_randomised_conv_geometries(emu):
         pc.check_upsample_conv_as_convT("cpu", b, h, w, cin, cout, relu=bool(flags & ops.CONV_RELU), seed=case)
         co4 = int(rs.choice([8, 16, 64, 132]))               # weight gradients need channel counts that are multiples of 4
         pc.check_wgrad("cpu", b, h, w, cin, co4, k=int(rs.choice([1, 3])), stride=int(rs.choice([1, 2])), seed=case)
+
+
+def test_batched_weight_packing(emu):
+    """dream_pack_weights_batched (one launch, a job table) writes exactly what the one-tensor pack entry points write."""
+    import torch
+    g = torch.Generator().manual_seed(5)
+    jobs, singles = [], []
+    for kind, fn, cout, cin, mode in [(ops.PACK_CONV1X1, ops.pack_conv1x1_weight, 64, 96, 0), (ops.PACK_CONV1X1, ops.pack_conv1x1_weight, 64, 40, 1),
+                                      (ops.PACK_WINOGRAD2, ops.pack_weight_winograd, 24, 32, 0), (ops.PACK_WINOGRAD2, ops.pack_weight_winograd, 48, 16, 1),
+                                      (ops.PACK_WINOGRAD4, ops.pack_weight_winograd4, 20, 32, 0), (ops.PACK_WINOGRAD4, ops.pack_weight_winograd4, 64, 48, 1)]:
+        k = 1 if kind == ops.PACK_CONV1X1 else 3
+        w = torch.randn(cout, cin, k, k, generator=g)
+        with ops.record_packs() as descs:
+            ref = fn(w, mode)[0]
+        assert len(descs) == 1 and descs[0][0] == kind
+        out = ref.clone()
+        n_body = out.numel() if kind == ops.PACK_CONV1X1 else out.numel() - (6 if kind == ops.PACK_WINOGRAD2 else 4) * ((((cout if mode == 0 else cin) + 127) // 128) * 128) * 16
+        out[:n_body] = float("nan")                           # the batched kernel must rewrite the body (not the zero tail)
+        jobs.append((kind, w, out, cout, cin, mode))
+        singles.append(ref)
+    table = ops.pack_job_table(jobs, "cpu")
+    ops.pack_weights_batched(table, len(jobs), workgroups_per_job=3)
+    for (kind, w, out, cout, cin, mode), ref in zip(jobs, singles):
+        assert torch.equal(out, ref), (kind, cout, cin, mode)

@@ -807,6 +807,36 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch):
         assert torch.equal(m, ref[0]) and torch.equal(k, ref[1])
 
 
+def test_resnet_batched_packing_equals_lazy_packing(monkeypatch):
+    """ResnetSimple._repack_weights: from the second training step on the packed weight copies are refreshed by ONE launch
+    (dream_pack_weights_batched).  Four Adam steps and an evaluation in between must equal the same with DREAM_PACK_BATCHED=0
+    (one launch per tensor, on demand), bit for bit."""
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(4, 64, 96, seed=43)).to(DEV)
+
+    def run(flag):
+        monkeypatch.setenv("DREAM_PACK_BATCHED", flag)
+        net = _dp_network("resnet_h", [0], optimizer="adam", lr=1e-5, in_res=(96, 64), weights=wts)
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=(96, 64), seed=43)).to(DEV)
+        losses = [net.train([x], t).item() for _ in range(3)]
+        net.enable_evaluation()
+        with torch.no_grad():
+            maps = net.inference(x)[0].clone()             # evaluation re-packs (folded BatchNorm) outside the graph ...
+        net.enable_training()
+        losses.append(net.train([x], t).item())            # ... and the next training step must not use those copies
+        return net, losses, maps
+
+    a, la, ma = run("1")
+    b, lb, mb = run("0")
+    st = a.model.module._pack_state
+    assert st["table"] is not None and st["njobs"] >= 190 and "_pack_state" not in b.model.module.__dict__, st.get("njobs")
+    assert la == lb and torch.equal(ma, mb), (la, lb)
+    for (k, pa), (_, pb) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        assert torch.equal(pa, pb), k
+
+
 def test_allreduce_entry_point(monkeypatch):
     """dream_allreduce_sum_f32: buffers that share the one GPU of this box are summed locally; with DREAM_FORCE_RCCL=1 a
     one-device list goes through RCCL itself (dlopen, ncclCommInitAll, group call) -- the sequence an 8-GPU node runs."""

@@ -9,9 +9,13 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [16, 18, 2, 9, 11, 108]          # >= 100: product code with another weight-ring size (k - 100)
+KS = [201, 202, 203, 204, 205]          # >= 100: product code with another weight-ring size (k - 100)
 OUT = os.path.join(ROOT, "dream_amd", "diag")       # travels with the snapshot (git-ignored *.so)
-NAMES = {0: "product", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
+VARIANTS = {201: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 202: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
+            203: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 204: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
+            205: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
+NAMES = {0: "product (S1 10, S2 13, loads over 3 slots)", 201: "S1 6 S2 9", 202: "S1 8 S2 13", 203: "S1 10 S2 13, loads in slot 0", 204: "S1 11 S2 14",
+         205: "S1 4 S2 8, loads in slot 0", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
          11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 108: "product, weight ring 8 (6 ahead)"}
 
 
@@ -22,7 +26,7 @@ def build():
     for k in KS:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-I", os.path.join(csrc, "include"), "-DDREAM_W4_DIAG=%d" % (k if k < 100 else 0)] + (
-                   ["-DDREAM_W4_RING=%d" % (k - 100)] if k >= 100 else []) + [os.path.join(csrc, "conv_wino4.hip"),
+                   ["-DDREAM_W4_RING=%d" % (k - 100)] if 100 <= k < 200 else []) + VARIANTS.get(k, []) + [os.path.join(csrc, "conv_wino4.hip"),
                os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino4_diag_%d.so" % k)]
         procs.append(subprocess.Popen(cmd))
     assert all(p.wait() == 0 for p in procs)
