@@ -1,0 +1,21 @@
+#!/bin/bash
+# Turn gpurun_out/r03final/ (tools/gpu_r03_final.sh) into the committed summaries under profiles/.
+cd /root/repo
+O=gpurun_out/r03final
+for n in default train resnet_h_train16; do
+  cp $O/bench_${n}_kernel_stats.csv profiles/r03_bench_${n}_kernel_stats.csv
+  cp $O/bench_${n}_conv_dispatches.csv profiles/r03_bench_${n}_conv_dispatches.csv
+done
+cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json
+cp $O/pmc_traffic_resnet_train.json profiles/r03_pmc_traffic_resnet_train.json
+cp $O/pmc_mfma.json profiles/r03_pmc_mfma.json
+for n in default train resnet_h_train16 resnet_f_b32 resnet_h_b128 vgg_f_b32; do tail -1 $O/bench_$n.log > profiles/r03_bench_${n}_line.json; done
+grep -h '^{"metric' $O/rocprof_default.log > profiles/r03_bench_default_under_rocprof_line.json
+tail -3 $O/pytest_gpu.log > profiles/r03_pytest_gpu_tail.txt
+for f in $O/layer_profile_*.txt; do cp $f profiles/r03_$(basename $f); done
+cp $O/microbench_wino_b128.txt profiles/r03_microbench_wino_b128.txt
+cp $O/microbench_wino4_b128.txt profiles/r03_microbench_wino4_b128.txt
+cp $O/wino4_diag.txt profiles/r03_wino4_diag.txt
+tail -1 $O/rehearsal_2ranks_selflaunch.log > profiles/r03_rehearsal_2ranks_gloo_selflaunch_line.json
+tail -1 $O/rehearsal_single_process_train.log > profiles/r03_rehearsal_single_process_4replicas_train_line.json
+tail -3 $O/smoke.log > profiles/r03_smoke_tail.txt

@@ -54,9 +54,10 @@ def main():
         return sum(r["dispatches"] for r in sel), sum(r["sum_kib"] for r in sel) * 1024.0
 
     # the conv kernel families of the fp32 path: the Winograd kernel and the direct implicit-GEMM kernel
-    nf, fb = [a + b for a, b in zip(family(fetch, "mfma_kernel"), family(fetch, "wino_kernel"))]
-    nw, wb = [a + b for a, b in zip(family(write, "mfma_kernel"), family(write, "wino_kernel"))]
+    nf, fb = [a + b + c for a, b, c in zip(family(fetch, "mfma_kernel"), family(fetch, "wino_kernel"), family(fetch, "wino4_kernel"))]
+    nw, wb = [a + b + c for a, b, c in zip(family(write, "mfma_kernel"), family(write, "wino_kernel"), family(write, "wino4_kernel"))]
     n_wino = family(fetch, "wino_kernel")[0]
+    n_wino4 = family(fetch, "wino4_kernel")[0]
     npool, pool_fetch = family(fetch, "maxpool2_kernel")
     # un-fused pools of vgg_q at B=128: 256ch@100x100 and 512ch@50x50 inputs, one of each per forward pass
     pool_alg = 4.0 * B * (100 * 100 * 256 + 50 * 50 * 512) * (npool / 2.0)
@@ -83,7 +84,7 @@ def main():
                                         "fetch_gb_algorithmic": pool_alg / 1e9,
                                         "raw_to_algorithmic": pool_alg / pool_fetch if pool_fetch else None},
         "conv_kernels": {
-            "families": "conv_wino_kernel (%d dispatches) + conv_mfma_kernel (%d)" % (n_wino, nf - n_wino),
+            "families": "conv_wino4_kernel (%d dispatches) + conv_wino_kernel (%d) + conv_mfma_kernel (%d)" % (n_wino4, n_wino, nf - n_wino - n_wino4),
             "dispatches": nf,
             "fetch_gb_per_launch_corrected": 2.0 * fb / nf / 1e9,
             "write_gb_per_launch": wb / nw / 1e9,
