@@ -42,7 +42,7 @@ with emulated_hip():
     x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=1))
     t = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=1))
     losses = []
-    for epoch in range(2):                                        # :464-514 epoch / batch loop
+    for epoch in range(1):                                        # :464-514 epoch / batch loop
         net.enable_training()
         loss = net.train([x], t)                                  # :505
         losses.append(loss.item())                                # :507
@@ -53,8 +53,8 @@ with emulated_hip():
         net.save_network(out, "epoch_%%d" %% epoch, overwrite=True)    # :612-659
         assert os.path.exists(os.path.join(out, "epoch_%%d.pth" %% epoch))
     assert all(np.isfinite(losses)) and np.isfinite(vloss)
-    net2 = dream.create_network_from_config_file(os.path.join(out, "epoch_1.yaml"))      # analysis.py:136-149
-    net2.model.load_state_dict(torch.load(os.path.join(out, "epoch_1.pth")))
+    net2 = dream.create_network_from_config_file(os.path.join(out, "epoch_0.yaml"))      # analysis.py:136-149
+    net2.model.load_state_dict(torch.load(os.path.join(out, "epoch_0.pth")))
     net2.enable_evaluation()
     with torch.no_grad():
         maps, kps = net2.inference(x)                             # analysis.py:210
