@@ -232,6 +232,10 @@ class DreamHourglass(nn.Module):
         50x50 (13.8 vs 11.3 + 0.15 ms, profiles/r01_pool_fusion.txt) but saves a 1.3 ms pass at 400x400."""
         if not (li + 1 < len(layers) and layers[li + 1][0] == "pool") or li in self._skip_sources:
             return False
+        mod = layers[li][1]
+        if (self.conv_algorithm == "winograd" and self.precision == "fp32" and mod is not None and int(mod.weight.shape[1]) == int(x_nhwc.shape[3])
+                and ops.winograd_tile(int(x_nhwc.shape[1]), int(x_nhwc.shape[2]), int(x_nhwc.shape[3]), int(mod.weight.shape[0]), int(x_nhwc.shape[0])) == 4):
+            return True         # F(4x4,3x3) works on whole 4x4 tiles anyway: the pooled store is free at every map size (saves the 100^2 / 50^2 passes)
         return min(int(x_nhwc.shape[1]), int(x_nhwc.shape[2])) >= 160
 
     def _use_winograd(self, cin, cout, flags):
