@@ -44,7 +44,8 @@
 #include "../../include/dream_hip.h"
 
 // Timing diagnostics only (tools/wino4_diag.py builds separate libraries with -DDREAM_W4_DIAG=k; never the product library; results
-// are then wrong by construction): bit 0 no patch loads, bit 1 no weight stream, bit 2 no barriers, bit 3 no pass 1 / pass 2, bit 4 patch loads out of range.
+// are then wrong by construction): bit 0 no patch loads, bit 1 no weight stream, bit 2 no barriers, bit 3 no pass 1 / pass 2, bit 4 patch loads out of range, bit 5 every weight load reads position 0 of
+// chunk 0 (L1 hits: the instruction stream without its L2 traffic), bit 6 every chunk's patch loads read chunk 0's channels.
 #ifndef DREAM_W4_DIAG
 #define DREAM_W4_DIAG 0
 #endif
@@ -259,9 +260,9 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
                 if (DREAM_W4_DIAG & 2) return;
                 const int kn = pp + half + W4_AHEAD;
                 const int spos = kn >= W4P ? cnext + (kn - W4P) : c * W4P + kn;
-                bq[(PH * W4P + kn) % W4_RING] = buffer_load_x4(ubuf, b_lane, (unsigned)spos * u_pos_stride);
+                bq[(PH * W4P + kn) % W4_RING] = buffer_load_x4(ubuf, b_lane, (DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
             };
-            auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), coff); };
+            auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), (DREAM_W4_DIAG & 64) ? 0u : coff); };
             auto pair = [&](int r) {
                 const int i0 = (PH * W4P + pp) % W4_RING, i1 = (PH * W4P + pp + 1) % W4_RING;
                 acc[pp] = mfma_f32_16x16x4(a[s & 1][0][r], bq[i0][r], acc[pp]);

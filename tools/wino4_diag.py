@@ -9,12 +9,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [201, 202, 203, 204, 205]          # >= 100: product code with another weight-ring size (k - 100)
+KS = [15, 11, 9, 16, 32, 64, 96, 48, 108]          # >= 100: product code with another weight-ring size (k - 100)
 OUT = os.path.join(ROOT, "dream_amd", "diag")       # travels with the snapshot (git-ignored *.so)
 VARIANTS = {201: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 202: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
             203: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 204: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
             205: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
-NAMES = {0: "product (S1 10, S2 13, loads over 3 slots)", 201: "S1 6 S2 9", 202: "S1 8 S2 13", 203: "S1 10 S2 13, loads in slot 0", 204: "S1 11 S2 14",
+NAMES = {0: "product", 32: "weights from L1 (one position)", 64: "patches: chunk 0 only", 96: "weights from L1 + patches chunk 0", 48: "weights from L1 + patches out of range", 201: "S1 6 S2 9", 202: "S1 8 S2 13", 203: "S1 10 S2 13, loads in slot 0", 204: "S1 11 S2 14",
          205: "S1 4 S2 8, loads in slot 0", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
          11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 108: "product, weight ring 8 (6 ahead)"}
 
