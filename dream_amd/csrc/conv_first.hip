@@ -4,18 +4,26 @@
 // K = 9*Cin = 27 is far too shallow for the matrix cores and the layer is store-bound (it writes
 // 256 B per pixel for 1.7 kFLOP), so it runs on the vector ALU with lane == output channel:
 // every lane keeps its 9*Cin weights in VGPRs, the input patch sits in LDS and is read with
-// wave-uniform (broadcast) ds_read_b128/b64, and each pixel's 64 channels leave as one fully
-// coalesced 256-B store.  Four horizontally adjacent pixels are produced together so each
-// broadcast read feeds 12 FMAs.
+// wave-uniform (broadcast) ds_read_b128, and each pixel's 64 channels leave as one fully
+// coalesced 256-B store.  A lane produces 2 rows x 4 columns of pixels together with PACKED fp32 FMAs
+// (v_pk_fma_f32: the two rows in the two halves of a register pair, the weight broadcast to both), so the
+// 27 x 8 multiply-adds of a pixel group cost 108 VALU instructions instead of 216 -- the scalar version was
+// bound by them (41 TFLOP/s of FMAs at 3.1 TB/s of stores), not by the stores.  The patch is staged twice,
+// rows interleaved in pairs (2k, 2k+1) and (2k+1, 2k+2), so that the pair of input rows a filter row needs is
+// one aligned register pair per pixel whatever the filter row's parity.
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
 
 namespace {
 constexpr int FT = 16;            // 16 x 16 output pixels per workgroup
-constexpr int FPW = FT + 4;       // patch row: 1 halo + 16 + 1 halo, padded to 20 floats (16-B rows)
+constexpr int FPW = FT + 4;       // patch row: 1 halo + 16 + 1 halo, padded to 20 pixels
 constexpr int FPH = FT + 2;
 constexpr int FMAXC = 4;
+constexpr int FPAIRS = FPH - 1;   // row pairs (r, r + 1), r = 0 .. FPH - 2
+constexpr int FPLANE = FPAIRS * FPW * 2;      // floats per channel: [row pair][pixel][2 rows]
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct FirstParams {
     const float *x;
@@ -29,7 +37,7 @@ struct FirstParams {
 };
 
 __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p) {
-    DREAM_DYNAMIC_LDS(float, smem);     // [Cin][FPH][FPW]
+    DREAM_DYNAMIC_LDS(float, smem);     // [Cin][FPAIRS][FPW][2]: element (c, r, px, h) = patch row r + h, pixel px
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
     int t = blockIdx.x;
     const int tix = t % p.tiles_x;
@@ -39,7 +47,8 @@ __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p)
     const int y0 = tiy * FT, x0 = tix * FT;
     const int cout = blockIdx.y * 64 + lane;
 
-    // stage the patch: coalesced along x inside each NCHW plane, zero outside the image
+    // stage the patch: coalesced along x inside each NCHW plane, zero outside the image; every patch row but the first and
+    // the last is written twice (upper half of pair r - 1, lower half of pair r)
     const int npatch = p.Cin * FPH * FPW;
     for (int idx = tid; idx < npatch; idx += 256) {
         const int c = idx / (FPH * FPW);
@@ -49,7 +58,8 @@ __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p)
         float v = 0.0f;
         if (px < FT + 2 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
             v = p.x[(((size_t)b * p.Cin + c) * p.H + gy) * p.W + gx];
-        smem[idx] = v;
+        if (py < FPAIRS) smem[c * FPLANE + (py * FPW + px) * 2] = v;
+        if (py > 0) smem[c * FPLANE + ((py - 1) * FPW + px) * 2 + 1] = v;
     }
     // this lane's filter: w[cout][c][ky][kx] (OIHW as stored by torch)
     float wr[FMAXC * 9];
@@ -58,37 +68,46 @@ __global__ void __launch_bounds__(256) conv3x3_first_kernel(const FirstParams p)
     const float bv = p.bias ? p.bias[cout] : 0.0f;
     __syncthreads();
 
-    // wave w owns rows 4w..4w+3; 4 groups of 4 pixels per row
+    // wave w owns rows 4w..4w+3 as two row pairs; 4 groups of 4 pixels per row pair
     float amax = 0.0f;
-    for (int g = 0; g < 16; ++g) {
-        const int row = wave * 4 + (g >> 2), xg = (g & 3) * 4;
-        float acc0 = bv, acc1 = bv, acc2 = bv, acc3 = bv;
+    for (int g = 0; g < 8; ++g) {
+        const int row = wave * 4 + 2 * (g >> 2), xg = (g & 3) * 4;           // output rows row, row + 1
+        f32x2 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x2{bv, bv};
 #pragma unroll
         for (int c = 0; c < FMAXC; ++c) {
             if (c < p.Cin) {
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    const float *src = smem + (c * FPH + row + ky) * FPW + xg;   // wave-uniform address
-                    const f32x4 v0 = *(const f32x4 *)src;
-                    const float v4 = src[4], v5 = src[5];
-                    const float w0 = wr[c * 9 + ky * 3 + 0], w1 = wr[c * 9 + ky * 3 + 1], w2 = wr[c * 9 + ky * 3 + 2];
-                    acc0 = fmaf(v0[0], w0, acc0); acc0 = fmaf(v0[1], w1, acc0); acc0 = fmaf(v0[2], w2, acc0);
-                    acc1 = fmaf(v0[1], w0, acc1); acc1 = fmaf(v0[2], w1, acc1); acc1 = fmaf(v0[3], w2, acc1);
-                    acc2 = fmaf(v0[2], w0, acc2); acc2 = fmaf(v0[3], w1, acc2); acc2 = fmaf(v4, w2, acc2);
-                    acc3 = fmaf(v0[3], w0, acc3); acc3 = fmaf(v4, w1, acc3); acc3 = fmaf(v5, w2, acc3);
+                    // input rows (row + ky, row + 1 + ky) of pixels xg .. xg + 5: six aligned pairs, wave-uniform address
+                    const float *src = smem + c * FPLANE + ((row + ky) * FPW + xg) * 2;
+                    const f32x4 q0 = *(const f32x4 *)src, q1 = *(const f32x4 *)(src + 4), q2 = *(const f32x4 *)(src + 8);
+                    const f32x2 v[6] = {{q0[0], q0[1]}, {q0[2], q0[3]}, {q1[0], q1[1]}, {q1[2], q1[3]}, {q2[0], q2[1]}, {q2[2], q2[3]}};
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = wr[c * 9 + ky * 3 + kx];
+                        const f32x2 w2 = {wv, wv};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_fma(v[i + kx], w2, acc[i]);
+                    }
                 }
             }
         }
         if (p.relu) {
-            acc0 = fmaxf(acc0, 0.0f); acc1 = fmaxf(acc1, 0.0f); acc2 = fmaxf(acc2, 0.0f); acc3 = fmaxf(acc3, 0.0f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = f32x2{fmaxf(acc[i][0], 0.0f), fmaxf(acc[i][1], 0.0f)};
         }
-        const int oy = y0 + row, ox = x0 + xg;
-        if (oy < p.H) {
-            float *dst = p.y + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cout;
-            if (ox + 0 < p.W) { dst[0] = acc0; amax = fmaxf(amax, fabsf(acc0)); }
-            if (ox + 1 < p.W) { dst[(size_t)p.Cout] = acc1; amax = fmaxf(amax, fabsf(acc1)); }
-            if (ox + 2 < p.W) { dst[(size_t)2 * p.Cout] = acc2; amax = fmaxf(amax, fabsf(acc2)); }
-            if (ox + 3 < p.W) { dst[(size_t)3 * p.Cout] = acc3; amax = fmaxf(amax, fabsf(acc3)); }
+        const int ox = x0 + xg;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int oy = y0 + row + h;
+            if (oy < p.H) {
+                float *dst = p.y + (((size_t)b * p.H + oy) * p.W + ox) * p.Cout + cout;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (ox + i < p.W) { dst[(size_t)i * p.Cout] = acc[i][h]; amax = fmaxf(amax, fabsf(acc[i][h])); }
+            }
         }
     }
     if (p.amax_out != nullptr) publish_amax(p.amax_out, amax);
@@ -105,7 +124,7 @@ static int first_impl(const float *x_nchw, const float *w_oihw, const float *bia
     p.x = x_nchw; p.w = w_oihw; p.bias = bias; p.y = y_nhwc; p.amax_out = amax_out;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
     p.tiles_x = ceil_div(W, FT); p.tiles_y = ceil_div(H, FT);
-    const size_t lds = (size_t)Cin * FPH * FPW * sizeof(float);
+    const size_t lds = (size_t)Cin * FPLANE * sizeof(float);
     const dim3 grid((unsigned)((size_t)B * p.tiles_x * p.tiles_y), (unsigned)(Cout / 64));
     hipLaunchKernelGGL(conv3x3_first_kernel, grid, dim3(256), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
