@@ -23,7 +23,6 @@ constexpr int FMAXC = 4;
 constexpr int FPAIRS = FPH - 1;   // row pairs (r, r + 1), r = 0 .. FPH - 2
 constexpr int FPLANE = FPAIRS * FPW * 2;      // floats per channel: [row pair][pixel][2 rows]
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct FirstParams {
     const float *x;

@@ -54,7 +54,7 @@ namespace {
 
 struct Wino4Params {
     const float *x;          // [B,H,W,Cin]
-    const float *u;          // [Cin/16][36][CoutPad][16] (+ W4_AHEAD zero positions)
+    const float *u;          // [Cin/K][36][CoutPad][K] (+ AHEAD zero positions), K = 16 (wide) or 8 (narrow)
     const float *scale;      // per-channel multiplier (eval-mode BatchNorm fold) or null
     const float *shift;      // per-channel addend (bias / BN shift) or null
     const float *residual;   // ReLU mask source (DREAM_CONV_RELUMASK) or addend of the output's shape, or null
@@ -68,28 +68,45 @@ struct Wino4Params {
 };
 
 constexpr int W4T = 16;       // tiles per workgroup
-constexpr int W4K = 16;       // input channels per chunk
-constexpr int W4NW = 8;       // wavefronts: 128 output channels
-constexpr int W4PAD = 128;    // output channels the packed weights are padded to
 constexpr int W4P = 36;       // positions
-// V plane p = 6 i + j: [16 tiles][16 channels] = 256 floats = exactly one wavefront-wide b128 read; planes 272 floats apart
-// (68 float4 slots = 4 mod 8), so that the pass-2 stores of the lanes (q = 0..3, j, j + 1) of a store group fall on all 32 banks
-// of the LDS store path
-constexpr int V4PS = W4T * W4K + 16;          // plane stride in floats
-DREAM_DEVICE constexpr int v4_plane(int p) { return p * V4PS; }
-constexpr int V4B = W4P * V4PS;               // floats per V buffer
-// staging tile of pass 1: float4 slot [(tile, row)][6 q + j], 25 slots per (tile, row): the 8 lanes of a store group
-// (q = 0..3 of two consecutive rows) write slots 6 q + j and 25 + 6 q + j -- eight different residues mod 8
-constexpr int S4ROW = 25;
-constexpr int S4B = W4T * 6 * S4ROW * 4;      // floats
 #ifndef DREAM_W4_RING
 #define DREAM_W4_RING 6
 #endif
-constexpr int W4_RING = DREAM_W4_RING;   // operand registers of the weight stream: position k of the chunk of parity PH lives in bq[(36 PH + k) % RING]
-                                         // (chunks run in pairs: 72 % 8 == 0 and 36 % 6 == 0, so RING may be 8 or 6)
-constexpr int W4_AHEAD = W4_RING - 2;    // positions the weight stream runs ahead of the MFMAs (two are in use)
 
-DREAM_DEVICE int v4_slot(int q, int t) { return q ^ ((t >> 2) & 2); }       // float4 slot of channel quad q in row t of a V plane
+
+// Two workgroup shapes.  WIDE (layers with more than 64 output channels): 8 wavefronts x 16 output channels, 16 input channels
+// per chunk; one workgroup per CU.  NARROW (up to 64 output channels: VGG's conv1_2, its data gradient, the decoder's 64-channel
+// layers): 4 wavefronts x 16 channels, 8 input channels per chunk -- the same 16 tiles, the same 48 transform items per wavefront
+// and pass, half the MFMAs per position (two k-steps), every LDS region half the size, so that TWO workgroups share a CU and one's
+// epilogue and barriers hide behind the other's MFMAs.
+template <bool NARROW>
+struct W4Cfg {
+    static constexpr int NW = NARROW ? 4 : 8;            // wavefronts: 16 output channels each
+    static constexpr int K = NARROW ? 8 : 16;            // input channels per chunk
+    static constexpr int Q = K / 4;                      // channel quads per chunk (transform items: tile x quad x row)
+    static constexpr int KS = K / 4;                     // MFMA k-steps per position
+    static constexpr int PAD = 16 * NW;                  // output channels the packed weights are padded to
+    // V plane p = 6 i + j: [16 tiles][K channels]: one wavefront-wide b128 (b64) read.  WIDE: planes 272 floats apart (68 float4
+    // slots = 4 mod 8), so that the pass-2 stores of the lanes (q = 0..3, j, j + 1) of a store group fall on all 32 banks of the
+    // LDS store path.  NARROW: the eight lanes of a store group are (q = 0..1, four consecutive tiles) of ONE plane: any stride.
+    static constexpr int VPS = NARROW ? W4T * K : W4T * K + 16;     // plane stride in floats
+    static constexpr int VB = W4P * VPS;                 // floats per V buffer
+    // staging tile of pass 1: float4 slot [(tile, row)][QS q + j], SROW slots per (tile, row): the 8 lanes of a store group write
+    // eight different residues mod 8 (WIDE: q = 0..3 of two consecutive rows, slots 6 q + j and 25 + 6 q + j; NARROW: q = 0..1 of
+    // four consecutive rows, slots 7 q + j + 14 r)
+    static constexpr int SROW = NARROW ? 14 : 25;
+    static constexpr int QS = NARROW ? 7 : 6;
+    static constexpr int SB = W4T * 6 * SROW * 4;        // floats
+    // operand registers of the weight stream: position k of the chunk of parity PH lives in bq[(36 PH + k) % RING] (chunks run in
+    // pairs, so RING must divide 72).  NARROW positions take half the time: twice the positions in flight for the same latency.
+    static constexpr int RING = NARROW ? 2 * DREAM_W4_RING : DREAM_W4_RING;
+    static constexpr int AHEAD = RING - 2;               // positions the weight stream runs ahead of the MFMAs (two are in use)
+    static_assert(72 % RING == 0, "the weight ring must divide two chunks' positions");
+    using vec = std::conditional_t<NARROW, f32x2, f32x4>;   // one lane's MFMA operands of a position: KS floats
+};
+// float4 slot of channel quad q in row t of a V plane
+template <bool NARROW>
+DREAM_DEVICE int v4_slot(int q, int t) { return NARROW ? q ^ ((t >> 3) & 1) : q ^ ((t >> 2) & 2); }
 
 DREAM_DEVICE f32x4 fma4(float c, f32x4 a, f32x4 b) {
     f32x4 r;
@@ -114,14 +131,16 @@ DREAM_DEVICE f32x4 bt_row(int j, const f32x4 *d) {
 }
 
 // MODE: 0 plain, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask (conv_wino.hip)
-template <int MODE>
-__global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Params p) {
-    constexpr int NT = 64 * W4NW;
+template <int MODE, bool NARROW>
+__global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(const Wino4Params p) {
+    using C = W4Cfg<NARROW>;
+    using vec = typename C::vec;
+    constexpr int W4K = C::K, W4NW = C::NW, V4PS = C::VPS, V4B = C::VB, S4ROW = C::SROW, W4_RING = C::RING, W4_AHEAD = C::AHEAD;
     DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer, then the staging tile
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = wave_index();
-    // 384 items per pass on 512 threads: every wavefront takes 48 of each pass (lanes 48..63 repeat the items of lanes 32..47:
+    // 384 (narrow: 192) items per pass on 512 (256) threads: every wavefront takes 48 of each pass (lanes 48..63 repeat the items of lanes 32..47:
     // same loads, same values to the same LDS addresses from a different store group -- no branch, no predication), so that all
     // eight wavefronts carry the same work between two barriers and none of them idles at one.
     const int item_id = wave * 48 + (lane < 48 ? lane : lane - 16);
@@ -136,12 +155,15 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
     const size_t img_floats = (size_t)p.H * p.W * p.Cin;
 
     // ---- pass 1 item: (tile t1, channel quad q1, patch row r1)
-    const int q1 = item_id & 3, r1 = (item_id >> 2) % 6, t1 = (item_id >> 2) / 6;
-    const int s1_off = ((t1 * 6 + r1) * S4ROW + 6 * q1) * 4;                 // staging float offset of column j = 0
-    // ---- pass 2 item: (tile t2, channel quad q2, transformed column j2)
-    const int q2 = item_id & 3, j2 = (item_id >> 2) % 6, t2 = (item_id >> 2) / 6;
-    const int s2_off = ((t2 * 6) * S4ROW + 6 * q2 + j2) * 4;                  // staging float offset of row r = 0 (rows: + S4ROW * 4)
-    const int v2_off = v4_plane(j2) + t2 * W4K + 4 * v4_slot(q2, t2);         // V float offset of plane (i = 0, j2); plane 6 i + j2: + 6 i * V4PS
+    const int q1 = item_id % C::Q, r1 = (item_id / C::Q) % 6, t1 = (item_id / C::Q) / 6;
+    const int s1_off = ((t1 * 6 + r1) * S4ROW + C::QS * q1) * 4;             // staging float offset of column j = 0
+    // ---- pass 2 item: (tile t2, channel quad q2, transformed column j2); narrow: the items run (q, four tiles, j, tile / 4), so
+    //      that a store group of eight lanes fills eight consecutive float4 slots of one V plane
+    const int q2 = item_id % C::Q;
+    const int j2 = NARROW ? (item_id >> 3) % 6 : (item_id >> 2) % 6;
+    const int t2 = NARROW ? 4 * (item_id / 48) + ((item_id >> 1) & 3) : (item_id >> 2) / 6;
+    const int s2_off = ((t2 * 6) * S4ROW + C::QS * q2 + j2) * 4;              // staging float offset of row r = 0 (rows: + S4ROW * 4)
+    const int v2_off = j2 * V4PS + t2 * W4K + 4 * v4_slot<NARROW>(q2, t2);    // V float offset of plane (i = 0, j2); plane 6 i + j2: + 6 i * V4PS
 
     // offsets of the item's six loads: byte offset of column 0 relative to the first image of the block + a validity bit per
     // column (BUFFER_OOB where the patch leaves the image: the hardware returns zeros).  Recomputed per block from the thread's
@@ -176,10 +198,11 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
         return make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
     };
 
-    // ---- MFMA operand addresses: A lane l -> tile (l & 15), k = 4 (l >> 4) .. +3 (one float4 feeds the 4 MFMAs of a position)
+    // ---- MFMA operand addresses: A lane l -> tile (l & 15), channels KS (l >> 4) .. + KS - 1 of the chunk (one float4 / float2
+    //      feeds the 4 / 2 MFMAs of a position: MFMA r multiplies channel KS (l >> 4) + r, on both operands)
     const int lt = lane & 15, lg = lane >> 4;
-    const int a_off = lt * W4K + 4 * v4_slot(lg, lt);
-    const unsigned b_lane = (unsigned)(((wave * 16 + lt) * W4K + 4 * lg) * 4);
+    const int a_off = NARROW ? lt * W4K + 4 * v4_slot<NARROW>(lg >> 1, lt) + 2 * (lg & 1) : lt * W4K + 4 * v4_slot<NARROW>(lg, lt);
+    const unsigned b_lane = (unsigned)(((wave * 16 + lt) * W4K + C::KS * lg) * 4);
     const unsigned u_pos_stride = (unsigned)(p.CoutPad * W4K * 4);
     const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * W4K, ((size_t)((p.Cin / W4K) * W4P + W4_AHEAD) * p.CoutPad - (size_t)n0) * W4K * sizeof(float));
 
@@ -188,9 +211,13 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
 
     // weight stream: the k-th position of the chunk sequence (k counted from the start of the block, 36 per chunk) lives in
     // bq[k % 8]; the chunk loop is unrolled by two so that the ring index is a compile-time constant (72 % 8 == 0)
-    f32x4 bq[W4_RING];
+    vec bq[W4_RING];
+    auto load_u = [&](unsigned soff) {
+        if constexpr (NARROW) return buffer_load_x2(ubuf, b_lane, soff);
+        else return buffer_load_x4(ubuf, b_lane, soff);
+    };
 #pragma unroll
-    for (int k = 0; k < W4_AHEAD; ++k) bq[k] = buffer_load_x4(ubuf, b_lane, (unsigned)k * u_pos_stride);
+    for (int k = 0; k < W4_AHEAD; ++k) bq[k] = load_u((unsigned)k * u_pos_stride);
 
     // LDS addresses: one per-lane base register per (role, V buffer), everything else in the instructions' 16-bit immediate
     // offsets (every plane / row offset below is < 64 KB from its base).  `opaque` keeps the compiler from folding the buffer
@@ -198,10 +225,11 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
     // between the two V buffers and their number is even, so chunk parity PH reads buffer PH and fills buffer 1 - PH.
     // (offsets in float4 units, so that the accesses stay provably 16-byte aligned: b128 LDS instructions)
     f32x4 *const sV4 = (f32x4 *)sV;
+    vec *const sVa = (vec *)sV;                        // the A operands: float4 (float2) units
     int vrd[2], vwr[2], s1p = (2 * V4B + s1_off) / 4, s2p = (2 * V4B + s2_off) / 4;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        vrd[h] = (h * V4B + a_off) / 4;
+        vrd[h] = (h * V4B + a_off) / C::KS;
         vwr[h] = (h * V4B + v2_off) / 4;
         asm volatile("" : "+v"(vrd[h]), "+v"(vwr[h]));
     }
@@ -211,10 +239,10 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
     auto pass2_read = [&](int r) { d[r] = sV4[s2p + r * S4ROW]; };
     auto pass2_piece = [&](int i, int h) { sV4[vwr[h] + i * (6 * V4PS / 4)] = bt_row(i, d); };
 
-    f32x4 a[2][2];                                     // [set][position of the pair]
+    vec a[2][2];                                       // [set][position of the pair]
     auto read_a = [&](int set, int pp, int h) {
-        a[set][0] = sV4[vrd[h] + v4_plane(pp) / 4];
-        a[set][1] = sV4[vrd[h] + v4_plane(pp + 1) / 4];
+        a[set][0] = sVa[vrd[h] + pp * V4PS / C::KS];
+        a[set][1] = sVa[vrd[h] + (pp + 1) * V4PS / C::KS];
     };
 
     // ---- first block of this workgroup: plan, chunk 0 through both passes into buffer 0 ------------------------------------------
@@ -260,7 +288,7 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
                 if (DREAM_W4_DIAG & 2) return;
                 const int kn = pp + half + W4_AHEAD;
                 const int spos = kn >= W4P ? cnext + (kn - W4P) : c * W4P + kn;
-                bq[(PH * W4P + kn) % W4_RING] = buffer_load_x4(ubuf, b_lane, (DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
+                bq[(PH * W4P + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
             };
             auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), (DREAM_W4_DIAG & 64) ? 0u : coff); };
             auto pair = [&](int r) {
@@ -269,23 +297,41 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
                 acc[pp + 1] = mfma_f32_16x16x4(a[s & 1][1][r], bq[i1][r], acc[pp + 1]);
                 __builtin_amdgcn_sched_barrier(0);
             };
-            pair(0);
-            load_b(0);
-            if (s + 1 < 18) read_a((s + 1) & 1, pp + 2, PH);
-            if (PH == 1 && s == 0 && last) plan_item(tile0n, b0n);
-            if (s < LX) { for (int c2 = 0; c2 < 3 / LX; ++c2) load_x((6 / LX) * s + c2); }
-            if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1));
-            if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(0); pass2_read(1); }
-            if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1), 1 - PH);
-            pair(1);
-            load_b(1);
-            if (s < LX) { for (int c2 = 3 / LX; c2 < 6 / LX; ++c2) load_x((6 / LX) * s + c2); }
-            if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(2); pass2_read(3); }
-            pair(2);
-            if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1) + 1);
-            if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(4); pass2_read(5); }
-            if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1) + 1, 1 - PH);
-            pair(3);
+            // the four interleave points of a slot; the narrow shape has two MFMA pairs per slot: two points behind each
+            auto after = [&](int k) {
+                if (k == 0) {
+                    load_b(0);
+                    if (s + 1 < 18) read_a((s + 1) & 1, pp + 2, PH);
+                    if (PH == 1 && s == 0 && last) plan_item(tile0n, b0n);
+                    if (s < LX) { for (int c2 = 0; c2 < 3 / LX; ++c2) load_x((6 / LX) * s + c2); }
+                    if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1));
+                    if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(0); pass2_read(1); }
+                    if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1), 1 - PH);
+                } else if (k == 1) {
+                    load_b(1);
+                    if (s < LX) { for (int c2 = 3 / LX; c2 < 6 / LX; ++c2) load_x((6 / LX) * s + c2); }
+                    if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(2); pass2_read(3); }
+                } else if (k == 2) {
+                    if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1) + 1);
+                    if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(4); pass2_read(5); }
+                    if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1) + 1, 1 - PH);
+                }
+            };
+            if constexpr (NARROW) {
+                pair(0);
+                after(0);
+                after(1);
+                pair(1);
+                after(2);
+            } else {
+                pair(0);
+                after(0);
+                pair(1);
+                after(1);
+                pair(2);
+                after(2);
+                pair(3);
+            }
             if (s == S1 + 2 && !(DREAM_W4_DIAG & 4)) {                       // pass 1 of the next chunk is staged
                 __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
@@ -410,35 +456,55 @@ __global__ void __launch_bounds__(64 * W4NW, 2) conv_wino4_kernel(const Wino4Par
 }
 
 // OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1) -> U = G g G^T in fp64, rounded once to fp32,
-// laid out [cols/16][36 positions][RowsPad][16]: pack_device.h (dream_pack::winograd4)
-static_assert(W4K == 16 && W4PAD == 128 && W4P == 36, "pack_device.h assumes 16-channel chunks, 36 positions, rows padded to 128");
+// laid out [cols/K][36 positions][RowsPad][K] with (K, RowsPad) = (16, rows up to a multiple of 128), or (8, 64) for rows <= 64
+// (the narrow workgroup shape): pack_device.h (dream_pack::winograd4)
+static_assert(W4Cfg<false>::K == 16 && W4Cfg<false>::PAD == 128 && W4Cfg<true>::K == 8 && W4Cfg<true>::PAD == 64 && W4P == 36,
+              "pack_device.h assumes 16-channel chunks padded to 128 rows / 8-channel chunks padded to 64 rows, 36 positions");
 __global__ void __launch_bounds__(256) wino4_pack_kernel(const float *w, float *u, int Cout, int Cin, int mode) {
     dream_pack::winograd4(w, u, Cout, Cin, mode, (int)blockIdx.x, (int)gridDim.x);
 }
 
-int g_max_workgroups4 = 0;     // test hook: cap on resident workgroups (0 = the chip's 256 CUs)
+int g_max_workgroups4 = 0;     // test hook: cap on resident workgroups (0 = the chip's 256 CUs, two narrow workgroups on each)
 
-template <int MODE>
+bool narrow_rows(int rows) { return rows <= W4Cfg<true>::PAD; }
+struct PackShape { int k, rows_pad, ahead; };
+PackShape pack_shape(int rows) {
+    if (narrow_rows(rows)) return {W4Cfg<true>::K, W4Cfg<true>::PAD, W4Cfg<true>::AHEAD};
+    return {W4Cfg<false>::K, (rows + W4Cfg<false>::PAD - 1) / W4Cfg<false>::PAD * W4Cfg<false>::PAD, W4Cfg<false>::AHEAD};
+}
+
+template <int MODE, bool NARROW>
 int launch_wino4(const Wino4Params &p, void *stream) {
-    void (*kernel)(const Wino4Params) = conv_wino4_kernel<MODE>;
-    const size_t lds = ((size_t)2 * V4B + S4B) * sizeof(float);
+    using C = W4Cfg<NARROW>;
+    void (*kernel)(const Wino4Params) = conv_wino4_kernel<MODE, NARROW>;
+    const size_t lds = ((size_t)2 * C::VB + C::SB) * sizeof(float);
     if (dream_allow_full_lds((const void *)kernel)) return 2;
-    const int ny = (p.Cout + 16 * W4NW - 1) / (16 * W4NW);
-    const int resident = g_max_workgroups4 > 0 ? g_max_workgroups4 : 256;
+    const int ny = (p.Cout + 16 * C::NW - 1) / (16 * C::NW);
+    const int resident = g_max_workgroups4 > 0 ? g_max_workgroups4 : (NARROW ? 512 : 256);
     int gx = resident / ny / 8 * 8;
     if (gx < 8) gx = 8;
     if (gx > (p.nblk + 7) / 8 * 8) gx = (p.nblk + 7) / 8 * 8;
     const dim3 grid((unsigned)gx, (unsigned)ny);
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * W4NW), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * C::NW), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
+}
+
+template <bool NARROW>
+int launch_wino4_mode(const Wino4Params &p, int mode, void *stream) {
+    switch (mode) {
+        case 0: return launch_wino4<0, NARROW>(p, stream);
+        case 1: return launch_wino4<1, NARROW>(p, stream);
+        case 2: return launch_wino4<2, NARROW>(p, stream);
+        default: return launch_wino4<3, NARROW>(p, stream);
+    }
 }
 
 }  // namespace
 
 extern "C" size_t dream_conv3x3_winograd4_weight_floats(int rows, int cols) {
-    const size_t rows_pad = (size_t)((rows + W4PAD - 1) / W4PAD) * W4PAD;
-    return ((size_t)(cols / W4K) * W4P + W4_AHEAD) * rows_pad * W4K;
+    const PackShape ps = pack_shape(rows);
+    return ((size_t)(cols / ps.k) * W4P + ps.ahead) * ps.rows_pad * ps.k;
 }
 
 extern "C" int dream_conv3x3_winograd4_set_max_workgroups(int n) {
@@ -452,20 +518,21 @@ extern "C" int dream_conv3x3_winograd4_set_max_workgroups(int n) {
 extern "C" int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u, int Cout, int Cin, int mode, void *stream) {
     DREAM_REQUIRE(w_oihw && u && Cout > 0 && Cin > 0 && (mode == 0 || mode == 1), "winograd F(4x4) pack: bad arguments");
     const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
-    DREAM_REQUIRE(cols % (2 * W4K) == 0, "winograd F(4x4) pack: %d input channels, must be a multiple of %d", cols, 2 * W4K);
-    const int rows_pad = (rows + W4PAD - 1) / W4PAD * W4PAD;
-    const size_t total = (size_t)(cols / W4K) * rows_pad * W4K;
+    const PackShape ps = pack_shape(rows);
+    DREAM_REQUIRE(cols % (2 * ps.k) == 0, "winograd F(4x4) pack: %d input channels, must be a multiple of %d", cols, 2 * ps.k);
+    const size_t total = (size_t)(cols / ps.k) * ps.rows_pad * ps.k;
     size_t grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode);
     DREAM_LAUNCH_OK();
-    DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / W4K) * W4P * rows_pad * W4K, 0, (size_t)W4_AHEAD * rows_pad * W4K * sizeof(float),
+    DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / ps.k) * W4P * ps.rows_pad * ps.k, 0, (size_t)ps.ahead * ps.rows_pad * ps.k * sizeof(float),
                                 (hipStream_t)stream));
     return 0;
 }
 
 // y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32, by F(4x4,3x3).
-// Cin a multiple of 32; flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor), DREAM_CONV_RELUMASK.
+// Cin a multiple of 32 (of 16 for Cout <= 64); flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor),
+// DREAM_CONV_RELUMASK.
 extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                                 const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                                 void *stream) {
@@ -474,15 +541,16 @@ extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_p
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd F(4x4) conv: ReLU mask without a mask tensor");
     DREAM_REQUIRE(x && u_packed && y, "winograd F(4x4) conv: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd F(4x4) conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
-    DREAM_REQUIRE(Cin % (2 * W4K) == 0, "winograd F(4x4) conv: Cin=%d must be a multiple of %d", Cin, 2 * W4K);
+    const PackShape ps = pack_shape(Cout);
+    DREAM_REQUIRE(Cin % (2 * ps.k) == 0, "winograd F(4x4) conv: Cin=%d must be a multiple of %d", Cin, 2 * ps.k);
     Wino4Params p;
     const size_t span_imgs = (size_t)W4T / ((size_t)((H + 3) / 4) * ((W + 3) / 4)) + 2;
     DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) && span_imgs * H * W * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
                   "winograd F(4x4) conv: image too large for 32-bit offsets");
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
-    p.CoutPad = (Cout + W4PAD - 1) / W4PAD * W4PAD;
-    DREAM_REQUIRE(((size_t)(Cin / W4K) * W4P + W4_AHEAD) * (size_t)p.CoutPad * W4K * sizeof(float) < ((size_t)1 << 31), "winograd F(4x4) conv: weights too large");
+    p.CoutPad = Cout <= ps.rows_pad ? ps.rows_pad : (Cout + ps.rows_pad - 1) / ps.rows_pad * ps.rows_pad;
+    DREAM_REQUIRE(((size_t)(Cin / ps.k) * W4P + ps.ahead) * (size_t)p.CoutPad * ps.k * sizeof(float) < ((size_t)1 << 31), "winograd F(4x4) conv: weights too large");
     p.TY = (H + 3) / 4; p.TX = (W + 3) / 4;
     const long ntiles = (long)B * p.TY * p.TX;
     DREAM_REQUIRE(ntiles < ((long)1 << 24), "winograd F(4x4) conv: %ld tiles, the tile decomposition handles < 2^24", ntiles);
@@ -493,10 +561,5 @@ extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_p
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
     const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
-    switch (mode) {
-        case 0: return launch_wino4<0>(p, stream);
-        case 1: return launch_wino4<1>(p, stream);
-        case 2: return launch_wino4<2>(p, stream);
-        default: return launch_wino4<3>(p, stream);
-    }
+    return narrow_rows(Cout) ? launch_wino4_mode<true>(p, mode, stream) : launch_wino4_mode<false>(p, mode, stream);
 }

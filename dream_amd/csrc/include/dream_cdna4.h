@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -75,6 +76,11 @@ DREAM_DEVICE f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned
     return __builtin_bit_cast(f32x4, v);
 }
 
+DREAM_DEVICE f32x2 buffer_load_x2(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voffset_bytes, soffset_bytes, 0);
+    return __builtin_bit_cast(f32x2, v);
+}
 DREAM_DEVICE float buffer_load_f32(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.r, voffset_bytes, soffset_bytes, 0));
 }

@@ -71,7 +71,8 @@ DREAM_DEVICE void winograd2(const float *w, float *u, int Cout, int Cin, int mod
     }
 }
 
-// Winograd F(4x4,3x3) (conv_wino4.hip), interpolation points (0, 1, -1, 1/2, -2, inf): [cols/16][36 positions][RowsPad][16]
+// Winograd F(4x4,3x3) (conv_wino4.hip), interpolation points (0, 1, -1, 1/2, -2, inf): [cols/K][36 positions][RowsPad][K] with
+// (K, RowsPad) = (16, rows up to a multiple of 128), or (8, 64) when rows <= 64 (the kernel's narrow workgroup shape)
 DREAM_DEVICE void winograd4(const float *w, float *u, int Cout, int Cin, int mode, int blk, int nblk) {
     const double G[6][3] = {{1.0, 0.0, 0.0},
                             {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
@@ -80,15 +81,16 @@ DREAM_DEVICE void winograd4(const float *w, float *u, int Cout, int Cin, int mod
                             {1.0 / 15.0, -2.0 / 15.0, 4.0 / 15.0},
                             {0.0, 0.0, 1.0}};
     const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
-    const int RowsPad = (rows + 127) / 128 * 128;
-    const size_t total = (size_t)(cols / 16) * RowsPad * 16;
+    const int K = rows <= 64 ? 8 : 16;
+    const int RowsPad = rows <= 64 ? 64 : (rows + 127) / 128 * 128;
+    const size_t total = (size_t)(cols / K) * RowsPad * K;
     for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
-        const int kk = (int)(i % 16);
-        const size_t rest = i / 16;
+        const int kk = (int)(i % K);
+        const size_t rest = i / K;
         const int n = (int)(rest % RowsPad);
         const int ch = (int)(rest / RowsPad);
         double g[3][3];
-        filter3x3(w, Cin, rows, mode, n, ch * 16 + kk, g);
+        filter3x3(w, Cin, rows, mode, n, ch * K + kk, g);
         double t[6][3];                                             // G g
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -99,7 +101,7 @@ DREAM_DEVICE void winograd4(const float *w, float *u, int Cout, int Cin, int mod
 #pragma unroll
             for (int b = 0; b < 6; ++b) {                           // (G g) G^T
                 const double v = t[a][0] * G[b][0] + t[a][1] * G[b][1] + t[a][2] * G[b][2];
-                u[(((size_t)ch * 36 + (a * 6 + b)) * RowsPad + n) * 16 + kk] = (float)v;
+                u[(((size_t)ch * 36 + (a * 6 + b)) * RowsPad + n) * K + kk] = (float)v;
             }
     }
 }

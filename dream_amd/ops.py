@@ -120,20 +120,30 @@ def conv3x3_winograd(x_nhwc, packed_u, cout, scale=None, shift=None, residual=No
     return y
 
 
+def winograd4_applies(cin, cout):
+    """The F(4x4,3x3) kernel's two workgroup shapes: wide (more than 64 output channels: 128 per workgroup, 16-channel input
+    chunks in pairs) and narrow (up to 64: 64 per workgroup, 8-channel chunks in pairs)."""
+    if cout > 64:
+        return cin % 32 == 0 and cin >= 64 and cout >= 128
+    return cin % 16 == 0 and cin >= 32 and cout >= 48
+
+
 def winograd_tile(h, w, cin, cout, batch=None):
     """Output tile of the Winograd kernel for a stride-1 3x3 conv on an h x w map: 4 = F(4x4,3x3) (csrc/conv_wino4.hip: 2.25
-    multiplications per output, measured 1.3-1.4x F(2x2,3x3) on its layers, profiles/r03_microbench_wino4_b128.txt) where its
-    workgroup shape applies (128 output channels per workgroup, Cin a multiple of 32 and >= 64), rounding the map up to whole
-    4 x 4 tiles costs less than that gain, and the batch gives every CU at least two workgroups' worth of tiles; else 2 = F(2x2,3x3) (csrc/conv_wino.hip).  DREAM_WINOGRAD_TILE=2 forces F(2x2)."""
-    if _WINOGRAD_TILE_FORCED == 2 or cin % 32 != 0 or cin < 64 or cout < 128:
+    multiplications per output, measured 1.3-1.4x F(2x2,3x3) on its layers, profiles/r03_microbench_wino4_b128.txt) where one of
+    its workgroup shapes applies (winograd4_applies), rounding the map up to whole 4 x 4 tiles costs less than that gain, and the
+    batch gives every CU at least two workgroups' worth of tiles; else 2 = F(2x2,3x3) (csrc/conv_wino.hip).
+    DREAM_WINOGRAD_TILE=2 forces F(2x2)."""
+    if _WINOGRAD_TILE_FORCED == 2 or not winograd4_applies(cin, cout):
         return 2
     if _WINOGRAD_TILE_FORCED == 4:
         return 4                       # tests: F(4x4) wherever the kernel applies, whatever the map and batch size
     t4 = ((h + 3) // 4) * ((w + 3) // 4)
     pad4 = t4 * 16
     pad2 = ((h + 1) // 2) * ((w + 1) // 2) * 4
-    if batch is not None and ((batch * t4 + 15) // 16) * ((cout + 127) // 128) < 2 * 256:
-        return 2                       # fewer than two 16-tile blocks per CU: the 32-tile F(2x2) blocks fill the chip better
+    resident = 256 if cout > 64 else 512
+    if batch is not None and ((batch * t4 + 15) // 16) * ((cout + 127) // 128) < 2 * resident:
+        return 2                       # fewer than two 16-tile blocks per resident workgroup: the 32-tile F(2x2) blocks fill the chip better
     return 4 if pad4 < 1.25 * pad2 else 2
 
 
@@ -158,7 +168,7 @@ def conv3x3_winograd_tile(tile, x_nhwc, packed_u, cout, scale=None, shift=None, 
 
 
 def pack_weight_winograd4(w_oihw, mode=0):
-    """OIHW [Cout,Cin,3,3] -> the transformed weights of the Winograd F(4x4,3x3) kernel ([cols/16][36][rows_pad][16]); mode as
+    """OIHW [Cout,Cin,3,3] -> the transformed weights of the Winograd F(4x4,3x3) kernel ([cols/K][36][rows_pad][K], K = 16 or -- up to 64 rows -- 8); mode as
     pack_weight_winograd.  Returns (packed, rows)."""
     w = _f32(w_oihw)
     cout, cin = int(w.shape[0]), int(w.shape[1])
@@ -171,7 +181,7 @@ def pack_weight_winograd4(w_oihw, mode=0):
 
 
 def conv3x3_winograd4(x_nhwc, packed_u, cout, scale=None, shift=None, residual=None, flags=0):
-    """3x3 stride-1 pad-1 conv by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): same contract as conv3x3_winograd; Cin % 32 == 0."""
+    """3x3 stride-1 pad-1 conv by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): same contract as conv3x3_winograd; Cin % 32 == 0 (Cin % 16 == 0 for Cout <= 64)."""
     x = _f32(x_nhwc)
     b, h, w, cin = (int(v) for v in x.shape)
     shape = (b, h // 2, w // 2, cout) if flags & CONV_POOL2 else (b, h, w, cout)

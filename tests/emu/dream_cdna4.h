@@ -82,6 +82,13 @@ inline f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffs
         __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 16);
     return v;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+inline f32x2 buffer_load_x2(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    f32x2 v = {0.0f, 0.0f};
+    if ((unsigned long long)voffset_bytes + 8ull <= (unsigned long long)b.bytes)
+        __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 8);
+    return v;
+}
 inline float buffer_load_f32(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
     float v = 0.0f;
     if ((unsigned long long)voffset_bytes + 4ull <= (unsigned long long)b.bytes)

@@ -558,7 +558,11 @@ def check_train_steps(dev, opt, steps=3):
             for key, p in net.model.named_parameters():
                 ref = float(g["gradnorm/" + key])
                 assert abs(float(p.grad.double().norm()) - ref) <= 1e-3 * max(ref, 1e-9), key
-    assert np.allclose(losses, g["losses"][:steps], rtol=1e-4), (losses, g["losses"])
+    # The first loss is a pure forward pass: 1e-4 whatever the optimizer.  Later losses under Adam follow parameters whose update
+    # is lr x sign-like for elements with round-off-level gradients (see below): measured 1.0e-4 on the third loss with F(4x4,3x3)
+    # on every layer it serves, 1e-6 with F(2x2); held to 5e-4.  SGD: 1e-4 throughout.
+    assert np.allclose(losses[:1], g["losses"][:1], rtol=1e-4), (losses, g["losses"])
+    assert np.allclose(losses, g["losses"][:steps], rtol=5e-4 if opt == "adam" else 1e-4), (losses, g["losses"])
     if steps == 3:
         # Updated parameters.  SGD: the update is lr x gradient, held tight.  Adam: the update is lr x m / (sqrt(v) + eps) --
         # a sign flip of a gradient element at round-off level (two correct fp32 convolution algorithms differ there) moves

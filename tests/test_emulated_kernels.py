@@ -51,17 +51,26 @@ def test_conv_winograd(emu, variant):
 
 
 def test_conv_winograd4(emu):
+    # up to 64 output channels: the narrow workgroup shape (4 wavefronts, 8-channel chunks, two workgroups per CU)
     errs = [pc.check_conv_winograd4("cpu", 1, 8, 8, 32, 16, max_workgroups=()),                          # one workgroup, ragged cout
             pc.check_conv_winograd4("cpu", 2, 13, 25, 32, 64, ops.CONV_RELU, seed=1),                     # extents not multiples of 4
-            pc.check_conv_winograd4("cpu", 3, 5, 3, 64, 7, 0, seed=3, max_workgroups=()),                 # images smaller than a tile block, 4 chunks
-            pc.check_conv_winograd4("cpu", 2, 12, 20, 32, 144, ops.CONV_RELU | ops.CONV_POOL2, seed=4),   # two channel blocks, fused pool
-            pc.check_conv_winograd4("cpu", 2, 13, 9, 32, 64, ops.CONV_RELU | ops.CONV_POOL2, seed=8, max_workgroups=()),   # odd extents: floor
+            pc.check_conv_winograd4("cpu", 3, 5, 3, 48, 7, 0, seed=3, max_workgroups=()),                 # images smaller than a tile block, 6 chunks
+            pc.check_conv_winograd4("cpu", 2, 13, 9, 16, 64, ops.CONV_RELU | ops.CONV_POOL2, seed=8, max_workgroups=()),   # odd extents: floor; 2 chunks
             pc.check_conv_winograd4("cpu", 1, 10, 14, 64, 32, ops.CONV_RELU, seed=5, with_scale=True, residual="add", max_workgroups=()),
             pc.check_conv_winograd4("cpu", 1, 9, 11, 32, 48, ops.CONV_RELUMASK, seed=6, residual="mask", max_workgroups=()),
             pc.check_conv_winograd4("cpu", 2, 7, 9, 32, 64, 0, seed=7, mode=1, max_workgroups=()),
             # 25 tile blocks on a grid of 8 workgroups: several blocks per workgroup, the next block's first chunk transformed
             # during the last chunk of the current one
             pc.check_conv_winograd4("cpu", 2, 40, 40, 32, 64, ops.CONV_RELU | ops.CONV_POOL2, seed=9)]
+    # more than 64: the wide shape (8 wavefronts, 16-channel chunks)
+    errs += [pc.check_conv_winograd4("cpu", 1, 8, 8, 32, 80, max_workgroups=()),
+             pc.check_conv_winograd4("cpu", 2, 13, 25, 32, 128, ops.CONV_RELU, seed=1),
+             pc.check_conv_winograd4("cpu", 3, 5, 3, 64, 71, 0, seed=3, max_workgroups=()),                # 4 chunks
+             pc.check_conv_winograd4("cpu", 2, 12, 20, 32, 144, ops.CONV_RELU | ops.CONV_POOL2, seed=4),   # two channel blocks, fused pool
+             pc.check_conv_winograd4("cpu", 1, 10, 14, 64, 96, ops.CONV_RELU, seed=5, with_scale=True, residual="add", max_workgroups=()),
+             pc.check_conv_winograd4("cpu", 1, 9, 11, 32, 112, ops.CONV_RELUMASK, seed=6, residual="mask", max_workgroups=()),
+             pc.check_conv_winograd4("cpu", 2, 7, 9, 32, 128, 0, seed=7, mode=1, max_workgroups=()),
+             pc.check_conv_winograd4("cpu", 2, 40, 40, 32, 128, ops.CONV_RELU | ops.CONV_POOL2, seed=9)]
     print("winograd F(4x4) max rel err", max(errs))
 
 

@@ -598,11 +598,19 @@ def test_conv_winograd(b, h, w, cin, cout, flags, kw):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
-    (1, 8, 8, 32, 16, 0, {}), (2, 13, 25, 32, 64, ops.CONV_RELU, {}), (3, 5, 3, 64, 7, 0, {}),
-    (2, 12, 20, 32, 144, ops.CONV_RELU | ops.CONV_POOL2, {}), (2, 13, 9, 32, 64, ops.CONV_RELU | ops.CONV_POOL2, {}),
+    # narrow workgroup shape (up to 64 output channels)
+    (1, 8, 8, 32, 16, 0, {}), (2, 13, 25, 32, 64, ops.CONV_RELU, {}), (3, 5, 3, 48, 7, 0, {}),
+    (2, 13, 9, 16, 64, ops.CONV_RELU | ops.CONV_POOL2, {}),
     (1, 10, 14, 64, 32, ops.CONV_RELU, dict(with_scale=True, residual="add")), (1, 9, 11, 32, 48, ops.CONV_RELUMASK, dict(residual="mask")),
     (2, 7, 9, 32, 64, 0, dict(mode=1)),
+    # wide shape
+    (1, 8, 8, 32, 80, 0, {}), (2, 13, 25, 32, 128, ops.CONV_RELU, {}), (3, 5, 3, 64, 71, 0, {}),
+    (2, 12, 20, 32, 144, ops.CONV_RELU | ops.CONV_POOL2, {}), (2, 13, 9, 32, 128, ops.CONV_RELU | ops.CONV_POOL2, {}),
+    (1, 10, 14, 64, 96, ops.CONV_RELU, dict(with_scale=True, residual="add")), (1, 9, 11, 32, 112, ops.CONV_RELUMASK, dict(residual="mask")),
+    (2, 7, 9, 32, 128, 0, dict(mode=1)),
     # the vgg_q layers F(4x4,3x3) serves (batch 2; the data gradients of the same layers through mode 1 / the mask)
+    (2, 400, 400, 64, 64, ops.CONV_RELU | ops.CONV_POOL2, {}), (2, 400, 400, 64, 64, ops.CONV_RELUMASK, dict(mode=1, residual="mask")),
+    (2, 200, 200, 128, 64, ops.CONV_RELUMASK, dict(mode=1, residual="mask")), (4, 100, 100, 64, 64, ops.CONV_RELU, {}),
     (2, 200, 200, 64, 128, ops.CONV_RELU, {}), (2, 200, 200, 128, 128, ops.CONV_RELU | ops.CONV_POOL2, {}),
     (2, 100, 100, 128, 256, ops.CONV_RELU, {}), (2, 100, 100, 256, 256, ops.CONV_RELU, {}), (4, 50, 50, 256, 512, ops.CONV_RELU, {}),
     (4, 50, 50, 512, 512, ops.CONV_RELU, {}), (8, 25, 25, 512, 512, ops.CONV_RELU, {}), (4, 50, 50, 256, 256, 0, {}),
