@@ -240,9 +240,16 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     auto pass2_piece = [&](int i, int h) { sV4[vwr[h] + i * (6 * V4PS / 4)] = bt_row(i, d); };
 
     vec a[2][2];                                       // [set][position of the pair]
+    // narrow: two ds_read_b64 (2 LDS cycles each, 64 banks: conflict-free on this layout); merged into one ds_read2st64_b64 by the
+    // compiler they would run in 16-lane groups on 32 banks -- 8 cycles, and 2-way conflicts on top.  Volatile accesses are not merged.
     auto read_a = [&](int set, int pp, int h) {
-        a[set][0] = sVa[vrd[h] + pp * V4PS / C::KS];
-        a[set][1] = sVa[vrd[h] + (pp + 1) * V4PS / C::KS];
+        if constexpr (NARROW) {
+            a[set][0] = lds_read_unmerged(sVa + vrd[h] + pp * V4PS / C::KS);
+            a[set][1] = lds_read_unmerged(sVa + vrd[h] + (pp + 1) * V4PS / C::KS);
+        } else {
+            a[set][0] = sVa[vrd[h] + pp * V4PS / C::KS];
+            a[set][1] = sVa[vrd[h] + (pp + 1) * V4PS / C::KS];
+        }
     };
 
     // ---- first block of this workgroup: plan, chunk 0 through both passes into buffer 0 ------------------------------------------
@@ -347,7 +354,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     auto epilogue = [&](int tile0e, int b0e) {
         // Everything the epilogue needs is read again from the kernel-argument segment (scalar loads, once per block): kept in
         // SGPRs across the MFMA phases these values push the kernel past its scalar register file (spills through VGPR lanes).
-        const Wino4Params &e = *DREAM_KERNARG(p);
+        const auto &e = *DREAM_KERNARG(p);
         const bool relu = (e.flags & DREAM_CONV_RELU) != 0;
         const int Ho = pool ? e.H / 2 : e.H, Wo = pool ? e.W / 2 : e.W;
         const size_t out_img = (size_t)Ho * Wo * e.Cout;
@@ -361,78 +368,105 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         const BufferRsrc ybuf = make_buffer(e.y + (size_t)b0e * out_img, (size_t)(e.B - b0e) * out_img * sizeof(float));
         const BufferRsrc rbuf = make_buffer(has_res ? e.residual + (size_t)b0e * out_img : e.y,
                                             has_res ? (size_t)(e.B - b0e) * out_img * sizeof(float) : 0);
-        // C/D layout: reg r of lane l is tile 4 (l >> 4) + r of the block: the lane's four tiles are consecutive
+        // C/D layout: reg r of lane l is tile 4 (l >> 4) + r of the block: the lane's four tiles are consecutive.  They go through the
+        // inverse transform in PAIRS (regs 2 rp, 2 rp + 1: an aligned register pair of every accumulator), on packed fp32 operations.
         const int tau0 = tile0e + lg * 4;
         int b = div_magic40(tau0, p.magic_tpi);
         const int rem = tau0 - b * tiles_per_img;
         int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
+        constexpr int NS = pool ? 2 : 4;               // stored positions of a tile: a 4x4 block of outputs, or its 2x2 block of pooled outputs
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool tok = cok & ((tau0 + r) < p.ntiles);
-            // stored positions of this tile: a 4x4 block of outputs, or its 2x2 block of pooled outputs
-            constexpr int NS = pool ? 2 : 4;
-            const int oy = NS * ty, ox = NS * tx;
-            const unsigned base = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * e.Cout + col) * 4);
-            // byte offset of stored position (i, jj) of this tile, BUFFER_OOB where nothing may be written -- computed where it is
-            // used (the accumulators leave no registers for a table)
-            auto out_off = [&](int i, int jj) {
-                const bool inb = tok & ((oy + i) < Ho) & ((ox + jj) < Wo);
-                return inb ? base + (unsigned)i * row_b + (unsigned)jj * px_b : BUFFER_OOB;
+        for (int rp = 0; rp < 2; ++rp) {
+            unsigned base[2];
+            int lim[2];                                // bits 0..3: stored row i inside the image, bits 4..7: stored column jj (0 for a tile that stores nothing)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool tok = cok & ((tau0 + 2 * rp + h) < p.ntiles);
+                const int oy = NS * ty, ox = NS * tx;
+                base[h] = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * e.Cout + col) * 4);
+                int m = 0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) m |= ((oy + i) < Ho ? 1 << i : 0) | ((ox + i) < Wo ? 16 << i : 0);
+                lim[h] = tok ? m : 0;
+                const bool wrap_x = (tx + 1 == p.TX);
+                const bool wrap_y = wrap_x & (ty + 1 == p.TY);
+                tx = wrap_x ? 0 : tx + 1;
+                ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
+                b += wrap_y ? 1 : 0;
+            }
+            // byte offset of stored position (i, jj) of tile h of the pair, BUFFER_OOB where nothing may be written -- computed where
+            // it is used (the accumulators leave no registers for a table)
+            auto out_off = [&](int h, int i, int jj) {
+                const bool inb = ((lim[h] >> i) & (lim[h] >> (4 + jj)) & 1) != 0;
+                return inb ? base[h] + (unsigned)i * row_b + (unsigned)jj * px_b : BUFFER_OOB;
             };
+            constexpr int FULL = pool ? 0x33 : 0xff;
+            const bool all_interior = wave_all((lim[0] == FULL) & (lim[1] == FULL));
+            auto fm = [](float c, f32x2 x, f32x2 y) { return __builtin_elementwise_fma(f32x2{c, c}, x, y); };
             // A^T M A in two lane-local steps that shrink the live set: rows first (6 x 6 -> 6 x 4, in place of the
             // accumulator values just read), then one output column at a time, stored as soon as it exists
-            float sA[6][4];
+            f32x2 sA[6][4];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const float m0 = acc[6 * i][r], m1 = acc[6 * i + 1][r], m2 = acc[6 * i + 2][r], m3 = acc[6 * i + 3][r],
-                            m4 = acc[6 * i + 4][r], m5 = acc[6 * i + 5][r];
-                const float t1 = m1 - m2, t2 = m1 + m2;
-                sA[i][0] = (m0 + t2) + (m3 + m4);
-                sA[i][1] = __builtin_fmaf(-2.0f, m4, __builtin_fmaf(0.5f, m3, t1));
-                sA[i][2] = __builtin_fmaf(4.0f, m4, __builtin_fmaf(0.25f, m3, t2));
-                sA[i][3] = __builtin_fmaf(-8.0f, m4, __builtin_fmaf(0.125f, m3, t1)) + m5;
+                f32x2 m[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = f32x2{acc[6 * i + j][2 * rp], acc[6 * i + j][2 * rp + 1]};
+                const f32x2 t1 = pk_sub2(m[1], m[2]), t2 = m[1] + m[2];
+                sA[i][0] = (m[0] + t2) + (m[3] + m[4]);
+                sA[i][1] = fm(-2.0f, m[4], fm(0.5f, m[3], t1));
+                sA[i][2] = fm(4.0f, m[4], fm(0.25f, m[3], t2));
+                sA[i][3] = fm(-8.0f, m[4], fm(0.125f, m[3], t1)) + m[5];
             }
-            auto finish = [&](float v, unsigned o) {                  // scale / shift, residual or mask, ReLU
-                v = v * sc + sh;
+            auto finish = [&](float v, unsigned o, unsigned so) {     // residual or mask, ReLU (scale / shift applied before)
                 if (has_res) {
-                    const float rv = buffer_load_f32(rbuf, o, 0);
+                    const float rv = buffer_load_f32(rbuf, o, so);
                     v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
                 }
                 const float vr = fmaxf(v, 0.0f);
                 return relu ? vr : v;
             };
-            float keep[4];                                            // pool: the even column's values wait for the odd one
+            float keep[2][2];                                         // pool: the even column's values wait for the odd one
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const float t1 = sA[1][jj] - sA[2][jj], t2 = sA[1][jj] + sA[2][jj];
-                float o4[4];
+                const f32x2 t1 = pk_sub2(sA[1][jj], sA[2][jj]), t2 = sA[1][jj] + sA[2][jj];
+                f32x2 o4[4];
                 o4[0] = (sA[0][jj] + t2) + (sA[3][jj] + sA[4][jj]);
-                o4[1] = __builtin_fmaf(-2.0f, sA[4][jj], __builtin_fmaf(0.5f, sA[3][jj], t1));
-                o4[2] = __builtin_fmaf(4.0f, sA[4][jj], __builtin_fmaf(0.25f, sA[3][jj], t2));
-                o4[3] = __builtin_fmaf(-8.0f, sA[4][jj], __builtin_fmaf(0.125f, sA[3][jj], t1)) + sA[5][jj];
-                if (pool) {
+                o4[1] = fm(-2.0f, sA[4][jj], fm(0.5f, sA[3][jj], t1));
+                o4[2] = fm(4.0f, sA[4][jj], fm(0.25f, sA[3][jj], t2));
+                o4[3] = fm(-8.0f, sA[4][jj], fm(0.125f, sA[3][jj], t1)) + sA[5][jj];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o4[i] = finish(o4[i], 0u);
-                    if ((jj & 1) == 0) {
-                        keep[0] = fmaxf(o4[0], o4[1]);
-                        keep[1] = fmaxf(o4[2], o4[3]);
-                    } else {
-                        buffer_store_f32(ybuf, fmaxf(keep[0], fmaxf(o4[0], o4[1])), out_off(0, jj >> 1), 0);
-                        buffer_store_f32(ybuf, fmaxf(keep[1], fmaxf(o4[2], o4[3])), out_off(1, jj >> 1), 0);
-                    }
-                } else {
+                for (int i = 0; i < 4; ++i) o4[i] = o4[i] * f32x2{sc, sc} + f32x2{sh, sh};
+                // stores of this column: `interior` (wave-uniform) -- every tile of the wavefront lies wholly inside the image: the
+                // lane's offset is the tile's base and the position inside the tile rides in the scalar offset; otherwise per-element masks
+                auto store_column = [&](auto interior_tag) {
+                    constexpr bool interior = decltype(interior_tag)::value;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const unsigned o = out_off(i, jj);
-                        buffer_store_f32(ybuf, finish(o4[i], o), o, 0);
+                    for (int h = 0; h < 2; ++h) {
+                        auto voff = [&](int i, int j2) { return interior ? base[h] : out_off(h, i, j2); };
+                        auto soff = [&](int i, int j2) { return interior ? (unsigned)i * row_b + (unsigned)j2 * px_b : 0u; };
+                        if (pool) {
+                            float v[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = finish(o4[i][h], 0u, 0u);
+                            if ((jj & 1) == 0) {
+                                keep[h][0] = fmaxf(v[0], v[1]);
+                                keep[h][1] = fmaxf(v[2], v[3]);
+                            } else {
+                                buffer_store_f32(ybuf, fmaxf(keep[h][0], fmaxf(v[0], v[1])), voff(0, jj >> 1), soff(0, jj >> 1));
+                                buffer_store_f32(ybuf, fmaxf(keep[h][1], fmaxf(v[2], v[3])), voff(1, jj >> 1), soff(1, jj >> 1));
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const unsigned vo = voff(i, jj), so = soff(i, jj);
+                                buffer_store_f32(ybuf, finish(o4[i][h], vo, so), vo, so);
+                            }
+                        }
                     }
-                }
+                };
+                if (all_interior) store_column(std::true_type{});
+                else store_column(std::false_type{});
             }
-            const bool wrap_x = (tx + 1 == p.TX);
-            const bool wrap_y = wrap_x & (ty + 1 == p.TY);
-            tx = wrap_x ? 0 : tx + 1;
-            ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
-            b += wrap_y ? 1 : 0;
         }
     };
 

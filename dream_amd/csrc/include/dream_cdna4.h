@@ -21,8 +21,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // pointer opaque, so the loads cannot be merged with the kernel's initial argument loads and hoisted).  `arg` must be the
 // kernel's single by-value struct.
 template <class T>
-DREAM_DEVICE const T *kernarg_again(const T &) {
-    const T *kp = (const T *)__builtin_amdgcn_kernarg_segment_ptr();
+DREAM_DEVICE const __attribute__((address_space(4))) T *kernarg_again(const T &) {
+    // constant address space: the reads become s_load (a generic pointer would make them flat loads into VGPRs -- VMEM latency, and
+    // every buffer descriptor built from them non-uniform: a waterfall loop around each access)
+    const __attribute__((address_space(4))) T *kp = (const __attribute__((address_space(4))) T *)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
     return kp;
 }
@@ -57,6 +59,20 @@ DREAM_DEVICE f32x4 pk_sub4(f32x4 y, f32x4 x) {
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(ylo), "v"(xlo));
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(hi) : "v"(yhi), "v"(xhi));
     const f32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return r;
+}
+
+// One LDS read that the compiler may not merge with a neighbour into a ds_read2 (volatile, LDS address space kept explicit):
+// ds_read2_b64 runs in 16-lane groups on 32 banks (8 cycles), two ds_read_b64 in 32-lane groups on 64 banks (2 cycles each).
+template <class T>
+DREAM_DEVICE T lds_read_unmerged(const T *p) {
+    return *(const volatile __attribute__((address_space(3))) T *)p;
+}
+
+// the same on two floats
+DREAM_DEVICE f32x2 pk_sub2(f32x2 y, f32x2 x) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(y), "v"(x));
     return r;
 }
 
@@ -115,6 +131,7 @@ DREAM_DEVICE int    lane_xor(int v, int m)    { return __shfl_xor(v, m, 64); }
 DREAM_DEVICE int    lane_up(int v, int d)     { return __shfl_up(v, d, 64); }
 DREAM_DEVICE unsigned long long wave_ballot(int pred) { return __ballot(pred); }
 DREAM_DEVICE int    popcount64(unsigned long long v) { return __popcll(v); }
+DREAM_DEVICE bool   wave_all(int pred) { return __ballot(pred) == __ballot(1); }      // wave-uniform
 
 // IEEE fp64 ops that the compiler must not contract into FMAs (bit-exactness with NumPy/SciPy)
 DREAM_DEVICE double dmul(double a, double b) { return __dmul_rn(a, b); }

@@ -70,6 +70,9 @@ inline f32x16 mfma_f32_32x32x16_f16(f16x8 a, f16x8 b, f32x16 c) {
     return c;
 }
 inline f32x4 pk_sub4(f32x4 y, f32x4 x) { return y - x; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+inline f32x2 pk_sub2(f32x2 y, f32x2 x) { return y - x; }
+template <class T> inline T lds_read_unmerged(const T *p) { return *p; }
 // raw buffer loads: zeros for lanes whose voffset is outside the descriptor (see the product header)
 struct BufferRsrc { const char *base; unsigned bytes; };
 constexpr unsigned BUFFER_OOB = 0x80000000u;
@@ -82,7 +85,6 @@ inline f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffs
         __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 16);
     return v;
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 inline f32x2 buffer_load_x2(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
     f32x2 v = {0.0f, 0.0f};
     if ((unsigned long long)voffset_bytes + 8ull <= (unsigned long long)b.bytes)
@@ -113,6 +115,7 @@ inline int lane_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 inline int lane_up(int v, int d) { return __shfl_up(v, d, 64); }
 inline unsigned long long wave_ballot(int pred) { return __ballot(pred); }
 inline int popcount64(unsigned long long v) { return __popcll(v); }
+inline bool wave_all(int pred) { return __ballot(pred) == __ballot(1); }
 inline double dmul(double a, double b) { return a * b; }
 inline double dadd(double a, double b) { return a + b; }
 inline double ddiv(double a, double b) { return a / b; }
