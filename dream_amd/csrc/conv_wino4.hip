@@ -45,9 +45,14 @@
 
 // Timing diagnostics only (tools/wino4_diag.py builds separate libraries with -DDREAM_W4_DIAG=k; never the product library; results
 // are then wrong by construction): bit 0 no patch loads, bit 1 no weight stream, bit 2 no barriers, bit 3 no pass 1 / pass 2, bit 4 patch loads out of range, bit 5 every weight load reads position 0 of
-// chunk 0 (L1 hits: the instruction stream without its L2 traffic), bit 6 every chunk's patch loads read chunk 0's channels.
+// chunk 0 (L1 hits: the instruction stream without its L2 traffic), bit 6 every chunk's patch loads read chunk 0's channels, bit 7 no
+// epilogue, bit 8 the epilogue's stores out of range.
 #ifndef DREAM_W4_DIAG
 #define DREAM_W4_DIAG 0
+#endif
+// (the non-temporal hint on the output stores, buffer_store_f32_nt, measured 0-3 % SLOWER in round-robin A/B: tools/wino4_diag.py)
+#ifndef DREAM_W4_STORE
+#define DREAM_W4_STORE buffer_store_f32
 #endif
 
 namespace {
@@ -354,6 +359,11 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     auto epilogue = [&](int tile0e, int b0e) {
         // Everything the epilogue needs is read again from the kernel-argument segment (scalar loads, once per block): kept in
         // SGPRs across the MFMA phases these values push the kernel past its scalar register file (spills through VGPR lanes).
+        if (DREAM_W4_DIAG & 128) {                     // diagnostics: no epilogue (the accumulators stay live)
+#pragma unroll
+            for (int pp = 0; pp < W4P; ++pp) asm volatile("" :: "v"(acc[pp]));
+            return;
+        }
         const auto &e = *DREAM_KERNARG(p);
         const bool relu = (e.flags & DREAM_CONV_RELU) != 0;
         const int Ho = pool ? e.H / 2 : e.H, Wo = pool ? e.W / 2 : e.W;
@@ -365,7 +375,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         const bool cok = col < e.Cout;
         const float sc = (e.scale != nullptr && cok) ? e.scale[col] : 1.0f;
         const float sh = (e.shift != nullptr && cok) ? e.shift[col] : 0.0f;
-        const BufferRsrc ybuf = make_buffer(e.y + (size_t)b0e * out_img, (size_t)(e.B - b0e) * out_img * sizeof(float));
+        const BufferRsrc ybuf = make_buffer(e.y + (size_t)b0e * out_img, (DREAM_W4_DIAG & 256) ? 0 : (size_t)(e.B - b0e) * out_img * sizeof(float));
         const BufferRsrc rbuf = make_buffer(has_res ? e.residual + (size_t)b0e * out_img : e.y,
                                             has_res ? (size_t)(e.B - b0e) * out_img * sizeof(float) : 0);
         // C/D layout: reg r of lane l is tile 4 (l >> 4) + r of the block: the lane's four tiles are consecutive.  They go through the
@@ -452,14 +462,14 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                                 keep[h][0] = fmaxf(v[0], v[1]);
                                 keep[h][1] = fmaxf(v[2], v[3]);
                             } else {
-                                buffer_store_f32(ybuf, fmaxf(keep[h][0], fmaxf(v[0], v[1])), voff(0, jj >> 1), soff(0, jj >> 1));
-                                buffer_store_f32(ybuf, fmaxf(keep[h][1], fmaxf(v[2], v[3])), voff(1, jj >> 1), soff(1, jj >> 1));
+                                DREAM_W4_STORE(ybuf, fmaxf(keep[h][0], fmaxf(v[0], v[1])), voff(0, jj >> 1), soff(0, jj >> 1));
+                                DREAM_W4_STORE(ybuf, fmaxf(keep[h][1], fmaxf(v[2], v[3])), voff(1, jj >> 1), soff(1, jj >> 1));
                             }
                         } else {
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 const unsigned vo = voff(i, jj), so = soff(i, jj);
-                                buffer_store_f32(ybuf, finish(o4[i][h], vo, so), vo, so);
+                                DREAM_W4_STORE(ybuf, finish(o4[i][h], vo, so), vo, so);
                             }
                         }
                     }

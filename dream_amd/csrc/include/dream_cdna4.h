@@ -104,6 +104,14 @@ DREAM_DEVICE float buffer_load_f32(BufferRsrc b, unsigned voffset_bytes, unsigne
 DREAM_DEVICE void buffer_store_f32(BufferRsrc b, float v, unsigned voffset_bytes, unsigned soffset_bytes) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voffset_bytes, soffset_bytes, 0);
 }
+// the same with the non-temporal hint (aux bit 1 = nt on gfx94x/gfx950): a write-once stream that should not displace L2 residents
+DREAM_DEVICE void buffer_store_f32_nt(BufferRsrc b, float v, unsigned voffset_bytes, unsigned soffset_bytes) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.r, voffset_bytes, soffset_bytes, 2);
+}
+DREAM_DEVICE void buffer_store_x4(BufferRsrc b, f32x4 v, unsigned voffset_bytes, unsigned soffset_bytes) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_, v), b.r, voffset_bytes, soffset_bytes, 0);
+}
 // n / d for n < 2^24 with magic = ceil(2^40 / d) (host side: magic_div40): exact, 3 VALU instead of ~40
 DREAM_DEVICE int div_magic40(int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); }
 

@@ -101,6 +101,11 @@ inline void buffer_store_f32(BufferRsrc b, float v, unsigned voffset_bytes, unsi
     if ((unsigned long long)voffset_bytes + 4ull <= (unsigned long long)b.bytes)
         __builtin_memcpy(const_cast<char *>(b.base) + (size_t)voffset_bytes + soffset_bytes, &v, 4);
 }
+inline void buffer_store_f32_nt(BufferRsrc b, float v, unsigned voffset_bytes, unsigned soffset_bytes) { buffer_store_f32(b, v, voffset_bytes, soffset_bytes); }
+inline void buffer_store_x4(BufferRsrc b, f32x4 v, unsigned voffset_bytes, unsigned soffset_bytes) {
+    if ((unsigned long long)voffset_bytes + 16ull <= (unsigned long long)b.bytes)
+        __builtin_memcpy(const_cast<char *>(b.base) + (size_t)voffset_bytes + soffset_bytes, &v, 16);
+}
 inline int div_magic40(int n, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)n * magic) >> 40); }
 inline float quad_perm_2211(float v) {
     const int l = emu::lane(), src = (l & ~3) | ((l & 3) < 2 ? 2 : 1);

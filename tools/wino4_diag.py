@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Knock-out timing of the Winograd F(4x4,3x3) kernel: libraries built with -DDREAM_W4_DIAG=k (bit 0: no patch loads, bit 1: no
-weight stream, bit 2: no barriers, bit 3: no pass 1 / pass 2; results are wrong by construction) against the product library, same
+weight stream, bit 2: no barriers, bit 3: no pass 1 / pass 2, bit 7: no epilogue, bit 8: epilogue without stores; results are wrong by construction) against the product library, same
 layer, same box.  `build` runs here (hipcc), `run` on the GPU box.   python tools/wino4_diag.py build | run [--batch 128]"""
 import ctypes
 import os
@@ -9,14 +9,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [15, 11, 9, 16, 32, 64, 96, 48, 108]          # >= 100: product code with another weight-ring size (k - 100)
+KS = [3001, 128, 256, 143, 15, 11, 9, 16, 32, 64, 96, 48]          # 1000 + r: product code with weight-ring size r; 2001..: schedule variants
 OUT = os.path.join(ROOT, "dream_amd", "diag")       # travels with the snapshot (git-ignored *.so)
-VARIANTS = {201: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 202: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
-            203: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 204: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
-            205: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
-NAMES = {0: "product", 32: "weights from L1 (one position)", 64: "patches: chunk 0 only", 96: "weights from L1 + patches chunk 0", 48: "weights from L1 + patches out of range", 201: "S1 6 S2 9", 202: "S1 8 S2 13", 203: "S1 10 S2 13, loads in slot 0", 204: "S1 11 S2 14",
-         205: "S1 4 S2 8, loads in slot 0", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
-         11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 108: "product, weight ring 8 (6 ahead)"}
+VARIANTS = {3001: ["-DDREAM_W4_STORE=buffer_store_f32_nt"], 2001: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 2002: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
+            2003: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 2004: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
+            2005: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
+NAMES = {0: "product", 3001: "non-temporal stores", 128: "no epilogue", 256: "epilogue without stores", 143: "MFMAs + operand reads only, no epilogue", 32: "weights from L1 (one position)", 64: "patches: chunk 0 only", 96: "weights from L1 + patches chunk 0", 48: "weights from L1 + patches out of range", 2001: "S1 6 S2 9", 2002: "S1 8 S2 13", 2003: "S1 10 S2 13, loads in slot 0", 2004: "S1 11 S2 14",
+         2005: "S1 4 S2 8, loads in slot 0", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
+         11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 1008: "product, weight ring 8 (6 ahead)"}
 
 
 def build():
@@ -25,8 +25,8 @@ def build():
     procs = []
     for k in KS:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-               "-I", os.path.join(csrc, "include"), "-DDREAM_W4_DIAG=%d" % (k if k < 100 else 0)] + (
-                   ["-DDREAM_W4_RING=%d" % (k - 100)] if 100 <= k < 200 else []) + VARIANTS.get(k, []) + [os.path.join(csrc, "conv_wino4.hip"),
+               "-I", os.path.join(csrc, "include"), "-DDREAM_W4_DIAG=%d" % (k if k < 1000 else 0)] + (
+                   ["-DDREAM_W4_RING=%d" % (k - 1000)] if 1000 <= k < 2000 else []) + VARIANTS.get(k, []) + [os.path.join(csrc, "conv_wino4.hip"),
                os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino4_diag_%d.so" % k)]
         procs.append(subprocess.Popen(cmd))
     assert all(p.wait() == 0 for p in procs)
@@ -41,31 +41,35 @@ def run(batch):
         fn = h.dream_conv3x3_winograd4_nhwc_f32
         fn.restype, fn.argtypes = _hip._SIGNATURES["dream_conv3x3_winograd4_nhwc_f32"]
         libs[k] = h
-    for (res, cin, cout) in [(200, 128, 128), (100, 256, 256), (50, 512, 512), (25, 512, 512)]:
+    for (res, cin, cout) in [(400, 64, 64), (200, 64, 128), (200, 128, 128), (100, 256, 256), (50, 512, 512), (25, 512, 512)]:
         x = torch.randn(batch, res, res, cin, device="cuda")
         w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.05
         u, _ = ops.pack_weight_winograd4(w, 0)
         y = torch.empty(batch, res, res, cout, device="cuda")
         flops = 2.0 * batch * res * res * cin * cout * 9 / 4.0
-        line = []
+        # round-robin over the variants, minimum per variant: whatever runs first after a pause is a few per cent slower (clocks),
+        # which a variant-by-variant loop books to the first variant
+        calls = {}
         for k in [0] + KS:
             fn = libs[k].dream_conv3x3_winograd4_nhwc_f32
 
-            def call():
+            def call(fn=fn):
                 rc = fn(x.data_ptr(), u.data_ptr(), None, None, None, y.data_ptr(), batch, res, res, cin, cout, 1,
                         torch.cuda.current_stream().cuda_stream)
                 assert rc == 0
             call()
-            torch.cuda.synchronize()
-            best = 1e9
-            for _ in range(5):
+            calls[k] = call
+        torch.cuda.synchronize()
+        best = {k: 1e9 for k in calls}
+        for _ in range(6):
+            for k, call in calls.items():
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 call()
                 e.record()
                 torch.cuda.synchronize()
-                best = min(best, s.elapsed_time(e))
-            line.append("%s %.3f ms (%.2f)" % (NAMES[k], best, flops / best / 1e9 / 157.3))
+                best[k] = min(best[k], s.elapsed_time(e))
+        line = ["%s %.3f ms (%.2f)" % (NAMES[k], best[k], flops / best[k] / 1e9 / 157.3) for k in calls]
         print("%d %d->%d b=%d: " % (res, cin, cout, batch) + " | ".join(line), flush=True)
 
 
