@@ -120,8 +120,11 @@ int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const
 
 /* The same convolution by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): 36 multiplications per 4x4 outputs and input channel
  * (2.25 per output; F(2x2,3x3): 4; direct: 9), interpolation points (0, 1, -1, 1/2, -2, inf), IEEE fp32 throughout, weights
- * transformed in fp64 at pack time.  For the layers of dream/models.py:598-615,695-710 with >= 128 output channels.
- * Cin a multiple of 32.  Packed weights: dream_conv3x3_winograd4_weight_floats(rows, cols) floats; mode / flags as above. */
+ * transformed in fp64 at pack time.  For the stride-1 3x3 layers of dream/models.py:598-615,695-710 behind the first one.
+ * Two workgroup shapes, chosen by the number of output channels (rows of the packed operator): more than 64 -- 128 channels per
+ * workgroup, Cin a multiple of 32, weights packed [Cin/16][36][rows up to a multiple of 128][16]; up to 64 -- 64 channels per
+ * workgroup, Cin a multiple of 16, weights packed [Cin/8][36][64][8].  Packed weights: dream_conv3x3_winograd4_weight_floats(rows,
+ * cols) floats (either shape); mode / flags as above. */
 size_t dream_conv3x3_winograd4_weight_floats(int rows, int cols);
 int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u, int Cout, int Cin, int mode, void *stream);
 int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
