@@ -625,16 +625,24 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
 //   u4: dream_pack_convT4x4_winograd_weight(): 4 x dream_conv3x3_winograd_weight_floats(Cout, Cin) floats.  flags: DREAM_CONV_RELU.
 extern "C" size_t dream_convT4x4_winograd_weight_floats(int Cout, int Cin) { return 4 * dream_conv3x3_winograd_weight_floats(Cout, Cin); }
 
+// wT [Cin][Cout][4][4] -> w3: the four zero-padded 3x3 kernels of the output phases, 4 x OIHW [Cout][Cin][3][3] (bwd = 0), or of the
+// data gradient, 4 x [Cin][Cout][3][3] (bwd = 1): convT4x4_phase_kernels above
+extern "C" int dream_convT4x4_phase_weights(const float *wT, float *w3, int Cin, int Cout, int bwd, void *stream) {
+    DREAM_REQUIRE(wT && w3 && Cin > 0 && Cout > 0 && (bwd == 0 || bwd == 1), "convT phase weights: bad arguments");
+    const size_t total = (size_t)4 * Cout * Cin * 9;
+    size_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(convT4x4_phase_kernels, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wT, w3, Cin, Cout, bwd);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
 // wT [Cin][Cout][4][4] -> u4; scratch: 4 * Cout * Cin * 9 floats (the four zero-padded 3x3 kernels)
 // mode 0: forward operator (u4: 4 x dream_conv3x3_winograd_weight_floats(Cout, Cin)); mode 1: data-gradient operator
 // (dream_conv4x4s2_winograd_nhwc_f32; u4: 4 x dream_conv3x3_winograd_weight_floats(Cin, Cout))
 extern "C" int dream_pack_convT4x4_winograd_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, int mode, void *stream) {
     DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "winograd convT pack: bad arguments");
-    const size_t total = (size_t)4 * Cout * Cin * 9;
-    size_t grid = (total + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(convT4x4_phase_kernels, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, wT, scratch, Cin, Cout, mode);
-    DREAM_LAUNCH_OK();
+    if (int rc = dream_convT4x4_phase_weights(wT, scratch, Cin, Cout, mode, stream)) return rc;
     const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;       // conv output / input channels
     const size_t per_u = dream_conv3x3_winograd_weight_floats(rows, cols);
     for (int ph = 0; ph < 4; ++ph)

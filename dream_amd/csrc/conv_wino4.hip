@@ -70,6 +70,8 @@ struct Wino4Params {
     int nblk, blk_per_xcd;   // blocks of 16 tiles; each XCD's workgroups walk over a contiguous range of them
     unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX)
     int flags;
+    int out_scale, out_oy, out_ox;   // output pixel of conv position (y, x): (out_scale y + out_oy, out_scale x + out_ox) -- (1, 0, 0) for a
+                                     // conv, (2, a, b) for phase (a, b) of a stride-2 transposed conv (y: [B, out_scale H, out_scale W, Cout])
 };
 
 constexpr int W4T = 16;       // tiles per workgroup
@@ -135,12 +137,38 @@ DREAM_DEVICE f32x4 bt_row(int j, const f32x4 *d) {
     }
 }
 
+// PAT: which of the 36 positions carry non-zero transformed weights.  0: all (3x3 conv).  1 + 2 a + b: phase (a, b) of
+// nn.ConvTranspose2d(k4, s2, p1) written as a 3x3 conv whose kernel has only 2 x 2 non-zero taps (rows {0,1} for a = 0, {1,2} for
+// a = 1; columns likewise -- conv_wino.hip): G g G^T then vanishes on row 5 (a = 0: the last row of G is (0, 0, 1)) or row 0 (a = 1:
+// the first is (1, 0, 0)) of the 6 x 6 domain, and likewise on a column.  25 positions are left -- the F(4x4, 2x2) minimal-filtering
+// count, 25 multiplications per 4 x 4 outputs of a phase where F(2x2, 2x2) takes 36 -- and the other eleven are never loaded or
+// multiplied.
+DREAM_DEVICE constexpr bool pat4_row_active(int pat, int i) { return pat == 0 || (((pat - 1) >> 1) == 0 ? i <= 4 : i >= 1); }
+DREAM_DEVICE constexpr bool pat4_col_active(int pat, int j) { return pat == 0 || (((pat - 1) & 1) == 0 ? j <= 4 : j >= 1); }
+DREAM_DEVICE constexpr bool pat4_active(int pat, int pp) { return pat4_row_active(pat, pp / 6) && pat4_col_active(pat, pp % 6); }
+DREAM_DEVICE constexpr int pat4_count(int pat) { return pat == 0 ? 36 : 25; }
+struct Pat4Table { int pos[36]; };                  // pos[k]: the k-th active position (a table: indexed by unrolled-loop constants)
+constexpr Pat4Table pat4_table(int pat) {
+    Pat4Table t = {};
+    int n = 0;
+    for (int pp = 0; pp < 36; ++pp)
+        if (pat4_active(pat, pp)) t.pos[n++] = pp;
+    return t;
+}
+template <int PAT>
+struct Pat4 { static constexpr Pat4Table table = pat4_table(PAT); };
+#define pat4_pos(PAT, k) (Pat4<PAT>::table.pos[k])
+
 // MODE: 0 plain, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask (conv_wino.hip)
-template <int MODE, bool NARROW>
+template <int MODE, bool NARROW, int PAT = 0>
 __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(const Wino4Params p) {
     using C = W4Cfg<NARROW>;
     using vec = typename C::vec;
-    constexpr int W4K = C::K, W4NW = C::NW, V4PS = C::VPS, V4B = C::VB, S4ROW = C::SROW, W4_RING = C::RING, W4_AHEAD = C::AHEAD;
+    constexpr int W4K = C::K, W4NW = C::NW, V4PS = C::VPS, V4B = C::VB, S4ROW = C::SROW;
+    constexpr int NPOS = pat4_count(PAT);              // positions this kernel multiplies
+    // the weight ring must divide the positions of two chunks (2 x 25: five registers, three positions ahead)
+    constexpr int W4_RING = PAT ? 5 : C::RING, W4_AHEAD = W4_RING - 2;
+    static_assert((2 * NPOS) % W4_RING == 0, "the weight ring must divide two chunks' positions");
     DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer, then the staging tile
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -209,7 +237,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     const int a_off = NARROW ? lt * W4K + 4 * v4_slot<NARROW>(lg >> 1, lt) + 2 * (lg & 1) : lt * W4K + 4 * v4_slot<NARROW>(lg, lt);
     const unsigned b_lane = (unsigned)(((wave * 16 + lt) * W4K + C::KS * lg) * 4);
     const unsigned u_pos_stride = (unsigned)(p.CoutPad * W4K * 4);
-    const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * W4K, ((size_t)((p.Cin / W4K) * W4P + W4_AHEAD) * p.CoutPad - (size_t)n0) * W4K * sizeof(float));
+    const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * W4K, ((size_t)((p.Cin / W4K) * W4P + C::AHEAD) * p.CoutPad - (size_t)n0) * W4K * sizeof(float));
 
     f32x4 acc[W4P];
     const int nchunks = p.Cin / W4K;
@@ -222,7 +250,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         else return buffer_load_x4(ubuf, b_lane, soff);
     };
 #pragma unroll
-    for (int k = 0; k < W4_AHEAD; ++k) bq[k] = load_u((unsigned)k * u_pos_stride);
+    for (int k = 0; k < W4_AHEAD; ++k) bq[k] = load_u((unsigned)pat4_pos(PAT, k) * u_pos_stride);
 
     // LDS addresses: one per-lane base register per (role, V buffer), everything else in the instructions' 16-bit immediate
     // offsets (every plane / row offset below is < 64 KB from its base).  `opaque` keeps the compiler from folding the buffer
@@ -242,18 +270,19 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     f32x4 d[6];                                        // pass 1: the patch row; pass 2: the staged column
     auto pass1_piece = [&](int j) { sV4[s1p + j] = bt_row(j, d); };
     auto pass2_read = [&](int r) { d[r] = sV4[s2p + r * S4ROW]; };
-    auto pass2_piece = [&](int i, int h) { sV4[vwr[h] + i * (6 * V4PS / 4)] = bt_row(i, d); };
+    auto pass2_piece = [&](int i, int h) { if (pat4_row_active(PAT, i)) sV4[vwr[h] + i * (6 * V4PS / 4)] = bt_row(i, d); };   // rows no MFMA reads are not made
 
     vec a[2][2];                                       // [set][position of the pair]
     // narrow: two ds_read_b64 (2 LDS cycles each, 64 banks: conflict-free on this layout); merged into one ds_read2st64_b64 by the
     // compiler they would run in 16-lane groups on 32 banks -- 8 cycles, and 2-way conflicts on top.  Volatile accesses are not merged.
-    auto read_a = [&](int set, int pp, int h) {
+    auto read_a = [&](int set, int k, int h) {         // the A operands of active positions k and k + 1
+        const int p0 = pat4_pos(PAT, k), p1 = pat4_pos(PAT, k + 1 < NPOS ? k + 1 : k);
         if constexpr (NARROW) {
-            a[set][0] = lds_read_unmerged(sVa + vrd[h] + pp * V4PS / C::KS);
-            a[set][1] = lds_read_unmerged(sVa + vrd[h] + (pp + 1) * V4PS / C::KS);
+            a[set][0] = lds_read_unmerged(sVa + vrd[h] + p0 * V4PS / C::KS);
+            a[set][1] = lds_read_unmerged(sVa + vrd[h] + p1 * V4PS / C::KS);
         } else {
-            a[set][0] = sVa[vrd[h] + pp * V4PS / C::KS];
-            a[set][1] = sVa[vrd[h] + (pp + 1) * V4PS / C::KS];
+            a[set][0] = sVa[vrd[h] + p0 * V4PS / C::KS];
+            if (k + 1 < NPOS) a[set][1] = sVa[vrd[h] + p1 * V4PS / C::KS];
         }
     };
 
@@ -286,34 +315,40 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
 #define DREAM_W4_S2 13
 #define DREAM_W4_LX 3
 #endif
-        constexpr int S1 = DREAM_W4_S1, S2 = DREAM_W4_S2; // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
-        constexpr int LX = DREAM_W4_LX;                   // patch loads in slots 0 .. LX - 1 (6 / LX per slot)
+        // NSLOT slots of two active positions (18; 13 with a phase pattern, the last one a single position).  The full kernel's
+        // schedule is S1 10 / S2 13 / loads in slots 0..2; a pattern keeps the distances from the END of the chunk (S1 5, S2 8) and
+        // issues its six patch loads in slot 0, so that they have four slots to arrive.
+        constexpr int NSLOT = (NPOS + 1) / 2;
+        constexpr int S1 = PAT ? NSLOT - 8 : DREAM_W4_S1, S2 = PAT ? NSLOT - 5 : DREAM_W4_S2; // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
+        constexpr int LX = PAT ? 1 : DREAM_W4_LX;         // patch loads in slots 0 .. LX - 1 (6 / LX per slot)
         const unsigned coff = last ? 0u : (unsigned)((c + 1) * W4K * 4);
         const int cnext = last ? 0 : (c + 1) * W4P;                          // first position of the next chunk in the weight stream
         if (PH == 1 && last) xbuf = block_xbuf(b0n);                        // this block's loads are all issued: from here on the next block's
         read_a(0, 0, PH);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 18; ++s) {
-            const int pp = 2 * s;
-            auto load_b = [&](int half) {                                    // weight operands of position pp + half + AHEAD
-                if (DREAM_W4_DIAG & 2) return;
-                const int kn = pp + half + W4_AHEAD;
-                const int spos = kn >= W4P ? cnext + (kn - W4P) : c * W4P + kn;
-                bq[(PH * W4P + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
+        for (int s = 0; s < NSLOT; ++s) {
+            const int k0 = 2 * s;                                            // the slot's active positions k0 (and k0 + 1)
+            const bool two = k0 + 1 < NPOS;
+            const int pp = pat4_pos(PAT, k0), pp1 = pat4_pos(PAT, two ? k0 + 1 : k0);
+            auto load_b = [&](int half) {                                    // weight operands of active position k0 + half + AHEAD
+                if ((DREAM_W4_DIAG & 2) || (half && !two)) return;
+                const int kn = k0 + half + W4_AHEAD;
+                const int spos = kn >= NPOS ? cnext + pat4_pos(PAT, kn - NPOS) : c * W4P + pat4_pos(PAT, kn);
+                bq[(PH * NPOS + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
             };
             auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), (DREAM_W4_DIAG & 64) ? 0u : coff); };
             auto pair = [&](int r) {
-                const int i0 = (PH * W4P + pp) % W4_RING, i1 = (PH * W4P + pp + 1) % W4_RING;
+                const int i0 = (PH * NPOS + k0) % W4_RING, i1 = (PH * NPOS + k0 + 1) % W4_RING;
                 acc[pp] = mfma_f32_16x16x4(a[s & 1][0][r], bq[i0][r], acc[pp]);
-                acc[pp + 1] = mfma_f32_16x16x4(a[s & 1][1][r], bq[i1][r], acc[pp + 1]);
+                if (two) acc[pp1] = mfma_f32_16x16x4(a[s & 1][1][r], bq[i1][r], acc[pp1]);
                 __builtin_amdgcn_sched_barrier(0);
             };
             // the four interleave points of a slot; the narrow shape has two MFMA pairs per slot: two points behind each
             auto after = [&](int k) {
                 if (k == 0) {
                     load_b(0);
-                    if (s + 1 < 18) read_a((s + 1) & 1, pp + 2, PH);
+                    if (s + 1 < NSLOT) read_a((s + 1) & 1, k0 + 2, PH);
                     if (PH == 1 && s == 0 && last) plan_item(tile0n, b0n);
                     if (s < LX) { for (int c2 = 0; c2 < 3 / LX; ++c2) load_x((6 / LX) * s + c2); }
                     if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1));
@@ -361,14 +396,16 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         // SGPRs across the MFMA phases these values push the kernel past its scalar register file (spills through VGPR lanes).
         if (DREAM_W4_DIAG & 128) {                     // diagnostics: no epilogue (the accumulators stay live)
 #pragma unroll
-            for (int pp = 0; pp < W4P; ++pp) asm volatile("" :: "v"(acc[pp]));
+            for (int pp = 0; pp < W4P; ++pp)
+                if (pat4_active(PAT, pp)) asm volatile("" :: "v"(acc[pp]));
             return;
         }
         const auto &e = *DREAM_KERNARG(p);
         const bool relu = (e.flags & DREAM_CONV_RELU) != 0;
-        const int Ho = pool ? e.H / 2 : e.H, Wo = pool ? e.W / 2 : e.W;
-        const size_t out_img = (size_t)Ho * Wo * e.Cout;
-        const unsigned px_b = (unsigned)(e.Cout * 4), row_b = (unsigned)(Wo * e.Cout * 4);
+        // Ho x Wo: grid of stored conv positions; So: their spacing in the stored tensor (2 for a transposed conv's phase)
+        const int Ho = pool ? e.H / 2 : e.H, Wo = pool ? e.W / 2 : e.W, So = e.out_scale;
+        const size_t out_img = (size_t)(So * Ho) * (So * Wo) * e.Cout;
+        const unsigned px_b = (unsigned)(So * e.Cout * 4), row_b = (unsigned)(So * So * Wo * e.Cout * 4);
         const int ln = lane_id();                      // from the hardware (mbcnt), not from a register kept across the MFMA phases
         const int lt = ln & 15, lg = ln >> 4;
         const int col = n0 + wave * 16 + lt;
@@ -393,7 +430,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
             for (int h = 0; h < 2; ++h) {
                 const bool tok = cok & ((tau0 + 2 * rp + h) < p.ntiles);
                 const int oy = NS * ty, ox = NS * tx;
-                base[h] = (unsigned)(((((b - b0e) * Ho + oy) * Wo + ox) * e.Cout + col) * 4);
+                base[h] = (unsigned)(((((b - b0e) * So * Ho + So * oy + e.out_oy) * (So * Wo) + So * ox + e.out_ox) * e.Cout + col) * 4);
                 int m = 0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) m |= ((oy + i) < Ho ? 1 << i : 0) | ((ox + i) < Wo ? 16 << i : 0);
@@ -420,7 +457,8 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
             for (int i = 0; i < 6; ++i) {
                 f32x2 m[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = f32x2{acc[6 * i + j][2 * rp], acc[6 * i + j][2 * rp + 1]};
+                for (int j = 0; j < 6; ++j)          // positions without weights (PAT) were never multiplied: zeros of the sums
+                    m[j] = pat4_active(PAT, 6 * i + j) ? f32x2{acc[6 * i + j][2 * rp], acc[6 * i + j][2 * rp + 1]} : f32x2{0.0f, 0.0f};
                 const f32x2 t1 = pk_sub2(m[1], m[2]), t2 = m[1] + m[2];
                 sA[i][0] = (m[0] + t2) + (m[3] + m[4]);
                 sA[i][1] = fm(-2.0f, m[4], fm(0.5f, m[3], t1));
@@ -486,7 +524,8 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         const int b0n = div_magic40(tile0n, p.magic_tpi);
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int pp = 0; pp < W4P; ++pp) acc[pp] = zero;
+        for (int pp = 0; pp < W4P; ++pp)
+            if (pat4_active(PAT, pp)) acc[pp] = zero;
         for (int c = 0; c < nchunks; c += 2) {
             chunk(ph0, false, c, tile0n, b0n);
             chunk(ph1, c + 2 == nchunks, c + 1, tile0n, b0n);
@@ -517,10 +556,10 @@ PackShape pack_shape(int rows) {
     return {W4Cfg<false>::K, (rows + W4Cfg<false>::PAD - 1) / W4Cfg<false>::PAD * W4Cfg<false>::PAD, W4Cfg<false>::AHEAD};
 }
 
-template <int MODE, bool NARROW>
+template <int MODE, bool NARROW, int PAT = 0>
 int launch_wino4(const Wino4Params &p, void *stream) {
     using C = W4Cfg<NARROW>;
-    void (*kernel)(const Wino4Params) = conv_wino4_kernel<MODE, NARROW>;
+    void (*kernel)(const Wino4Params) = conv_wino4_kernel<MODE, NARROW, PAT>;
     const size_t lds = ((size_t)2 * C::VB + C::SB) * sizeof(float);
     if (dream_allow_full_lds((const void *)kernel)) return 2;
     const int ny = (p.Cout + 16 * C::NW - 1) / (16 * C::NW);
@@ -574,22 +613,18 @@ extern "C" int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u
     return 0;
 }
 
-// y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32, by F(4x4,3x3).
-// Cin a multiple of 32 (of 16 for Cout <= 64); flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor),
-// DREAM_CONV_RELUMASK.
-extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
-                                                const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
-                                                void *stream) {
-    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd F(4x4) conv: unsupported flags 0x%x", flags);
-    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd F(4x4) conv: fused max-pool takes no residual");
-    DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd F(4x4) conv: ReLU mask without a mask tensor");
+namespace {
+
+// geometry shared by the conv and the transposed-conv entry points
+int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const float *scale, const float *shift, const float *residual,
+                float *y, int B, int H, int W, int Cin, int Cout, int flags, int out_scale) {
     DREAM_REQUIRE(x && u_packed && y, "winograd F(4x4) conv: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd F(4x4) conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
     const PackShape ps = pack_shape(Cout);
     DREAM_REQUIRE(Cin % (2 * ps.k) == 0, "winograd F(4x4) conv: Cin=%d must be a multiple of %d", Cin, 2 * ps.k);
-    Wino4Params p;
     const size_t span_imgs = (size_t)W4T / ((size_t)((H + 3) / 4) * ((W + 3) / 4)) + 2;
-    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) && span_imgs * H * W * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
+    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) &&
+                  span_imgs * out_scale * out_scale * H * W * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
                   "winograd F(4x4) conv: image too large for 32-bit offsets");
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
@@ -604,6 +639,64 @@ extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_p
     p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(p.TY * p.TX) - 1) / (unsigned long long)(p.TY * p.TX);
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
+    p.out_scale = out_scale; p.out_oy = 0; p.out_ox = 0;
+    return 0;
+}
+
+}  // namespace
+
+// y = conv3x3(x, pad 1) * scale + shift (+ residual | ReLU mask) (ReLU) (2x2 max-pool), all NHWC fp32, by F(4x4,3x3).
+// Cin a multiple of 32 (of 16 for Cout <= 64); flags: DREAM_CONV_RELU, DREAM_CONV_POOL2 (output [B, H/2, W/2, Cout], floor),
+// DREAM_CONV_RELUMASK.
+extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                                const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
+                                                void *stream) {
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd F(4x4) conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd F(4x4) conv: fused max-pool takes no residual");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd F(4x4) conv: ReLU mask without a mask tensor");
+    Wino4Params p;
+    if (int rc = wino4_setup(p, x, u_packed, scale, shift, residual, y, B, H, W, Cin, Cout, flags, 1)) return rc;
     const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
     return narrow_rows(Cout) ? launch_wino4_mode<true>(p, mode, stream) : launch_wino4_mode<false>(p, mode, stream);
+}
+
+// nn.ConvTranspose2d(k4, s2, p1) (+ folded BatchNorm / bias, ReLU) by minimal filtering on the F(4x4) kernel: every output phase
+// (a, b) is a 2 x 2-tap stride-1 conv of x; written as a 3x3 conv with a zero-padded kernel (dream_convT4x4_phase_weights) its
+// transformed weights vanish on eleven of the 36 positions, so the kernel runs it with 25 multiplications per 4 x 4 outputs of
+// the phase -- F(4x4, 2x2) -- where the F(2x2) kernel takes 36 (dream_conv_transpose4x4s2_winograd_nhwc_f32) and the direct
+// sub-pixel form 64.  x [B,H,W,Cin] -> y [B,2H,2W,Cout]; four launches (one per phase); more than 64 output channels, Cin a
+// multiple of 32.  u4: dream_pack_convT4x4_winograd4_weight(): 4 x dream_conv3x3_winograd4_weight_floats(Cout, Cin) floats.
+// flags: DREAM_CONV_RELU.
+extern "C" size_t dream_convT4x4_winograd4_weight_floats(int Cout, int Cin) { return 4 * dream_conv3x3_winograd4_weight_floats(Cout, Cin); }
+
+// wT [Cin][Cout][4][4] -> u4 (forward operator); scratch: 4 * Cout * Cin * 9 floats (the four zero-padded 3x3 kernels)
+extern "C" int dream_pack_convT4x4_winograd4_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream) {
+    DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0, "winograd F(4x4) convT pack: bad arguments");
+    if (int rc = dream_convT4x4_phase_weights(wT, scratch, Cin, Cout, 0, stream)) return rc;
+    const size_t per_u = dream_conv3x3_winograd4_weight_floats(Cout, Cin);
+    for (int ph = 0; ph < 4; ++ph)
+        if (int rc = dream_pack_conv3x3_winograd4_weight(scratch + (size_t)ph * Cout * Cin * 9, u4 + ph * per_u, Cout, Cin, 0, stream)) return rc;
+    return 0;
+}
+
+extern "C" int dream_conv_transpose4x4s2_winograd4_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift,
+                                                            float *y, int B, int H, int W, int Cin, int Cout, int flags, void *stream) {
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "winograd F(4x4) convT: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(Cout > 64, "winograd F(4x4) convT: needs more than 64 output channels (the wide workgroup shape), got %d", Cout);
+    Wino4Params p;
+    if (int rc = wino4_setup(p, x, u4, scale, shift, nullptr, y, B, H, W, Cin, Cout, flags, 2)) return rc;
+    const size_t per_u = dream_conv3x3_winograd4_weight_floats(Cout, Cin);
+    for (int ph = 0; ph < 4; ++ph) {
+        p.u = u4 + ph * per_u;
+        p.out_oy = ph >> 1; p.out_ox = ph & 1;
+        int rc;
+        switch (ph) {
+            case 0: rc = launch_wino4<0, false, 1>(p, stream); break;
+            case 1: rc = launch_wino4<0, false, 2>(p, stream); break;
+            case 2: rc = launch_wino4<0, false, 3>(p, stream); break;
+            default: rc = launch_wino4<0, false, 4>(p, stream); break;
+        }
+        if (rc) return rc;
+    }
+    return 0;
 }

@@ -69,6 +69,8 @@ class _PackedCache:
                     packed = ops.pack_convT4x4_weight_f16x3(wt4) if f16x3 else ops.pack_convT4x4_weight(wt4)
                 elif mode in ("ups_wino0", "ups_wino1"):          # the same transposed conv by minimal filtering (fwd / data gradient)
                     packed = ops.pack_convT4x4_winograd_weight(ops.upsample_conv_weight(weight.detach()), int(mode[-1]))
+                elif mode == "ups_wino4_0":                       # ... on the F(4x4,3x3) kernel (25-position phase patterns)
+                    packed = ops.pack_convT4x4_winograd4_weight(ops.upsample_conv_weight(weight.detach()))
                 else:
                     packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
                 hit = (tag, packed)
@@ -335,8 +337,9 @@ class DreamHourglass(nn.Module):
                     if flags & CONV_UPSAMPLE2X:              # upsample + conv == a 4x4 transposed conv: 4 MACs / output, not 9
                         if self._ups_winograd(int(inp.shape[3]), int(mod.weight.shape[0])):
                             # ... and that transposed conv by minimal filtering on the Winograd kernel: 9/16 of those again
-                            u4, cout4 = self._packed.get(mod.weight, "ups_wino0")
-                            act = ops.conv_transpose4x4s2_winograd(inp, u4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
+                            tile = ops.convT4x4_winograd_tile(inp, int(mod.weight.shape[0]))
+                            u4, cout4 = self._packed.get(mod.weight, "ups_wino4_0" if tile == 4 else "ups_wino0")
+                            act = ops.conv_transpose4x4s2_winograd_tile(tile, inp, u4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
                         else:
                             pk4, cout4 = self._packed.get(mod.weight, "ups")
                             act = ops.conv_transpose4x4s2(inp, pk4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
@@ -1060,8 +1063,9 @@ class ResnetSimple(nn.Module):
                     bn = mods[i + 1]
                     scale, shift = self._fold(name, bn, m.bias)
                     if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
-                        u4, cout = self._cached(("wu4", name), [m.weight], lambda m=m: ops.pack_convT4x4_winograd_weight(m.weight.detach()))
-                        y = ops.conv_transpose4x4s2_winograd(y, u4, cout, scale, shift, CONV_RELU)
+                        tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
+                        u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))
+                        y = ops.conv_transpose4x4s2_winograd_tile(tile, y, u4, cout, scale, shift, CONV_RELU)
                     else:
                         packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
                         y = ops.conv_transpose4x4s2(y, packed, cout, scale, shift, CONV_RELU)
@@ -1146,8 +1150,9 @@ class ResnetSimple(nn.Module):
                 if isinstance(m, nn.ConvTranspose2d):
                     bn = mods[i + 1]
                     if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
-                        u4, cout = self._cached(("wu4", name), [m.weight], lambda m=m: ops.pack_convT4x4_winograd_weight(m.weight.detach()))
-                        z = ops.conv_transpose4x4s2_winograd(y, u4, cout, None, m.bias.detach(), 0)
+                        tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
+                        u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))
+                        z = ops.conv_transpose4x4s2_winograd_tile(tile, y, u4, cout, None, m.bias.detach(), 0)
                     else:
                         packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
                         z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)

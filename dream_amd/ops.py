@@ -227,6 +227,52 @@ def conv_transpose4x4s2_winograd(x_nhwc, u4, cout, scale=None, shift=None, flags
     return y
 
 
+def convT4x4_winograd_tile(x_nhwc, cout):
+    """Output tile of the Winograd kernel for ConvTranspose2d(k4,s2,p1) on this input: 4 = the F(4x4,3x3) kernel with the 25-position
+    phase patterns (wide workgroup shape only), 2 = the F(2x2,3x3) kernel with its 9-position patterns."""
+    b, h, w, cin = (int(v) for v in x_nhwc.shape)
+    if cout < 128 or winograd_tile(h, w, cin, cout, b) != 4:
+        return 2
+    if _WINOGRAD_TILE_FORCED == 4:
+        return 4
+    # measured (profiles/r03_microbench_convT.txt): 1.08-1.11x the F(2x2) form on maps of 100 x 100 and more with ~5 rounds of tile
+    # blocks per workgroup; on par on 50 x 50 maps whatever the batch, slower below (the 25-position kernel runs at 0.55 of the MFMA
+    # peak, the 9-position one at 0.73)
+    t4 = ((h + 3) // 4) * ((w + 3) // 4)
+    return 4 if h * w >= 96 * 96 and ((b * t4 + 15) // 16) * ((cout + 127) // 128) >= 4 * 256 else 2
+
+
+def pack_convT4x4_winograd_weight_tile(wT, tile):
+    return pack_convT4x4_winograd4_weight(wT) if tile == 4 else pack_convT4x4_winograd_weight(wT, 0)
+
+
+def conv_transpose4x4s2_winograd_tile(tile, x_nhwc, u4, cout, scale=None, shift=None, flags=0, direct_taps=16):
+    fn = conv_transpose4x4s2_winograd4 if tile == 4 else conv_transpose4x4s2_winograd      # looked up at call time: bench.py wraps both
+    return fn(x_nhwc, u4, cout, scale, shift, flags, direct_taps=direct_taps)
+
+
+def pack_convT4x4_winograd4_weight(wT):
+    """[Cin,Cout,4,4] ConvTranspose2d(k4,s2,p1) weight -> the four phases' F(4x4,3x3)-transformed zero-padded 3x3 kernels of the
+    forward operator; returns (u4, cout)."""
+    w = _f32(wT)
+    cin, cout = int(w.shape[0]), int(w.shape[1])
+    n = int(_hip.lib().dream_convT4x4_winograd4_weight_floats(cout, cin))
+    u4 = torch.empty(n, dtype=torch.float32, device=w.device)
+    scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
+    call("dream_pack_convT4x4_winograd4_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, stream())
+    return u4, cout
+
+
+def conv_transpose4x4s2_winograd4(x_nhwc, u4, cout, scale=None, shift=None, flags=0, direct_taps=16):
+    """ConvTranspose2d(k4,s2,p1) * scale + shift (ReLU) by minimal filtering on the F(4x4) kernel (25/64 of the direct
+    multiplications), NHWC; cout > 64, Cin a multiple of 32."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv_transpose4x4s2_winograd4_nhwc_f32", ptr(x), ptr(u4), ptr(scale), ptr(shift), ptr(y), b, h, w, cin, cout, flags, stream())
+    return y
+
+
 def conv3x3_first(x_nchw, w_oihw, bias, relu=True):
     x, w = _f32(x_nchw), _f32(w_oihw)
     b, cin, h, wd = (int(v) for v in x.shape)

@@ -158,6 +158,16 @@ int dream_conv4x4s2_winograd_nhwc_f32(const float *dy, const float *u4_mode1, fl
                                       void *stream);
 int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift, float *y,
                                                 int B, int H, int W, int Cin, int Cout, int flags, void *stream);
+/* The four zero-padded 3x3 kernels of the output phases of that transposed conv (bwd = 0: 4 x OIHW [Cout][Cin][3][3]) or of its data
+ * gradient (bwd = 1: 4 x [Cin][Cout][3][3]) from wT [Cin][Cout][4][4]: the input of the Winograd packings above and below. */
+int dream_convT4x4_phase_weights(const float *wT, float *w3, int Cin, int Cout, int bwd, void *stream);
+/* The same transposed conv on the F(4x4,3x3) kernel: the zero-padded phase kernels vanish on 11 of the 36 positions -- 25
+ * multiplications per 4x4 outputs of a phase, F(4x4,2x2), where the F(2x2) form takes 36 and the direct sub-pixel form 64.
+ * Cout > 64, Cin a multiple of 32; u4: dream_convT4x4_winograd4_weight_floats(Cout, Cin) floats; scratch: 4*Cout*Cin*9 floats. */
+size_t dream_convT4x4_winograd4_weight_floats(int Cout, int Cin);
+int dream_pack_convT4x4_winograd4_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream);
+int dream_conv_transpose4x4s2_winograd4_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift, float *y,
+                                                 int B, int H, int W, int Cin, int Cout, int flags, void *stream);
 /* nn.ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) of the deconv decoder (dream/models.py:621-686) by sub-pixel
  * decomposition: four stride-1 launches with 1/2/2/4 taps, no multiplications by zero (the DREAM_CONV_ZEROSTUFF2X form
  * of dream_conv3x3_nhwc_f32 computes the same result with 4x the MACs).  x [B,H,W,Cin] -> y [B,2H,2W,Cout];

@@ -146,15 +146,16 @@ def check_conv_winograd4(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_
     return err
 
 
-def check_convT4x4_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, with_scale=False, max_workgroups=(8,)):
-    """ConvTranspose2d(k4,s2,p1) by minimal filtering on the Winograd kernel vs an fp64 conv_transpose2d: error relative to the
-    output maximum at fp32 round-off level."""
+def check_convT4x4_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, with_scale=False, max_workgroups=(8,), tile=2):
+    """ConvTranspose2d(k4,s2,p1) by minimal filtering on the Winograd kernels (tile 2: F(2x2,3x3) with the 9-position phase patterns,
+    tile 4: F(4x4,3x3) with the 25-position ones) vs an fp64 conv_transpose2d: error relative to the output maximum at fp32 round-off
+    level (tile 4: the F(4x4) class, <= 1e-5)."""
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(B, Cin, H, W, generator=g)
     wT = torch.randn(Cin, Cout, 4, 4, generator=g) * (2.0 / (4 * Cin)) ** 0.5
     bias = torch.randn(Cout, generator=g)
     scale = torch.rand(Cout, generator=g) + 0.5 if with_scale else None
-    u4, rows = ops.pack_convT4x4_winograd_weight(to(dev, wT))
+    u4, rows = ops.pack_convT4x4_winograd_weight_tile(to(dev, wT), tile)
     assert rows == Cout
     ref = F.conv_transpose2d(x.double(), wT.double(), None, stride=2, padding=1)
     if with_scale:
@@ -162,17 +163,20 @@ def check_convT4x4_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, with_scale
     ref = ref + bias.double().view(1, -1, 1, 1)
     if flags & ops.CONV_RELU:
         ref = ref.relu()
-    args = (to(dev, _nhwc(x)), u4, Cout, to(dev, scale) if with_scale else None, to(dev, bias), flags)
-    y = ops.conv_transpose4x4s2_winograd(*args).cpu().permute(0, 3, 1, 2)
+    args = (tile, to(dev, _nhwc(x)), u4, Cout, to(dev, scale) if with_scale else None, to(dev, bias), flags)
+    y = ops.conv_transpose4x4s2_winograd_tile(*args).cpu().permute(0, 3, 1, 2)
     assert y.shape == ref.shape, (tuple(y.shape), tuple(ref.shape))
     err = float((y.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
-    assert err <= 2e-6, (B, H, W, Cin, Cout, flags, err)
+    # F(4x4): the error grows with the square root of the reduction length -- 6e-6 at 512 input channels, 1.5e-5 at 2048 (a shape
+    # ops.convT4x4_winograd_tile never gives to this kernel: its 13x13 map has too few tiles)
+    assert err <= ((2e-5 if Cin > 1024 else 1e-5) if tile == 4 else 2e-6), (B, H, W, Cin, Cout, flags, tile, err)
+    setter = _hip.lib().dream_conv3x3_winograd4_set_max_workgroups if tile == 4 else _hip.lib().dream_conv3x3_winograd_set_max_workgroups
     for cap in max_workgroups:                          # persistent grid sized for fewer workgroups: same result, bit for bit
-        _hip.lib().dream_conv3x3_winograd_set_max_workgroups(cap)
+        setter(cap)
         try:
-            y_cap = ops.conv_transpose4x4s2_winograd(*args).cpu().permute(0, 3, 1, 2)
+            y_cap = ops.conv_transpose4x4s2_winograd_tile(*args).cpu().permute(0, 3, 1, 2)
         finally:
-            _hip.lib().dream_conv3x3_winograd_set_max_workgroups(0)
+            setter(0)
         assert torch.equal(y, y_cap), ("persistent grid", cap)
     return err
 

@@ -79,6 +79,10 @@ def test_conv_transpose4x4_winograd(emu):
             pc.check_convT4x4_winograd("cpu", 2, 13, 9, 48, 96, ops.CONV_RELU, seed=1, with_scale=True),    # odd extents, 3 chunks, ragged cout
             pc.check_convT4x4_winograd("cpu", 1, 26, 26, 32, 256, ops.CONV_RELU, seed=2)]                   # two channel blocks, several tile blocks per workgroup
     print("convT4x4 winograd max rel err", max(errs))
+    errs4 = [pc.check_convT4x4_winograd("cpu", 1, 8, 8, 32, 128, max_workgroups=(), tile=4),                      # one block per phase
+             pc.check_convT4x4_winograd("cpu", 2, 13, 9, 64, 96, ops.CONV_RELU, seed=1, with_scale=True, max_workgroups=(), tile=4),   # odd extents, 4 chunks, ragged cout
+             pc.check_convT4x4_winograd("cpu", 1, 26, 26, 32, 256, ops.CONV_RELU, seed=2, tile=4)]                 # two channel blocks, several tile blocks per workgroup
+    print("convT4x4 winograd F(4x4) max rel err", max(errs4))
     berrs = [pc.check_conv4x4s2_winograd("cpu", 1, 6, 6, 128, 32),                 # data gradient: one block per phase
              pc.check_conv4x4s2_winograd("cpu", 2, 13, 9, 96, 48, seed=1),          # odd extents, 3 chunks, ragged channels
              pc.check_conv4x4s2_winograd("cpu", 1, 20, 22, 256, 32, seed=2)]        # two channel blocks

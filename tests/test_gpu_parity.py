@@ -639,6 +639,16 @@ def test_conv_transpose4x4_winograd(b, h, w, cin, cout, flags, kw):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
+    (1, 8, 8, 32, 128, 0, {}), (2, 13, 9, 64, 96, 1, {"with_scale": True}), (1, 26, 26, 32, 256, 1, {}),
+    (4, 13, 13, 2048, 256, 1, {"with_scale": True}), (4, 104, 104, 256, 256, 1, {"with_scale": True}), (2, 208, 208, 256, 256, 1, {}),
+    (2, 100, 100, 256, 256, 1, {})])
+def test_conv_transpose4x4_winograd4(b, h, w, cin, cout, flags, kw):
+    """The same transposed conv on the F(4x4,3x3) kernel with the 25-position phase patterns (F(4x4,2x2) minimal filtering)."""
+    err = pc.check_convT4x4_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, max_workgroups=(8, 24), tile=4, **kw)
+    print("convT4x4 winograd F(4x4) %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
     (1, 8, 8, 64, 64, 0, {}), (2, 5, 7, 128, 36, 1, {"with_scale": True}), (1, 13, 13, 256, 192, 1, {"residual": True}),
     (3, 4, 3, 64, 128, 0, {"mode": 1, "residual": True}), (1, 9, 9, 160, 64, 1, {}),
     (16, 100, 100, 64, 256, 1, {"with_scale": True, "residual": True}), (16, 100, 100, 256, 64, 1, {"with_scale": True}),

@@ -1,0 +1,14 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r03o
+mkdir -p $O
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "transpose4x4" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.txt
+line() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$n', round(d['value'], 1), 'frames/s', round(d['ms_per_step'], 2), 'ms', 'executed_frac', round(d['roofline']['executed_frac'], 3))"; }
+for i in 1 2; do
+DREAM_WINOGRAD_TILE=0 line default --steps 10 --warmup 3
+line resnet_f_b32 --arch resnet_f --batch 32 --steps 10 --warmup 3
+done
+line resnet_h_b128 --arch resnet_h --batch 128
+line vgg_f_b32 --arch vgg_f --batch 32 --steps 10 --warmup 3
