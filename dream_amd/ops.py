@@ -235,7 +235,7 @@ def convT4x4_winograd_tile(x_nhwc, cout):
         return 2
     if _WINOGRAD_TILE_FORCED == 4:
         return 4
-    # measured (profiles/r03_microbench_convT.txt): 1.08-1.11x the F(2x2) form on maps of 100 x 100 and more with ~5 rounds of tile
+    # measured (profiles/r03_microbench_convT4.txt): 1.08-1.11x the F(2x2) form on maps of 100 x 100 and more with ~5 rounds of tile
     # blocks per workgroup; on par on 50 x 50 maps whatever the batch, slower below (the 25-position kernel runs at 0.55 of the MFMA
     # peak, the 9-position one at 0.73)
     t4 = ((h + 3) // 4) * ((w + 3) // 4)

@@ -16,6 +16,7 @@ for f in $O/layer_profile_*.txt; do cp $f profiles/r03_$(basename $f); done
 cp $O/microbench_wino_b128.txt profiles/r03_microbench_wino_b128.txt
 cp $O/microbench_wino4_b128.txt profiles/r03_microbench_wino4_b128.txt
 cp $O/wino4_diag.txt profiles/r03_wino4_diag.txt
+cp $O/microbench_convT4.txt profiles/r03_microbench_convT4.txt
 tail -1 $O/rehearsal_2ranks_selflaunch.log > profiles/r03_rehearsal_2ranks_gloo_selflaunch_line.json
 tail -1 $O/rehearsal_single_process_train.log > profiles/r03_rehearsal_single_process_4replicas_train_line.json
 tail -3 $O/smoke.log > profiles/r03_smoke_tail.txt

@@ -53,5 +53,8 @@ for cfg in "resnet_h train 16" "vgg_q infer 128"; do set -- $cfg
 done
 echo "== microbenches"; timeout 300 python tools/microbench_wino4.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino4_b128.txt; tail -1 $O/microbench_wino4_b128.txt
 timeout 300 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/wino4_diag.txt
+timeout 300 python tools/microbench_convT4.py 2>&1 | grep -v amdgpu.ids > $O/microbench_convT4.txt; tail -2 $O/microbench_convT4.txt
 timeout 300 python tools/microbench_wino.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino_b128.txt; tail -1 $O/microbench_wino_b128.txt
+cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json
+echo "== default bench again (now with the PMC traffic of this bench.py)"; timeout 900 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
 ls -la $O | head -60; du -sh $O
