@@ -76,8 +76,22 @@ struct Wino4Params {
 
 constexpr int W4T = 16;       // tiles per workgroup
 constexpr int W4P = 36;       // positions
+// weight ring of the wide shape: 8 (six positions ahead) fits since the epilogue rewrite (255 VGPRs, no spills) and is 1.5-3 % faster
+// than 6 on every layer (round-robin A/B, profiles/r03_wino4_diag.txt); the narrow shape's positions take half the time: 12 or 18
 #ifndef DREAM_W4_RING
-#define DREAM_W4_RING 6
+#define DREAM_W4_RING 8
+#endif
+#ifndef DREAM_W4_NARROW_RING
+#define DREAM_W4_NARROW_RING 18
+#endif
+// the phase-pattern kernels (25 positions): weight ring (a divisor of 50) and the distance of pass 1 from the end of the chunk
+// (ring 10 = eight positions ahead: 0.62 of the MFMA peak on 256 -> 256 @ 200x200 against 0.56 with a ring of five, tools/microbench_convT4.py;
+// the kernel has the registers: 25 accumulators instead of 36)
+#ifndef DREAM_W4_PAT_RING
+#define DREAM_W4_PAT_RING 10
+#endif
+#ifndef DREAM_W4_PAT_S1OFF
+#define DREAM_W4_PAT_S1OFF 8
 #endif
 
 
@@ -106,7 +120,7 @@ struct W4Cfg {
     static constexpr int SB = W4T * 6 * SROW * 4;        // floats
     // operand registers of the weight stream: position k of the chunk of parity PH lives in bq[(36 PH + k) % RING] (chunks run in
     // pairs, so RING must divide 72).  NARROW positions take half the time: twice the positions in flight for the same latency.
-    static constexpr int RING = NARROW ? 2 * DREAM_W4_RING : DREAM_W4_RING;
+    static constexpr int RING = NARROW ? DREAM_W4_NARROW_RING : DREAM_W4_RING;
     static constexpr int AHEAD = RING - 2;               // positions the weight stream runs ahead of the MFMAs (two are in use)
     static_assert(72 % RING == 0, "the weight ring must divide two chunks' positions");
     using vec = std::conditional_t<NARROW, f32x2, f32x4>;   // one lane's MFMA operands of a position: KS floats
@@ -166,8 +180,8 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     using vec = typename C::vec;
     constexpr int W4K = C::K, W4NW = C::NW, V4PS = C::VPS, V4B = C::VB, S4ROW = C::SROW;
     constexpr int NPOS = pat4_count(PAT);              // positions this kernel multiplies
-    // the weight ring must divide the positions of two chunks (2 x 25: five registers, three positions ahead)
-    constexpr int W4_RING = PAT ? 5 : C::RING, W4_AHEAD = W4_RING - 2;
+    // the weight ring must divide the positions of two chunks (2 x 25: five or ten registers)
+    constexpr int W4_RING = PAT ? DREAM_W4_PAT_RING : C::RING, W4_AHEAD = W4_RING - 2;
     static_assert((2 * NPOS) % W4_RING == 0, "the weight ring must divide two chunks' positions");
     DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer, then the staging tile
     const int tid = threadIdx.x;
@@ -319,7 +333,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         // schedule is S1 10 / S2 13 / loads in slots 0..2; a pattern keeps the distances from the END of the chunk (S1 5, S2 8) and
         // issues its six patch loads in slot 0, so that they have four slots to arrive.
         constexpr int NSLOT = (NPOS + 1) / 2;
-        constexpr int S1 = PAT ? NSLOT - 8 : DREAM_W4_S1, S2 = PAT ? NSLOT - 5 : DREAM_W4_S2; // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
+        constexpr int S1 = PAT ? NSLOT - DREAM_W4_PAT_S1OFF : DREAM_W4_S1, S2 = PAT ? S1 + 3 : DREAM_W4_S2; // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
         constexpr int LX = PAT ? 1 : DREAM_W4_LX;         // patch loads in slots 0 .. LX - 1 (6 / LX per slot)
         const unsigned coff = last ? 0u : (unsigned)((c + 1) * W4K * 4);
         const int cnext = last ? 0 : (c + 1) * W4P;                          // first position of the next chunk in the weight stream

@@ -231,15 +231,13 @@ def convT4x4_winograd_tile(x_nhwc, cout):
     """Output tile of the Winograd kernel for ConvTranspose2d(k4,s2,p1) on this input: 4 = the F(4x4,3x3) kernel with the 25-position
     phase patterns (wide workgroup shape only), 2 = the F(2x2,3x3) kernel with its 9-position patterns."""
     b, h, w, cin = (int(v) for v in x_nhwc.shape)
-    if cout < 128 or winograd_tile(h, w, cin, cout, b) != 4:
-        return 2
+    if cout < (128 if _WINOGRAD_TILE_FORCED == 4 else 256) or winograd_tile(h, w, cin, cout, b) != 4:
+        return 2                       # (128 output channels = one channel block per tile block: measured slower than F(2x2) in vgg_q / vgg_f)
     if _WINOGRAD_TILE_FORCED == 4:
         return 4
-    # measured (profiles/r03_microbench_convT4.txt): 1.08-1.11x the F(2x2) form on maps of 100 x 100 and more with ~5 rounds of tile
-    # blocks per workgroup; on par on 50 x 50 maps whatever the batch, slower below (the 25-position kernel runs at 0.55 of the MFMA
-    # peak, the 9-position one at 0.73)
-    t4 = ((h + 3) // 4) * ((w + 3) // 4)
-    return 4 if h * w >= 96 * 96 and ((b * t4 + 15) // 16) * ((cout + 127) // 128) >= 4 * 256 else 2
+    # measured (profiles/r03_microbench_convT4.txt, 256 -> 256): 1.21x the F(2x2) form on maps of 100 x 100 and more, 1.05-1.13x on
+    # 50 x 50, slower on 13 x 13 (the 25-position kernel runs at 0.62 of the MFMA peak, the 9-position one at 0.73)
+    return 4 if h * w >= 48 * 48 else 2
 
 
 def pack_convT4x4_winograd_weight_tile(wT, tile):

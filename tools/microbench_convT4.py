@@ -21,6 +21,15 @@ def main():
         u4, _ = ops.pack_convT4x4_winograd4_weight(wT)
         fns = {"F(2x2)": lambda: ops.conv_transpose4x4s2_winograd(x, u2, c, None, bias, ops.CONV_RELU),
                "F(4x4)": lambda: ops.conv_transpose4x4s2_winograd4(x, u4, c, None, bias, ops.CONV_RELU)}
+        # schedule variants of the F(4x4) kernel: DREAM_ALT_LIBS="name=path.so,..." (libraries built with other -DDREAM_W4_PAT_* values)
+        y_alt = torch.empty(b, 2 * h, 2 * h, c, device="cuda")
+        for item in filter(None, os.environ.get("DREAM_ALT_LIBS", "").split(",")):
+            name, path = item.split("=")
+            import ctypes
+            from dream_amd import _hip
+            fn = ctypes.CDLL(path).dream_conv_transpose4x4s2_winograd4_nhwc_f32
+            fn.restype, fn.argtypes = _hip._SIGNATURES["dream_conv_transpose4x4s2_winograd4_nhwc_f32"]
+            fns[name] = lambda fn=fn: fn(x.data_ptr(), u4.data_ptr(), None, bias.data_ptr(), y_alt.data_ptr(), b, h, h, c, c, 1, torch.cuda.current_stream().cuda_stream)
         y2, y4 = fns["F(2x2)"](), fns["F(4x4)"]()
         torch.cuda.synchronize()
         diff = float((y2 - y4).abs().max() / y2.abs().max())
@@ -34,6 +43,9 @@ def main():
                 torch.cuda.synchronize()
                 best[k] = min(best[k], s.elapsed_time(e))
         fl = 2.0 * 16 * c * c * h * h * b
+        for k in fns:
+            if k not in ("F(2x2)", "F(4x4)"):
+                print("      %-24s %7.3f ms (%.2f of peak)" % (k, best[k], fl * (25.0 / 64.0) / best[k] / 1e9 / 157.3))
         print("b=%3d %3dx%-3d %d->%d  F(2x2) %7.3f ms %6.1f TF | F(4x4) %7.3f ms %6.1f TF (%.2f of peak on its own MACs)  speedup %.2f  max diff / max %.1e"
               % (b, h, h, c, c, best["F(2x2)"], fl / best["F(2x2)"] / 1e9, best["F(4x4)"], fl / best["F(4x4)"] / 1e9,
                  fl * (25.0 / 64.0) / best["F(4x4)"] / 1e9 / 157.3, best["F(2x2)"] / best["F(4x4)"], diff), flush=True)

@@ -9,14 +9,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [3001, 128, 256, 143, 15, 11, 9, 16, 32, 64, 96, 48]          # 1000 + r: product code with weight-ring size r; 2001..: schedule variants
+KS = [1006, 1112, 3001, 128, 256, 143, 15, 11, 9, 16, 32, 64, 96, 48]          # 1000 + r: product code with weight-ring size r; 2001..: schedule variants
+if os.environ.get("DREAM_W4_DIAG_KS"):          # a subset of the variants: DREAM_W4_DIAG_KS=1008,128
+    KS = [int(v) for v in os.environ["DREAM_W4_DIAG_KS"].split(",")]
 OUT = os.path.join(ROOT, "dream_amd", "diag")       # travels with the snapshot (git-ignored *.so)
 VARIANTS = {3001: ["-DDREAM_W4_STORE=buffer_store_f32_nt"], 2001: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 2002: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
             2003: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 2004: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
             2005: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
 NAMES = {0: "product", 3001: "non-temporal stores", 128: "no epilogue", 256: "epilogue without stores", 143: "MFMAs + operand reads only, no epilogue", 32: "weights from L1 (one position)", 64: "patches: chunk 0 only", 96: "weights from L1 + patches chunk 0", 48: "weights from L1 + patches out of range", 2001: "S1 6 S2 9", 2002: "S1 8 S2 13", 2003: "S1 10 S2 13, loads in slot 0", 2004: "S1 11 S2 14",
          2005: "S1 4 S2 8, loads in slot 0", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
-         11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 1008: "product, weight ring 8 (6 ahead)"}
+         11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 1006: "weight ring 6 (4 ahead; the product has 8)", 1112: "narrow shape: weight ring 12 (product 18)"}
 
 
 def build():
@@ -26,8 +28,8 @@ def build():
     for k in KS:
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                "-I", os.path.join(csrc, "include"), "-DDREAM_W4_DIAG=%d" % (k if k < 1000 else 0)] + (
-                   ["-DDREAM_W4_RING=%d" % (k - 1000)] if 1000 <= k < 2000 else []) + VARIANTS.get(k, []) + [os.path.join(csrc, "conv_wino4.hip"),
-               os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino4_diag_%d.so" % k)]
+                   ["-DDREAM_W4_RING=%d" % (k - 1000)] if 1000 <= k < 1100 else ["-DDREAM_W4_NARROW_RING=%d" % (k - 1100)] if 1100 <= k < 2000 else []) + VARIANTS.get(k, []) + [os.path.join(csrc, "conv_wino4.hip"),
+               os.path.join(csrc, "conv_wino.hip"), os.path.join(csrc, "api.hip"), "-o", os.path.join(OUT, "libwino4_diag_%d.so" % k)]
         procs.append(subprocess.Popen(cmd))
     assert all(p.wait() == 0 for p in procs)
 
