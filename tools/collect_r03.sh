@@ -11,7 +11,7 @@ cp $O/pmc_traffic_resnet_train.json profiles/r03_pmc_traffic_resnet_train.json
 cp $O/pmc_mfma.json profiles/r03_pmc_mfma.json
 for n in default train resnet_h_train16 resnet_f_b32 resnet_h_b128 vgg_f_b32; do tail -1 $O/bench_$n.log > profiles/r03_bench_${n}_line.json; done
 grep -h '^{"metric' $O/rocprof_default.log > profiles/r03_bench_default_under_rocprof_line.json
-tail -3 $O/pytest_gpu.log > profiles/r03_pytest_gpu_tail.txt
+grep -E "passed|failed" $O/pytest_gpu.log | tail -1 > profiles/r03_pytest_gpu_tail.txt
 for f in $O/layer_profile_*.txt; do cp $f profiles/r03_$(basename $f); done
 cp $O/microbench_wino_b128.txt profiles/r03_microbench_wino_b128.txt
 cp $O/microbench_wino4_b128.txt profiles/r03_microbench_wino4_b128.txt
