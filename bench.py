@@ -208,6 +208,9 @@ class ConvTimer:
         if hasattr(ops, "conv_transpose4x4s2_winograd4"):     # F(4x4,2x2): 25 multiplications per 4x4 outputs of a phase (64 direct)
             ops.conv_transpose4x4s2_winograd4 = w(ops.conv_transpose4x4s2_winograd4, lambda y, x, u4, cout, *a, **k: 2.0 * x.numel() * cout * k.get("direct_taps", 16),
                                                   kernel_launches=4, executed=lambda k: 6.25 / k.get("direct_taps", 16))
+        if hasattr(ops, "conv4x4s2_winograd4"):
+            ops.conv4x4s2_winograd4 = w(ops.conv4x4s2_winograd4, lambda y, dy, u4, cin: 2.0 * y.numel() * dy.shape[3] * 16,
+                                        kernel_launches=4, executed=6.25 / 16.0)
         ops.conv4x4s2_winograd = w(ops.conv4x4s2_winograd, lambda y, dy, u4, cin: 2.0 * y.numel() * dy.shape[3] * 16,
                                    kernel_launches=4, executed=9.0 / 16.0)
         ops.conv_transpose3x3s2_f16x3 = w(ops.conv_transpose3x3s2_f16x3, lambda y, x, amax, p16, cout, *a, **k: 2.0 * x.numel() * cout * 9,

@@ -93,7 +93,8 @@ _SIGNATURES = {
     "dream_conv_transpose4x4s2_winograd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_convT4x4_phase_weights": (_I, [_P, _P, _I, _I, _I, _P]),
     "dream_convT4x4_winograd4_weight_floats": (_SZ, [_I, _I]),
-    "dream_pack_convT4x4_winograd4_weight": (_I, [_P, _P, _P, _I, _I, _P]),
+    "dream_pack_convT4x4_winograd4_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "dream_conv4x4s2_winograd4_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dream_conv_transpose4x4s2_winograd4_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_upsample_conv3x3_weight_as_convT4x4": (_I, [_P, _P, _I, _I, _P]),
     "dream_conv2d_s2_bwd_data_nhwc_f32": (_I, [_P, _P, _P] + [_I] * 9 + [_P]),

@@ -72,6 +72,8 @@ struct Wino4Params {
     int flags;
     int out_scale, out_oy, out_ox;   // output pixel of conv position (y, x): (out_scale y + out_oy, out_scale x + out_ox) -- (1, 0, 0) for a
                                      // conv, (2, a, b) for phase (a, b) of a stride-2 transposed conv (y: [B, out_scale H, out_scale W, Cout])
+    int in_scale, in_oy, in_ox;      // stored input pixel of conv position (y, x), likewise: (2, a, b) for the phase views of the gradient in the
+                                     // transposed conv's data gradient (x: [B, in_scale H, in_scale W, Cin]); read by the PAT kernels only
 };
 
 constexpr int W4T = 16;       // tiles per workgroup
@@ -199,7 +201,8 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     if (tb >= blk_end) return;
     const int n0 = blockIdx.y * (16 * W4NW);
     const int tiles_per_img = p.TY * p.TX;
-    const size_t img_floats = (size_t)p.H * p.W * p.Cin;
+    const int Si = PAT ? p.in_scale : 1;                                      // spacing of the conv positions in the stored input
+    const size_t img_floats = (size_t)(Si * p.H) * (Si * p.W) * p.Cin;
 
     // ---- pass 1 item: (tile t1, channel quad q1, patch row r1)
     const int q1 = item_id % C::Q, r1 = (item_id / C::Q) % 6, t1 = (item_id / C::Q) / 6;
@@ -226,12 +229,13 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         const int gy = 4 * ty - 1 + r, x0 = 4 * tx - 1;
         const bool rok = tv & ((unsigned)gy < (unsigned)p.H);
-        goff0 = (unsigned)(((((b - b0) * p.H + gy) * p.W + x0) * p.Cin + 4 * q) * 4);
+        goff0 = PAT ? (unsigned)(((((b - b0) * Si * p.H + Si * gy + p.in_oy) * (Si * p.W) + Si * x0 + p.in_ox) * p.Cin + 4 * q) * 4)
+                    : (unsigned)(((((b - b0) * p.H + gy) * p.W + x0) * p.Cin + 4 * q) * 4);
         item1 &= 0xffffff;
 #pragma unroll
         for (int c = 0; c < 6; ++c) item1 |= (rok & ((unsigned)(x0 + c) < (unsigned)p.W)) ? (1 << (24 + c)) : 0;
     };
-    const unsigned px_in = (unsigned)(p.Cin * 4);
+    const unsigned px_in = (unsigned)(Si * p.Cin * 4);
     auto item_offset = [&](int c) {
         if (DREAM_W4_DIAG & 16) {                      // diagnostics: the loads are issued but out of range (zeros, no memory traffic)
             unsigned o = BUFFER_OOB;
@@ -631,13 +635,13 @@ namespace {
 
 // geometry shared by the conv and the transposed-conv entry points
 int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const float *scale, const float *shift, const float *residual,
-                float *y, int B, int H, int W, int Cin, int Cout, int flags, int out_scale) {
+                float *y, int B, int H, int W, int Cin, int Cout, int flags, int out_scale, int in_scale = 1) {
     DREAM_REQUIRE(x && u_packed && y, "winograd F(4x4) conv: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "winograd F(4x4) conv: bad shape B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
     const PackShape ps = pack_shape(Cout);
     DREAM_REQUIRE(Cin % (2 * ps.k) == 0, "winograd F(4x4) conv: Cin=%d must be a multiple of %d", Cin, 2 * ps.k);
     const size_t span_imgs = (size_t)W4T / ((size_t)((H + 3) / 4) * ((W + 3) / 4)) + 2;
-    DREAM_REQUIRE(span_imgs * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) &&
+    DREAM_REQUIRE(span_imgs * in_scale * in_scale * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) &&
                   span_imgs * out_scale * out_scale * H * W * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
                   "winograd F(4x4) conv: image too large for 32-bit offsets");
     p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
@@ -654,6 +658,7 @@ int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const flo
     p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)p.TX - 1) / (unsigned long long)p.TX;
     p.flags = flags;
     p.out_scale = out_scale; p.out_oy = 0; p.out_ox = 0;
+    p.in_scale = in_scale; p.in_oy = 0; p.in_ox = 0;
     return 0;
 }
 
@@ -683,13 +688,42 @@ extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_p
 // flags: DREAM_CONV_RELU.
 extern "C" size_t dream_convT4x4_winograd4_weight_floats(int Cout, int Cin) { return 4 * dream_conv3x3_winograd4_weight_floats(Cout, Cin); }
 
-// wT [Cin][Cout][4][4] -> u4 (forward operator); scratch: 4 * Cout * Cin * 9 floats (the four zero-padded 3x3 kernels)
-extern "C" int dream_pack_convT4x4_winograd4_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream) {
-    DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0, "winograd F(4x4) convT pack: bad arguments");
-    if (int rc = dream_convT4x4_phase_weights(wT, scratch, Cin, Cout, 0, stream)) return rc;
-    const size_t per_u = dream_conv3x3_winograd4_weight_floats(Cout, Cin);
+// wT [Cin][Cout][4][4] -> u4; scratch: 4 * Cout * Cin * 9 floats (the four zero-padded 3x3 kernels).  mode 0: forward operator (u4:
+// dream_convT4x4_winograd4_weight_floats(Cout, Cin)); mode 1: data-gradient operator (dream_conv4x4s2_winograd4_nhwc_f32; u4:
+// dream_convT4x4_winograd4_weight_floats(Cin, Cout))
+extern "C" int dream_pack_convT4x4_winograd4_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, int mode, void *stream) {
+    DREAM_REQUIRE(wT && u4 && scratch && Cin > 0 && Cout > 0 && (mode == 0 || mode == 1), "winograd F(4x4) convT pack: bad arguments");
+    if (int rc = dream_convT4x4_phase_weights(wT, scratch, Cin, Cout, mode, stream)) return rc;
+    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;       // conv output / input channels
+    const size_t per_u = dream_conv3x3_winograd4_weight_floats(rows, cols);
     for (int ph = 0; ph < 4; ++ph)
-        if (int rc = dream_pack_conv3x3_winograd4_weight(scratch + (size_t)ph * Cout * Cin * 9, u4 + ph * per_u, Cout, Cin, 0, stream)) return rc;
+        if (int rc = dream_pack_conv3x3_winograd4_weight(scratch + (size_t)ph * Cout * Cin * 9, u4 + ph * per_u, rows, cols, 0, stream)) return rc;
+    return 0;
+}
+
+// Data gradient of the transposed conv = a 4x4 stride-2 pad-1 conv of dY [B,2H,2W,Cout] -> dX [B,H,W,Cin], as the sum over the four
+// output phases of a 2 x 2-tap conv on the phase's stride-2 view of dY: the same 25-position scheme (patterns mirrored), the phases
+// accumulate into dX through the residual input of the epilogue.  Cin > 64, Cout a multiple of 32.  u4: mode 1 of the pack above.
+extern "C" int dream_conv4x4s2_winograd4_nhwc_f32(const float *dy, const float *u4, float *dx, int B, int H, int W, int Cout, int Cin,
+                                                  void *stream) {
+    DREAM_REQUIRE(Cin > 64, "winograd F(4x4) conv4x4s2: needs more than 64 output channels (the wide workgroup shape), got %d", Cin);
+    Wino4Params p;
+    if (int rc = wino4_setup(p, dy, u4, nullptr, nullptr, nullptr, dx, B, H, W, Cout, Cin, 0, 1, 2)) return rc;
+    const size_t per_u = dream_conv3x3_winograd4_weight_floats(Cin, Cout);
+    for (int ph = 0; ph < 4; ++ph) {
+        p.u = u4 + ph * per_u;
+        p.in_oy = ph >> 1; p.in_ox = ph & 1;
+        p.residual = ph == 0 ? nullptr : dx;         // phases 1..3 add to what is there (same thread reads and writes an element)
+        int rc;
+        // the data gradient's kernels have their taps in the opposite corner: pattern of phase (1 - a, 1 - b)
+        switch (ph) {
+            case 0: rc = launch_wino4<0, false, 4>(p, stream); break;
+            case 1: rc = launch_wino4<2, false, 3>(p, stream); break;
+            case 2: rc = launch_wino4<2, false, 2>(p, stream); break;
+            default: rc = launch_wino4<2, false, 1>(p, stream); break;
+        }
+        if (rc) return rc;
+    }
     return 0;
 }
 

@@ -69,8 +69,8 @@ class _PackedCache:
                     packed = ops.pack_convT4x4_weight_f16x3(wt4) if f16x3 else ops.pack_convT4x4_weight(wt4)
                 elif mode in ("ups_wino0", "ups_wino1"):          # the same transposed conv by minimal filtering (fwd / data gradient)
                     packed = ops.pack_convT4x4_winograd_weight(ops.upsample_conv_weight(weight.detach()), int(mode[-1]))
-                elif mode == "ups_wino4_0":                       # ... on the F(4x4,3x3) kernel (25-position phase patterns)
-                    packed = ops.pack_convT4x4_winograd4_weight(ops.upsample_conv_weight(weight.detach()))
+                elif mode in ("ups_wino4_0", "ups_wino4_1"):      # ... on the F(4x4,3x3) kernel (25-position phase patterns)
+                    packed = ops.pack_convT4x4_winograd4_weight(ops.upsample_conv_weight(weight.detach()), int(mode[-1]))
                 else:
                     packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
                 hit = (tag, packed)
@@ -445,8 +445,9 @@ class DreamHourglass(nn.Module):
                         and g.shape[1] % 2 == 0 and g.shape[2] % 2 == 0):
                     # data gradient of the equivalent transposed conv, straight at half resolution (no full-resolution
                     # intermediate, no upsample2_bwd pass): four phase convs of nine positions each
-                    u4b, rows_b = self._packed.get(mod.weight, "ups_wino1")
-                    g = ops.conv4x4s2_winograd(g, u4b, rows_b)
+                    tile = ops.conv4x4s2_winograd_tile_of(g, cin)
+                    u4b, rows_b = self._packed.get(mod.weight, "ups_wino4_1" if tile == 4 else "ups_wino1")
+                    g = ops.conv4x4s2_winograd_tile(tile, g, u4b, rows_b)
                 elif self._use_winograd(int(g.shape[3]), cin, 0) and int(g.shape[3]) == cout:
                     tile = ops.winograd_tile(int(g.shape[1]), int(g.shape[2]), cout, cin, int(g.shape[0]))
                     u_t, rows_t = self._packed.get(mod.weight, "wino4_1" if tile == 4 else "wino1")
@@ -1201,8 +1202,9 @@ class ResnetSimple(nn.Module):
                 cin_t, cout_t = int(m.weight.shape[0]), int(m.weight.shape[1])
                 if (self.convT_algorithm == "winograd" and cout_t % 16 == 0 and cout_t >= 32 and cin_t > 64
                         and int(dz.shape[3]) == cout_t and dz.shape[1] % 2 == 0 and dz.shape[2] % 2 == 0):
-                    u4b, rows = self._cached(("wu4b", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_winograd_weight(m.weight.detach(), 1))
-                    g = ops.conv4x4s2_winograd(dz, u4b, rows)
+                    tile = ops.conv4x4s2_winograd_tile_of(dz, cin_t)
+                    u4b, rows = self._cached(("wu4b", rec["name"], tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile, 1))
+                    g = ops.conv4x4s2_winograd_tile(tile, dz, u4b, rows)
                 else:
                     pk, rows = self._cached(("wTb", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_bwd_weight(m.weight.detach()))
                     g = ops.conv4x4s2(dz, pk, rows)

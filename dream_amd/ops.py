@@ -231,6 +231,10 @@ def convT4x4_winograd_tile(x_nhwc, cout):
     """Output tile of the Winograd kernel for ConvTranspose2d(k4,s2,p1) on this input: 4 = the F(4x4,3x3) kernel with the 25-position
     phase patterns (wide workgroup shape only), 2 = the F(2x2,3x3) kernel with its 9-position patterns."""
     b, h, w, cin = (int(v) for v in x_nhwc.shape)
+    return _convT4x4_tile(b, h, w, cin, cout)
+
+
+def _convT4x4_tile(b, h, w, cin, cout):
     if cout < (128 if _WINOGRAD_TILE_FORCED == 4 else 256) or winograd_tile(h, w, cin, cout, b) != 4:
         return 2                       # (128 output channels = one channel block per tile block: measured slower than F(2x2) in vgg_q / vgg_f)
     if _WINOGRAD_TILE_FORCED == 4:
@@ -240,8 +244,25 @@ def convT4x4_winograd_tile(x_nhwc, cout):
     return 4 if h * w >= 48 * 48 else 2
 
 
-def pack_convT4x4_winograd_weight_tile(wT, tile):
-    return pack_convT4x4_winograd4_weight(wT) if tile == 4 else pack_convT4x4_winograd_weight(wT, 0)
+def pack_convT4x4_winograd_weight_tile(wT, tile, mode=0):
+    return pack_convT4x4_winograd4_weight(wT, mode) if tile == 4 else pack_convT4x4_winograd_weight(wT, mode)
+
+
+def conv4x4s2_winograd_tile(tile, dy_nhwc, u4_mode1, cin):
+    fn = conv4x4s2_winograd4 if tile == 4 else conv4x4s2_winograd            # looked up at call time: bench.py wraps both
+    return fn(dy_nhwc, u4_mode1, cin)
+
+
+def conv4x4s2_winograd_tile_of(dy_nhwc, cin):
+    """Tile of the data gradient of ConvTranspose2d(k4,s2,p1) (dy [B,2H,2W,Cout] -> dx [B,H,W,cin]): the forward rule on the
+    gradient's own conv (map H x W, cin output channels)."""
+    b, h2, w2, cout = (int(v) for v in dy_nhwc.shape)
+    # measured (profiles/r03_microbench_convT4.txt): no gain over the 9-position F(2x2) form on any map (1.00x at 200x200, 0.88-0.96x
+    # below): the gradient reads stride-2 phase views of dy -- a 6x6 patch spans 12x12 stored pixels -- and the 1.44x fewer
+    # multiplications do not pay for that.  The F(4x4) form stays reachable for the tests (set_winograd_tile(4)).
+    if _WINOGRAD_TILE_FORCED != 4:
+        return 2
+    return _convT4x4_tile(b, h2 // 2, w2 // 2, cout, cin)        # the gradient's conv: cout input channels, cin output channels
 
 
 def conv_transpose4x4s2_winograd_tile(tile, x_nhwc, u4, cout, scale=None, shift=None, flags=0, direct_taps=16):
@@ -249,16 +270,26 @@ def conv_transpose4x4s2_winograd_tile(tile, x_nhwc, u4, cout, scale=None, shift=
     return fn(x_nhwc, u4, cout, scale, shift, flags, direct_taps=direct_taps)
 
 
-def pack_convT4x4_winograd4_weight(wT):
+def pack_convT4x4_winograd4_weight(wT, mode=0):
     """[Cin,Cout,4,4] ConvTranspose2d(k4,s2,p1) weight -> the four phases' F(4x4,3x3)-transformed zero-padded 3x3 kernels of the
-    forward operator; returns (u4, cout)."""
+    forward operator (mode 0; returns (u4, cout)) or of the data-gradient operator (mode 1; returns (u4, cin))."""
     w = _f32(wT)
     cin, cout = int(w.shape[0]), int(w.shape[1])
-    n = int(_hip.lib().dream_convT4x4_winograd4_weight_floats(cout, cin))
+    rows, cols = (cout, cin) if mode == 0 else (cin, cout)
+    n = int(_hip.lib().dream_convT4x4_winograd4_weight_floats(rows, cols))
     u4 = torch.empty(n, dtype=torch.float32, device=w.device)
     scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
-    call("dream_pack_convT4x4_winograd4_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, stream())
-    return u4, cout
+    call("dream_pack_convT4x4_winograd4_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, mode, stream())
+    return u4, rows
+
+
+def conv4x4s2_winograd4(dy_nhwc, u4_mode1, cin):
+    """Data gradient of ConvTranspose2d(k4,s2,p1) on the F(4x4) kernel's 25-position patterns: dy [B,2H,2W,Cout] -> dx [B,H,W,cin]."""
+    dy = _f32(dy_nhwc)
+    b, h2, w2, cout = (int(v) for v in dy.shape)
+    dx = torch.empty((b, h2 // 2, w2 // 2, cin), dtype=torch.float32, device=dy.device)
+    call("dream_conv4x4s2_winograd4_nhwc_f32", ptr(dy), ptr(u4_mode1), ptr(dx), b, h2 // 2, w2 // 2, cout, cin, stream())
+    return dx
 
 
 def conv_transpose4x4s2_winograd4(x_nhwc, u4, cout, scale=None, shift=None, flags=0, direct_taps=16):

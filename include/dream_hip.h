@@ -165,7 +165,12 @@ int dream_convT4x4_phase_weights(const float *wT, float *w3, int Cin, int Cout, 
  * multiplications per 4x4 outputs of a phase, F(4x4,2x2), where the F(2x2) form takes 36 and the direct sub-pixel form 64.
  * Cout > 64, Cin a multiple of 32; u4: dream_convT4x4_winograd4_weight_floats(Cout, Cin) floats; scratch: 4*Cout*Cin*9 floats. */
 size_t dream_convT4x4_winograd4_weight_floats(int Cout, int Cin);
-int dream_pack_convT4x4_winograd4_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, void *stream);
+/* mode 0: forward operator; mode 1: data-gradient operator (u4: dream_convT4x4_winograd4_weight_floats(Cin, Cout) floats) */
+int dream_pack_convT4x4_winograd4_weight(const float *wT, float *u4, float *scratch, int Cin, int Cout, int mode, void *stream);
+/* data gradient of that transposed conv on the same 25-position scheme: dy [B,2H,2W,Cout] -> dx [B,H,W,Cin], Cin > 64, Cout a
+ * multiple of 32, the four phases of dy summed */
+int dream_conv4x4s2_winograd4_nhwc_f32(const float *dy, const float *u4_mode1, float *dx, int B, int H, int W, int Cout, int Cin,
+                                       void *stream);
 int dream_conv_transpose4x4s2_winograd4_nhwc_f32(const float *x, const float *u4, const float *scale, const float *shift, float *y,
                                                  int B, int H, int W, int Cin, int Cout, int flags, void *stream);
 /* nn.ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) of the deconv decoder (dream/models.py:621-686) by sub-pixel

@@ -181,20 +181,21 @@ def check_convT4x4_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, with_scale
     return err
 
 
-def check_conv4x4s2_winograd(dev, B, H, W, Cin, Cout, seed=0):
+def check_conv4x4s2_winograd(dev, B, H, W, Cin, Cout, seed=0, tile=2):
     """Data gradient of ConvTranspose2d(k4,s2,p1) (x [B,Cin,H,W] -> y [B,Cout,2H,2W]) by the four phase convs on the Winograd
-    kernel vs fp64 autograd: error relative to the maximum of the result at fp32 round-off level."""
+    kernels (tile 2: nine positions each; tile 4: 25 of 36) vs fp64 autograd: error relative to the maximum of the result at fp32
+    round-off level (tile 4: the F(4x4) class)."""
     g = torch.Generator().manual_seed(seed)
     wT = torch.randn(Cin, Cout, 4, 4, generator=g) * (2.0 / (4 * Cout)) ** 0.5
     dy = torch.randn(B, Cout, 2 * H, 2 * W, generator=g)
     xref = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
     F.conv_transpose2d(xref, wT.double(), None, stride=2, padding=1).backward(dy.double())
-    u4, rows = ops.pack_convT4x4_winograd_weight(to(dev, wT), 1)
+    u4, rows = ops.pack_convT4x4_winograd_weight_tile(to(dev, wT), tile, 1)
     assert rows == Cin
-    dx = ops.conv4x4s2_winograd(to(dev, _nhwc(dy)), u4, Cin).cpu().permute(0, 3, 1, 2)
+    dx = ops.conv4x4s2_winograd_tile(tile, to(dev, _nhwc(dy)), u4, Cin).cpu().permute(0, 3, 1, 2)
     assert dx.shape == xref.grad.shape
     err = float((dx.double() - xref.grad).abs().max()) / max(1.0, float(xref.grad.abs().max()))
-    assert err <= 2e-6, (B, H, W, Cin, Cout, err)
+    assert err <= (1e-5 if tile == 4 else 2e-6), (B, H, W, Cin, Cout, tile, err)
     return err
 
 

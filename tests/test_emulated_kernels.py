@@ -87,6 +87,10 @@ def test_conv_transpose4x4_winograd(emu):
              pc.check_conv4x4s2_winograd("cpu", 2, 13, 9, 96, 48, seed=1),          # odd extents, 3 chunks, ragged channels
              pc.check_conv4x4s2_winograd("cpu", 1, 20, 22, 256, 32, seed=2)]        # two channel blocks
     print("conv4x4s2 (convT data gradient) winograd max rel err", max(berrs))
+    berrs4 = [pc.check_conv4x4s2_winograd("cpu", 1, 8, 8, 128, 32, tile=4),                 # one block per phase
+              pc.check_conv4x4s2_winograd("cpu", 2, 13, 9, 96, 64, seed=1, tile=4),          # odd extents, 4 chunks, ragged channels
+              pc.check_conv4x4s2_winograd("cpu", 1, 20, 22, 256, 32, seed=2, tile=4)]        # two channel blocks
+    print("conv4x4s2 (convT data gradient) winograd F(4x4) max rel err", max(berrs4))
 
 
 def test_conv1x1_gemm(emu):

@@ -629,6 +629,14 @@ def test_conv4x4s2_winograd(b, h, w, cin, cout):
     print("conv4x4s2 winograd %dx%dx%d %d<-%d: rel err %.2e" % (b, h, w, cin, cout, err))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(1, 8, 8, 128, 32), (2, 13, 9, 96, 64), (1, 20, 22, 256, 32), (4, 104, 104, 256, 256),
+                                            (2, 100, 100, 256, 256)])
+def test_conv4x4s2_winograd4(b, h, w, cin, cout):
+    """The same data gradient on the F(4x4,3x3) kernel's 25-position phase patterns."""
+    err = pc.check_conv4x4s2_winograd(DEV, b, h, w, cin, cout, seed=h + cin, tile=4)
+    print("conv4x4s2 winograd F(4x4) %dx%dx%d %d<-%d: rel err %.2e" % (b, h, w, cin, cout, err))
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
     (1, 6, 6, 32, 128, 0, {}), (2, 13, 9, 48, 96, 1, {"with_scale": True}), (1, 26, 26, 32, 256, 1, {}),
     (4, 13, 13, 2048, 256, 1, {"with_scale": True}), (4, 104, 104, 256, 256, 1, {"with_scale": True}), (2, 208, 208, 256, 256, 1, {})])

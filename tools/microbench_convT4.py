@@ -49,7 +49,26 @@ def main():
         print("b=%3d %3dx%-3d %d->%d  F(2x2) %7.3f ms %6.1f TF | F(4x4) %7.3f ms %6.1f TF (%.2f of peak on its own MACs)  speedup %.2f  max diff / max %.1e"
               % (b, h, h, c, c, best["F(2x2)"], fl / best["F(2x2)"] / 1e9, best["F(4x4)"], fl / best["F(4x4)"] / 1e9,
                  fl * (25.0 / 64.0) / best["F(4x4)"] / 1e9 / 157.3, best["F(2x2)"] / best["F(4x4)"], diff), flush=True)
-        del x, y2, y4
+        # the data gradient (dy [b,2h,2h,c] -> dx [b,h,h,c]): four phase convs on stride-2 views of dy, summed
+        dy = torch.randn(b, 2 * h, 2 * h, c, device="cuda")
+        ub2, _ = ops.pack_convT4x4_winograd_weight(wT, 1)
+        ub4, _ = ops.pack_convT4x4_winograd4_weight(wT, 1)
+        gf = {"F(2x2)": lambda: ops.conv4x4s2_winograd(dy, ub2, c), "F(4x4)": lambda: ops.conv4x4s2_winograd4(dy, ub4, c)}
+        d2, d4 = gf["F(2x2)"](), gf["F(4x4)"]()
+        torch.cuda.synchronize()
+        gdiff = float((d2 - d4).abs().max() / d2.abs().max())
+        gbest = {k: 1e9 for k in gf}
+        for _ in range(5):
+            for k, fn in gf.items():
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                fn()
+                e.record()
+                torch.cuda.synchronize()
+                gbest[k] = min(gbest[k], s.elapsed_time(e))
+        print("      data gradient:     F(2x2) %7.3f ms %6.1f TF | F(4x4) %7.3f ms %6.1f TF  speedup %.2f  max diff / max %.1e"
+              % (gbest["F(2x2)"], fl / gbest["F(2x2)"] / 1e9, gbest["F(4x4)"], fl / gbest["F(4x4)"] / 1e9, gbest["F(2x2)"] / gbest["F(4x4)"], gdiff), flush=True)
+        del x, y2, y4, dy, d2, d4
 
 
 if __name__ == "__main__":
