@@ -3,8 +3,10 @@
 // needs 4 and the direct algorithm 9.  Every product and sum is IEEE fp32; the weight transform runs once, in fp64, at pack time.
 //
 // Replaces torch.nn.Conv2d(k=3,s=1,p=1) (+ReLU, + the following MaxPool2d(2)) at /root/reference/dream/models.py:598-615 (VGG19
-// encoder), :695-710 (decoder convs not preceded by an upsample) for the layers with at least 128 output channels -- 78 % of a
-// DREAM-vgg-Q forward pass -- and, on mode-1 packed weights, their data gradients.
+// encoder), :695-710 (decoder convs not preceded by an upsample) for every layer behind the 3-channel first one -- 88 % of a
+// DREAM-vgg-Q forward pass -- and, on mode-1 packed weights, their data gradients; nn.ConvTranspose2d(k4,s2,p1) of the ResNet decoder
+// (models.py:37-136) through the 25-position phase patterns (PAT below).  The description that follows is the WIDE workgroup shape
+// (more than 64 output channels); W4Cfg has the narrow one.
 //
 //   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A        d: 6x6 input patch, g: 3x3 filter, Y: 4x4 outputs
 //
@@ -31,12 +33,14 @@
 //     (B^T has 4-5 non-zeros per row: the cross-lane exchange F(2x2)'s kernel does with one DPP move would take four here).
 //     384 items per pass on 512 threads: 48 per wavefront and pass, the same work on every wavefront between two barriers;
 //   * U (the transformed weights, packed [Cin/16][36][CoutPad][16]) never touches LDS: every wavefront streams its own 16-channel
-//     operand rows straight from L2 into a ring of registers, 1 KB coalesced per position, several positions ahead;
+//     operand rows straight from L2 into a ring of eight registers, 1 KB coalesced per position, six positions ahead;
 //   * all global traffic through buffer descriptors (32-bit offsets, zero padding and store masking by the bounds check);
 //   * positions are multiplied in PAIRS with alternating accumulators (a dependent v_mfma_f32_16x16x4_f32 has 40 cycles of
 //     latency against 32 of issue), one memory instruction or transform piece behind each pair of MFMAs (pinned order);
 //   * persistent workgroups walking over the tile blocks of their XCD's range, the next block's first chunk transformed during
-//     the current block's last chunk -- as conv_wino.hip.
+//     the current block's last chunk -- as conv_wino.hip;
+//   * epilogue: the lane's four tiles go through A^T M A in register pairs (packed fp32), parameters re-read through the constant
+//     address space (s_load), offsets = tile base + scalar when all 16 tiles of the wavefront are interior.
 #include <type_traits>
 #include <dream_cdna4.h>
 #include "common.h"
