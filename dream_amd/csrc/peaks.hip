@@ -13,8 +13,7 @@
 //   * centroid: 25 products in fp64 laid out [col offset][row offset], summed with NumPy's
 //     8-lane pairwise scheme, divided, offset added, then rounded once to fp32.
 //   * no FMA contraction anywhere on these paths (dmul/dadd/ddiv = __dmul_rn/__dadd_rn/__ddiv_rn).
-// All three kernels are HBM/L2-bound streaming kernels (4 B/pixel compulsory read); fp64 rate is
-// irrelevant at 25 taps/pixel.
+// The Gaussian passes stage their inputs in LDS (25 taps per output from there); fp64 rate is irrelevant at 25 taps / pixel.
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
@@ -37,34 +36,50 @@ DREAM_DEVICE int reflect_index(int i, int n) {
     return i < n ? i : period - 1 - i;
 }
 
-// One 1-D pass.  Workgroup = 64 x 4 pixels of one map (3-D grid: no 64-bit index division per pixel); lanes run along
-// x, so both the row pass and the column pass read whole 256-B row segments.  Pixels at least R away from both ends of
-// the filtered axis take the tap loop without the reflection arithmetic (same values, same order: bit-identical).
+// One 1-D pass.  Workgroup = 256 threads on a 64-column strip of one map (3-D grid: no 64-bit index division per pixel); lanes
+// run along x.  The inputs of the strip are staged ONCE in LDS, reflected where the strip leaves the map, and every output takes
+// its 25 taps from there: the row pass (AXIS 1) stages 4 rows x (64 + 24) columns for 4 x 64 outputs, the column pass (AXIS 0)
+// (16 + 24) rows x 64 columns for 16 x 64 outputs (four per thread) -- 1.4 / 2.5 coalesced loads per output where the unstaged
+// version issued 25 (it ran at 0.26 TB/s on the 400 x 400 maps of DREAM-resnet-F: bound by its load instructions, not by memory).
+// Same values, same order of additions as before: bit-identical.
+constexpr int GT = 16;            // output rows per workgroup of the column pass
 template <int AXIS>
 __global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float *out, int N, int H, int W) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= W || y >= H) return;
+    __shared__ float tile[AXIS == 0 ? (GT + 2 * R) * 64 : 4 * (64 + 2 * R)];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * (AXIS == 0 ? GT : 4);
     const float *base = in + (size_t)blockIdx.z * H * W;
-    const int l = AXIS == 0 ? y : x;
-    const int len = AXIS == 0 ? H : W;
-    const float *centre = base + (size_t)y * W + x;
-    const int step = AXIS == 0 ? W : 1;
-    double acc;
-    if (l >= R && l + R < len) {
-        acc = dmul((double)centre[0], kTaps[R]);
+    float *obase = out + (size_t)blockIdx.z * H * W;
+    auto tap_sum = [&](auto at) {                     // acc = x[l] w[c]; for i = -12..-1: acc += (x[l+i] + x[l-i]) w[c+i]
+        double acc = dmul((double)at(0), kTaps[R]);
 #pragma unroll
-        for (int i = -R; i < 0; ++i)
-            acc = dadd(acc, dmul(dadd((double)centre[i * step], (double)centre[-i * step]), kTaps[R + i]));
+        for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd((double)at(i), (double)at(-i)), kTaps[R + i]));
+        return (float)acc;
+    };
+    if (AXIS == 0) {
+        const int x = x0 + tx;
+        for (int r = ty; r < GT + 2 * R; r += 4) {    // staged row r = map row y0 - R + r, reflected
+            const int yy = y0 - R + r;
+            const int q = (yy >= 0 && yy < H) ? yy : reflect_index(yy, H);
+            tile[r * 64 + tx] = x < W ? base[(size_t)q * W + x] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < GT / 4; ++k) {
+            const int ly = ty + 4 * k, y = y0 + ly;
+            if (x < W && y < H) obase[(size_t)y * W + x] = tap_sum([&](int i) { return tile[(ly + R + i) * 64 + tx]; });
+        }
     } else {
-        auto at = [&](int pos) -> double {
-            const int q = (pos >= 0 && pos < len) ? pos : reflect_index(pos, len);
-            return (double)(AXIS == 0 ? base[(size_t)q * W + x] : base[(size_t)y * W + q]);
-        };
-        acc = dmul(at(l), kTaps[R]);
-#pragma unroll
-        for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd(at(l + i), at(l - i)), kTaps[R + i]));
+        const int y = y0 + ty;
+        for (int c = tx; c < 64 + 2 * R; c += 64) {   // staged column c = map column x0 - R + c, reflected
+            const int xx = x0 - R + c;
+            const int q = (xx >= 0 && xx < W) ? xx : reflect_index(xx, W);
+            tile[ty * (64 + 2 * R) + c] = y < H ? base[(size_t)y * W + q] : 0.0f;
+        }
+        __syncthreads();
+        const int x = x0 + tx;
+        if (x < W && y < H) obase[(size_t)y * W + x] = tap_sum([&](int i) { return tile[ty * (64 + 2 * R) + tx + R + i]; });
     }
-    out[(size_t)blockIdx.z * H * W + (size_t)y * W + x] = (float)acc;
 }
 
 DREAM_DEVICE double pairwise_sum25(const double *a) {
@@ -210,10 +225,11 @@ int smooth_maps(const float *maps, float *tmp, float *out, int N, int H, int W, 
     for (int n0 = 0; n0 < N; n0 += 65535) {                  // grid.z limit
         const int nn = N - n0 < 65535 ? N - n0 : 65535;
         const size_t off = (size_t)n0 * H * W;
-        const dim3 grid((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)nn);
-        hipLaunchKernelGGL(gauss_pass_kernel<0>, grid, dim3(256), 0, s, maps + off, tmp + off, nn, H, W);
+        const dim3 grid0((unsigned)((W + 63) / 64), (unsigned)((H + GT - 1) / GT), (unsigned)nn);
+        const dim3 grid1((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)nn);
+        hipLaunchKernelGGL(gauss_pass_kernel<0>, grid0, dim3(256), 0, s, maps + off, tmp + off, nn, H, W);
         DREAM_LAUNCH_OK();
-        hipLaunchKernelGGL(gauss_pass_kernel<1>, grid, dim3(256), 0, s, (const float *)(tmp + off), out + off, nn, H, W);
+        hipLaunchKernelGGL(gauss_pass_kernel<1>, grid1, dim3(256), 0, s, (const float *)(tmp + off), out + off, nn, H, W);
         DREAM_LAUNCH_OK();
     }
     return 0;

@@ -155,6 +155,20 @@ def test_peaks_bit_exact(emu, name):
     pc.check_peaks_case("cpu", name)
 
 
+def test_gaussian_staged_strips_ragged_sizes(emu):
+    """The LDS-staged Gaussian passes (64-column strips, 16 / 4 output rows per workgroup, reflection at staging time) on maps that
+    are smaller than the filter radius, one pixel wide or tall, and not multiples of the strip sizes: scipy's bits."""
+    import numpy as np
+    import torch
+    from oracle import peaks as op
+    rng = np.random.default_rng(0)
+    for (n, h, w) in [(2, 5, 7), (1, 13, 70), (2, 40, 130), (1, 17, 64), (1, 16, 65), (3, 1, 1), (1, 2, 200), (1, 33, 3)]:
+        m = rng.standard_normal((n, h, w)).astype(np.float32)
+        sm = ops.gaussian_sigma3(torch.from_numpy(m)).numpy()
+        for i in range(n):
+            assert np.array_equal(sm[i], op.gaussian_filter_sigma3(m[i])), (n, h, w, i)
+
+
 def test_peak_rule_settings(emu):
     pc.check_peak_rule_settings("cpu")
 
