@@ -145,7 +145,29 @@ __global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const flo
     const float NEG_INF = -__builtin_huge_valf();
     Top2 best = {NEG_INF, NEG_INF, -1};
     int running = 0;                                   // peaks found in earlier chunks (uniform)
-    for (int base = 0; base < total; base += 256) {
+    if (!LIST) {
+        // Only the count and the two best scores are wanted: no ordered compaction, hence no ballot and no barrier per chunk -- a
+        // plain strided scan (the top-2 merge is independent of the order it is applied in: ties go to the smaller index), the
+        // per-thread counts summed at the end.  (The chunked form below took 0.69 ms on 544 maps of 400 x 400.)
+        int mine_cnt = 0;
+        for (int idx = tid; idx < total; idx += 256) {
+            const int y = idx / W, x = idx - y * W;
+            const float v = sm[idx];
+            const float up = y > 0 ? sm[idx - W] : 0.0f, down = y + 1 < H ? sm[idx + W] : 0.0f;
+            const float left = x > 0 ? sm[idx - 1] : 0.0f, right = x + 1 < W ? sm[idx + 1] : 0.0f;
+            if ((v >= up) && (v >= down) && (v >= left) && (v >= right) && (v > thresh)) {
+                const Top2 mine = {ori[idx], NEG_INF, idx};
+                best = top2_merge(best, mine);
+                ++mine_cnt;
+            }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mine_cnt += lane_xor(mine_cnt, m);
+        if (lane == 0) s_wave_cnt[wave] = mine_cnt;
+        __syncthreads();
+        running = s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+    }
+    for (int base = 0; LIST && base < total; base += 256) {
         const int idx = base + tid;
         bool is_peak = false;
         int x = 0, y = 0;
