@@ -50,6 +50,16 @@ _SIGNATURES = {
     "dream_bn_train_fwd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _F, _F, _I, _P]),
     "dream_bn_train_bwd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),
     "dream_channel_sum_nhwc_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
+    "dream_bn_stats_workspace": (_SZ, [_I]),
+    "dream_bn_stats_counters": (_I, [_I]),
+    "dream_bn_stats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _SZ, _I, _P]),
+    "dream_bn_apply_ab_nhwc_f32": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _P]),
+    "dream_bn_bwd_stats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),
+    "dream_bn_bwd_apply_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),
+    "dream_conv1x1_bn_workspace": (_SZ, [_c.c_long, _I]),
+    "dream_conv1x1_bnstats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "dream_conv1x1_bwd_bnmask_nhwc_f32": (_I, [_P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "dream_conv1x1_wgrad_pre_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P]),
     "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
     "dream_allreduce_sum_f32": (_I, [_I, _c.POINTER(_I), _c.POINTER(_P), _SZ, _c.POINTER(_P)]),

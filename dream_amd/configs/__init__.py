@@ -19,6 +19,14 @@ def manip_config_path(manip):
 def default_network_config(arch="vgg_q", manip="panda", optimizer="adam", learning_rate=1e-4, batch_size=128,
                            gpu_ids=None):
     from ..network import _load_yaml
+    if gpu_ids is None:
+        # This helper builds a ONE-GPU configuration unless told otherwise: an empty ``gpu_ids`` means "every visible GPU" to
+        # DreamNetwork (train_network.py:755-762, "Nothing specified means all GPUs"), which on an 8-GPU node would silently turn
+        # every test / smoke / tool built on this helper into an 8-replica data-parallel run.  Pass ``gpu_ids=[]`` for that.
+        import torch
+        gpu_ids_cfg = [torch.cuda.current_device()] if torch.cuda.is_available() else []
+    else:
+        gpu_ids_cfg = [int(i) for i in gpu_ids]
     a = _load_yaml(arch_config_path(arch))
     m = _load_yaml(manip_config_path(manip))
     architecture = dict(a["architecture"])
@@ -36,6 +44,6 @@ def default_network_config(arch="vgg_q", manip="panda", optimizer="adam", learni
                 "image_preprocessing": a["training"]["config"]["image_preprocessing"],
                 "net_input_resolution": list(a["training"]["config"]["net_input_resolution"]),
             },
-            "platform": {"gpu_ids": list(gpu_ids) if gpu_ids else []},
+            "platform": {"gpu_ids": gpu_ids_cfg},
         },
     }

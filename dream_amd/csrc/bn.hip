@@ -224,6 +224,223 @@ inline unsigned stream_grid(size_t n) {
     return (unsigned)(g ? g : 1);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same BatchNorm with fewer passes over memory and fewer launches (a ResNet-101 step at 16 frames per GPU spent 24 %
+// of its time in 656 BatchNorm launches, most of them on 10-MB tensors where a launch costs more than its traffic).
+//   * the per-channel statistics are FINISHED INSIDE the launch that sums them: workgroup = (block of pixels) x (slab of 64
+//     channels); it writes one row of fp64 partial sums for its slab, draws a ticket from the slab's counter, and the workgroup
+//     that draws the last ticket sums the rows in index order (deterministic) and writes the per-channel results -- no finalize
+//     launch, nobody spins (dream_cdna4.h: "last arriver finishes");
+//   * the forward statistics are published as the affine map  y = a z + b  (a = gamma * invstd, b = beta - mean * a), so that a
+//     consumer can apply BatchNorm + ReLU while LOADING z (gemm1x1.hip: PRE) and the normalised tensor is never written; where it
+//     must exist (Bottleneck outputs: the residual sum) ONE kernel writes it from (z, a, b);
+//   * producers that can, sum the statistics in their own epilogue (gemm1x1.hip: EPI 1 / 2) and skip the reduce launch too.
+// Every kernel evaluates BatchNorm + ReLU as max(fmaf(a, z, b), 0): the backward pass recomputes exactly the forward's mask.
+
+constexpr int kStatRows = 256;        // at most this many partial rows per launch
+
+struct BnStatParams {
+    const float *z, *dy, *y_act;      // MODE 1: dy = incoming gradient; mask 1: y_act > 0, mask 2: fmaf(a, z, b) > 0
+    const float *ab;                  // [2][C] (mask 2)
+    const float *mean, *invstd;       // MODE 1: in; MODE 0: out
+    double *partials;                 // [nrows][C][2]
+    unsigned *counters;               // [C / 64]
+    size_t npix;
+    int C, mask;
+    // MODE 0 outputs
+    const float *gamma, *beta;
+    float *running_mean, *running_var;
+    long long *nbt;
+    float eps, momentum;
+    float *out_ab, *out_mean, *out_invstd;
+    // MODE 1 outputs
+    float *dgamma, *dbeta;
+};
+
+// MODE 0: v0 = z, v1 = z * z          MODE 1: v0 = g, v1 = g * xhat   (g = dy masked)
+template <int MODE>
+__global__ void __launch_bounds__(256) bn_stats_slab_kernel(const BnStatParams p) {
+    __shared__ double sred[16 * 16 * 8];              // [pixel row][channel quad][4 channels][2]
+    __shared__ unsigned s_ticket;
+    const int cq = threadIdx.x & 15, prow = threadIdx.x >> 4;
+    const int slab = blockIdx.y, C4 = p.C >> 2;
+    const int c4 = slab * 16 + cq;                    // this thread's channel quad
+    const bool cok = c4 < C4;
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    f32x4 mu = {0, 0, 0, 0}, is = {1, 1, 1, 1}, za = {0, 0, 0, 0}, zb = {0, 0, 0, 0};
+    if (MODE == 1 && cok) {
+        mu = ((const f32x4 *)p.mean)[c4];
+        is = ((const f32x4 *)p.invstd)[c4];
+        if (p.mask == 2) { za = ((const f32x4 *)p.ab)[c4]; zb = ((const f32x4 *)(p.ab + p.C))[c4]; }
+    }
+    const int mask = p.mask;
+    auto add = [&](const f32x4 v, f32x4 g, const f32x4 ya) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a0[k] += (double)v[k]; a1[k] += (double)v[k] * (double)v[k]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool on = mask == 0 || (mask == 1 ? ya[k] > 0.0f : __builtin_fmaf(za[k], v[k], zb[k]) > 0.0f);
+                const float gk = on ? g[k] : 0.0f;
+                const float xh = (v[k] - mu[k]) * is[k];
+                a0[k] += (double)gk;
+                a1[k] += (double)gk * (double)xh;
+            }
+        }
+    };
+    if (cok) {
+        const size_t stride = (size_t)gridDim.x * 16;
+        size_t px = (size_t)blockIdx.x * 16 + prow;
+        for (; px + 3 * stride < p.npix; px += 4 * stride) {          // four pixels per trip in flight, added in pixel order
+            f32x4 v[4], g[4], ya[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t i = (px + u * stride) * C4 + c4;
+                v[u] = ((const f32x4 *)p.z)[i];
+                g[u] = MODE == 1 ? ((const f32x4 *)p.dy)[i] : v[u];
+                ya[u] = (MODE == 1 && mask == 1) ? ((const f32x4 *)p.y_act)[i] : v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) add(v[u], g[u], ya[u]);
+        }
+        for (; px < p.npix; px += stride) {
+            const size_t i = px * C4 + c4;
+            const f32x4 v = ((const f32x4 *)p.z)[i];
+            add(v, MODE == 1 ? ((const f32x4 *)p.dy)[i] : v, (MODE == 1 && mask == 1) ? ((const f32x4 *)p.y_act)[i] : v);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        sred[((prow * 16 + cq) * 4 + k) * 2 + 0] = a0[k];
+        sred[((prow * 16 + cq) * 4 + k) * 2 + 1] = a1[k];
+    }
+    __syncthreads();
+    if (prow == 0 && cok) {
+        double *dst = p.partials + ((size_t)blockIdx.x * p.C + (size_t)c4 * 4) * 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double s0 = 0, s1 = 0;
+            for (int r = 0; r < 16; ++r) {
+                s0 += sred[((r * 16 + cq) * 4 + k) * 2 + 0];
+                s1 += sred[((r * 16 + cq) * 4 + k) * 2 + 1];
+            }
+            dst[2 * k] = s0;
+            dst[2 * k + 1] = s1;
+        }
+    }
+    // the partial row was written by the first 16 lanes of wavefront 0: that wavefront publishes it and draws the ticket
+    if (threadIdx.x < 64) {
+        grid_release();
+        const unsigned t = grid_ticket(p.counters + slab);
+        if (threadIdx.x == 0) s_ticket = t;
+    }
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    grid_acquire();
+    // last workgroup of the slab: 64 channels x 4 row slices (one per wavefront), combined through LDS in slice order
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6, c = slab * 64 + lane, nrows = (int)gridDim.x;
+    double s0 = 0, s1 = 0;
+    if (c < p.C) {
+        const double2 *src = (const double2 *)p.partials + c;
+        int r = slice;
+        for (; r + 12 < nrows; r += 16) {
+            const double2 v0 = src[(size_t)r * p.C], v1 = src[(size_t)(r + 4) * p.C];
+            const double2 v2 = src[(size_t)(r + 8) * p.C], v3 = src[(size_t)(r + 12) * p.C];
+            s0 += v0.x; s1 += v0.y;
+            s0 += v1.x; s1 += v1.y;
+            s0 += v2.x; s1 += v2.y;
+            s0 += v3.x; s1 += v3.y;
+        }
+        for (; r < nrows; r += 4) { const double2 v = src[(size_t)r * p.C]; s0 += v.x; s1 += v.y; }
+    }
+    __syncthreads();                                  // sred is reused
+    sred[(slice * 64 + lane) * 2 + 0] = s0;
+    sred[(slice * 64 + lane) * 2 + 1] = s1;
+    __syncthreads();
+    if (slice != 0) return;
+    double t0 = 0, t1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { t0 += sred[(k * 64 + lane) * 2 + 0]; t1 += sred[(k * 64 + lane) * 2 + 1]; }
+    if (c < p.C) {
+        if (MODE == 0) {
+            const double n = (double)p.npix, mean = t0 / n;
+            double var = t1 / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const double invstd = 1.0 / sqrt(var + (double)p.eps);
+            const float a = (float)((double)p.gamma[c] * invstd);
+            p.out_ab[c] = a;
+            p.out_ab[p.C + c] = (float)((double)p.beta[c] - mean * (double)a);
+            p.out_mean[c] = (float)mean;
+            p.out_invstd[c] = (float)invstd;
+            if (p.running_mean != nullptr) {
+                const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var, mo = (double)p.momentum;
+                p.running_mean[c] = (float)((1.0 - mo) * (double)p.running_mean[c] + mo * mean);
+                p.running_var[c] = (float)((1.0 - mo) * (double)p.running_var[c] + mo * unbiased);
+            }
+            if (c == 0 && p.nbt != nullptr) *p.nbt += 1;
+        } else {
+            p.dbeta[c] = (float)t0;
+            p.dgamma[c] = (float)t1;
+        }
+    }
+    grid_counter_reset(p.counters + slab);
+}
+
+// y = a z + b (+ residual) (ReLU) from the published affine map
+__global__ void __launch_bounds__(256) bn_apply_ab_kernel(const f32x4 *z, const float *ab, const f32x4 *residual, f32x4 *y, size_t n4,
+                                                          int C4, int relu) {
+    const f32x4 *a4 = (const f32x4 *)ab, *b4 = (const f32x4 *)(ab + 4 * (size_t)C4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const f32x4 v = z[i], a = a4[c], b = b4[c];
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(a[k], v[k], b[k]);
+        if (residual) {
+            const f32x4 r = residual[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] += r[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaxf(o[k], 0.0f);
+        }
+        y[i] = o;
+    }
+}
+
+// dz = gamma * invstd * (g - dbeta / N - xhat * dgamma / N);  g = dy masked (mask 0: as is, 1: y_act > 0, 2: fmaf(a, z, b) > 0)
+__global__ void __launch_bounds__(256) bn_bwd_apply_mask_kernel(const f32x4 *z, const f32x4 *dy, const f32x4 *y_act, const float *ab,
+                                                                const f32x4 *mean, const f32x4 *invstd, const f32x4 *gamma,
+                                                                const f32x4 *dgamma, const f32x4 *dbeta, f32x4 *dz, f32x4 *g_out,
+                                                                size_t n4, int C4, float inv_n, int mask) {
+    const f32x4 *a4 = (const f32x4 *)ab, *b4 = (const f32x4 *)(ab + 4 * (size_t)C4);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        const f32x4 v = z[i], mu = mean[c], is = invstd[c], ga = gamma[c], dg = dgamma[c], db = dbeta[c];
+        f32x4 g = dy[i];
+        if (mask == 1) {
+            const f32x4 ya = y_act[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = ya[k] > 0.0f ? g[k] : 0.0f;
+        } else if (mask == 2) {
+            const f32x4 a = a4[c], b = b4[c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = __builtin_fmaf(a[k], v[k], b[k]) > 0.0f ? g[k] : 0.0f;
+        }
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float xh = (v[k] - mu[k]) * is[k];
+            o[k] = ga[k] * is[k] * (g[k] - db[k] * inv_n - xh * dg[k] * inv_n);
+        }
+        dz[i] = o;
+        if (g_out) g_out[i] = g;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t dream_bn_workspace(int C) { return (size_t)kStatBlocks * C * 2 * sizeof(double) + (size_t)C * sizeof(float); }
@@ -290,6 +507,76 @@ extern "C" int dream_bn_train_bwd_nhwc_f32(const float *x, const float *dy, cons
                        (const f32x4 *)dy, (const f32x4 *)y_act, (const f32x4 *)save_mean, (const f32x4 *)save_invstd,
                        (const f32x4 *)gamma, (const f32x4 *)dgamma, (const f32x4 *)dbeta, (f32x4 *)dx, (f32x4 *)g_out, n4, C4,
                        (float)(1.0 / (double)npix), relu);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// ---- round 4 entry points (see the kernels above) ----------------------------------------------------------------------------------
+extern "C" size_t dream_bn_stats_workspace(int C) { return (size_t)kStatRows * (size_t)C * 2 * sizeof(double); }
+extern "C" int dream_bn_stats_counters(int C) { return (C + 63) / 64; }
+
+static inline int host_stat_rows(size_t npix) {
+    size_t nb = (npix + 127) / 128;
+    return (int)(nb < 1 ? 1 : (nb > (size_t)kStatRows ? (size_t)kStatRows : nb));
+}
+
+// Batch statistics of z [npix][C] in ONE launch: save_mean, save_invstd, out_ab = (gamma * invstd, beta - mean * gamma * invstd),
+// running statistics updated (nn.BatchNorm2d, train mode).  counters: dream_bn_stats_counters(C) zero words, left zero.
+extern "C" int dream_bn_stats_nhwc_f32(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                       long long *num_batches_tracked, float eps, float momentum, float *out_ab, float *save_mean,
+                                       float *save_invstd, void *workspace, unsigned *counters, size_t npix, int C, void *stream) {
+    DREAM_REQUIRE(z && gamma && beta && out_ab && save_mean && save_invstd && workspace && counters, "bn_stats: null pointer");
+    DREAM_REQUIRE(C > 0 && C % 4 == 0 && npix > 0, "bn_stats: unsupported C=%d", C);
+    BnStatParams p = {};
+    p.z = z; p.partials = (double *)workspace; p.counters = counters; p.npix = npix; p.C = C;
+    p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var; p.nbt = num_batches_tracked;
+    p.eps = eps; p.momentum = momentum; p.out_ab = out_ab; p.out_mean = save_mean; p.out_invstd = save_invstd;
+    hipLaunchKernelGGL(bn_stats_slab_kernel<0>, dim3((unsigned)host_stat_rows(npix), (unsigned)((C + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// y = ab[0] z + ab[1] (+ residual) (ReLU)
+extern "C" int dream_bn_apply_ab_nhwc_f32(const float *z, const float *ab, const float *residual, float *y, size_t npix, int C,
+                                          int relu, void *stream) {
+    DREAM_REQUIRE(z && ab && y && C > 0 && C % 4 == 0 && npix > 0, "bn_apply_ab: bad arguments");
+    const size_t n4 = npix * (size_t)(C / 4);
+    hipLaunchKernelGGL(bn_apply_ab_kernel, dim3(stream_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)z, ab,
+                       (const f32x4 *)residual, (f32x4 *)y, n4, C / 4, relu);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// dbeta = sum g, dgamma = sum g * xhat in ONE launch; g = dy masked: mask 0 none, 1 y_act > 0, 2 ab[0] z + ab[1] > 0
+extern "C" int dream_bn_bwd_stats_nhwc_f32(const float *z, const float *dy, const float *y_act, const float *ab, const float *save_mean,
+                                           const float *save_invstd, float *dgamma, float *dbeta, void *workspace, unsigned *counters,
+                                           size_t npix, int C, int mask, void *stream) {
+    DREAM_REQUIRE(z && dy && save_mean && save_invstd && dgamma && dbeta && workspace && counters, "bn_bwd_stats: null pointer");
+    DREAM_REQUIRE(mask == 0 || (mask == 1 && y_act) || (mask == 2 && ab), "bn_bwd_stats: mask %d without its source", mask);
+    DREAM_REQUIRE(C > 0 && C % 4 == 0 && npix > 0, "bn_bwd_stats: unsupported C=%d", C);
+    BnStatParams p = {};
+    p.z = z; p.dy = dy; p.y_act = y_act; p.ab = ab; p.mean = save_mean; p.invstd = save_invstd;
+    p.partials = (double *)workspace; p.counters = counters; p.npix = npix; p.C = C; p.mask = mask;
+    p.dgamma = dgamma; p.dbeta = dbeta;
+    hipLaunchKernelGGL(bn_stats_slab_kernel<1>, dim3((unsigned)host_stat_rows(npix), (unsigned)((C + 63) / 64)), dim3(256), 0,
+                       (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// dz = gamma * invstd * (g - dbeta / N - xhat * dgamma / N), g = dy masked as above; g_out (optional) receives g
+extern "C" int dream_bn_bwd_apply_nhwc_f32(const float *z, const float *dy, const float *y_act, const float *ab, const float *gamma,
+                                           const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta,
+                                           float *dz, float *g_out, size_t npix, int C, int mask, void *stream) {
+    DREAM_REQUIRE(z && dy && gamma && save_mean && save_invstd && dgamma && dbeta && dz, "bn_bwd_apply: null pointer");
+    DREAM_REQUIRE(mask == 0 || (mask == 1 && y_act) || (mask == 2 && ab), "bn_bwd_apply: mask %d without its source", mask);
+    DREAM_REQUIRE(C > 0 && C % 4 == 0 && npix > 0, "bn_bwd_apply: unsupported C=%d", C);
+    const size_t n4 = npix * (size_t)(C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_mask_kernel, dim3(stream_grid(n4)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)z,
+                       (const f32x4 *)dy, (const f32x4 *)y_act, ab ? ab : gamma, (const f32x4 *)save_mean, (const f32x4 *)save_invstd,
+                       (const f32x4 *)gamma, (const f32x4 *)dgamma, (const f32x4 *)dbeta, (f32x4 *)dz, (f32x4 *)g_out, n4, C / 4,
+                       (float)(1.0 / (double)npix), mask);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -38,6 +38,7 @@ struct Rccl {
     fnAllReduce all_reduce = nullptr;
     fnErrorString error_string = nullptr;
     bool tried = false, ok = false;
+    char why[256] = "not tried";                     // the first dlopen / dlsym failure (dlerror() clears itself when read)
 };
 
 std::mutex g_mu;
@@ -48,9 +49,12 @@ bool load_rccl() {
     if (g_rccl.tried) return g_rccl.ok;
     g_rccl.tried = true;
     void *h = nullptr;
+    bool noted = false;
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
         h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (h) break;
+        const char *e = dlerror();
+        if (!noted) { snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen failed"); noted = true; }
     }
     if (!h) return false;
     g_rccl.comm_init_all = (fnCommInitAll)dlsym(h, "ncclCommInitAll");
@@ -59,6 +63,7 @@ bool load_rccl() {
     g_rccl.all_reduce = (fnAllReduce)dlsym(h, "ncclAllReduce");
     g_rccl.error_string = (fnErrorString)dlsym(h, "ncclGetErrorString");
     g_rccl.ok = g_rccl.comm_init_all && g_rccl.group_start && g_rccl.group_end && g_rccl.all_reduce && g_rccl.error_string;
+    snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", g_rccl.ok ? "" : "a required ncclXxx symbol is missing from librccl");
     return g_rccl.ok;
 }
 
@@ -75,6 +80,18 @@ bool use_rccl(int n, const int *devices) {
     return force != nullptr && force[0] == '1';
 }
 
+// restores the calling thread's device (and closes an open RCCL group) on every exit path
+struct DeviceGuard {
+    int saved = -1;
+    bool group_open = false;
+    hipEvent_t ev = nullptr;
+    ~DeviceGuard() {
+        if (group_open) g_rccl.group_end();
+        if (ev) (void)hipEventDestroy(ev);
+        if (saved >= 0) (void)hipSetDevice(saved);
+    }
+};
+
 #define DREAM_RCCL_OK(call)                                                                                        \
     do {                                                                                                           \
         const int r_ = (call);                                                                                     \
@@ -86,7 +103,7 @@ bool use_rccl(int n, const int *devices) {
 
 int allreduce_rccl(int n, const int *devices, void *const *bufs, size_t count, void *const *streams) {
     std::lock_guard<std::mutex> lock(g_mu);
-    DREAM_REQUIRE(load_rccl(), "allreduce: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "missing symbol");
+    DREAM_REQUIRE(load_rccl(), "allreduce: librccl.so could not be loaded (%s)", g_rccl.why);
     const std::vector<int> key(devices, devices + n);
     auto it = g_comms.find(key);
     if (it == g_comms.end()) {
@@ -94,25 +111,26 @@ int allreduce_rccl(int n, const int *devices, void *const *bufs, size_t count, v
         DREAM_RCCL_OK(g_rccl.comm_init_all(comms.data(), n, devices));
         it = g_comms.emplace(key, comms).first;
     }
-    int saved = 0;
-    DREAM_HIP_OK(hipGetDevice(&saved));
+    DeviceGuard guard;
+    DREAM_HIP_OK(hipGetDevice(&guard.saved));
     DREAM_RCCL_OK(g_rccl.group_start());
+    guard.group_open = true;
     for (int i = 0; i < n; ++i)
         DREAM_RCCL_OK(g_rccl.all_reduce(bufs[i], bufs[i], count, kNcclFloat32, kNcclSum, it->second[(size_t)i], (hipStream_t)streams[i]));
+    guard.group_open = false;
     DREAM_RCCL_OK(g_rccl.group_end());
-    DREAM_HIP_OK(hipSetDevice(saved));
     return 0;
 }
 
 // buffers that share a GPU (or a lone buffer): sum into bufs[0] in list order, copy the sum back; every stream waits for it
 int allreduce_local(int n, const int *devices, void *const *bufs, size_t count, void *const *streams) {
     if (n == 1) return 0;
-    int saved = 0;
-    DREAM_HIP_OK(hipGetDevice(&saved));
+    DeviceGuard guard;
+    DREAM_HIP_OK(hipGetDevice(&guard.saved));
     DREAM_HIP_OK(hipSetDevice(devices[0]));
     hipStream_t s0 = (hipStream_t)streams[0];
-    hipEvent_t ev;
-    DREAM_HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    DREAM_HIP_OK(hipEventCreateWithFlags(&guard.ev, hipEventDisableTiming));
+    hipEvent_t ev = guard.ev;
     for (int i = 1; i < n; ++i) {
         if (streams[i] != streams[0]) {
             DREAM_HIP_OK(hipEventRecord(ev, (hipStream_t)streams[i]));
@@ -125,8 +143,6 @@ int allreduce_local(int n, const int *devices, void *const *bufs, size_t count, 
     DREAM_HIP_OK(hipEventRecord(ev, s0));
     for (int i = 1; i < n; ++i)
         if (streams[i] != streams[0]) DREAM_HIP_OK(hipStreamWaitEvent((hipStream_t)streams[i], ev, 0));
-    DREAM_HIP_OK(hipEventDestroy(ev));
-    DREAM_HIP_OK(hipSetDevice(saved));
     return 0;
 }
 

@@ -38,9 +38,55 @@ struct GemmParams {
     int M, K, N, NPad, x_stride;
     int nrb, ncb;            // 64-row / 64-column blocks
     int flags;               // DREAM_CONV_RELU
+    // ---- train-mode BatchNorm folded into this GEMM (dream/models.py:22-32: conv -> BatchNorm2d -> ReLU chains of the Bottlenecks)
+    // PRE: the A operand is relu(a[k] * x + b[k]) -- the PREVIOUS BatchNorm + ReLU applied in the loader, its output never stored
+    const float *pre_ab;     // [2][K]: a then b
+    // EPI 1: batch statistics of y (sum, sum of squares per output channel) -> scale / shift of the FOLLOWING BatchNorm
+    // EPI 2: y = g * [fmaf(a, z, b) > 0] (ReLU mask recomputed from the masked BatchNorm's input z), sums of y and y * xhat
+    //        -> dbeta, dgamma of that BatchNorm
+    double *st_partials;     // [nrb * KS][N][2]
+    unsigned *st_counters;   // [ncb]: zero on entry, zero again on exit
+    const float *st_gamma, *st_beta;
+    float *st_running_mean, *st_running_var;
+    long long *st_nbt;
+    float st_eps, st_momentum;
+    float *st_ab;            // EPI 1 out: [2][N]   (a = gamma * invstd, b = beta - mean * a)
+    float *st_mean, *st_invstd;       // EPI 1: out; EPI 2: in
+    const float *st_z;       // EPI 2: [M][N]
+    const float *st_zab;     // EPI 2: [2][N]
+    float *st_dgamma, *st_dbeta;      // EPI 2 out
 };
 
-template <int KS>
+// y = relu(a * x + b), the one expression every kernel uses for a train-mode BatchNorm + ReLU (single rounding: the ReLU mask
+// recomputed in the backward pass is exactly the forward's)
+DREAM_DEVICE f32x4 bn_relu4(f32x4 x, f32x4 a, f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = fmaxf(__builtin_fmaf(a[e], x[e], b[e]), 0.0f);
+    return r;
+}
+
+// the last wave to arrive for a 64-channel column block sums the partial rows in index order (eight loads in flight, same
+// order whatever their number: deterministic) -> (sum v0, sum v1) of channel c in this lane
+DREAM_DEVICE void sum_stat_rows(const double *partials, int nrows, int N, int c, double *s0, double *s1) {
+    double a = 0.0, b = 0.0;
+    if (c < N) {
+        const double2 *src = (const double2 *)partials + c;
+        int r = 0;
+        for (; r + 8 <= nrows; r += 8) {
+            double2 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(r + j) * N];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { a += v[j].x; b += v[j].y; }
+        }
+        for (; r < nrows; ++r) { const double2 v = src[(size_t)r * N]; a += v.x; b += v.y; }
+    }
+    *s0 = a;
+    *s1 = b;
+}
+
+template <int KS, bool PRE = false, int EPI = 0>
 __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     __shared__ float s_part[KS > 1 ? 4 * 64 * 64 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
     const int lane = threadIdx.x & 63;
@@ -75,13 +121,23 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     f32x4 xa[2][4], xb[2][4];
+    f32x4 pa[2], pb[2];                              // PRE: scale / shift of this lane's four k's of the chunk
+    const BufferRsrc abbuf = make_buffer(PRE ? p.pre_ab : p.x, PRE ? (size_t)2 * p.K * sizeof(float) : 0);
     auto load = [&](int set, int t) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) xa[set][m] = buffer_load_x4(xbuf, a_off[m], (unsigned)t * 64u);
+        if (PRE) {
+            pa[set] = buffer_load_x4(abbuf, (unsigned)(4 * lg * 4), (unsigned)t * 64u);
+            pb[set] = buffer_load_x4(abbuf, (unsigned)((p.K + 4 * lg) * 4), (unsigned)t * 64u);
+        }
 #pragma unroll
         for (int n = 0; n < 4; ++n) xb[set][n] = buffer_load_x4(wbuf, b_off[n], (unsigned)t * b_chunk);
     };
     auto multiply = [&](int set) {
+        if (PRE) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xa[set][m] = bn_relu4(xa[set][m], pa[set], pb[set]);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -130,6 +186,14 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     if (p.scale != nullptr && cok) sc = *(const f32x4 *)(p.scale + c0);
     if (p.shift != nullptr && cok) sh = *(const f32x4 *)(p.shift + c0);
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
+    double st0[4] = {0.0, 0.0, 0.0, 0.0}, st1[4] = {0.0, 0.0, 0.0, 0.0};      // EPI: this lane's sums over its rows
+    f32x4 za = {0.0f, 0.0f, 0.0f, 0.0f}, zb = za, zmu = za, zis = za;
+    if (EPI == 2 && cok) {
+        za = *(const f32x4 *)(p.st_zab + c0);
+        zb = *(const f32x4 *)(p.st_zab + p.N + c0);
+        zmu = *(const f32x4 *)(p.st_mean + c0);
+        zis = *(const f32x4 *)(p.st_invstd + c0);
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -144,9 +208,69 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
                 }
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { st0[e] += (double)v[e]; st1[e] += (double)v[e] * (double)v[e]; }
+                }
+                if (EPI == 2) {
+                    const f32x4 z = *(const f32x4 *)(p.st_z + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f ? v[e] : 0.0f;
+                        const float xh = (z[e] - zmu[e]) * zis[e];
+                        st0[e] += (double)v[e];
+                        st1[e] += (double)v[e] * (double)xh;
+                    }
+                }
                 *(f32x4 *)(p.y + o) = v;
             }
         }
+    if (EPI != 0) {
+        // the four lanes l, l + 16, l + 32, l + 48 hold the same four channels on different rows: (0 + 1) + (2 + 3) in every lane
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            st0[e] += lane_xor(st0[e], 16);
+            st1[e] += lane_xor(st1[e], 16);
+            st0[e] += lane_xor(st0[e], 32);
+            st1[e] += lane_xor(st1[e], 32);
+        }
+        const int prow = KS == 1 ? rb : rb * KS + kpart, nprows = p.nrb * KS;
+        if (lg == 0 && cok) {
+            double *dst = p.st_partials + ((size_t)prow * p.N + c0) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dst[2 * e] = st0[e]; dst[2 * e + 1] = st1[e]; }
+        }
+        grid_release();
+        const unsigned ticket = grid_ticket(p.st_counters + cb);
+        if (ticket != (unsigned)(nprows - 1)) return;
+        grid_acquire();
+        const int c = cb * 64 + lane;
+        double s0, s1;
+        sum_stat_rows(p.st_partials, nprows, p.N, c, &s0, &s1);
+        if (c < p.N) {
+            if (EPI == 1) {
+                const double n = (double)p.M, mean = s0 / n;
+                double var = s1 / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const double invstd = 1.0 / sqrt(var + (double)p.st_eps);
+                const float a = (float)((double)p.st_gamma[c] * invstd);
+                p.st_ab[c] = a;
+                p.st_ab[p.N + c] = (float)((double)p.st_beta[c] - mean * (double)a);
+                p.st_mean[c] = (float)mean;
+                p.st_invstd[c] = (float)invstd;
+                if (p.st_running_mean != nullptr) {
+                    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var, mo = (double)p.st_momentum;
+                    p.st_running_mean[c] = (float)((1.0 - mo) * (double)p.st_running_mean[c] + mo * mean);
+                    p.st_running_var[c] = (float)((1.0 - mo) * (double)p.st_running_var[c] + mo * unbiased);
+                }
+                if (c == 0 && p.st_nbt != nullptr) *p.st_nbt += 1;
+            } else {
+                p.st_dbeta[c] = (float)s0;
+                p.st_dgamma[c] = (float)s1;
+            }
+        }
+        grid_counter_reset(p.st_counters + cb);
+    }
 }
 
 // packed operand layout: pack_device.h (dream_pack::conv1x1)
@@ -171,8 +295,10 @@ struct Wgrad1x1Params {
     int M, Cin, Cout, Cdy;
     int ncob, ncib;          // 64-channel blocks
     int chunks_per_wave;     // chunks of 16 positions each wave sums (even)
+    const float *pre_ab;     // PRE: x is the INPUT of a BatchNorm + ReLU that was never stored: the operand is relu(a[ci] x + b[ci]); [2][Cin]
 };
 
+template <bool PRE>
 __global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const Wgrad1x1Params p) {
     __shared__ float s_part[4 * 64 * 64];
     const int lane = threadIdx.x & 63;
@@ -195,6 +321,11 @@ __global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const Wgrad1x1Params p
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     f32x4 ya[2][4], xa[2][4];                        // [register set][k-step of the chunk]
+    f32x4 pa = {1.0f, 1.0f, 1.0f, 1.0f}, pb = {0.0f, 0.0f, 0.0f, 0.0f};      // a lane's four input channels never change
+    if (PRE) {
+        pa = *(const f32x4 *)(p.pre_ab + cib * 64 + 4 * li);
+        pb = *(const f32x4 *)(p.pre_ab + p.Cin + cib * 64 + 4 * li);
+    }
     auto load = [&](int set, int c) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -205,6 +336,11 @@ __global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const Wgrad1x1Params p
         }
     };
     auto multiply = [&](int set) {
+        if (PRE) {
+            // (positions beyond the tensor read zeros on BOTH operands: relu(b) there meets dy = 0)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xa[set][s] = bn_relu4(xa[set][s], pa, pb);
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -283,6 +419,32 @@ Wgrad1x1Plan wgrad1x1_plan(long M, int Cin, int Cout) {
 
 int g_conv1x1_ksplit = 0;     // test hook: 0 = by shape, 1 / 2 / 4 = force
 
+template <bool PRE, int EPI>
+int gemm1x1_launch_ks(const GemmParams &p, int ks, unsigned grid, void *stream) {
+    if (ks == 1) hipLaunchKernelGGL((gemm1x1_kernel<1, PRE, EPI>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (ks == 2) hipLaunchKernelGGL((gemm1x1_kernel<2, PRE, EPI>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm1x1_kernel<4, PRE, EPI>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+int gemm1x1_launch(GemmParams p, long M, int K, int N, int x_stride, bool pre, int epi, void *stream) {
+    p.M = (int)M; p.K = K; p.N = N; p.NPad = (N + 63) / 64 * 64; p.x_stride = x_stride;
+    p.nrb = (int)((M + 63) / 64); p.ncb = p.NPad / 64;
+    const long tiles = (long)p.nrb * p.ncb;
+    // the chip holds 3072 waves of this kernel (256 CUs x 4 SIMDs x 3): split K until the tiles give ~2 waves per SIMD
+    int ks = 1;
+    if (g_conv1x1_ksplit > 0) ks = g_conv1x1_ksplit;
+    else if (tiles < 768 && K % 128 == 0) ks = 4;
+    else if (tiles < 1536 && K % 64 == 0) ks = 2;
+    DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
+    const int per_wg = 4 / ks;
+    const unsigned grid = (unsigned)(((tiles + per_wg - 1) / per_wg + 7) / 8 * 8);
+    if (epi == 0) return gemm1x1_launch_ks<false, 0>(p, ks, grid, stream);
+    if (epi == 1) return pre ? gemm1x1_launch_ks<true, 1>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 1>(p, ks, grid, stream);
+    return gemm1x1_launch_ks<false, 2>(p, ks, grid, stream);
+}
+
 }  // namespace
 
 // Test hook: force the K split (0 = by problem size).  The result depends on it only through the summation order.
@@ -320,25 +482,63 @@ extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, con
     DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "conv1x1: unsupported flags 0x%x", flags);
     DREAM_REQUIRE((size_t)M * (size_t)x_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
                   "conv1x1: tensor too large for 32-bit offsets");
-    GemmParams p;
+    GemmParams p = {};
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
-    p.M = (int)M; p.K = K; p.N = N; p.NPad = (N + 63) / 64 * 64; p.x_stride = x_stride;
-    p.nrb = (int)((M + 63) / 64); p.ncb = p.NPad / 64;
     p.flags = flags;
-    const long tiles = (long)p.nrb * p.ncb;
-    // the chip holds 3072 waves of this kernel (256 CUs x 4 SIMDs x 3): split K until the tiles give ~2 waves per SIMD
-    int ks = 1;
-    if (g_conv1x1_ksplit > 0) ks = g_conv1x1_ksplit;
-    else if (tiles < 768 && K % 128 == 0) ks = 4;
-    else if (tiles < 1536 && K % 64 == 0) ks = 2;
-    DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
-    const int per_wg = 4 / ks;
-    const unsigned grid = (unsigned)(((tiles + per_wg - 1) / per_wg + 7) / 8 * 8);
-    if (ks == 1) hipLaunchKernelGGL(gemm1x1_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else if (ks == 2) hipLaunchKernelGGL(gemm1x1_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(gemm1x1_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    DREAM_LAUNCH_OK();
-    return 0;
+    return gemm1x1_launch(p, M, K, N, x_stride, false, 0, stream);
+}
+
+// ---- the same GEMM with a train-mode BatchNorm folded in on either side (see GemmParams) ---------------------------------------
+extern "C" size_t dream_conv1x1_bn_workspace(long M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)((M + 63) / 64) * 4 * (size_t)N * 2 * sizeof(double);       // up to K split 4: nrb * 4 partial rows
+}
+
+// Forward of  [BatchNorm(batch stats) -> ReLU ->] conv1x1 -> (statistics of the result for the BatchNorm that follows):
+//   y = relu(pre_ab[0][k] * x + pre_ab[1][k]) . w^T + shift          (pre_ab null: y = x . w^T + shift)
+//   save_mean / save_invstd = batch statistics of y per channel (biased variance, eps inside the root), out_ab[0] = gamma * invstd,
+//   out_ab[1] = beta - mean * out_ab[0]; running statistics updated as nn.BatchNorm2d does (momentum, unbiased variance).
+// The statistics are finished inside the launch by the last wave to arrive per 64-channel block (fixed summation order:
+// deterministic).  counters: N / 64 (rounded up) zero words, left zero; workspace: dream_conv1x1_bn_workspace(M, N) bytes.
+extern "C" int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_packed, const float *shift, const float *pre_ab, float *y,
+                                              long M, int K, int N, int x_stride, const float *gamma, const float *beta,
+                                              float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
+                                              float momentum, float *out_ab, float *save_mean, float *save_invstd, void *workspace,
+                                              unsigned *counters, void *stream) {
+    DREAM_REQUIRE(x && w_packed && y && gamma && beta && out_ab && save_mean && save_invstd && workspace && counters,
+                  "conv1x1_bnstats: null pointer");
+    DREAM_REQUIRE(M > 0 && K > 0 && N > 0 && x_stride >= K, "conv1x1_bnstats: bad shape M=%ld K=%d N=%d stride=%d", M, K, N, x_stride);
+    DREAM_REQUIRE(K % 32 == 0 && N % 4 == 0 && x_stride % 4 == 0, "conv1x1_bnstats: K %% 32, N %% 4, stride %% 4 (got %d, %d, %d)", K, N, x_stride);
+    DREAM_REQUIRE((size_t)M * (size_t)x_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
+                  "conv1x1_bnstats: tensor too large for 32-bit offsets");
+    GemmParams p = {};
+    p.x = x; p.w = w_packed; p.shift = shift; p.y = y; p.pre_ab = pre_ab;
+    p.st_partials = (double *)workspace; p.st_counters = counters;
+    p.st_gamma = gamma; p.st_beta = beta; p.st_running_mean = running_mean; p.st_running_var = running_var;
+    p.st_nbt = num_batches_tracked; p.st_eps = eps; p.st_momentum = momentum;
+    p.st_ab = out_ab; p.st_mean = save_mean; p.st_invstd = save_invstd;
+    return gemm1x1_launch(p, M, K, N, x_stride, pre_ab != nullptr, 1, stream);
+}
+
+// Data gradient of a 1x1 conv whose INPUT was relu(BatchNorm(z)) (never stored):  g = (dy . w) * [ab[0] z + ab[1] > 0], written to
+// g_out, and -- finished inside the launch -- dbeta = sum g, dgamma = sum g * (z - mean) * invstd of that BatchNorm.
+// w_packed_t: mode-1 packing; K = channels of dy, N = channels of z.
+extern "C" int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, float *g_out, long M, int K, int N,
+                                                 int dy_stride, const float *z, const float *ab, const float *mean,
+                                                 const float *invstd, float *dgamma, float *dbeta, void *workspace,
+                                                 unsigned *counters, void *stream) {
+    DREAM_REQUIRE(dy && w_packed_t && g_out && z && ab && mean && invstd && dgamma && dbeta && workspace && counters,
+                  "conv1x1_bwd_bnmask: null pointer");
+    DREAM_REQUIRE(M > 0 && K > 0 && N > 0 && dy_stride >= K, "conv1x1_bwd_bnmask: bad shape M=%ld K=%d N=%d stride=%d", M, K, N, dy_stride);
+    DREAM_REQUIRE(K % 32 == 0 && N % 4 == 0 && dy_stride % 4 == 0, "conv1x1_bwd_bnmask: K %% 32, N %% 4, stride %% 4 (got %d, %d, %d)", K, N, dy_stride);
+    DREAM_REQUIRE((size_t)M * (size_t)dy_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
+                  "conv1x1_bwd_bnmask: tensor too large for 32-bit offsets");
+    GemmParams p = {};
+    p.x = dy; p.w = w_packed_t; p.y = g_out;
+    p.st_partials = (double *)workspace; p.st_counters = counters;
+    p.st_z = z; p.st_zab = ab; p.st_mean = const_cast<float *>(mean); p.st_invstd = const_cast<float *>(invstd);
+    p.st_dgamma = dgamma; p.st_dbeta = dbeta;
+    return gemm1x1_launch(p, M, K, N, dy_stride, false, 2, stream);
 }
 
 extern "C" size_t dream_conv1x1_wgrad_workspace(long M, int Cin, int Cout) {
@@ -349,8 +549,24 @@ extern "C" size_t dream_conv1x1_wgrad_workspace(long M, int Cin, int Cout) {
 
 // x [M][Cin], dy [M][Cdy] (Cdy >= Cout: gradient tensors may carry padded channels) -> dw [Cout][Cin] (= OIHW with 1x1 taps),
 // overwritten.  Cin % 64 == 0, Cout % 4 == 0, Cdy % 4 == 0; workspace: dream_conv1x1_wgrad_workspace() bytes.
+static int conv1x1_wgrad(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout, int Cdy,
+                         const float *pre_ab, void *stream);
+
 extern "C" int dream_conv1x1_wgrad_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout,
                                             int Cdy, void *stream) {
+    return conv1x1_wgrad(x, dy, dw, workspace, M, Cin, Cout, Cdy, nullptr, stream);
+}
+
+// the same for a conv whose input was relu(pre_ab[0][ci] * x + pre_ab[1][ci]) (train-mode BatchNorm + ReLU folded into the conv's
+// loader, never stored): x is the BatchNorm's input
+extern "C" int dream_conv1x1_wgrad_pre_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin,
+                                                int Cout, int Cdy, const float *pre_ab, void *stream) {
+    DREAM_REQUIRE(pre_ab != nullptr, "conv1x1 wgrad (pre): null scale / shift");
+    return conv1x1_wgrad(x, dy, dw, workspace, M, Cin, Cout, Cdy, pre_ab, stream);
+}
+
+static int conv1x1_wgrad(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout, int Cdy,
+                         const float *pre_ab, void *stream) {
     DREAM_REQUIRE(x && dy && dw && workspace, "conv1x1 wgrad: null pointer");
     DREAM_REQUIRE(M > 0 && Cin > 0 && Cout > 0 && Cdy >= Cout, "conv1x1 wgrad: bad shape");
     DREAM_REQUIRE(Cin % 64 == 0 && Cout % 4 == 0 && Cdy % 4 == 0, "conv1x1 wgrad: Cin %% 64, Cout %% 4, Cdy %% 4 (got %d, %d, %d)", Cin, Cout, Cdy);
@@ -361,7 +577,10 @@ extern "C" int dream_conv1x1_wgrad_nhwc_f32(const float *x, const float *dy, flo
     p.M = (int)M; p.Cin = Cin; p.Cout = Cout; p.Cdy = Cdy;
     p.ncob = (Cout + 63) / 64; p.ncib = Cin / 64;
     p.chunks_per_wave = pl.chunks_per_wave;
-    hipLaunchKernelGGL(wgrad1x1_kernel, dim3((unsigned)(p.ncob * p.ncib * pl.nsplit)), dim3(256), 0, (hipStream_t)stream, p);
+    p.pre_ab = pre_ab;
+    const dim3 wgrid((unsigned)(p.ncob * p.ncib * pl.nsplit));
+    if (pre_ab != nullptr) hipLaunchKernelGGL(wgrad1x1_kernel<true>, wgrid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad1x1_kernel<false>, wgrid, dim3(256), 0, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     const size_t n = (size_t)Cout * Cin;
     size_t rgrid = (n / 4 + 255) / 256;

@@ -141,6 +141,25 @@ DREAM_DEVICE unsigned long long wave_ballot(int pred) { return __ballot(pred); }
 DREAM_DEVICE int    popcount64(unsigned long long v) { return __popcll(v); }
 DREAM_DEVICE bool   wave_all(int pred) { return __ballot(pred) == __ballot(1); }      // wave-uniform
 
+// ---- "last arriver finishes" (a per-channel reduction finalised inside the launch that produced its partial sums) -------------
+// Every wave publishes its partial sums with plain stores, then grid_release() (agent-scope release fence: the stores of ALL
+// lanes of the wave are written back past this XCD's L2 -- the L2s of the eight XCDs are not coherent with one another) and takes
+// a ticket from a device-scope counter; the wave that draws the last ticket runs grid_acquire() (invalidates its own L1 / L2
+// view) and may then read every other wave's partial sums.  Nobody spins: no residency requirement, no deadlock.
+DREAM_DEVICE void grid_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
+DREAM_DEVICE void grid_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+// lane 0 of the wave draws the ticket (relaxed: the fences around it order the data); every lane receives it
+DREAM_DEVICE unsigned grid_ticket(unsigned *counter) {
+    unsigned t = 0;
+    if (lane_id() == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)t);
+}
+DREAM_DEVICE void grid_counter_reset(unsigned *counter) {
+    if (lane_id() == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// value of lane 0 in every lane (wave-uniform)
+DREAM_DEVICE int wave_bcast0(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 // IEEE fp64 ops that the compiler must not contract into FMAs (bit-exactness with NumPy/SciPy)
 DREAM_DEVICE double dmul(double a, double b) { return __dmul_rn(a, b); }
 DREAM_DEVICE double dadd(double a, double b) { return __dadd_rn(a, b); }

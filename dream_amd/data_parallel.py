@@ -181,6 +181,8 @@ class DreamDataParallel(nn.Module):
         object.__setattr__(self, "_graphs", {})           # (replica index, key) -> captured launch sequence
         object.__setattr__(self, "_reduced", 0)           # replicas whose flat gradient buffer holds this step's all-reduced sum
         object.__setattr__(self, "_opt_state", {})        # replica index -> optimizer state buffers on that replica's device
+        object.__setattr__(self, "_tick", [0])            # use counter for the LRU of captured graphs
+        object.__setattr__(self, "_grad_version", None)   # version of the master's flat gradient buffer right after the all-reduce
         # statistics of the last step (tests, bench): hipGraph replays / eager replica runs / captures
         object.__setattr__(self, "stats", {"replays": 0, "eager": 0, "captures": 0, "param_copies": 0, "replica_steps": 0})
 
@@ -204,7 +206,11 @@ class DreamDataParallel(nn.Module):
         return self._devices
 
     def n_devices(self, batch):
-        return max(1, min(len(self.devices()), int(batch)))
+        """Devices a batch is spread over = the number of chunks ``Tensor.chunk`` makes of it (12 frames over 8 devices: six
+        chunks of 2, the last two devices idle -- as nn.DataParallel.scatter)."""
+        n = max(1, min(len(self.devices()), int(batch)))
+        per = -(-int(batch) // n)
+        return max(1, -(-int(batch) // per))
 
     def use_graphs(self):
         """Replica launch sequences as hipGraphs: real GPUs, more than one replica, not switched off (DREAM_DP_GRAPHS=0)."""
@@ -322,7 +328,8 @@ class DreamDataParallel(nn.Module):
     def _replica_forward(self, i, x, save, post, post_key):
         """-> (outputs (+ post result), context for _replica_backward)."""
         rep = self._replica(i)
-        if not self.use_graphs():
+        if not self.use_graphs() or (rep.training and not save):
+            # (a train-mode forward without a backward updates the BatchNorm statistics it is keyed on: it would never replay)
             return self._eager_forward(rep, x, save, post)
         key = self._graph_key(x, save, post_key)
         entry = self._graphs.get((i, key))
@@ -330,8 +337,16 @@ class DreamDataParallel(nn.Module):
             # evaluation graphs of older parameter versions can never be replayed again: drop them (and their memory pools)
             for k in [k for k in self._graphs if k[0] == i and k[1][:5] == key[:5] and k[1] != key]:
                 del self._graphs[k]
-            entry = self._graphs[(i, key)] = {"seen": 0, "fwd": None, "bwd": None, "busy": False}
+            # every captured (replica, shape) keeps a private memory pool -- activations, packed weights, the backward pass: several
+            # GB for a ResNet-101 training step -- so ragged last batches or a varying batch size must not pile them up: least
+            # recently used first, beyond DREAM_DP_MAX_GRAPHS (4) per replica
+            mine = sorted((k for k in self._graphs if k[0] == i and not self._graphs[k]["busy"]), key=lambda k: self._graphs[k]["tick"])
+            for k in mine[:max(0, len(mine) + 1 - int(os.environ.get("DREAM_DP_MAX_GRAPHS", "4")))]:
+                del self._graphs[k]
+            entry = self._graphs[(i, key)] = {"seen": 0, "fwd": None, "bwd": None, "busy": False, "tick": 0}
         entry["seen"] += 1
+        self._tick[0] += 1
+        entry["tick"] = self._tick[0]
         if entry["fwd"] is None and (entry["seen"] < 2 or entry["busy"]):
             self.stats["eager"] += 1
             return self._eager_forward(rep, x, save, post)          # first sighting of this shape: run it as it comes
@@ -431,6 +446,7 @@ class DreamDataParallel(nn.Module):
         numels = [prm.numel() for prm in params]
         splits = [g.split(sizes, dim=0) if g is not None else [None] * n for g in grad_outs]
         flats = [self._grad_buffer(i) for i in range(n)]
+        self._release_grad_buffer(params, flats[0], offsets, numels)
 
         def job(i):
             def run():
@@ -446,7 +462,31 @@ class DreamDataParallel(nn.Module):
                 ops.allreduce_sum_(flats)
             object.__setattr__(self, "_reduced", n)
         total_flat = flats[0]
+        # what step_replicas checks: any in-place edit of the gradients autograd is about to receive (clip_grad_norm_, manual
+        # scaling: the views share the buffer's version counter) happens on the master only and must not be replayed blindly
+        object.__setattr__(self, "_grad_version", total_flat._version)
         return [total_flat[o:o + m].view(prm.shape) for o, m, prm in zip(offsets, numels, params)]
+
+    @staticmethod
+    def _release_grad_buffer(params, flat, offsets, numels):
+        """AccumulateGrad keeps the views this node returns as ``p.grad`` (it steals them when ``p.grad`` is None), so after
+        ``zero_grad(set_to_none=False)`` or with gradient accumulation (two backwards, one step) the master's ``p.grad`` still
+        aliases the persistent flat gradient buffer that the backward about to run overwrites in place -- ``p.grad += new`` would
+        then add the buffer to itself.  Before anything is written the kept gradients move to a private flat copy with the same
+        layout (one device copy, on this rare path only): autograd accumulates into the copy, the optimizer still sees ONE
+        contiguous gradient buffer, and ``step_replicas`` notices that it is not the all-reduced buffer and lets the replicas
+        be refreshed from the master instead."""
+        lo = flat.data_ptr()
+        hi = lo + 4 * flat.numel()
+        held = [i for i, prm in enumerate(params) if prm.grad is not None and lo <= prm.grad.data_ptr() < hi]
+        if not held:
+            return
+        with torch.no_grad():
+            keep = flat.clone()
+            for i in held:
+                prm = params[i]
+                off = (prm.grad.data_ptr() - lo) // 4
+                prm.grad = keep[off:off + prm.grad.numel()].view(prm.grad.shape)
 
     # ---- optimizer hook: the identical update on every replica (dream_amd/optim.py) -------------------------------------------
     def step_replicas(self, kind, flat_params, flat_grads, hyper, master_state):
@@ -460,6 +500,8 @@ class DreamDataParallel(nn.Module):
         mrec = self.module._dream_flat
         if n <= 1 or n != len(self._replicas) + 1 or self._pstamp != _param_stamp(self.module) or mrec.get("grads") is None:
             return False
+        if mrec["grads"]._version != self._grad_version:
+            return False                                    # the master's gradients were edited after the all-reduce (clipping, scaling)
         lo, count = (flat_params.data_ptr() - mrec["params"].data_ptr()) // 4, int(flat_params.numel())
         if not (0 <= lo and lo + count <= mrec["params"].numel() and flat_grads.data_ptr() == mrec["grads"].data_ptr() + 4 * lo
                 and int(flat_grads.numel()) == count):

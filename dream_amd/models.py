@@ -849,6 +849,10 @@ class ResnetSimple(nn.Module):
         self.convT_algorithm = os.environ.get("DREAM_CONVT_ALGORITHM", "winograd")
         # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
+        # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
+        # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
+        # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
+        self.bn_fusion = os.environ.get("DREAM_BN_FUSION", "1") != "0"
         self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         inplanes = 64
@@ -1119,6 +1123,8 @@ class ResnetSimple(nn.Module):
         return ops.conv2d_bwd_data(dz, packed_t, cin, k, stride, in_hw, residual=residual)
 
     def run_forward_train(self, x):
+        if self.bn_fusion:
+            return self.run_forward_train_fused(x)
         self._repack_weights()
         tape = []
         col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
@@ -1172,6 +1178,8 @@ class ResnetSimple(nn.Module):
     def run_backward(self, tape, grad_out_nchw, reducer=None):
         """-> {parameter: gradient}.  Walks the tape backwards; gradients that meet at a Bottleneck input are summed
         by the residual input of the data-gradient conv (no separate add kernel)."""
+        if tape and tape[0].get("fused"):
+            return self.run_backward_fused(tape, grad_out_nchw, reducer)
         grads = _GradDict(reducer)
         # Measured (resnet_h, 400x400, one MI355X): +6.5 / +5.7 / +5.3 % at 16 / 32 / 64 frames, -2.7 % at 128, where
         # every kernel already fills the chip and the two streams only disturb each other's L2.
@@ -1247,6 +1255,219 @@ class ResnetSimple(nn.Module):
             elif kind == "stem":
                 bn = rec["bn"]
                 dz, _, dgam, dbet = ops.bn_train_bwd(rec["z"], g, rec["y"], bn.weight, rec["mean"], rec["invstd"], True)
+                grads[bn.weight], grads[bn.bias] = dgam, dbet
+                dw, _ = ops.conv2d_wgrad(rec["x"], dz, 64, 160, 1, 1)
+                grads[rec["conv"].weight] = dw.reshape(64, 160)[:, :147].reshape(64, 3, 7, 7).contiguous()
+                g = None
+        if side is not None:
+            side.join()
+        return grads
+
+    # ---- training, round 4: BatchNorm folded into its neighbours (csrc/bn.hip "round 4", csrc/gemm1x1.hip PRE / EPI) -------------
+    def _ctr(self, device, channels):
+        """A slice of this replica's zero ticket words for one BatchNorm launch (ops.bn_counter_buffer)."""
+        buf = self._cache.get(("bnctr",))
+        if buf is None or buf.device != device:
+            buf = self._cache[("bnctr",)] = ops.bn_counter_buffer(device)
+            self._ctr_pos = 0
+        n = (int(channels) + 63) // 64
+        if self._ctr_pos + n > buf.numel():
+            self._ctr_pos = 0
+        out = buf[self._ctr_pos:self._ctr_pos + n]
+        self._ctr_pos += n
+        return out
+
+    def _unit_fused(self, tape, name, x, conv, bn, relu, residual=None, pre=None, materialize=True):
+        """conv -> BatchNorm(batch statistics) (+ residual) (ReLU).  ``x``: the conv's input tensor, or -- with ``pre`` = the record of
+        the producing unit -- that unit's un-normalised output z, whose BatchNorm + ReLU this conv applies while loading.
+        ``materialize=False``: the normalised output is left to the consumer's loader (returns the record instead of a tensor)."""
+        k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
+        bias = conv.bias.detach() if conv.bias is not None else None
+        cout = int(conv.weight.shape[0])
+        rec = dict(kind="conv", name=name, conv=conv, bn=bn, relu=relu, x=x, pre=pre, k=k, stride=stride, has_res=residual is not None,
+                   y=None)
+        if self._gemm1x1(conv, x):
+            packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
+            rec["z"], rec["ab"], rec["mean"], rec["invstd"] = ops.conv1x1_bn(
+                x, packed, rows, bn, self._ctr(x.device, cout), pre_ab=None if pre is None else pre["ab"], shift=bias)
+        else:
+            assert pre is None
+            if self._wino_train(conv):
+                tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), int(conv.weight.shape[1]), cout, int(x.shape[0]))
+                u, rows = self._cached(("wino", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 0, tile))
+                z = ops.conv3x3_winograd_tile(tile, x, u, rows, None, bias, None, 0)
+            else:
+                packed, rows, _ = self._packed_w(name, conv, 0)
+                z = ops.conv2d(x, packed, rows, k, stride, None, bias, None, 0)
+            rec["z"] = z
+            rec["ab"], rec["mean"], rec["invstd"] = ops.bn_stats(z, bn, self._ctr(x.device, cout))
+        tape.append(rec)
+        if not materialize:
+            return rec
+        rec["y"] = ops.bn_apply_ab(rec["z"], rec["ab"], residual, relu)
+        return rec["y"]
+
+    def run_forward_train_fused(self, x):
+        self._repack_weights()
+        self._ctr_pos = 0
+        tape = [dict(kind="begin", fused=True)]
+        col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
+        w1 = self._cached(("w", "conv1"), [self.conv1.weight],
+                          lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
+        z = ops.conv2d(col, w1[0], 64, 1, 1)
+        ab, mean, invstd = ops.bn_stats(z, self.bn1, self._ctr(z.device, 64))
+        y = ops.bn_apply_ab(z, ab, None, True)
+        tape.append(dict(kind="stem", conv=self.conv1, bn=self.bn1, relu=True, x=col, z=z, y=y, ab=ab, mean=mean, invstd=invstd))
+        yp = ops.maxpool3s2(y)
+        tape.append(dict(kind="pool", x=y))
+        y = yp
+        for li in (1, 2, 3, 4):
+            for bi, blk in enumerate(getattr(self, "layer%d" % li)):
+                name = "layer%d.%d" % (li, bi)
+                tape.append(dict(kind="block_begin", name=name, ds=hasattr(blk, "downsample")))
+                idt = y
+                if hasattr(blk, "downsample"):
+                    idt = self._unit_fused(tape, name + ".ds", y, blk.downsample[0], blk.downsample[1], relu=False)
+                o = self._unit_fused(tape, name + ".1", y, blk.conv1, blk.bn1, relu=True)
+                # conv2's BatchNorm + ReLU is applied by conv3's loader when conv3 runs on the GEMM kernel (always, for ResNet-101)
+                r2 = self._unit_fused(tape, name + ".2", o, blk.conv2, blk.bn2, relu=True, materialize=False)
+                if self._gemm1x1(blk.conv3, r2["z"]):
+                    y = self._unit_fused(tape, name + ".3", r2["z"], blk.conv3, blk.bn3, relu=True, residual=idt, pre=r2)
+                else:
+                    r2["y"] = ops.bn_apply_ab(r2["z"], r2["ab"], None, True)
+                    y = self._unit_fused(tape, name + ".3", r2["y"], blk.conv3, blk.bn3, relu=True, residual=idt)
+                tape.append(dict(kind="block_end", name=name))
+        seqs = [("upsample", self.upsample)] + ([("upsample2", self.upsample2)] if self.full else [])
+        for sname, seq in seqs:
+            mods = list(seq)
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                name = "%s.%d" % (sname, i)
+                if isinstance(m, nn.ConvTranspose2d):
+                    bn = mods[i + 1]
+                    if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
+                        tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
+                        u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))
+                        z = ops.conv_transpose4x4s2_winograd_tile(tile, y, u4, cout, None, m.bias.detach(), 0)
+                    else:
+                        packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
+                        z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)
+                    ab, mean, invstd = ops.bn_stats(z, bn, self._ctr(z.device, int(z.shape[3])))
+                    y2 = ops.bn_apply_ab(z, ab, None, True)
+                    tape.append(dict(kind="convT", name=name, conv=m, bn=bn, relu=True, x=y, z=z, y=y2, ab=ab, mean=mean, invstd=invstd))
+                    y = y2
+                    i += 3
+                else:
+                    packed, rows, _ = self._packed_w(name, m, 0)
+                    out = ops.conv2d(y, packed, rows, 1, 1, None, m.bias.detach(), None, CONV_OUT_NCHW)
+                    tape.append(dict(kind="final", name=name, conv=m, x=y))
+                    y = out
+                    i += 1
+        return y, tape
+
+    def _bn_bwd_fused(self, rec, dy, want_g=False):
+        """BatchNorm backward of a unit in two launches: (dgamma, dbeta) finished inside the reduction launch, then dz (and the masked
+        gradient g when the Bottleneck's identity branch needs it).  The ReLU mask comes from the stored activation where the forward
+        pass wrote one, else it is recomputed from (z, ab).  ``dy`` = ("masked", g, dgamma, dbeta): the consumer's data-gradient
+        epilogue already masked and summed (conv1x1_bwd_bnmask) -- one launch."""
+        bn = rec["bn"]
+        dev, c = rec["z"].device, int(rec["z"].shape[3])
+        if isinstance(dy, tuple):
+            _, g, dgam, dbet = dy
+            dz, _ = ops.bn_bwd_apply(rec["z"], g, bn.weight, rec["mean"], rec["invstd"], dgam, dbet)
+            return dz, None, dgam, dbet
+        y_act = rec["y"] if rec["relu"] else None
+        ab = rec["ab"] if (rec["relu"] and y_act is None) else None
+        dgam, dbet = ops.bn_bwd_stats(rec["z"], dy, rec["mean"], rec["invstd"], self._ctr(dev, c), y_act=y_act, ab=ab)
+        dz, g = ops.bn_bwd_apply(rec["z"], dy, bn.weight, rec["mean"], rec["invstd"], dgam, dbet, y_act=y_act, ab=ab, want_g=want_g)
+        return dz, g, dgam, dbet
+
+    def run_backward_fused(self, tape, grad_out_nchw, reducer=None):
+        """run_backward for a tape of run_forward_train_fused."""
+        grads = _GradDict(reducer)
+        stem_x = tape[1]["x"]
+        input_px = 4 * int(stem_x.shape[0]) * int(stem_x.shape[1]) * int(stem_x.shape[2])
+        side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= 96 * 400 * 400)
+        g = None
+        block = None
+        for rec in reversed(tape):
+            kind = rec["kind"]
+            if kind == "final":
+                m = rec["conv"]
+                cout, cin = int(m.weight.shape[0]), int(m.weight.shape[1])
+                gy = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))
+                def leaf(m=m, x=rec["x"], gy=gy, cout=cout, cin=cin):
+                    grads[m.weight], grads[m.bias] = ops.conv2d_wgrad(x, gy, cout, cin, 1, 1, 0, want_bias=True)
+                _on_side(side, leaf, rec["x"], gy)
+                packed_t, rows, _ = self._packed_w(rec["name"], m, 1)
+                g = ops.conv2d(gy, packed_t, rows, 1, 1)
+            elif kind == "convT":
+                m, bn = rec["conv"], rec["bn"]
+                dz, _, dgam, dbet = self._bn_bwd_fused(rec, g)
+                grads[bn.weight], grads[bn.bias] = dgam, dbet
+                def leaf(m=m, x=rec["x"], dz=dz):
+                    grads[m.weight] = ops.convT4x4_wgrad(x, dz)
+                    grads[m.bias] = ops.channel_sum(dz)
+                _on_side(side, leaf, rec["x"], dz)
+                cin_t, cout_t = int(m.weight.shape[0]), int(m.weight.shape[1])
+                if (self.convT_algorithm == "winograd" and cout_t % 16 == 0 and cout_t >= 32 and cin_t > 64
+                        and int(dz.shape[3]) == cout_t and dz.shape[1] % 2 == 0 and dz.shape[2] % 2 == 0):
+                    tile = ops.conv4x4s2_winograd_tile_of(dz, cin_t)
+                    u4b, rows = self._cached(("wu4b", rec["name"], tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile, 1))
+                    g = ops.conv4x4s2_winograd_tile(tile, dz, u4b, rows)
+                else:
+                    pk, rows = self._cached(("wTb", rec["name"]), [m.weight], lambda m=m: ops.pack_convT4x4_bwd_weight(m.weight.detach()))
+                    g = ops.conv4x4s2(dz, pk, rows)
+            elif kind == "block_end":
+                block = dict(g_out=g, g_idt=None, g_ds=None)
+            elif kind == "conv":
+                conv, bn, name = rec["conv"], rec["bn"], rec["name"]
+                cout, cin = int(conv.weight.shape[0]), int(conv.weight.shape[1])
+                is_ds = name.endswith(".ds")
+                dy = block["g_idt"] if is_ds else g
+                dz, gm, dgam, dbet = self._bn_bwd_fused(rec, dy, want_g=rec["has_res"])
+                grads[bn.weight], grads[bn.bias] = dgam, dbet
+                if rec["has_res"]:
+                    block["g_idt"] = gm          # masked block-output gradient == gradient of the identity branch
+                pre = rec["pre"]
+                def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"], pre=pre):
+                    if pre is not None:          # the conv's input was relu(BN(x)), applied by its loader: so does the weight gradient's
+                        if not ops.conv1x1_wgrad_applies(x, dz, cout):
+                            y_in = ops.bn_apply_ab(x, pre["ab"], None, True)
+                            grads[conv.weight] = ops.conv2d_wgrad(y_in, dz, cout, cin, k, stride)[0]
+                        else:
+                            grads[conv.weight] = ops.conv1x1_wgrad(x, dz, cout, cin, pre_ab=pre["ab"])
+                    elif self._wino_train(conv) and ops.wgrad_winograd_pays(int(dz.shape[0]) * int(dz.shape[1]) * int(dz.shape[2]), cin, cout):
+                        grads[conv.weight] = ops.conv3x3_wgrad_winograd(x, dz, cout, cin, want_bias=False)[0]
+                    elif self.conv1x1_algorithm == "gemm" and k == 1 and stride == 1 and ops.conv1x1_wgrad_applies(x, dz, cout):
+                        grads[conv.weight] = ops.conv1x1_wgrad(x, dz, cout, cin)
+                    else:
+                        grads[conv.weight] = ops.conv2d_wgrad(x, dz, cout, cin, k, stride)[0]
+                _on_side(side, leaf, *([rec["x"], dz] + ([pre["ab"]] if pre is not None else [])))
+                in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
+                if is_ds:
+                    block["g_ds"] = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
+                elif name.endswith(".1"):
+                    block["dz1"] = (name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
+                elif pre is not None:
+                    # data gradient + the ReLU mask and the two reductions of the producer's BatchNorm in ONE launch
+                    packed_t, rows = self._cached(("g1", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 1))
+                    gmask, dg2, db2 = ops.conv1x1_bwd_bnmask(dz, packed_t, cin, pre["z"], pre["ab"], pre["mean"], pre["invstd"],
+                                                            self._ctr(dz.device, cin))
+                    g = ("masked", gmask, dg2, db2)
+                else:
+                    g = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
+            elif kind == "block_begin":
+                name1, conv1, dz, cin, k, stride, in_hw = block["dz1"]
+                other = block["g_ds"] if rec["ds"] else block["g_idt"]
+                g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
+                block = None
+            elif kind == "pool":
+                g = ops.maxpool3s2_bwd(g, rec["x"])
+            elif kind == "stem":
+                bn = rec["bn"]
+                dz, _, dgam, dbet = self._bn_bwd_fused(rec, g)
                 grads[bn.weight], grads[bn.bias] = dgam, dbet
                 dw, _ = ops.conv2d_wgrad(rec["x"], dz, 64, 160, 1, 1)
                 grads[rec["conv"].weight] = dw.reshape(64, 160)[:, :147].reshape(64, 3, 7, 7).contiguous()

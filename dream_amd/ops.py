@@ -603,14 +603,18 @@ def conv1x1_wgrad_applies(x_nhwc, dy_nhwc, cout):
             and (x_nhwc.shape[0] * x_nhwc.shape[1] * x_nhwc.shape[2] + 64) * max(cin, cdy) * 4 < (1 << 31))
 
 
-def conv1x1_wgrad(x_nhwc, dy_nhwc, cout, cin):
-    """Weight gradient of a stride-1 1x1 conv -> dW [cout, cin, 1, 1] (the GEMM over positions of gemm1x1.hip)."""
+def conv1x1_wgrad(x_nhwc, dy_nhwc, cout, cin, pre_ab=None):
+    """Weight gradient of a stride-1 1x1 conv -> dW [cout, cin, 1, 1] (the GEMM over positions of gemm1x1.hip).  ``pre_ab``: the
+    conv's input was relu(pre_ab[0] x + pre_ab[1]) (BatchNorm + ReLU folded into its loader), x is the BatchNorm's input."""
     x, dy = _f32(x_nhwc), _f32(dy_nhwc)
     m = int(x.shape[0]) * int(x.shape[1]) * int(x.shape[2])
     nbytes = int(_hip.lib().dream_conv1x1_wgrad_workspace(m, cin, cout))
     ws = _workspace(nbytes, x.device)
     dw = torch.empty((cout, cin, 1, 1), dtype=torch.float32, device=x.device)
-    call("dream_conv1x1_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), m, cin, cout, int(dy.shape[3]), stream())
+    if pre_ab is not None:
+        call("dream_conv1x1_wgrad_pre_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), m, cin, cout, int(dy.shape[3]), ptr(pre_ab), stream())
+    else:
+        call("dream_conv1x1_wgrad_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), m, cin, cout, int(dy.shape[3]), stream())
     return dw
 
 
@@ -718,6 +722,108 @@ def bn_train_bwd(x_nhwc, dy, y_act, gamma, mean, invstd, relu=True, want_g=False
     call("dream_bn_train_bwd_nhwc_f32", ptr(x), ptr(_f32(dy)), ptr(y_act), ptr(gamma.detach()), ptr(mean), ptr(invstd), ptr(dx),
          ptr(g), ptr(dgamma), ptr(dbeta), ptr(ws), npix, c, 1 if relu else 0, stream())
     return dx, g, dgamma, dbeta
+
+
+# ---- round 4: train-mode BatchNorm without its separate passes (csrc/bn.hip "round 4", csrc/gemm1x1.hip PRE / EPI) -----------------
+def bn_counter_buffer(device, words=16384):
+    """Zero 32-bit words for the "last arriver finishes" tickets (every launch leaves its words zero again).  One buffer per
+    model replica; each BatchNorm call site takes its own slice (bn_counter_slice), so launches on different streams never share."""
+    return torch.zeros((int(words),), dtype=torch.int32, device=device)
+
+
+def _bn_args(bn):
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return (ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
+            float(bn.eps), float(momentum))
+
+
+def _bn_outputs(c, device):
+    ab = torch.empty((2, c), dtype=torch.float32, device=device)
+    mean = torch.empty((c,), dtype=torch.float32, device=device)
+    return ab, mean, torch.empty_like(mean)
+
+
+def _bn_bump(bn):
+    for t in (bn.running_mean, bn.running_var, bn.num_batches_tracked):
+        bump_version(t)
+
+
+def bn_stats(z_nhwc, bn, counters):
+    """Batch statistics of z in ONE launch -> (ab [2,C], save_mean, save_invstd); updates bn's running statistics."""
+    z = _f32(z_nhwc)
+    c = int(z.shape[-1])
+    ab, mean, invstd = _bn_outputs(c, z.device)
+    ws = _workspace(_hip.lib().dream_bn_stats_workspace(c), z.device)
+    call("dream_bn_stats_nhwc_f32", ptr(z), *_bn_args(bn), ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(counters), z.numel() // c, c,
+         stream())
+    _bn_bump(bn)
+    return ab, mean, invstd
+
+
+def bn_apply_ab(z_nhwc, ab, residual=None, relu=True):
+    z = _f32(z_nhwc)
+    c = int(z.shape[-1])
+    y = torch.empty_like(z)
+    call("dream_bn_apply_ab_nhwc_f32", ptr(z), ptr(ab), ptr(residual), ptr(y), z.numel() // c, c, 1 if relu else 0, stream())
+    return y
+
+
+def _mask_mode(y_act, ab):
+    return 1 if y_act is not None else (2 if ab is not None else 0)
+
+
+def bn_bwd_stats(z_nhwc, dy, mean, invstd, counters, y_act=None, ab=None):
+    """-> (dgamma, dbeta) in ONE launch; the ReLU mask from ``y_act`` (> 0) or recomputed from (z, ab), none when both are None."""
+    z = _f32(z_nhwc)
+    c = int(z.shape[-1])
+    dgamma = torch.empty((c,), dtype=torch.float32, device=z.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace(_hip.lib().dream_bn_stats_workspace(c), z.device)
+    call("dream_bn_bwd_stats_nhwc_f32", ptr(z), ptr(_f32(dy)), ptr(y_act), ptr(ab), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
+         ptr(ws), ptr(counters), z.numel() // c, c, _mask_mode(y_act, ab), stream())
+    return dgamma, dbeta
+
+
+def bn_bwd_apply(z_nhwc, dy, gamma, mean, invstd, dgamma, dbeta, y_act=None, ab=None, want_g=False):
+    """-> (dz, g or None): dz = gamma invstd (g - dbeta / N - xhat dgamma / N), g = dy masked as in bn_bwd_stats."""
+    z = _f32(z_nhwc)
+    c = int(z.shape[-1])
+    dz = torch.empty_like(z)
+    g = torch.empty_like(z) if want_g else None
+    call("dream_bn_bwd_apply_nhwc_f32", ptr(z), ptr(_f32(dy)), ptr(y_act), ptr(ab), ptr(gamma.detach()), ptr(mean), ptr(invstd),
+         ptr(dgamma), ptr(dbeta), ptr(dz), ptr(g), z.numel() // c, c, _mask_mode(y_act, ab), stream())
+    return dz, g
+
+
+def conv1x1_bn(x_nhwc, packed, cout, bn, counters, pre_ab=None, shift=None):
+    """[BatchNorm + ReLU of the producer, applied while loading: pre_ab ->] 1x1 conv -> (z, ab, save_mean, save_invstd) with the
+    batch statistics of z summed in the GEMM's epilogue and finished inside the launch; updates bn's running statistics."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    m = b * h * w
+    z = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    ab, mean, invstd = _bn_outputs(cout, x.device)
+    ws = _workspace(_hip.lib().dream_conv1x1_bn_workspace(m, cout), x.device)
+    call("dream_conv1x1_bnstats_nhwc_f32", ptr(x), ptr(packed), ptr(shift), ptr(pre_ab), ptr(z), m, cin, cout, cin, *_bn_args(bn),
+         ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(counters), stream())
+    _bn_bump(bn)
+    return z, ab, mean, invstd
+
+
+def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counters):
+    """Data gradient of a 1x1 conv whose input was relu(BN(z)): -> (g = (dy . w) masked, dgamma, dbeta of that BN)."""
+    dy = _f32(dy_nhwc)
+    b, h, w, k = (int(v) for v in dy.shape)
+    m = b * h * w
+    if tuple(z_nhwc.shape) != (b, h, w, cin):
+        raise RuntimeError("conv1x1_bwd_bnmask: z shape %s != %s" % (tuple(z_nhwc.shape), (b, h, w, cin)))
+    g = torch.empty((b, h, w, cin), dtype=torch.float32, device=dy.device)
+    dgamma = torch.empty((cin,), dtype=torch.float32, device=dy.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace(_hip.lib().dream_conv1x1_bn_workspace(m, cin), dy.device)
+    call("dream_conv1x1_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_t), ptr(g), m, k, cin, k, ptr(_f32(z_nhwc)), ptr(ab), ptr(mean),
+         ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(counters), stream())
+    return g, dgamma, dbeta
 
 
 def channel_sum(x_nhwc):

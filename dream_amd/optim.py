@@ -119,6 +119,9 @@ class HipAdam(_FlatStepMixin, torch.optim.Optimizer):
         moment buffers are the source of truth of the one-launch step) is dropped so that the next step adopts them."""
         super().load_state_dict(state_dict)
         self._plan = None
+        dp = getattr(self, "_dp", None)
+        if dp is not None:
+            dp._opt_state.clear()                          # the replicas' moment buffers belonged to the state just replaced
 
     def _adopt_moments(self, plan, params, offs):
         """Build the flat moment buffers of ``plan``; per-parameter state that already exists (a resumed optimizer:

@@ -386,6 +386,50 @@ int dream_bn_train_bwd_nhwc_f32(const float *x, const float *dy, const float *y_
                                 float *dgamma, float *dbeta, void *workspace, size_t npix, int C, int relu,
                                 void *stream);
 int dream_channel_sum_nhwc_f32(const float *x, float *out, void *workspace, size_t npix, int C, void *stream);
+/* ---- round 4: the same train-mode BatchNorm without its separate passes (torchvision Bottleneck conv -> BN -> ReLU chains,
+ * dream/models.py:22-32 via network.py:328-364).  Statistics are published as the affine map y = ab[0][c] * z + ab[1][c]
+ * (ab[0] = gamma * invstd, ab[1] = beta - mean * ab[0]; every kernel evaluates BN + ReLU as max(fmaf(a, z, b), 0)) and are
+ * FINISHED INSIDE the launch that sums them (the last workgroup / wavefront to arrive per 64-channel slab adds the partial rows in
+ * a fixed order: deterministic, no finalize launch).  `counters`: dream_bn_stats_counters(C) zero 32-bit words, zero again when
+ * the launch ends; a buffer must not be shared by launches that may run concurrently.  workspace: dream_bn_stats_workspace(C)
+ * bytes (dream_conv1x1_bn_workspace(M, N) for the GEMM forms). */
+size_t dream_bn_stats_workspace(int C);
+int dream_bn_stats_counters(int C);
+/* batch statistics of z [npix][C] in one launch (+ running statistics update as nn.BatchNorm2d in train mode) */
+int dream_bn_stats_nhwc_f32(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                            long long *num_batches_tracked, float eps, float momentum, float *out_ab, float *save_mean,
+                            float *save_invstd, void *workspace, unsigned *counters, size_t npix, int C, void *stream);
+/* y = ab[0] z + ab[1] (+ residual) (ReLU) */
+int dream_bn_apply_ab_nhwc_f32(const float *z, const float *ab, const float *residual, float *y, size_t npix, int C, int relu,
+                               void *stream);
+/* backward: g = dy masked (mask 0: as is; 1: y_act > 0; 2: ab[0] z + ab[1] > 0, the ReLU mask recomputed from the BN input);
+ * dbeta = sum g, dgamma = sum g * xhat in one launch; then dz = gamma * invstd * (g - dbeta / N - xhat * dgamma / N),
+ * g_out (optional) = g */
+int dream_bn_bwd_stats_nhwc_f32(const float *z, const float *dy, const float *y_act, const float *ab, const float *save_mean,
+                                const float *save_invstd, float *dgamma, float *dbeta, void *workspace, unsigned *counters,
+                                size_t npix, int C, int mask, void *stream);
+int dream_bn_bwd_apply_nhwc_f32(const float *z, const float *dy, const float *y_act, const float *ab, const float *gamma,
+                                const float *save_mean, const float *save_invstd, const float *dgamma, const float *dbeta,
+                                float *dz, float *g_out, size_t npix, int C, int mask, void *stream);
+/* 1x1 conv (dream_conv1x1_nhwc_f32's GEMM) with the BatchNorm on either side folded in:
+ *   y = relu(pre_ab[0][k] x + pre_ab[1][k]) . w^T + shift   (pre_ab null: y = x . w^T + shift)   -- the previous BN + ReLU applied
+ *   in the loader, its output never stored; and the batch statistics of y (for the BN that follows) summed in the epilogue and
+ *   finished in the launch: out_ab / save_mean / save_invstd / running statistics as dream_bn_stats_nhwc_f32. */
+size_t dream_conv1x1_bn_workspace(long M, int N);
+int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_packed, const float *shift, const float *pre_ab, float *y,
+                                   long M, int K, int N, int x_stride, const float *gamma, const float *beta,
+                                   float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
+                                   float momentum, float *out_ab, float *save_mean, float *save_invstd, void *workspace,
+                                   unsigned *counters, void *stream);
+/* data gradient of a 1x1 conv whose input was relu(BN(z)) (never stored): g_out = (dy . w) * [ab[0] z + ab[1] > 0] and, finished in
+ * the launch, dbeta = sum g, dgamma = sum g * (z - mean) * invstd of that BN.  w_packed_t: mode-1 packing, K = channels of dy,
+ * N = channels of z. */
+int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, float *g_out, long M, int K, int N, int dy_stride,
+                                      const float *z, const float *ab, const float *mean, const float *invstd, float *dgamma,
+                                      float *dbeta, void *workspace, unsigned *counters, void *stream);
+/* weight gradient of a 1x1 conv whose input was relu(pre_ab[0][ci] x + pre_ab[1][ci]) (x = the BN input) */
+int dream_conv1x1_wgrad_pre_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout,
+                                     int Cdy, const float *pre_ab, void *stream);
 /* MaxPool2d(3,2,1) backward (ATen first-max semantics; overlapping windows accumulate) */
 int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
 /* dst += src (gradient accumulation where two branches meet) */

@@ -121,6 +121,18 @@ inline int lane_up(int v, int d) { return __shfl_up(v, d, 64); }
 inline unsigned long long wave_ballot(int pred) { return __ballot(pred); }
 inline int popcount64(unsigned long long v) { return __popcll(v); }
 inline bool wave_all(int pred) { return __ballot(pred) == __ballot(1); }
+// "last arriver finishes" (see the device header): the emulator's workgroups run on several OS threads
+inline void grid_release() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void grid_acquire() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline int wave_bcast0(int v) { return emu_exchange(v, 0); }
+inline unsigned grid_ticket(unsigned *counter) {
+    unsigned t = 0;
+    if (emu::lane() == 0) t = __atomic_fetch_add(counter, 1u, __ATOMIC_SEQ_CST);
+    return (unsigned)emu_exchange((int)t, 0);
+}
+inline void grid_counter_reset(unsigned *counter) {
+    if (emu::lane() == 0) __atomic_store_n(counter, 0u, __ATOMIC_SEQ_CST);
+}
 inline double dmul(double a, double b) { return a * b; }
 inline double dadd(double a, double b) { return a + b; }
 inline double ddiv(double a, double b) { return a / b; }

@@ -565,9 +565,11 @@ def check_train_steps(dev, opt, steps=3):
                 assert abs(float(p.grad.double().norm()) - ref) <= 1e-3 * max(ref, 1e-9), key
     # The first loss is a pure forward pass: 1e-4 whatever the optimizer.  Later losses under Adam follow parameters whose update
     # is lr x sign-like for elements with round-off-level gradients (see below): measured 1.0e-4 on the third loss with F(4x4,3x3)
-    # on every layer it serves, 1e-6 with F(2x2); held to 5e-4.  SGD: 1e-4 throughout.
+    # on every layer it serves, 1e-6 with F(2x2): held to 5e-4 ONLY while the tests force F(4x4) onto this 2-frame batch
+    # (ops.set_winograd_tile(4)); by the layer-wise rule (F(2x2) at this size) and under SGD: 1e-4 throughout.
     assert np.allclose(losses[:1], g["losses"][:1], rtol=1e-4), (losses, g["losses"])
-    assert np.allclose(losses, g["losses"][:steps], rtol=5e-4 if opt == "adam" else 1e-4), (losses, g["losses"])
+    forced4 = ops._WINOGRAD_TILE_FORCED == 4
+    assert np.allclose(losses, g["losses"][:steps], rtol=5e-4 if (opt == "adam" and forced4) else 1e-4), (losses, g["losses"], forced4)
     if steps == 3:
         # Updated parameters.  SGD: the update is lr x gradient, held tight.  Adam: the update is lr x m / (sqrt(v) + eps) --
         # a sign flip of a gradient element at round-off level (two correct fp32 convolution algorithms differ there) moves
@@ -1053,3 +1055,119 @@ def check_wgrad(dev, B, H, W, Cin, Cout, k=3, stride=1, seed=0):
     dw, db = ops.conv2d_wgrad(to(dev, _nhwc(x)), to(dev, _nhwc(dy)), Cout, Cin, k, stride, want_bias=True)
     assert float((dw.cpu() - w.grad).abs().max()) <= tol(w.grad.numpy()), (B, H, W, Cin, Cout, k, stride)
     assert float((db.cpu() - dy.sum((0, 2, 3))).abs().max()) <= tol(dy.sum((0, 2, 3)).numpy())
+
+
+def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
+    """Round 4: train-mode BatchNorm without its separate passes (csrc/bn.hip "round 4", csrc/gemm1x1.hip PRE / EPI) against
+    torch's BatchNorm2d / conv2d / autograd on CPU: statistics finished inside the launch (stand-alone and in the GEMM epilogue),
+    BN + ReLU applied by the consumer's loader, the backward reductions in the data-gradient epilogue, the ticket words left zero."""
+    def nchw(t):
+        return t.permute(0, 3, 1, 2)
+
+    def make_bn(C):
+        bn = torch.nn.BatchNorm2d(C)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0.0, 0.5)
+        twin = torch.nn.BatchNorm2d(C)
+        twin.load_state_dict(bn.state_dict())
+        return bn, (twin.to(dev) if dev != "cpu" else twin)
+
+    torch.manual_seed(11)
+    # ---- stand-alone: statistics in one launch, apply from (a, b), backward with the three mask sources ------------------------
+    for (B, C, H, W, relu, res) in [(2, 64, 5, 7, True, True), (3, 256, 4, 4, True, False), (2, 2048, 3, 3, False, False),
+                                    (1, 48, 6, 5, True, False), (3, 128, 33, 41, True, False)]:
+        bn, bn2 = make_bn(C)
+        ctr = to(dev, torch.zeros(64, dtype=torch.int32))
+        x = (torch.randn(B, C, H, W) * 1.5 + 0.3).requires_grad_()
+        r = torch.randn(B, C, H, W) if res else None
+        y_ref = bn(x)
+        if res:
+            y_ref = y_ref + r
+        if relu:
+            y_ref = y_ref.relu()
+        dy = torch.randn_like(y_ref)
+        y_ref.backward(dy)
+        z = to(dev, _nhwc(x.detach()))
+        versions = [t._version for t in (bn2.running_mean, bn2.running_var, bn2.num_batches_tracked)]
+        ab, mean, invstd = ops.bn_stats(z, bn2, ctr)
+        assert all(t._version > v for t, v in zip((bn2.running_mean, bn2.running_var, bn2.num_batches_tracked), versions))
+        y = ops.bn_apply_ab(z, ab, to(dev, _nhwc(r)) if res else None, relu)
+        assert float((nchw(y.cpu()) - y_ref).abs().max()) < 1e-5
+        assert float((bn.running_mean - bn2.running_mean.cpu()).abs().max()) < 1e-6
+        assert float((bn.running_var - bn2.running_var.cpu()).abs().max()) < 1e-5
+        assert int(bn2.num_batches_tracked.item()) == 1
+        # the published affine map is BatchNorm: a = gamma * invstd, b = beta - mean * a
+        assert float((ab[0].cpu() - bn.weight.detach() * invstd.cpu()).abs().max()) < 1e-6
+        sources = [dict(y_act=y)] if relu else [dict()]
+        if relu and not res:
+            sources.append(dict(ab=ab))             # mask recomputed from the BatchNorm input
+        for src in sources:
+            dgam, dbet = ops.bn_bwd_stats(z, to(dev, _nhwc(dy)), mean, invstd, ctr, **src)
+            dx, g = ops.bn_bwd_apply(z, to(dev, _nhwc(dy)), bn2.weight, mean, invstd, dgam, dbet, want_g=True, **src)
+            assert float((nchw(dx.cpu()) - x.grad).abs().max()) < 1e-5, (C, src.keys())
+            assert float((dgam.cpu() - bn.weight.grad).abs().max()) < 1e-4 and float((dbet.cpu() - bn.bias.grad).abs().max()) < 1e-4
+            gm = dy * (y_ref > 0) if relu else dy
+            if "ab" in src:                          # a value within round-off of zero may flip: none here, and never silently many
+                assert float((nchw(g.cpu()) != gm).float().mean()) < 1e-4
+            else:
+                assert float((nchw(g.cpu()) - gm).abs().max()) == 0.0
+        assert int(ctr.cpu().abs().sum()) == 0       # every launch leaves its ticket words zero
+    # ---- the 1x1 conv with the BatchNorm on either side folded in --------------------------------------------------------------------
+    for (B, H, W, Cin, Cout, with_pre, with_bias) in [(2, 9, 11, 64, 96, True, False), (1, 13, 13, 128, 256, True, True),
+                                                      (3, 5, 5, 256, 64, False, False), (2, 7, 6, 32, 160, True, False)]:
+        bn_p, bn_p2 = make_bn(Cin)
+        bn_n, bn_n2 = make_bn(Cout)
+        zp = (torch.randn(B, Cin, H, W) + 0.2).requires_grad_()
+        w = (torch.randn(Cout, Cin, 1, 1) * 0.1).requires_grad_()
+        bias = torch.randn(Cout) * 0.1 if with_bias else None
+        xin = bn_p(zp).relu() if with_pre else zp
+        z_ref = F.conv2d(xin, w, bias)
+        y_ref = bn_n(z_ref).relu()
+        dyo = torch.randn_like(y_ref)
+        y_ref.backward(dyo)
+        ctr = to(dev, torch.zeros(64, dtype=torch.int32))
+        zp_d = to(dev, _nhwc(zp.detach()))
+        pre_ab = pre_mean = pre_invstd = None
+        if with_pre:
+            pre_ab, pre_mean, pre_invstd = ops.bn_stats(zp_d, bn_p2, ctr)
+        packed, rows = ops.pack_conv1x1_weight(to(dev, w.detach()), 0)
+        packed_t, rows_t = ops.pack_conv1x1_weight(to(dev, w.detach()), 1)
+        for ks in ksplits:
+            if ks and Cin % (32 * ks):
+                continue
+            bn_k, bn_k2 = make_bn(Cout)
+            bn_k2.load_state_dict({k_: v.to(bn_k2.weight.device) for k_, v in bn_n.state_dict().items()})
+            bn_k2.running_mean.zero_(); bn_k2.running_var.fill_(1.0); bn_k2.num_batches_tracked.zero_()
+            _hip.call("dream_conv1x1_set_ksplit", ks)
+            try:
+                z, ab, mean, invstd = ops.conv1x1_bn(zp_d, packed, rows, bn_k2, ctr, pre_ab=pre_ab, shift=to(dev, bias) if with_bias else None)
+            finally:
+                _hip.call("dream_conv1x1_set_ksplit", 0)
+            assert float((nchw(z.cpu()) - z_ref.detach()).abs().max()) <= tol(z_ref.detach().numpy()), (Cin, Cout, ks)
+            y = ops.bn_apply_ab(z, ab, None, True)
+            assert float((nchw(y.cpu()) - y_ref.detach()).abs().max()) < 2e-5, (Cin, Cout, ks)
+            assert float((bn_n.running_mean - bn_k2.running_mean.cpu()).abs().max()) < 1e-5
+            assert float((bn_n.running_var - bn_k2.running_var.cpu()).abs().max()) < 1e-5
+            assert int(bn_k2.num_batches_tracked.item()) == 1 and int(ctr.cpu().abs().sum()) == 0
+        # backward of the following BatchNorm from the stored activation, then this conv's data gradient with the PREVIOUS BatchNorm's
+        # ReLU mask and reductions in its epilogue, and the weight gradient through the loader-side BatchNorm
+        dgam, dbet = ops.bn_bwd_stats(z, to(dev, _nhwc(dyo)), mean, invstd, ctr, y_act=y)
+        dz, _ = ops.bn_bwd_apply(z, to(dev, _nhwc(dyo)), bn_n2.weight, mean, invstd, dgam, dbet, y_act=y)
+        assert float((dgam.cpu() - bn_n.weight.grad).abs().max()) < 2e-4 * max(1.0, float(bn_n.weight.grad.abs().max()))
+        dw = ops.conv1x1_wgrad(zp_d, dz, Cout, Cin, pre_ab=pre_ab) if (with_pre and Cin % 64 == 0) else None
+        if dw is not None:
+            assert float((dw.cpu() - w.grad).abs().max()) <= 3 * tol(w.grad.numpy()), (Cin, Cout)
+        if with_pre:
+            for ks in ksplits:
+                if ks and Cout % (32 * ks):
+                    continue
+                _hip.call("dream_conv1x1_set_ksplit", ks)
+                try:
+                    gm, dg_p, db_p = ops.conv1x1_bwd_bnmask(dz, packed_t, Cin, zp_d, pre_ab, pre_mean, pre_invstd, ctr)
+                finally:
+                    _hip.call("dream_conv1x1_set_ksplit", 0)
+                assert float((dg_p.cpu() - bn_p.weight.grad).abs().max()) < 3e-4 * max(1.0, float(bn_p.weight.grad.abs().max())), (Cin, ks)
+                assert float((db_p.cpu() - bn_p.bias.grad).abs().max()) < 3e-4 * max(1.0, float(bn_p.bias.grad.abs().max()))
+                dzp, _ = ops.bn_bwd_apply(zp_d, gm, bn_p2.weight, pre_mean, pre_invstd, dg_p, db_p)
+                assert float((nchw(dzp.cpu()) - zp.grad).abs().max()) <= 3 * tol(zp.grad.numpy()), (Cin, Cout, ks)
+                assert int(ctr.cpu().abs().sum()) == 0

@@ -207,3 +207,124 @@ def test_adam_resumes_from_a_saved_state_bit_for_bit(emu):
     of = HipAdam(list(fresh.parameters()), lr=1e-2)                   # the bug of round 2: moments and step restart from zero
     step(fresh, of, 2)
     assert not torch.equal(next(iter(fresh.parameters())), next(iter(a.parameters())))
+
+
+# ---- gradients that outlive a step (round-3 advisor findings) -----------------------------------------------------------------
+def _grad_dict(net):
+    return {k: p.grad.clone() for k, p in net.model.named_parameters()}
+
+
+def test_gradient_accumulation_and_zero_grad_in_place_do_not_alias_the_flat_buffer(emu, two_devices):
+    """AccumulateGrad keeps the views of the persistent flat gradient buffer as p.grad; a second backward without
+    zero_grad(set_to_none=True) used to overwrite them in place and then add the buffer to itself (2 g2 instead of g1 + g2; exactly
+    2x after zero_grad(set_to_none=False))."""
+    xa = torch.from_numpy(cases.image_batch(2, 32, 32, seed=11))
+    ta = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=11))
+    xb = torch.from_numpy(cases.image_batch(2, 32, 32, seed=12))
+    tb = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=12))
+    net = _net("vgg_q", lr=1e-5, opt="sgd")
+    net.enable_training()
+    net.optimizer.zero_grad()
+    net.loss([xa], ta).backward()
+    ga = _grad_dict(net)
+    net.optimizer.zero_grad()
+    net.loss([xb], tb).backward()
+    gb = _grad_dict(net)
+    # (1) zero_grad(set_to_none=False): p.grad stays a (zeroed) view of the buffer the next backward writes
+    net.optimizer.zero_grad(set_to_none=False)
+    net.loss([xa], ta).backward()
+    for k, g in _grad_dict(net).items():
+        assert torch.equal(g, ga[k]), k
+    # (2) accumulation: two backwards, no zero_grad in between
+    net.optimizer.zero_grad()
+    net.loss([xa], ta).backward()
+    net.loss([xb], tb).backward()
+    for k, g in _grad_dict(net).items():
+        assert torch.equal(g, ga[k] + gb[k]), k
+    # the optimizer still sees one contiguous gradient buffer, but it is not the all-reduced one: the replicas must not replay
+    # the step on their own copy (which holds g_b only) -- they are refreshed from the master instead
+    dp = net.model
+    steps, copies = dp.stats["replica_steps"], dp.stats["param_copies"]
+    net.optimizer.step()
+    assert dp.stats["replica_steps"] == steps
+    net.enable_evaluation()
+    with torch.no_grad():
+        net.model(xa)
+    assert dp.stats["param_copies"] == copies + 1
+    assert torch.equal(dp._replicas[0]._dream_flat["params"], dp.module._dream_flat["params"])
+
+
+def test_gradient_edits_between_backward_and_step_reach_the_replicas(emu, two_devices):
+    """clip_grad_norm_ (or any in-place edit of p.grad) happens on the master's buffer only: step_replicas must not replay the
+    un-clipped update on the replicas and stamp them as in sync."""
+    x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=13))
+    t = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=13))
+    net = _net("vgg_q", lr=1e-2, opt="sgd")
+    net.enable_training()
+    dp = net.model
+    net.optimizer.zero_grad()
+    net.loss([x], t).backward()
+    total = torch.nn.utils.clip_grad_norm_(list(net.model.parameters()), max_norm=1e-3)
+    assert float(total) > 1e-3                                         # the clip really scales
+    steps = dp.stats["replica_steps"]
+    net.optimizer.step()
+    assert dp.stats["replica_steps"] == steps                          # not replayed ...
+    copies = dp.stats["param_copies"]
+    net.optimizer.zero_grad()
+    net.loss([x], t).backward()                                        # ... and repaired by the flat copy of the next forward
+    assert dp.stats["param_copies"] == copies + 1
+    assert torch.equal(dp._replicas[0]._dream_flat["params"], dp.module._dream_flat["params"])
+    # an untouched step is replayed again
+    net.optimizer.step()
+    assert dp.stats["replica_steps"] == steps + 1
+    assert torch.equal(dp._replicas[0]._dream_flat["params"], dp.module._dream_flat["params"])
+
+
+def test_adam_load_state_dict_drops_the_replicas_moments(emu, two_devices):
+    x = torch.from_numpy(cases.image_batch(2, 32, 32, seed=14))
+    t = torch.from_numpy(cases.target_batch(2, 7, (8, 8), in_wh=(32, 32), seed=14))
+    net = _net("vgg_q", lr=1e-4, opt="adam")
+    net.enable_training()
+    net.train([x], t)
+    saved = copy.deepcopy(net.optimizer.state_dict())
+    net.train([x], t)
+    assert net.model._opt_state
+    net.optimizer.load_state_dict(saved)                               # back to the moments after step 1
+    assert not net.model._opt_state
+    net.train([x], t)
+    rep = net.model._replicas[0]
+    assert torch.equal(rep._dream_flat["params"], net.model.module._dream_flat["params"])
+    m_master = net.optimizer._plan["moments"][0]
+    assert torch.equal(net.model._opt_state[1][0], m_master)
+
+
+def test_eight_replicas_uneven_last_chunk_resnet(emu, monkeypatch):
+    """The shape of the first 8-GPU run: resnet_h, 12 frames over 8 devices (``Tensor.chunk`` gives six chunks of 2 -- the last two
+    devices idle, as nn.DataParallel.scatter), then 8 frames over 8.  Inference equals the single-device result bit for bit and in
+    order; a training step runs ONE all-reduce over the participating replicas and leaves them identical."""
+    monkeypatch.setenv("DREAM_DP_EMULATED_DEVICES", "8")
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    net = pc.build_network("resnet_h", "cpu", weights=wts, optimizer="sgd", lr=1e-6, in_res=(32, 32))
+    net.enable_evaluation()
+    x12 = torch.from_numpy(cases.image_batch(12, 32, 32, seed=21))
+    with torch.no_grad():
+        maps, kps = net.inference(x12)
+    dp = net.model
+    assert len(dp.devices()) == 8 and len(x12.chunk(8)) == 6 and len(dp._replicas) == 5
+    os.environ["DREAM_DP_EMULATED_DEVICES"] = "0"
+    single = pc.build_network("resnet_h", "cpu", weights=wts, optimizer="sgd", lr=1e-6, in_res=(32, 32))
+    single.enable_evaluation()
+    with torch.no_grad():
+        maps1, kps1 = single.inference(x12)
+    assert torch.equal(maps, maps1) and torch.equal(kps, kps1) and kps.shape == (12, 7, 2)
+    os.environ["DREAM_DP_EMULATED_DEVICES"] = "8"
+    reduced = []
+    real = ops.allreduce_sum_
+    monkeypatch.setattr(ops, "allreduce_sum_", lambda flats: (reduced.append(len(flats)), real(flats))[1])
+    net.enable_training()
+    x8 = torch.from_numpy(cases.image_batch(8, 32, 32, seed=22))
+    t8 = torch.from_numpy(cases.target_batch(8, 7, tuple(net.trained_net_output_resolution()[::-1]), in_wh=(32, 32), seed=22))
+    loss = net.train([x8], t8).item()
+    assert np.isfinite(loss) and reduced == [8] and len(dp._replicas) == 7 and dp.stats["replica_steps"] == 7
+    for rep in dp._replicas:
+        assert torch.equal(rep._dream_flat["params"], dp.module._dream_flat["params"])

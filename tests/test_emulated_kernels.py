@@ -205,6 +205,18 @@ def test_resnet_h_train_step(emu):
     pc.check_resnet_train_step("cpu", "resnet_h", (2, 64, 64))
 
 
+def test_bn_fused_ops(emu):
+    """Round 4: BatchNorm statistics finished inside the producing launch, BN + ReLU in the consumer's loader, backward reductions
+    in the data-gradient epilogue (csrc/bn.hip, csrc/gemm1x1.hip)."""
+    pc.check_bn_fused_ops("cpu")
+
+
+def test_resnet_h_train_step_three_launch_batchnorm(emu, monkeypatch):
+    """The round-1..3 BatchNorm kernels (DREAM_BN_FUSION=0) stay selectable and correct."""
+    monkeypatch.setenv("DREAM_BN_FUSION", "0")
+    pc.check_resnet_train_step("cpu", "resnet_h", (2, 64, 64))
+
+
 def test_split_precision_conv(emu):
     for v in range(6):
         emu.dream_conv_f16x3_set_variant(v)

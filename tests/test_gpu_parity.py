@@ -157,7 +157,44 @@ def test_resnet_train_step_reference_golden(case):
     print("resnet train golden", case, res)
 
 
+def test_bn_fused_ops():
+    """Round 4: BatchNorm statistics finished inside the producing launch ("last arriver finishes" across the eight XCDs), BN + ReLU
+    in the consumer's loader, the backward reductions in the data-gradient epilogue."""
+    pc.check_bn_fused_ops(DEV)
+
+
+def test_bn_fused_statistics_are_deterministic_and_tickets_rearm():
+    """The in-launch finalisation sums the partial rows in a fixed order: repeated launches on one ticket buffer (which every launch
+    must leave zero) give the same bits, on a tensor large enough for every XCD to contribute partial rows."""
+    torch.manual_seed(5)
+    bn = torch.nn.BatchNorm2d(256).to(DEV)
+    z = torch.randn(16, 25, 25, 256, device=DEV) * 2 + 0.5
+    ctr = torch.zeros(8, dtype=torch.int32, device=DEV)
+    outs = [ops.bn_stats(z, bn, ctr) for _ in range(5)]
+    assert int(ctr.abs().sum()) == 0
+    for o in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+    ref = z.double().mean((0, 1, 2))
+    assert float((outs[0][1].double() - ref).abs().max()) < 1e-6
+    w = torch.randn(1024, 256, 1, 1, device=DEV) * 0.05
+    packed, rows = ops.pack_conv1x1_weight(w, 0)
+    bn2 = torch.nn.BatchNorm2d(1024).to(DEV)
+    ctr2 = torch.zeros(16, dtype=torch.int32, device=DEV)
+    runs = [ops.conv1x1_bn(z, packed, rows, bn2, ctr2, pre_ab=outs[0][0]) for _ in range(5)]
+    assert int(ctr2.abs().sum()) == 0
+    for r in runs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(r, runs[0]))
+    zz = runs[0][0].double()
+    assert float((runs[0][2].double() - zz.mean((0, 1, 2))).abs().max()) < 1e-5 * float(zz.abs().max())
+
+
 def test_resnet_h_train_step():
+    pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
+
+
+def test_resnet_h_train_step_three_launch_batchnorm(monkeypatch):
+    """DREAM_BN_FUSION=0: the BatchNorm kernels of rounds 1-3 stay selectable (A/B runs) and correct."""
+    monkeypatch.setenv("DREAM_BN_FUSION", "0")
     pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
 
 
@@ -758,6 +795,42 @@ def test_single_process_data_parallel_two_replicas_on_one_gpu():
     torch.cuda.synchronize()
     for a, b in zip(dp.model.module.parameters(), dp.model._replicas[0].parameters()):
         assert torch.equal(a, b)
+
+
+def test_single_process_data_parallel_on_two_physical_gpus():
+    """gpu_ids = [0, 1] on a node with more than one MI355X (skipped on the one-GPU test box, so that the first multi-GPU driver
+    run is a TEST of the never-executed parts -- ncclCommInitAll over distinct devices, peer scatter / gather, one capture thread
+    per device -- rather than a discovery): inference equals the one-GPU result bit for bit and in order, two SGD steps equal the
+    one-GPU steps on the whole batch, the exchange is RCCL, the replicas stay identical without a parameter copy."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    x = torch.from_numpy(cases.image_batch(6, 64, 96, seed=37)).to(DEV)
+    t = torch.from_numpy(cases.target_batch(6, 7, (24, 16), in_wh=(96, 64), seed=37)).to(DEV)
+    dev0 = torch.cuda.current_device()
+    ids = [dev0, (dev0 + 1) % torch.cuda.device_count()]
+    assert ops.allreduce_uses_rccl(ids)
+    dp, one = _dp_network("vgg_q", ids, "sgd", 1e-4), _dp_network("vgg_q", [dev0], "sgd", 1e-4)
+    dp.enable_evaluation()
+    one.enable_evaluation()
+    with torch.no_grad():
+        m2, k2 = dp.inference(x)
+        m1, k1 = one.inference(x)
+    devs = dp.model.devices()
+    assert [d.index for d in devs] == ids and len(dp.model._replicas) == 1 and len(one.model.devices()) == 1
+    assert next(dp.model._replicas[0].parameters()).device == devs[1]
+    assert torch.equal(m2, m1) and torch.equal(k2, k1) and m2.device == x.device
+    dp.enable_training()
+    one.enable_training()
+    l2 = [dp.train([x], t).item() for _ in range(3)]          # eager, capture + replay, replay
+    l1 = [one.train([x], t).item() for _ in range(3)]
+    assert np.allclose(l2, l1, rtol=2e-6), (l2, l1)
+    for (k, a), (_, b) in zip(dp.model.named_parameters(), one.model.named_parameters()):
+        assert float((a - b).abs().max()) <= 1e-7 + 1e-5 * float(b.abs().max()), k
+    assert dp.model.stats["replica_steps"] == 3 and dp.model.stats["param_copies"] == 1
+    for d in devs:
+        torch.cuda.synchronize(d)
+    rep = dp.model._replicas[0]
+    assert torch.equal(rep._dream_flat["params"].to(devs[0]), dp.model.module._dream_flat["params"])
 
 
 def test_single_process_data_parallel_resnet_batchnorm_semantics():

@@ -24,7 +24,7 @@ def flops_of(name, args, out):
             x = t[0]
             cout = ints[0]
             return 2.0 * x.shape[0] * x.shape[1] * x.shape[2] * x.shape[3] * cout * 9
-        if name == "conv1x1":
+        if name in ("conv1x1", "conv1x1_bn", "conv1x1_bwd_bnmask"):
             x = t[0]
             return 2.0 * x.numel() * ints[0]
         if name == "conv1x1_wgrad":
@@ -100,7 +100,7 @@ def main():
             return out
         return timed
 
-    skip = {"round_up", "bump_version", "wgrad_winograd_pays", "new_amax", "conv1x1_applies", "conv1x1_wgrad_applies"}
+    skip = {"round_up", "bump_version", "wgrad_winograd_pays", "new_amax", "conv1x1_applies", "conv1x1_wgrad_applies", "bn_counter_buffer"}
     for name in dir(ops):
         fn = getattr(ops, name)
         if callable(fn) and getattr(fn, "__module__", None) == ops.__name__ and not name.startswith("_") and name not in skip:

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 KS = [1006, 1112, 3001, 128, 256, 143, 15, 11, 9, 16, 32, 64, 96, 48]          # 1000 + r: product code with weight-ring size r; 2001..: schedule variants
 if os.environ.get("DREAM_W4_DIAG_KS"):          # a subset of the variants: DREAM_W4_DIAG_KS=1008,128
     KS = [int(v) for v in os.environ["DREAM_W4_DIAG_KS"].split(",")]
-OUT = os.path.join(ROOT, "dream_amd", "diag")       # travels with the snapshot (git-ignored *.so)
+OUT = os.path.join(ROOT, "build", "diag")             # travels with the snapshot only while it exists: `rm -rf build/diag` after the measurement
 VARIANTS = {3001: ["-DDREAM_W4_STORE=buffer_store_f32_nt"], 2001: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 2002: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
             2003: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 2004: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
             2005: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
