@@ -57,6 +57,7 @@ _SIGNATURES = {
     "dream_bn_bwd_stats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),
     "dream_bn_bwd_apply_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),
     "dream_conv1x1_bn_workspace": (_SZ, [_c.c_long, _I]),
+    "dream_conv1x1_bn_counters": (_I, [_c.c_long, _I]),
     "dream_conv1x1_bnstats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
     "dream_conv1x1_bwd_bnmask_nhwc_f32": (_I, [_P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dream_conv1x1_wgrad_pre_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P]),

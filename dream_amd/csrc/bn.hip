@@ -12,6 +12,7 @@
 //              Bottleneck identity branch).
 #include <dream_cdna4.h>
 #include "common.h"
+#include "stat_tree.h"
 #include "../../include/dream_hip.h"
 
 namespace {
@@ -229,9 +230,9 @@ inline unsigned stream_grid(size_t n) {
 // Round 4: the same BatchNorm with fewer passes over memory and fewer launches (a ResNet-101 step at 16 frames per GPU spent 24 %
 // of its time in 656 BatchNorm launches, most of them on 10-MB tensors where a launch costs more than its traffic).
 //   * the per-channel statistics are FINISHED INSIDE the launch that sums them: workgroup = (block of pixels) x (slab of 64
-//     channels); it writes one row of fp64 partial sums for its slab, draws a ticket from the slab's counter, and the workgroup
-//     that draws the last ticket sums the rows in index order (deterministic) and writes the per-channel results -- no finalize
-//     launch, nobody spins (dream_cdna4.h: "last arriver finishes");
+//     channels); it writes one row of fp64 partial sums for its slab and arrives at the slab's two-level ticket tree
+//     (stat_tree.h): the last arriver of a group of rows adds the group, the last group adds the groups -- fixed order
+//     (deterministic), no finalize launch, no fence, nobody spins;
 //   * the forward statistics are published as the affine map  y = a z + b  (a = gamma * invstd, b = beta - mean * a), so that a
 //     consumer can apply BatchNorm + ReLU while LOADING z (gemm1x1.hip: PRE) and the normalised tensor is never written; where it
 //     must exist (Bottleneck outputs: the residual sum) ONE kernel writes it from (z, a, b);
@@ -243,26 +244,18 @@ constexpr int kStatRows = 256;        // at most this many partial rows per laun
 struct BnStatParams {
     const float *z, *dy, *y_act;      // MODE 1: dy = incoming gradient; mask 1: y_act > 0, mask 2: fmaf(a, z, b) > 0
     const float *ab;                  // [2][C] (mask 2)
-    const float *mean, *invstd;       // MODE 1: in; MODE 0: out
-    double *partials;                 // [nrows][C][2]
-    unsigned *counters;               // [C / 64]
+    const float *mean, *invstd;       // MODE 1: of the BatchNorm
+    StatTree st;                      // rows = workgroups along x
     size_t npix;
     int C, mask;
-    // MODE 0 outputs
-    const float *gamma, *beta;
-    float *running_mean, *running_var;
-    long long *nbt;
-    float eps, momentum;
-    float *out_ab, *out_mean, *out_invstd;
-    // MODE 1 outputs
-    float *dgamma, *dbeta;
+    BnFwdOut fwd;                     // MODE 0 outputs
+    float *dgamma, *dbeta;            // MODE 1 outputs
 };
 
 // MODE 0: v0 = z, v1 = z * z          MODE 1: v0 = g, v1 = g * xhat   (g = dy masked)
 template <int MODE>
 __global__ void __launch_bounds__(256) bn_stats_slab_kernel(const BnStatParams p) {
     __shared__ double sred[16 * 16 * 8];              // [pixel row][channel quad][4 channels][2]
-    __shared__ unsigned s_ticket;
     const int cq = threadIdx.x & 15, prow = threadIdx.x >> 4;
     const int slab = blockIdx.y, C4 = p.C >> 2;
     const int c4 = slab * 16 + cq;                    // this thread's channel quad
@@ -317,8 +310,9 @@ __global__ void __launch_bounds__(256) bn_stats_slab_kernel(const BnStatParams p
         sred[((prow * 16 + cq) * 4 + k) * 2 + 1] = a1[k];
     }
     __syncthreads();
+    if (threadIdx.x >= 64) return;                    // wavefront 0 publishes the workgroup's row and arrives at the tree
     if (prow == 0 && cok) {
-        double *dst = p.partials + ((size_t)blockIdx.x * p.C + (size_t)c4 * 4) * 2;
+        double *dst = p.st.rows + ((size_t)blockIdx.x * p.C + (size_t)c4 * 4) * 2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             double s0 = 0, s1 = 0;
@@ -326,66 +320,19 @@ __global__ void __launch_bounds__(256) bn_stats_slab_kernel(const BnStatParams p
                 s0 += sred[((r * 16 + cq) * 4 + k) * 2 + 0];
                 s1 += sred[((r * 16 + cq) * 4 + k) * 2 + 1];
             }
-            dst[2 * k] = s0;
-            dst[2 * k + 1] = s1;
+            coherent_store(dst + 2 * k, s0);
+            coherent_store(dst + 2 * k + 1, s1);
         }
     }
-    // the partial row was written by the first 16 lanes of wavefront 0: that wavefront publishes it and draws the ticket
-    if (threadIdx.x < 64) {
-        grid_release();
-        const unsigned t = grid_ticket(p.counters + slab);
-        if (threadIdx.x == 0) s_ticket = t;
+    double t0, t1;
+    if (!stat_tree_arrive(p.st, slab, (int)blockIdx.x, (int)threadIdx.x, &t0, &t1)) return;
+    const int c = slab * 64 + (int)threadIdx.x;
+    if (MODE == 0) {
+        bn_finish_forward(p.fwd, c, p.C, (double)p.npix, t0, t1);
+    } else if (c < p.C) {
+        p.dbeta[c] = (float)t0;
+        p.dgamma[c] = (float)t1;
     }
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    grid_acquire();
-    // last workgroup of the slab: 64 channels x 4 row slices (one per wavefront), combined through LDS in slice order
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6, c = slab * 64 + lane, nrows = (int)gridDim.x;
-    double s0 = 0, s1 = 0;
-    if (c < p.C) {
-        const double2 *src = (const double2 *)p.partials + c;
-        int r = slice;
-        for (; r + 12 < nrows; r += 16) {
-            const double2 v0 = src[(size_t)r * p.C], v1 = src[(size_t)(r + 4) * p.C];
-            const double2 v2 = src[(size_t)(r + 8) * p.C], v3 = src[(size_t)(r + 12) * p.C];
-            s0 += v0.x; s1 += v0.y;
-            s0 += v1.x; s1 += v1.y;
-            s0 += v2.x; s1 += v2.y;
-            s0 += v3.x; s1 += v3.y;
-        }
-        for (; r < nrows; r += 4) { const double2 v = src[(size_t)r * p.C]; s0 += v.x; s1 += v.y; }
-    }
-    __syncthreads();                                  // sred is reused
-    sred[(slice * 64 + lane) * 2 + 0] = s0;
-    sred[(slice * 64 + lane) * 2 + 1] = s1;
-    __syncthreads();
-    if (slice != 0) return;
-    double t0 = 0, t1 = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { t0 += sred[(k * 64 + lane) * 2 + 0]; t1 += sred[(k * 64 + lane) * 2 + 1]; }
-    if (c < p.C) {
-        if (MODE == 0) {
-            const double n = (double)p.npix, mean = t0 / n;
-            double var = t1 / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const double invstd = 1.0 / sqrt(var + (double)p.eps);
-            const float a = (float)((double)p.gamma[c] * invstd);
-            p.out_ab[c] = a;
-            p.out_ab[p.C + c] = (float)((double)p.beta[c] - mean * (double)a);
-            p.out_mean[c] = (float)mean;
-            p.out_invstd[c] = (float)invstd;
-            if (p.running_mean != nullptr) {
-                const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var, mo = (double)p.momentum;
-                p.running_mean[c] = (float)((1.0 - mo) * (double)p.running_mean[c] + mo * mean);
-                p.running_var[c] = (float)((1.0 - mo) * (double)p.running_var[c] + mo * unbiased);
-            }
-            if (c == 0 && p.nbt != nullptr) *p.nbt += 1;
-        } else {
-            p.dbeta[c] = (float)t0;
-            p.dgamma[c] = (float)t1;
-        }
-    }
-    grid_counter_reset(p.counters + slab);
 }
 
 // y = a z + b (+ residual) (ReLU) from the published affine map
@@ -512,8 +459,8 @@ extern "C" int dream_bn_train_bwd_nhwc_f32(const float *x, const float *dy, cons
 }
 
 // ---- round 4 entry points (see the kernels above) ----------------------------------------------------------------------------------
-extern "C" size_t dream_bn_stats_workspace(int C) { return (size_t)kStatRows * (size_t)C * 2 * sizeof(double); }
-extern "C" int dream_bn_stats_counters(int C) { return (C + 63) / 64; }
+extern "C" size_t dream_bn_stats_workspace(int C) { return stat_tree_doubles(kStatRows, C) * sizeof(double); }
+extern "C" int dream_bn_stats_counters(int C) { return stat_tree_counters(kStatRows, C); }
 
 static inline int host_stat_rows(size_t npix) {
     size_t nb = (npix + 127) / 128;
@@ -528,11 +475,12 @@ extern "C" int dream_bn_stats_nhwc_f32(const float *z, const float *gamma, const
     DREAM_REQUIRE(z && gamma && beta && out_ab && save_mean && save_invstd && workspace && counters, "bn_stats: null pointer");
     DREAM_REQUIRE(C > 0 && C % 4 == 0 && npix > 0, "bn_stats: unsupported C=%d", C);
     BnStatParams p = {};
-    p.z = z; p.partials = (double *)workspace; p.counters = counters; p.npix = npix; p.C = C;
-    p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var; p.nbt = num_batches_tracked;
-    p.eps = eps; p.momentum = momentum; p.out_ab = out_ab; p.out_mean = save_mean; p.out_invstd = save_invstd;
-    hipLaunchKernelGGL(bn_stats_slab_kernel<0>, dim3((unsigned)host_stat_rows(npix), (unsigned)((C + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    const int nrows = host_stat_rows(npix);
+    p.z = z; p.st = stat_tree_make(workspace, counters, nrows, C); p.npix = npix; p.C = C;
+    p.fwd.gamma = gamma; p.fwd.beta = beta; p.fwd.running_mean = running_mean; p.fwd.running_var = running_var;
+    p.fwd.nbt = num_batches_tracked; p.fwd.eps = eps; p.fwd.momentum = momentum;
+    p.fwd.ab = out_ab; p.fwd.mean = save_mean; p.fwd.invstd = save_invstd;
+    hipLaunchKernelGGL(bn_stats_slab_kernel<0>, dim3((unsigned)nrows, (unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }
@@ -556,11 +504,11 @@ extern "C" int dream_bn_bwd_stats_nhwc_f32(const float *z, const float *dy, cons
     DREAM_REQUIRE(mask == 0 || (mask == 1 && y_act) || (mask == 2 && ab), "bn_bwd_stats: mask %d without its source", mask);
     DREAM_REQUIRE(C > 0 && C % 4 == 0 && npix > 0, "bn_bwd_stats: unsupported C=%d", C);
     BnStatParams p = {};
+    const int nrows = host_stat_rows(npix);
     p.z = z; p.dy = dy; p.y_act = y_act; p.ab = ab; p.mean = save_mean; p.invstd = save_invstd;
-    p.partials = (double *)workspace; p.counters = counters; p.npix = npix; p.C = C; p.mask = mask;
+    p.st = stat_tree_make(workspace, counters, nrows, C); p.npix = npix; p.C = C; p.mask = mask;
     p.dgamma = dgamma; p.dbeta = dbeta;
-    hipLaunchKernelGGL(bn_stats_slab_kernel<1>, dim3((unsigned)host_stat_rows(npix), (unsigned)((C + 63) / 64)), dim3(256), 0,
-                       (hipStream_t)stream, p);
+    hipLaunchKernelGGL(bn_stats_slab_kernel<1>, dim3((unsigned)nrows, (unsigned)((C + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }

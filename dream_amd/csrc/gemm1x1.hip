@@ -24,6 +24,7 @@
 #include <dream_cdna4.h>
 #include "common.h"
 #include "pack_device.h"
+#include "stat_tree.h"
 #include "../../include/dream_hip.h"
 
 namespace {
@@ -44,17 +45,12 @@ struct GemmParams {
     // EPI 1: batch statistics of y (sum, sum of squares per output channel) -> scale / shift of the FOLLOWING BatchNorm
     // EPI 2: y = g * [fmaf(a, z, b) > 0] (ReLU mask recomputed from the masked BatchNorm's input z), sums of y and y * xhat
     //        -> dbeta, dgamma of that BatchNorm
-    double *st_partials;     // [nrb * KS][N][2]
-    unsigned *st_counters;   // [ncb]: zero on entry, zero again on exit
-    const float *st_gamma, *st_beta;
-    float *st_running_mean, *st_running_var;
-    long long *st_nbt;
-    float st_eps, st_momentum;
-    float *st_ab;            // EPI 1 out: [2][N]   (a = gamma * invstd, b = beta - mean * a)
-    float *st_mean, *st_invstd;       // EPI 1: out; EPI 2: in
+    StatTree st;             // one row of partial sums per 64-row block (stat_tree.h)
+    BnFwdOut st_fwd;         // EPI 1: statistics -> scale / shift of the following BatchNorm (st_fwd.mean / invstd: outputs)
     const float *st_z;       // EPI 2: [M][N]
     const float *st_zab;     // EPI 2: [2][N]
-    float *st_dgamma, *st_dbeta;      // EPI 2 out
+    const float *st_mean, *st_invstd;  // EPI 2: of the masked BatchNorm
+    float *st_dgamma, *st_dbeta;       // EPI 2 out
 };
 
 // y = relu(a * x + b), the one expression every kernel uses for a train-mode BatchNorm + ReLU (single rounding: the ReLU mask
@@ -66,29 +62,10 @@ DREAM_DEVICE f32x4 bn_relu4(f32x4 x, f32x4 a, f32x4 b) {
     return r;
 }
 
-// the last wave to arrive for a 64-channel column block sums the partial rows in index order (eight loads in flight, same
-// order whatever their number: deterministic) -> (sum v0, sum v1) of channel c in this lane
-DREAM_DEVICE void sum_stat_rows(const double *partials, int nrows, int N, int c, double *s0, double *s1) {
-    double a = 0.0, b = 0.0;
-    if (c < N) {
-        const double2 *src = (const double2 *)partials + c;
-        int r = 0;
-        for (; r + 8 <= nrows; r += 8) {
-            double2 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(r + j) * N];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { a += v[j].x; b += v[j].y; }
-        }
-        for (; r < nrows; ++r) { const double2 v = src[(size_t)r * N]; a += v.x; b += v.y; }
-    }
-    *s0 = a;
-    *s1 = b;
-}
-
 template <int KS, bool PRE = false, int EPI = 0>
 __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     __shared__ float s_part[KS > 1 ? 4 * 64 * 64 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
+    __shared__ double s_stat[(KS > 1 && EPI != 0) ? 4 * 16 * 8 : 1];      // [wave][lane & 15][4 channels][2]: the waves' sums
     const int lane = threadIdx.x & 63;
     const int wave = wave_index();
     // XCD-aware placement: workgroup b runs on XCD b % 8; give each XCD a contiguous range of wave tiles (column blocks of
@@ -176,7 +153,7 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
                     acc[m][n] = v;
                 }
             }
-        if (!live) return;
+        if (EPI == 0 && !live) return;               // (with statistics the dead waves stay for the second barrier)
     }
 
     // ---- epilogue: lane holds rows 4 (l >> 4) + r, column j = l & 15 of every block (m, n) = channels 4 j .. 4 j + 3 ----------
@@ -234,42 +211,42 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
             st0[e] += lane_xor(st0[e], 32);
             st1[e] += lane_xor(st1[e], 32);
         }
-        const int prow = KS == 1 ? rb : rb * KS + kpart, nprows = p.nrb * KS;
-        if (lg == 0 && cok) {
-            double *dst = p.st_partials + ((size_t)prow * p.N + c0) * 2;
+        if (KS > 1) {
+            // the KS waves of a tile hold disjoint row blocks: summed through LDS in wave order, wave kpart == 0 carries on
+            if (lg == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { dst[2 * e] = st0[e]; dst[2 * e + 1] = st1[e]; }
-        }
-        grid_release();
-        const unsigned ticket = grid_ticket(p.st_counters + cb);
-        if (ticket != (unsigned)(nprows - 1)) return;
-        grid_acquire();
-        const int c = cb * 64 + lane;
-        double s0, s1;
-        sum_stat_rows(p.st_partials, nprows, p.N, c, &s0, &s1);
-        if (c < p.N) {
-            if (EPI == 1) {
-                const double n = (double)p.M, mean = s0 / n;
-                double var = s1 / n - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const double invstd = 1.0 / sqrt(var + (double)p.st_eps);
-                const float a = (float)((double)p.st_gamma[c] * invstd);
-                p.st_ab[c] = a;
-                p.st_ab[p.N + c] = (float)((double)p.st_beta[c] - mean * (double)a);
-                p.st_mean[c] = (float)mean;
-                p.st_invstd[c] = (float)invstd;
-                if (p.st_running_mean != nullptr) {
-                    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var, mo = (double)p.st_momentum;
-                    p.st_running_mean[c] = (float)((1.0 - mo) * (double)p.st_running_mean[c] + mo * mean);
-                    p.st_running_var[c] = (float)((1.0 - mo) * (double)p.st_running_var[c] + mo * unbiased);
+                for (int e = 0; e < 4; ++e) { s_stat[((wave * 16 + li) * 4 + e) * 2] = st0[e]; s_stat[((wave * 16 + li) * 4 + e) * 2 + 1] = st1[e]; }
+            }
+            __syncthreads();
+            if (!live || kpart != 0) return;
+            if (lg == 0) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    double a = 0.0, b = 0.0;
+#pragma unroll
+                    for (int k = 0; k < KS; ++k) {
+                        a += s_stat[(((wave + k) * 16 + li) * 4 + e) * 2];
+                        b += s_stat[(((wave + k) * 16 + li) * 4 + e) * 2 + 1];
+                    }
+                    st0[e] = a;
+                    st1[e] = b;
                 }
-                if (c == 0 && p.st_nbt != nullptr) *p.st_nbt += 1;
-            } else {
-                p.st_dbeta[c] = (float)s0;
-                p.st_dgamma[c] = (float)s1;
             }
         }
-        grid_counter_reset(p.st_counters + cb);
+        if (lg == 0 && cok) {
+            double *dst = p.st.rows + ((size_t)rb * p.N + c0) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { coherent_store(dst + 2 * e, st0[e]); coherent_store(dst + 2 * e + 1, st1[e]); }
+        }
+        double s0, s1;
+        if (!stat_tree_arrive(p.st, cb, rb, lane, &s0, &s1)) return;
+        const int c = cb * 64 + lane;
+        if (EPI == 1) {
+            bn_finish_forward(p.st_fwd, c, p.N, (double)p.M, s0, s1);
+        } else if (c < p.N) {
+            p.st_dbeta[c] = (float)s0;
+            p.st_dgamma[c] = (float)s1;
+        }
     }
 }
 
@@ -491,7 +468,11 @@ extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, con
 // ---- the same GEMM with a train-mode BatchNorm folded in on either side (see GemmParams) ---------------------------------------
 extern "C" size_t dream_conv1x1_bn_workspace(long M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return (size_t)((M + 63) / 64) * 4 * (size_t)N * 2 * sizeof(double);       // up to K split 4: nrb * 4 partial rows
+    return stat_tree_doubles((int)((M + 63) / 64), N) * sizeof(double);
+}
+extern "C" int dream_conv1x1_bn_counters(long M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return stat_tree_counters((int)((M + 63) / 64), N);
 }
 
 // Forward of  [BatchNorm(batch stats) -> ReLU ->] conv1x1 -> (statistics of the result for the BatchNorm that follows):
@@ -499,7 +480,7 @@ extern "C" size_t dream_conv1x1_bn_workspace(long M, int N) {
 //   save_mean / save_invstd = batch statistics of y per channel (biased variance, eps inside the root), out_ab[0] = gamma * invstd,
 //   out_ab[1] = beta - mean * out_ab[0]; running statistics updated as nn.BatchNorm2d does (momentum, unbiased variance).
 // The statistics are finished inside the launch by the last wave to arrive per 64-channel block (fixed summation order:
-// deterministic).  counters: N / 64 (rounded up) zero words, left zero; workspace: dream_conv1x1_bn_workspace(M, N) bytes.
+// deterministic).  counters: dream_conv1x1_bn_counters(M, N) zero words, left zero; workspace: dream_conv1x1_bn_workspace(M, N) bytes.
 extern "C" int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_packed, const float *shift, const float *pre_ab, float *y,
                                               long M, int K, int N, int x_stride, const float *gamma, const float *beta,
                                               float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
@@ -513,10 +494,10 @@ extern "C" int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_pac
                   "conv1x1_bnstats: tensor too large for 32-bit offsets");
     GemmParams p = {};
     p.x = x; p.w = w_packed; p.shift = shift; p.y = y; p.pre_ab = pre_ab;
-    p.st_partials = (double *)workspace; p.st_counters = counters;
-    p.st_gamma = gamma; p.st_beta = beta; p.st_running_mean = running_mean; p.st_running_var = running_var;
-    p.st_nbt = num_batches_tracked; p.st_eps = eps; p.st_momentum = momentum;
-    p.st_ab = out_ab; p.st_mean = save_mean; p.st_invstd = save_invstd;
+    p.st = stat_tree_make(workspace, counters, (int)((M + 63) / 64), N);
+    p.st_fwd.gamma = gamma; p.st_fwd.beta = beta; p.st_fwd.running_mean = running_mean; p.st_fwd.running_var = running_var;
+    p.st_fwd.nbt = num_batches_tracked; p.st_fwd.eps = eps; p.st_fwd.momentum = momentum;
+    p.st_fwd.ab = out_ab; p.st_fwd.mean = save_mean; p.st_fwd.invstd = save_invstd;
     return gemm1x1_launch(p, M, K, N, x_stride, pre_ab != nullptr, 1, stream);
 }
 
@@ -535,8 +516,8 @@ extern "C" int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w
                   "conv1x1_bwd_bnmask: tensor too large for 32-bit offsets");
     GemmParams p = {};
     p.x = dy; p.w = w_packed_t; p.y = g_out;
-    p.st_partials = (double *)workspace; p.st_counters = counters;
-    p.st_z = z; p.st_zab = ab; p.st_mean = const_cast<float *>(mean); p.st_invstd = const_cast<float *>(invstd);
+    p.st = stat_tree_make(workspace, counters, (int)((M + 63) / 64), N);
+    p.st_z = z; p.st_zab = ab; p.st_mean = mean; p.st_invstd = invstd;
     p.st_dgamma = dgamma; p.st_dbeta = dbeta;
     return gemm1x1_launch(p, M, K, N, dy_stride, false, 2, stream);
 }

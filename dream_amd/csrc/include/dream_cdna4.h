@@ -142,13 +142,24 @@ DREAM_DEVICE int    popcount64(unsigned long long v) { return __popcll(v); }
 DREAM_DEVICE bool   wave_all(int pred) { return __ballot(pred) == __ballot(1); }      // wave-uniform
 
 // ---- "last arriver finishes" (a per-channel reduction finalised inside the launch that produced its partial sums) -------------
-// Every wave publishes its partial sums with plain stores, then grid_release() (agent-scope release fence: the stores of ALL
-// lanes of the wave are written back past this XCD's L2 -- the L2s of the eight XCDs are not coherent with one another) and takes
-// a ticket from a device-scope counter; the wave that draws the last ticket runs grid_acquire() (invalidates its own L1 / L2
-// view) and may then read every other wave's partial sums.  Nobody spins: no residency requirement, no deadlock.
-DREAM_DEVICE void grid_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); }
-DREAM_DEVICE void grid_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
-// lane 0 of the wave draws the ticket (relaxed: the fences around it order the data); every lane receives it
+// The L2s of the eight XCDs are not coherent with one another, and an agent-scope release / acquire FENCE costs a write-back /
+// invalidate of the whole L2 (measured in round 4: a GEMM whose 628 wavefronts each fenced once ran 2.5x slower).  So the partial
+// sums travel as agent-scope relaxed atomics -- `global_store_dwordx2 ... sc1` writes through to the memory side,
+// `global_load_dwordx2 ... sc1` does not hit a stale line -- ordered by hand: publish (coherent_store), wait until the stores are
+// acknowledged (publish_wait: s_waitcnt vmcnt(0) as inline asm, which no compiler pass removes), then draw a ticket from a
+// device-scope counter (relaxed RMW, performed at the memory side); the wave that draws the last ticket reads everybody's
+// partial sums with coherent_load.  Nobody spins: no residency requirement, no deadlock.
+DREAM_DEVICE void coherent_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DREAM_DEVICE double coherent_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DREAM_DEVICE void publish_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16 bytes (two doubles) per lane with the sc1 policy (cache-policy bit 4 of the buffer instructions)
+struct double2_ { double x, y; };
+DREAM_DEVICE double2_ buffer_load_d2_coherent(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(b.r, voffset_bytes, soffset_bytes, 16);
+    return __builtin_bit_cast(double2_, v);
+}
+// lane 0 of the wave draws the ticket; every lane receives it
 DREAM_DEVICE unsigned grid_ticket(unsigned *counter) {
     unsigned t = 0;
     if (lane_id() == 0) t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1264,18 +1264,21 @@ class ResnetSimple(nn.Module):
         return grads
 
     # ---- training, round 4: BatchNorm folded into its neighbours (csrc/bn.hip "round 4", csrc/gemm1x1.hip PRE / EPI) -------------
-    def _ctr(self, device, channels):
-        """A slice of this replica's zero ticket words for one BatchNorm launch (ops.bn_counter_buffer)."""
+    def _ctr(self, device):
+        """Allocator of zero ticket words for the BatchNorm launches of this replica (ops.bn_counter_buffer: every launch takes its own
+        slice of one persistent buffer and leaves it zero; the cursor restarts with every forward pass)."""
         buf = self._cache.get(("bnctr",))
         if buf is None or buf.device != device:
             buf = self._cache[("bnctr",)] = ops.bn_counter_buffer(device)
             self._ctr_pos = 0
-        n = (int(channels) + 63) // 64
-        if self._ctr_pos + n > buf.numel():
-            self._ctr_pos = 0
-        out = buf[self._ctr_pos:self._ctr_pos + n]
-        self._ctr_pos += n
-        return out
+
+        def take(n):
+            if self._ctr_pos + n > buf.numel():
+                self._ctr_pos = 0
+            out = buf[self._ctr_pos:self._ctr_pos + n]
+            self._ctr_pos += n
+            return out
+        return take
 
     def _unit_fused(self, tape, name, x, conv, bn, relu, residual=None, pre=None, materialize=True):
         """conv -> BatchNorm(batch statistics) (+ residual) (ReLU).  ``x``: the conv's input tensor, or -- with ``pre`` = the record of
@@ -1289,7 +1292,7 @@ class ResnetSimple(nn.Module):
         if self._gemm1x1(conv, x):
             packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
             rec["z"], rec["ab"], rec["mean"], rec["invstd"] = ops.conv1x1_bn(
-                x, packed, rows, bn, self._ctr(x.device, cout), pre_ab=None if pre is None else pre["ab"], shift=bias)
+                x, packed, rows, bn, self._ctr(x.device), pre_ab=None if pre is None else pre["ab"], shift=bias)
         else:
             assert pre is None
             if self._wino_train(conv):
@@ -1300,7 +1303,7 @@ class ResnetSimple(nn.Module):
                 packed, rows, _ = self._packed_w(name, conv, 0)
                 z = ops.conv2d(x, packed, rows, k, stride, None, bias, None, 0)
             rec["z"] = z
-            rec["ab"], rec["mean"], rec["invstd"] = ops.bn_stats(z, bn, self._ctr(x.device, cout))
+            rec["ab"], rec["mean"], rec["invstd"] = ops.bn_stats(z, bn, self._ctr(x.device))
         tape.append(rec)
         if not materialize:
             return rec
@@ -1315,7 +1318,7 @@ class ResnetSimple(nn.Module):
         w1 = self._cached(("w", "conv1"), [self.conv1.weight],
                           lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
         z = ops.conv2d(col, w1[0], 64, 1, 1)
-        ab, mean, invstd = ops.bn_stats(z, self.bn1, self._ctr(z.device, 64))
+        ab, mean, invstd = ops.bn_stats(z, self.bn1, self._ctr(z.device))
         y = ops.bn_apply_ab(z, ab, None, True)
         tape.append(dict(kind="stem", conv=self.conv1, bn=self.bn1, relu=True, x=col, z=z, y=y, ab=ab, mean=mean, invstd=invstd))
         yp = ops.maxpool3s2(y)
@@ -1353,7 +1356,7 @@ class ResnetSimple(nn.Module):
                     else:
                         packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
                         z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)
-                    ab, mean, invstd = ops.bn_stats(z, bn, self._ctr(z.device, int(z.shape[3])))
+                    ab, mean, invstd = ops.bn_stats(z, bn, self._ctr(z.device))
                     y2 = ops.bn_apply_ab(z, ab, None, True)
                     tape.append(dict(kind="convT", name=name, conv=m, bn=bn, relu=True, x=y, z=z, y=y2, ab=ab, mean=mean, invstd=invstd))
                     y = y2
@@ -1379,7 +1382,7 @@ class ResnetSimple(nn.Module):
             return dz, None, dgam, dbet
         y_act = rec["y"] if rec["relu"] else None
         ab = rec["ab"] if (rec["relu"] and y_act is None) else None
-        dgam, dbet = ops.bn_bwd_stats(rec["z"], dy, rec["mean"], rec["invstd"], self._ctr(dev, c), y_act=y_act, ab=ab)
+        dgam, dbet = ops.bn_bwd_stats(rec["z"], dy, rec["mean"], rec["invstd"], self._ctr(dev), y_act=y_act, ab=ab)
         dz, g = ops.bn_bwd_apply(rec["z"], dy, bn.weight, rec["mean"], rec["invstd"], dgam, dbet, y_act=y_act, ab=ab, want_g=want_g)
         return dz, g, dgam, dbet
 
@@ -1454,7 +1457,7 @@ class ResnetSimple(nn.Module):
                     # data gradient + the ReLU mask and the two reductions of the producer's BatchNorm in ONE launch
                     packed_t, rows = self._cached(("g1", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 1))
                     gmask, dg2, db2 = ops.conv1x1_bwd_bnmask(dz, packed_t, cin, pre["z"], pre["ab"], pre["mean"], pre["invstd"],
-                                                            self._ctr(dz.device, cin))
+                                                            self._ctr(dz.device))
                     g = ("masked", gmask, dg2, db2)
                 else:
                     g = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)

@@ -725,10 +725,19 @@ def bn_train_bwd(x_nhwc, dy, y_act, gamma, mean, invstd, relu=True, want_g=False
 
 
 # ---- round 4: train-mode BatchNorm without its separate passes (csrc/bn.hip "round 4", csrc/gemm1x1.hip PRE / EPI) -----------------
-def bn_counter_buffer(device, words=16384):
+def bn_counter_buffer(device, words=1 << 17):
     """Zero 32-bit words for the "last arriver finishes" tickets (every launch leaves its words zero again).  One buffer per
     model replica; each BatchNorm call site takes its own slice (bn_counter_slice), so launches on different streams never share."""
     return torch.zeros((int(words),), dtype=torch.int32, device=device)
+
+
+def _ctr_words(counters, n):
+    """``counters``: a zero int32 tensor of at least n words (tests), or an allocator n -> slice (a model's per-replica buffer)."""
+    if callable(counters):
+        return counters(int(n))
+    if counters.numel() < n:
+        raise RuntimeError("dream_amd: %d ticket words needed, %d given" % (n, counters.numel()))
+    return counters
 
 
 def _bn_args(bn):
@@ -754,7 +763,8 @@ def bn_stats(z_nhwc, bn, counters):
     c = int(z.shape[-1])
     ab, mean, invstd = _bn_outputs(c, z.device)
     ws = _workspace(_hip.lib().dream_bn_stats_workspace(c), z.device)
-    call("dream_bn_stats_nhwc_f32", ptr(z), *_bn_args(bn), ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(counters), z.numel() // c, c,
+    ctr = _ctr_words(counters, _hip.lib().dream_bn_stats_counters(c))
+    call("dream_bn_stats_nhwc_f32", ptr(z), *_bn_args(bn), ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(ctr), z.numel() // c, c,
          stream())
     _bn_bump(bn)
     return ab, mean, invstd
@@ -779,8 +789,9 @@ def bn_bwd_stats(z_nhwc, dy, mean, invstd, counters, y_act=None, ab=None):
     dgamma = torch.empty((c,), dtype=torch.float32, device=z.device)
     dbeta = torch.empty_like(dgamma)
     ws = _workspace(_hip.lib().dream_bn_stats_workspace(c), z.device)
+    ctr = _ctr_words(counters, _hip.lib().dream_bn_stats_counters(c))
     call("dream_bn_bwd_stats_nhwc_f32", ptr(z), ptr(_f32(dy)), ptr(y_act), ptr(ab), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
-         ptr(ws), ptr(counters), z.numel() // c, c, _mask_mode(y_act, ab), stream())
+         ptr(ws), ptr(ctr), z.numel() // c, c, _mask_mode(y_act, ab), stream())
     return dgamma, dbeta
 
 
@@ -804,8 +815,9 @@ def conv1x1_bn(x_nhwc, packed, cout, bn, counters, pre_ab=None, shift=None):
     z = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
     ab, mean, invstd = _bn_outputs(cout, x.device)
     ws = _workspace(_hip.lib().dream_conv1x1_bn_workspace(m, cout), x.device)
+    ctr = _ctr_words(counters, _hip.lib().dream_conv1x1_bn_counters(m, cout))
     call("dream_conv1x1_bnstats_nhwc_f32", ptr(x), ptr(packed), ptr(shift), ptr(pre_ab), ptr(z), m, cin, cout, cin, *_bn_args(bn),
-         ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(counters), stream())
+         ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(ctr), stream())
     _bn_bump(bn)
     return z, ab, mean, invstd
 
@@ -821,8 +833,9 @@ def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counter
     dgamma = torch.empty((cin,), dtype=torch.float32, device=dy.device)
     dbeta = torch.empty_like(dgamma)
     ws = _workspace(_hip.lib().dream_conv1x1_bn_workspace(m, cin), dy.device)
+    ctr = _ctr_words(counters, _hip.lib().dream_conv1x1_bn_counters(m, cin))
     call("dream_conv1x1_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_t), ptr(g), m, k, cin, k, ptr(_f32(z_nhwc)), ptr(ab), ptr(mean),
-         ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(counters), stream())
+         ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(ctr), stream())
     return g, dgamma, dbeta
 
 

@@ -389,8 +389,8 @@ int dream_channel_sum_nhwc_f32(const float *x, float *out, void *workspace, size
 /* ---- round 4: the same train-mode BatchNorm without its separate passes (torchvision Bottleneck conv -> BN -> ReLU chains,
  * dream/models.py:22-32 via network.py:328-364).  Statistics are published as the affine map y = ab[0][c] * z + ab[1][c]
  * (ab[0] = gamma * invstd, ab[1] = beta - mean * ab[0]; every kernel evaluates BN + ReLU as max(fmaf(a, z, b), 0)) and are
- * FINISHED INSIDE the launch that sums them (the last workgroup / wavefront to arrive per 64-channel slab adds the partial rows in
- * a fixed order: deterministic, no finalize launch).  `counters`: dream_bn_stats_counters(C) zero 32-bit words, zero again when
+ * FINISHED INSIDE the launch that sums them (a two-level ticket tree per 64-channel slab: the last producer of a group of partial
+ * rows adds the group, the last group adds the groups -- fixed order: deterministic; no finalize launch, no fence, nobody spins).  `counters`: dream_bn_stats_counters(C) zero 32-bit words, zero again when
  * the launch ends; a buffer must not be shared by launches that may run concurrently.  workspace: dream_bn_stats_workspace(C)
  * bytes (dream_conv1x1_bn_workspace(M, N) for the GEMM forms). */
 size_t dream_bn_stats_workspace(int C);
@@ -416,6 +416,7 @@ int dream_bn_bwd_apply_nhwc_f32(const float *z, const float *dy, const float *y_
  *   in the loader, its output never stored; and the batch statistics of y (for the BN that follows) summed in the epilogue and
  *   finished in the launch: out_ab / save_mean / save_invstd / running statistics as dream_bn_stats_nhwc_f32. */
 size_t dream_conv1x1_bn_workspace(long M, int N);
+int dream_conv1x1_bn_counters(long M, int N);            /* zero 32-bit words the two GEMM forms below need */
 int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_packed, const float *shift, const float *pre_ab, float *y,
                                    long M, int K, int N, int x_stride, const float *gamma, const float *beta,
                                    float *running_mean, float *running_var, long long *num_batches_tracked, float eps,

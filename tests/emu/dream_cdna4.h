@@ -122,8 +122,20 @@ inline unsigned long long wave_ballot(int pred) { return __ballot(pred); }
 inline int popcount64(unsigned long long v) { return __popcll(v); }
 inline bool wave_all(int pred) { return __ballot(pred) == __ballot(1); }
 // "last arriver finishes" (see the device header): the emulator's workgroups run on several OS threads
-inline void grid_release() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
-inline void grid_acquire() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void coherent_store(double *p, double v) { __atomic_store(p, &v, __ATOMIC_SEQ_CST); }
+inline double coherent_load(const double *p) { double v; __atomic_load(p, &v, __ATOMIC_SEQ_CST); return v; }
+struct double2_ { double x, y; };
+inline double2_ buffer_load_d2_coherent(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    double2_ v = {0.0, 0.0};
+    if ((unsigned long long)voffset_bytes + 16ull <= (unsigned long long)b.bytes) {
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        __builtin_memcpy(&v, b.base + (size_t)voffset_bytes + soffset_bytes, 16);
+    }
+    return v;
+}
+// on the device a wavefront's lanes run in lockstep: every lane's stores are issued before the s_waitcnt; the emulator's fibers
+// only meet at rendezvous points, so this is one (all lanes of the wavefront call it)
+inline void publish_wait() { __atomic_thread_fence(__ATOMIC_SEQ_CST); (void)emu_exchange(0, 0); __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 inline int wave_bcast0(int v) { return emu_exchange(v, 0); }
 inline unsigned grid_ticket(unsigned *counter) {
     unsigned t = 0;

@@ -1077,7 +1077,7 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
     for (B, C, H, W, relu, res) in [(2, 64, 5, 7, True, True), (3, 256, 4, 4, True, False), (2, 2048, 3, 3, False, False),
                                     (1, 48, 6, 5, True, False), (3, 128, 33, 41, True, False)]:
         bn, bn2 = make_bn(C)
-        ctr = to(dev, torch.zeros(64, dtype=torch.int32))
+        ctr = to(dev, torch.zeros(4096, dtype=torch.int32))
         x = (torch.randn(B, C, H, W) * 1.5 + 0.3).requires_grad_()
         r = torch.randn(B, C, H, W) if res else None
         y_ref = bn(x)
@@ -1114,7 +1114,8 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
         assert int(ctr.cpu().abs().sum()) == 0       # every launch leaves its ticket words zero
     # ---- the 1x1 conv with the BatchNorm on either side folded in --------------------------------------------------------------------
     for (B, H, W, Cin, Cout, with_pre, with_bias) in [(2, 9, 11, 64, 96, True, False), (1, 13, 13, 128, 256, True, True),
-                                                      (3, 5, 5, 256, 64, False, False), (2, 7, 6, 32, 160, True, False)]:
+                                                      (3, 5, 5, 256, 64, False, False), (2, 7, 6, 32, 160, True, False),
+                                                      (3, 33, 41, 64, 64, True, False)]:        # 64 row blocks: both levels of the ticket tree
         bn_p, bn_p2 = make_bn(Cin)
         bn_n, bn_n2 = make_bn(Cout)
         zp = (torch.randn(B, Cin, H, W) + 0.2).requires_grad_()
@@ -1125,7 +1126,7 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
         y_ref = bn_n(z_ref).relu()
         dyo = torch.randn_like(y_ref)
         y_ref.backward(dyo)
-        ctr = to(dev, torch.zeros(64, dtype=torch.int32))
+        ctr = to(dev, torch.zeros(4096, dtype=torch.int32))
         zp_d = to(dev, _nhwc(zp.detach()))
         pre_ab = pre_mean = pre_invstd = None
         if with_pre:

@@ -169,7 +169,7 @@ def test_bn_fused_statistics_are_deterministic_and_tickets_rearm():
     torch.manual_seed(5)
     bn = torch.nn.BatchNorm2d(256).to(DEV)
     z = torch.randn(16, 25, 25, 256, device=DEV) * 2 + 0.5
-    ctr = torch.zeros(8, dtype=torch.int32, device=DEV)
+    ctr = torch.zeros(4096, dtype=torch.int32, device=DEV)
     outs = [ops.bn_stats(z, bn, ctr) for _ in range(5)]
     assert int(ctr.abs().sum()) == 0
     for o in outs[1:]:
@@ -179,7 +179,7 @@ def test_bn_fused_statistics_are_deterministic_and_tickets_rearm():
     w = torch.randn(1024, 256, 1, 1, device=DEV) * 0.05
     packed, rows = ops.pack_conv1x1_weight(w, 0)
     bn2 = torch.nn.BatchNorm2d(1024).to(DEV)
-    ctr2 = torch.zeros(16, dtype=torch.int32, device=DEV)
+    ctr2 = torch.zeros(4096, dtype=torch.int32, device=DEV)
     runs = [ops.conv1x1_bn(z, packed, rows, bn2, ctr2, pre_ab=outs[0][0]) for _ in range(5)]
     assert int(ctr2.abs().sum()) == 0
     for r in runs[1:]:

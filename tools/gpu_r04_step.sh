@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-4 development call (kept as ONE parameterised script: tools/gpu_r04_step.sh <stage>), not part of the measurement set.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+O=gpurun_out/r04_$1
+mkdir -p $O
+export TMPDIR=/tmp
+line() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | cut -c1-230; }
+case "$1" in
+bn1)
+  echo "== pytest (new + touched)"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "bn_fused or resnet_h_train_step or reference_golden or resnet_training_ops or data_parallel or conv1x1" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in 1 2; do
+    DREAM_BN_FUSION=1 line rt16_fused_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_BN_FUSION=0 line rt16_three_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  DREAM_BN_FUSION=1 line rt128_fused --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  DREAM_BN_FUSION=0 line rt128_three --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 50 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_fused.txt; head -40 $O/layer_profile_fused.txt | cut -c1-160
+  ;;
+esac
