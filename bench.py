@@ -383,6 +383,13 @@ def timed_region(ctx, net, x, tgt, spec):
     del timer.events[:]
     for _ in range(spec["warmup"]):
         step()
+    if os.environ.get("DREAM_BENCH_PMC_CALIBRATE") == "1":
+        # the HBM-traffic PMC passes (tools/pmc_traffic.py): two stand-alone max-pool launches on tensors of known size, OUTSIDE the
+        # timed region -- pure streaming reads whose algorithmic byte count is exact, against which the FETCH_SIZE counter's unit
+        # on this device is calibrated (every pool of the product path is fused into a conv epilogue since round 3)
+        from dream_amd import ops as _ops
+        for shape in ((spec["batch"], 100, 100, 256), (spec["batch"], 50, 50, 512)):
+            _ops.maxpool2(torch.ones(shape, dtype=torch.float32, device="cuda"))
     sync()
     barrier()
     timer.recording = not spec.get("graph") and not ctx.single        # events cannot be timed inside a captured graph

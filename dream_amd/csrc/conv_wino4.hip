@@ -42,6 +42,7 @@
 //   * epilogue: the lane's four tiles go through A^T M A in register pairs (packed fp32), parameters re-read through the constant
 //     address space (s_load), offsets = tile base + scalar when all 16 tiles of the wavefront are interior.
 #include <type_traits>
+#include <stdlib.h>
 #include <dream_cdna4.h>
 #include "common.h"
 #include "pack_device.h"
@@ -78,6 +79,9 @@ struct Wino4Params {
                                      // conv, (2, a, b) for phase (a, b) of a stride-2 transposed conv (y: [B, out_scale H, out_scale W, Cout])
     int in_scale, in_oy, in_ox;      // stored input pixel of conv position (y, x), likewise: (2, a, b) for the phase views of the gradient in the
                                      // transposed conv's data gradient (x: [B, in_scale H, in_scale W, Cin]); read by the PAT kernels only
+    int ymap;                        // 0: output-channel block = blockIdx.y, every XCD walks all of them over its own eighth of the tile blocks;
+                                     // ny (2 | 4): 1-D grid, XCD k owns channel block k % ny and shares the tile blocks with the other 8 / ny - 1
+                                     // XCDs of that block (blk_per_xcd = their share): an XCD's L2 then streams ONE block's transformed weights
 };
 
 constexpr int W4T = 16;       // tiles per workgroup
@@ -199,11 +203,12 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     const int item_id = wave * 48 + (lane < 48 ? lane : lane - 16);
 
     const int xcd = (int)(blockIdx.x & 7), J = (int)(gridDim.x >> 3);
-    const int blk_hi = (xcd + 1) * p.blk_per_xcd;
+    const int part = p.ymap ? xcd / p.ymap : xcd;      // which share of the tile blocks this XCD walks
+    const int blk_hi = (part + 1) * p.blk_per_xcd;
     const int blk_end = blk_hi < p.nblk ? blk_hi : p.nblk;
-    int tb = xcd * p.blk_per_xcd + (int)(blockIdx.x >> 3);
+    int tb = part * p.blk_per_xcd + (int)(blockIdx.x >> 3);
     if (tb >= blk_end) return;
-    const int n0 = blockIdx.y * (16 * W4NW);
+    const int n0 = (p.ymap ? xcd % p.ymap : (int)blockIdx.y) * (16 * W4NW);
     const int tiles_per_img = p.TY * p.TX;
     const int Si = PAT ? p.in_scale : 1;                                      // spacing of the conv positions in the stored input
     const size_t img_floats = (size_t)(Si * p.H) * (Si * p.W) * p.Cin;
@@ -570,6 +575,9 @@ __global__ void __launch_bounds__(256) wino4_pack_kernel(const float *w, float *
 }
 
 int g_max_workgroups4 = 0;     // test hook: cap on resident workgroups (0 = the chip's 256 CUs, two narrow workgroups on each)
+int g_ymap4 = -1;              // channel blocks pinned to XCDs (Wino4Params::ymap): -1 = by the environment (DREAM_W4_YMAP=0 switches it off).
+                               // Measured round 4 (tools/ab_wino4_pinning.py, b=128): 0.5-1.3 % faster on every layer with 2 or 4 channel
+                               // blocks, headline +0.6 %: an XCD's L2 streams one block's transformed weights instead of all four
 
 bool narrow_rows(int rows) { return rows <= W4Cfg<true>::PAD; }
 struct PackShape { int k, rows_pad, ahead; };
@@ -586,11 +594,20 @@ int launch_wino4(const Wino4Params &p, void *stream) {
     if (dream_allow_full_lds((const void *)kernel)) return 2;
     const int ny = (p.Cout + 16 * C::NW - 1) / (16 * C::NW);
     const int resident = g_max_workgroups4 > 0 ? g_max_workgroups4 : (NARROW ? 512 : 256);
-    int gx = resident / ny / 8 * 8;
-    if (gx < 8) gx = 8;
-    if (gx > (p.nblk + 7) / 8 * 8) gx = (p.nblk + 7) / 8 * 8;
-    const dim3 grid((unsigned)gx, (unsigned)ny);
-    hipLaunchKernelGGL(kernel, grid, dim3(64 * C::NW), lds, (hipStream_t)stream, p);
+    Wino4Params q = p;
+    dim3 grid;
+    if (g_ymap4 && !NARROW && (ny == 2 || ny == 4) && resident >= 64 && p.nblk >= resident) {
+        // channel blocks pinned to XCDs (see Wino4Params::ymap): every XCD runs resident / 8 workgroups on its share of the tile blocks
+        q.ymap = ny;
+        q.blk_per_xcd = (p.nblk + 8 / ny - 1) / (8 / ny);
+        grid = dim3((unsigned)(resident / 8 * 8), 1u);
+    } else {
+        int gx = resident / ny / 8 * 8;
+        if (gx < 8) gx = 8;
+        if (gx > (p.nblk + 7) / 8 * 8) gx = (p.nblk + 7) / 8 * 8;
+        grid = dim3((unsigned)gx, (unsigned)ny);
+    }
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * C::NW), lds, (hipStream_t)stream, q);
     DREAM_LAUNCH_OK();
     return 0;
 }
@@ -610,6 +627,14 @@ int launch_wino4_mode(const Wino4Params &p, int mode, void *stream) {
 extern "C" size_t dream_conv3x3_winograd4_weight_floats(int rows, int cols) {
     const PackShape ps = pack_shape(rows);
     return ((size_t)(cols / ps.k) * W4P + ps.ahead) * ps.rows_pad * ps.k;
+}
+
+// A/B hook: 1 = pin the output-channel blocks to XCDs (Wino4Params::ymap), 0 = every XCD walks all of them (blockIdx.y),
+// -1 = by the environment (DREAM_W4_YMAP=0 switches it off; default on).  Same results either way (bit for bit).
+extern "C" int dream_conv3x3_winograd4_set_channel_block_pinning(int on) {
+    DREAM_REQUIRE(on >= -1 && on <= 1, "winograd F(4x4): pinning %d", on);
+    g_ymap4 = on;
+    return 0;
 }
 
 extern "C" int dream_conv3x3_winograd4_set_max_workgroups(int n) {
@@ -663,6 +688,11 @@ int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const flo
     p.flags = flags;
     p.out_scale = out_scale; p.out_oy = 0; p.out_ox = 0;
     p.in_scale = in_scale; p.in_oy = 0; p.in_ox = 0;
+    p.ymap = 0;
+    if (g_ymap4 < 0) {
+        const char *e = getenv("DREAM_W4_YMAP");
+        g_ymap4 = (e != nullptr && e[0] == '0') ? 0 : 1;
+    }
     return 0;
 }
 

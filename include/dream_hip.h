@@ -130,7 +130,8 @@ int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u, int Cout,
 int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                      const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                      void *stream);
-int dream_conv3x3_winograd4_set_max_workgroups(int n);     /* test hook, as dream_conv3x3_winograd_set_max_workgroups */
+int dream_conv3x3_winograd4_set_max_workgroups(int n);
+int dream_conv3x3_winograd4_set_channel_block_pinning(int on);   /* A/B hook: output-channel blocks pinned to XCDs (1) or walked by every XCD (0); -1: by DREAM_W4_YMAP (default: pinned) */     /* test hook, as dream_conv3x3_winograd_set_max_workgroups */
 
 /* ---- all packed weight copies of a network in one launch (training: every conv weight changes every step) ----------------------
  * jobs: DEVICE array of njobs entries; src = the weight tensor as the reference stores it (OIHW), dst = the packed copy

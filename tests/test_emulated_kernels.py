@@ -336,3 +336,26 @@ def test_batched_weight_packing(emu):
     ops.pack_weights_batched(table, len(jobs), workgroups_per_job=3)
     for (kind, w, out, cout, cin, mode), ref in zip(jobs, singles):
         assert torch.equal(out, ref), (kind, cout, cin, mode)
+
+
+def test_winograd4_channel_blocks_pinned_to_xcds_same_bits(emu):
+    """csrc/conv_wino4.hip, Wino4Params::ymap: the 1-D grid whose XCD k owns output-channel block k % ny gives the bits of the
+    (tile blocks) x (channel blocks) grid -- 67 tile blocks on 64 emulated workgroups, two and four channel blocks."""
+    from dream_amd import _hip
+    torch.manual_seed(0)
+    for cout in (256, 512):
+        x = torch.randn(2, 92, 92, 32).relu_()
+        w = torch.randn(cout, 32, 3, 3) * 0.1
+        u4, rows = ops.pack_weight_winograd4(w, 0)
+        outs = []
+        _hip.call("dream_conv3x3_winograd4_set_max_workgroups", 64)
+        try:
+            for pin in (0, 1):
+                _hip.call("dream_conv3x3_winograd4_set_channel_block_pinning", pin)
+                outs.append(ops.conv3x3_winograd4(x, u4, cout, None, None, None, ops.CONV_RELU))
+        finally:
+            _hip.call("dream_conv3x3_winograd4_set_channel_block_pinning", -1)
+            _hip.call("dream_conv3x3_winograd4_set_max_workgroups", 0)
+        assert torch.equal(outs[0], outs[1])
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).relu().permute(0, 2, 3, 1)
+        assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 1e-5

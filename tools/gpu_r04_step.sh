@@ -16,4 +16,16 @@ bn1)
   DREAM_BN_FUSION=0 line rt128_three --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
   timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 50 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_fused.txt; head -40 $O/layer_profile_fused.txt | cut -c1-160
   ;;
+w4pin)
+  for r in 1 2; do
+    DREAM_BN_FUSION=1 line rt16_fused_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_BN_FUSION=0 line rt16_three_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 30 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_fused.txt; sed -n 2,22p $O/layer_profile_fused.txt | cut -c1-120
+  timeout 300 python tools/ab_wino4_pinning.py 2>&1 | grep -v amdgpu.ids | tee $O/ab_wino4_pinning.txt
+  DREAM_W4_YMAP=0 line dflt_walked
+  DREAM_W4_YMAP=1 line dflt_pinned
+  DREAM_W4_YMAP=0 line dflt_walked2
+  DREAM_W4_YMAP=1 line dflt_pinned2
+  ;;
 esac

@@ -74,15 +74,22 @@ def main():
             json.dump(out_d, f, indent=1)
         print(json.dumps(out_d["families"], indent=1))
         return
+    # second calibration, on a store stream: the first conv writes B x 400 x 400 x 64 floats per dispatch and nothing else
+    nfirst, first_write = family(write, "conv3x3_first_kernel")
+    first_alg = 4.0 * B * 400 * 400 * 64 * nfirst
     res = {
         "bench_py_sha": bench_py_sha(),
-        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
-                   "--no-cpu-baseline --no-split-leg --no-secondary (one PMC counter per run)",
+        "command": "DREAM_BENCH_PMC_CALIBRATE=1 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps 1 --warmup 1 "
+                   "--no-cpu-baseline --no-split-leg --no-secondary (one PMC counter per run; the calibration launches are two "
+                   "stand-alone max-pools outside the timed region)",
         "workload": "DREAM-vgg-Q inference B=128 400x400",
         "units": "counters are KiB; FETCH_SIZE doubled per the gfx950 rule (see calibration)",
         "calibration_maxpool2_kernel": {"dispatches": npool, "fetch_gb_raw": pool_fetch / 1e9,
                                         "fetch_gb_algorithmic": pool_alg / 1e9,
                                         "raw_to_algorithmic": pool_alg / pool_fetch if pool_fetch else None},
+        "calibration_conv3x3_first_kernel_writes": {"dispatches": nfirst, "write_gb_raw": first_write / 1e9,
+                                                    "write_gb_algorithmic": first_alg / 1e9,
+                                                    "raw_to_algorithmic": first_alg / first_write if first_write else None},
         "conv_kernels": {
             "families": "conv_wino4_kernel (%d dispatches) + conv_wino_kernel (%d) + conv_mfma_kernel (%d)" % (n_wino4, n_wino, nf - n_wino - n_wino4),
             "dispatches": nf,
@@ -95,7 +102,7 @@ def main():
     }
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({k: res[k] for k in ("calibration_maxpool2_kernel", "conv_kernels")}, indent=1))
+    print(json.dumps({k: res[k] for k in ("calibration_maxpool2_kernel", "calibration_conv3x3_first_kernel_writes", "conv_kernels")}, indent=1))
 
 
 if __name__ == "__main__":
