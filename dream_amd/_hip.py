@@ -111,6 +111,7 @@ _SIGNATURES = {
     "dream_upsample_conv3x3_weight_as_convT4x4": (_I, [_P, _P, _I, _I, _P]),
     "dream_conv2d_s2_bwd_data_nhwc_f32": (_I, [_P, _P, _P] + [_I] * 9 + [_P]),
     "dream_conv_transpose3x3s2_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv_transpose3x3s2_res_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_set_variant": (_I, [_I]),
     "dream_conv3x3_num_variants": (_I, []),
     "dream_conv3x3_variant_name": (_c.c_char_p, [_I]),

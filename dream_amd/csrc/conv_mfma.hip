@@ -233,6 +233,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
     const bool nchw = (p.flags & DREAM_CONV_OUT_NCHW) != 0;
     const bool mask = (p.flags & DREAM_CONV_RELUMASK) != 0;
+    const bool late = (p.flags & DREAM_CONV_RES_AFTER_RELU) != 0;      // the residual is a skip connection: added after the ReLU
     float scale_v[NR], shift_v[NR];
     int ncol[NR];
 #pragma unroll
@@ -263,11 +264,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(const ConvParams p) {
                         float v = acc[ms][ns][r];
                         if (p.scale != nullptr) v = v * scale_v[ns];
                         v = v + shift_v[ns];
+                        float rv = 0.0f;
                         if (p.residual != nullptr) {
-                            const float rv = p.residual[o];
-                            v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
+                            rv = p.residual[o];
+                            v = mask ? (rv > 0.0f ? v : 0.0f) : (late ? v : v + rv);
                         }
                         if (relu) v = fmaxf(v, 0.0f);
+                        if (late) v = v + rv;
                         p.y[o] = v;
                         amax = fmaxf(amax, fabsf(v));
                     }
@@ -475,6 +478,8 @@ static int conv2d_impl(const float *x, const float *w_packed, const float *scale
     // zero-stuffing also accepts an odd extent 2*Hs-1 (data gradient of a stride-2 conv with an odd input)
     DREAM_REQUIRE(!(flags & DREAM_CONV_UPSAMPLE2X) || (H % 2 == 0 && W % 2 == 0), "fused x2 upsample needs even H, W (got %dx%d)", H, W);
     DREAM_REQUIRE(!ups || stride == 1, "fused upsample with a strided conv is not supported");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RES_AFTER_RELU) || (residual != nullptr && !(flags & (DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK))),
+                  "conv2d: residual-after-ReLU needs a residual and excludes the fused pool / the ReLU mask");
     DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (stride == 1 && !(flags & DREAM_CONV_OUT_NCHW) && residual == nullptr && H >= 2 && W >= 2),
                   "fused max-pool: stride 1, NHWC output, no residual");
     ConvGeom g;
@@ -542,8 +547,9 @@ extern "C" int dream_conv_transpose4x4s2_nhwc_f32(const float *x, const float *w
 // form uses ([9][CoutPad][Cin], slice t = transposed weights of tap 8 - (3 ky + kx)): the launches pick their slices.
 namespace {
 int conv_transpose3x3s2_impl(const float *x, const float *w_packed, const float *bias, float *y, int B, int H, int W,
-                             int Ho, int Wo, int Cin, int Cout, int CoutPad, int flags, void *stream) {
-    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "convT3x3: only the ReLU flag is supported");
+                             int Ho, int Wo, int Cin, int Cout, int CoutPad, int flags, void *stream, const float *residual = nullptr) {
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_RES_AFTER_RELU)) == 0, "convT3x3: only the ReLU / residual-after-ReLU flags are supported");
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RES_AFTER_RELU) || residual != nullptr, "convT3x3: residual-after-ReLU without a residual");
     DREAM_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1), "convT3x3: output %dx%d for input %dx%d", Ho, Wo, H, W);
     for (int ph = 0; ph < 4; ++ph) {
         const int a = ph >> 1, b = ph & 1;
@@ -559,11 +565,20 @@ int conv_transpose3x3s2_impl(const float *x, const float *w_packed, const float 
             }
         g.kext = 2;
         g.out_scale = 2; g.out_oy = a; g.out_ox = b;
-        if (int rc = launch_conv(x, w_packed, nullptr, bias, nullptr, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
+        if (int rc = launch_conv(x, w_packed, nullptr, bias, residual, y, B, Cin, Cout, CoutPad, g, flags, stream)) return rc;
     }
     return 0;
 }
 }  // namespace
+
+// the same with a tensor of the OUTPUT's shape [B,2H,2W,Cout] added in the epilogue (before the ReLU, or after it with
+// DREAM_CONV_RES_AFTER_RELU: the skip connection behind deconv_0_1, dream/models.py:796-799)
+extern "C" int dream_conv_transpose3x3s2_res_nhwc_f32(const float *x, const float *w_packed, const float *bias, const float *residual,
+                                                      float *y, int B, int H, int W, int Cin, int Cout, int CoutPad, int flags,
+                                                      void *stream) {
+    DREAM_REQUIRE(residual != nullptr, "convT3x3 (residual): null residual");
+    return conv_transpose3x3s2_impl(x, w_packed, bias, y, B, H, W, 2 * H, 2 * W, Cin, Cout, CoutPad, flags, stream, residual);
+}
 
 extern "C" int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
                                                   int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream) {

@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
     // written (tile beyond the batch, channel beyond Cout, odd-extent overhang): masked stores without branches.
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
     constexpr bool pool = MODE == 1, has_res = MODE >= 2, mask = MODE == 3;
+    const bool late = MODE == 2 && (p.flags & DREAM_CONV_RES_AFTER_RELU) != 0;      // the residual is a skip connection: added after the ReLU
     const int col = n0 + wave * 16 + lt;
     const bool cok = col < p.Cout;
     const float sc = (p.scale != nullptr && cok) ? p.scale[col] : 1.0f;
@@ -427,9 +428,10 @@ __global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams 
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
                         float v = out[i][jj] * sc + sh;                 // sc = 1 / sh = 0 when absent (exact)
-                        if (has_res) v = mask ? (rv[r][2 * i + jj] > 0.0f ? v : 0.0f) : v + rv[r][2 * i + jj];
+                        if (has_res) v = mask ? (rv[r][2 * i + jj] > 0.0f ? v : 0.0f) : (late ? v : v + rv[r][2 * i + jj]);
                         const float vr = fmaxf(v, 0.0f);
                         v = relu ? vr : v;
+                        if (MODE == 2) v = late ? v + rv[r][2 * i + jj] : v;
                         if (pool) best = fmaxf(best, v);
                         else buffer_store_f32(ybuf, v, off[r][2 * i + jj], 0);
                     }
@@ -598,7 +600,9 @@ __global__ void __launch_bounds__(256) convT4x4_phase_kernels(const float *wT, f
 extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                                const float *residual, float *y, int B, int H, int W, int Cin, int Cout,
                                                int flags, void *stream) {
-    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK | DREAM_CONV_RES_AFTER_RELU)) == 0, "winograd conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RES_AFTER_RELU) || (residual != nullptr && !(flags & (DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK))),
+                  "winograd conv: residual-after-ReLU needs a residual and excludes the fused pool / the ReLU mask");
     DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd conv: fused max-pool takes no residual");
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
     WinoParams p;

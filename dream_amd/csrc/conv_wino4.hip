@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         }
         const auto &e = *DREAM_KERNARG(p);
         const bool relu = (e.flags & DREAM_CONV_RELU) != 0;
+        const bool late = MODE == 2 && (e.flags & DREAM_CONV_RES_AFTER_RELU) != 0;    // the residual is a skip connection: added after the ReLU
         // Ho x Wo: grid of stored conv positions; So: their spacing in the stored tensor (2 for a transposed conv's phase)
         const int Ho = pool ? e.H / 2 : e.H, Wo = pool ? e.W / 2 : e.W, So = e.out_scale;
         const size_t out_img = (size_t)(So * Ho) * (So * Wo) * e.Cout;
@@ -493,12 +494,14 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                 sA[i][3] = fm(-8.0f, m[4], fm(0.125f, m[3], t1)) + m[5];
             }
             auto finish = [&](float v, unsigned o, unsigned so) {     // residual or mask, ReLU (scale / shift applied before)
+                float rv = 0.0f;
                 if (has_res) {
-                    const float rv = buffer_load_f32(rbuf, o, so);
-                    v = mask ? (rv > 0.0f ? v : 0.0f) : v + rv;
+                    rv = buffer_load_f32(rbuf, o, so);
+                    v = mask ? (rv > 0.0f ? v : 0.0f) : (late ? v : v + rv);
                 }
                 const float vr = fmaxf(v, 0.0f);
-                return relu ? vr : v;
+                v = relu ? vr : v;
+                return (MODE == 2 && late) ? v + rv : v;
             };
             float keep[2][2];                                         // pool: the even column's values wait for the odd one
 #pragma unroll
@@ -704,7 +707,9 @@ int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const flo
 extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                                 const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                                 void *stream) {
-    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK)) == 0, "winograd F(4x4) conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK | DREAM_CONV_RES_AFTER_RELU)) == 0, "winograd F(4x4) conv: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(!(flags & DREAM_CONV_RES_AFTER_RELU) || (residual != nullptr && !(flags & (DREAM_CONV_POOL2 | DREAM_CONV_RELUMASK))),
+                  "winograd F(4x4) conv: residual-after-ReLU needs a residual and excludes the fused pool / the ReLU mask");
     DREAM_REQUIRE(!(flags & DREAM_CONV_POOL2) || (residual == nullptr && H >= 2 && W >= 2), "winograd F(4x4) conv: fused max-pool takes no residual");
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd F(4x4) conv: ReLU mask without a mask tensor");
     Wino4Params p;

@@ -255,8 +255,9 @@ class DreamHourglass(nn.Module):
 
     @staticmethod
     def _join(a, b):
-        if a.shape != b.shape:        # what the reference's `+` raises for resolutions the pools do not divide
-            raise RuntimeError("The size of tensor a %s must match the size of tensor b %s" % (tuple(a.shape), tuple(b.shape)))
+        sa = tuple(a.shape) if torch.is_tensor(a) else tuple(int(v) for v in a)
+        if sa != tuple(b.shape):      # what the reference's `+` raises for resolutions the pools do not divide
+            raise RuntimeError("The size of tensor a %s must match the size of tensor b %s" % (sa, tuple(b.shape)))
 
     # ---- execution -------------------------------------------------------------------------------------
     def run_forward_f16x3(self, x, params, x_is_nhwc=False, x_amax=None):
@@ -314,19 +315,28 @@ class DreamHourglass(nn.Module):
         act = x
         pi = 0
         layers = self.plan_layers()
-        pool_done = False
+        pool_done = add_done = False
         for li, (kind, mod, flags) in enumerate(layers):
             inp = act
+            skip = None
             if kind == "pool":
                 if not pool_done:
                     act = ops.maxpool2(inp)
                 pool_done = False
             elif kind == "add":
-                self._join(inp, keep[flags])
-                act, _ = ops.add(inp, keep[flags])
+                if not add_done:
+                    self._join(inp, keep[flags])
+                    act, _ = ops.add(inp, keep[flags])
+                add_done = False
             else:
                 if not save and kind not in ("first", "wide") and self._fuse_pool(layers, li, inp):
                     flags, pool_done = flags | CONV_POOL2, True
+                # inference: the skip connection that follows this conv (models.py:774-799: x = x + x_0_k_d) is added in its own
+                # epilogue, after the ReLU -- no separate elementwise launch, the sum never round-trips through HBM.  (Training
+                # keeps the separate add: the backward pass reads the conv's own output as its ReLU mask.)
+                if (not save and kind in ("conv", "deconv") and li + 1 < len(layers) and layers[li + 1][0] == "add"
+                        and not (flags & (CONV_POOL2 | CONV_UPSAMPLE2X | CONV_OUT_NCHW)) and li not in self._skip_sources):
+                    skip = keep[layers[li + 1][2]]
                 w, bias = params[pi], params[pi + 1]
                 pi += 2
                 if kind == "first":
@@ -345,11 +355,22 @@ class DreamHourglass(nn.Module):
                             act = ops.conv_transpose4x4s2(inp, pk4, cout4, None, bias, flags & CONV_RELU, direct_taps=36)
                     elif kind == "deconv":                   # ConvTranspose weight [Cin,Cout,3,3], mode-1 packing; sub-pixel
                         packed, rows, _, _ = self._packed.get(mod.weight, 1)   # phases: a quarter of the zero-stuffed MACs
-                        act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU))
+                        if skip is not None:
+                            self._join((inp.shape[0], 2 * inp.shape[1], 2 * inp.shape[2], rows), skip)
+                        act = ops.conv_transpose3x3s2(inp, packed, bias, rows, relu=bool(flags & CONV_RELU), skip=skip)
+                        add_done = skip is not None
                     elif int(mod.weight.shape[1]) == int(inp.shape[3]) and self._use_winograd(int(inp.shape[3]), int(mod.weight.shape[0]), flags):
                         tile = ops.winograd_tile(int(inp.shape[1]), int(inp.shape[2]), int(inp.shape[3]), int(mod.weight.shape[0]), int(inp.shape[0]))
                         u, rows = self._packed.get(mod.weight, "wino4_0" if tile == 4 else "wino0")
-                        act = ops.conv3x3_winograd_tile(tile, inp, u, rows, None, bias, None, flags)
+                        if skip is not None:
+                            self._join(tuple(inp.shape[:3]) + (rows,), skip)
+                        act = ops.conv3x3_winograd_tile(tile, inp, u, rows, None, bias, skip, flags | (ops.CONV_RES_AFTER_RELU if skip is not None else 0))
+                        add_done = skip is not None
+                    elif skip is not None:
+                        packed, rows, _, _ = self._packed.get(mod.weight, 0)
+                        self._join(tuple(inp.shape[:3]) + (rows,), skip)
+                        act = ops.conv2d(inp, packed, rows, 3, 1, None, bias, skip, flags | ops.CONV_RES_AFTER_RELU)
+                        add_done = True
                     else:
                         packed, rows, _, _ = self._packed.get(mod.weight, 0)
                         act = ops.conv3x3(inp, packed, bias, rows, flags)

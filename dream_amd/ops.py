@@ -11,6 +11,7 @@ from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream, 
 CONV_ZEROSTUFF2X = 8
 CONV_POOL2 = 16
 CONV_RELUMASK = 32
+CONV_RES_AFTER_RELU = 64        # the residual is a skip connection: y = relu(conv + shift) + residual
 
 
 def _f32(t):
@@ -312,14 +313,21 @@ def conv3x3_first(x_nchw, w_oihw, bias, relu=True):
     return y
 
 
-def conv_transpose3x3s2(x_nhwc, packed_mode1, bias, cout, relu=True):
+def conv_transpose3x3s2(x_nhwc, packed_mode1, bias, cout, relu=True, skip=None):
     """ConvTranspose2d(k3,s2,p1,output_padding 1) (+ReLU) by sub-pixel phases: [B,H,W,Cin] -> [B,2H,2W,cout].
-    packed_mode1 = pack_weight(convT.weight, 1)[0] (the packing the zero-stuffed form uses)."""
+    packed_mode1 = pack_weight(convT.weight, 1)[0] (the packing the zero-stuffed form uses).  ``skip`` [B,2H,2W,cout]: a skip
+    connection added after the ReLU in the same epilogue (dream/models.py:796-799)."""
     x = _f32(x_nhwc)
     b, h, w, cin = (int(v) for v in x.shape)
     if cin != packed_mode1.shape[2]:
         raise RuntimeError("conv_transpose3x3s2: input has %d channels, packed weights expect %d" % (cin, packed_mode1.shape[2]))
     y = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=x.device)
+    if skip is not None:
+        if tuple(skip.shape) != tuple(y.shape):
+            raise RuntimeError("conv_transpose3x3s2: skip shape %s != output shape %s" % (tuple(skip.shape), tuple(y.shape)))
+        call("dream_conv_transpose3x3s2_res_nhwc_f32", ptr(x), ptr(packed_mode1), ptr(bias), ptr(_f32(skip)), ptr(y), b, h, w, cin, cout,
+             int(packed_mode1.shape[1]), (CONV_RELU if relu else 0) | CONV_RES_AFTER_RELU, stream())
+        return y
     call("dream_conv_transpose3x3s2_nhwc_f32", ptr(x), ptr(packed_mode1), ptr(bias), ptr(y), b, h, w, cin, cout,
          int(packed_mode1.shape[1]), CONV_RELU if relu else 0, stream())
     return y

@@ -42,6 +42,9 @@ extern "C" {
 #define DREAM_CONV_RELUMASK   32   /* `residual` is not added but used as a ReLU mask: y = residual > 0 ? conv : 0.  Backward
                                     * data-gradient convs use it to apply the previous layer's ReLU gradient in their
                                     * epilogue (residual = that layer's output), loss.backward() of dream/network.py:335 */
+#define DREAM_CONV_RES_AFTER_RELU 64 /* `residual` is added AFTER the ReLU: y = relu(conv + shift) + residual -- the hourglass skip
+                                      connections (dream/models.py:774-799: x = relu(conv(..)) ; x = x + x_0_k_d) folded into the
+                                      producing conv's epilogue (inference).  Not with DREAM_CONV_RELUMASK / DREAM_CONV_POOL2. */
 #define DREAM_CONV_ZEROSTUFF2X 8   /* input is [B,H/2,W/2,Cin] placed at the even positions of a zero [B,H,W,Cin]
                                       grid: with mode-1 packed weights this is ConvTranspose2d(k=3,s=2,p=1,
                                       output_padding=1) (dream/models.py:621-686) */
@@ -180,6 +183,10 @@ int dream_conv_transpose4x4s2_winograd4_nhwc_f32(const float *x, const float *u4
  * w_packed: dream_pack_conv3x3_weight(mode 1) of the [Cin,Cout,3,3] ConvTranspose weight; flags: DREAM_CONV_RELU. */
 int dream_conv_transpose3x3s2_nhwc_f32(const float *x, const float *w_packed, const float *bias, float *y, int B,
                                        int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream);
+/* the same with a tensor of the output's shape added in the epilogue: before the ReLU, or -- DREAM_CONV_RES_AFTER_RELU -- after it
+ * (the skip connection behind deconv_0_1, dream/models.py:796-799); flags: DREAM_CONV_RELU | DREAM_CONV_RES_AFTER_RELU */
+int dream_conv_transpose3x3s2_res_nhwc_f32(const float *x, const float *w_packed, const float *bias, const float *residual, float *y,
+                                           int B, int H, int W, int Cin, int Cout, int CoutPad, int flags, void *stream);
 /* Data gradient of a k x k (1 | 3) stride-2 pad-k/2 convolution -- the strided 3x3 and 1x1 (downsample) convs of the
  * torchvision ResNet-101 trunk behind dream/models.py:22-32, reached from loss.backward() (dream/network.py:335):
  * dy [B,Hy,Wy,C] -> dx [B,Hx,Wx,Cx], Hx in {2Hy-1, 2Hy}; w_packed_mode1 = dream_pack_conv_weight(mode 1) of the forward

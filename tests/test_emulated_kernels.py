@@ -359,3 +359,16 @@ def test_winograd4_channel_blocks_pinned_to_xcds_same_bits(emu):
         assert torch.equal(outs[0], outs[1])
         ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).relu().permute(0, 2, 3, 1)
         assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("algorithm", ["winograd", "direct"])
+def test_skip_connections_fold_into_the_producing_conv(emu, monkeypatch, algorithm):
+    """K13 (dream/models.py:774-799): in inference the skip-connection sums x + x_0_k_d are made by the producing conv's epilogue
+    (DREAM_CONV_RES_AFTER_RELU) -- no stand-alone add launch -- and the reference's golden maps still hold; training keeps the add."""
+    monkeypatch.setenv("DREAM_CONV_ALGORITHM", algorithm)
+    adds = []
+    real = ops.add
+    monkeypatch.setattr(ops, "add", lambda *a, **k: (adds.append(1), real(*a, **k))[1])
+    for name in ("vgg_q_skip", "vgg_f_skip"):
+        pc.check_variant("cpu", name, train=False)
+    assert not adds

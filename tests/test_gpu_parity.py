@@ -968,3 +968,16 @@ def test_wgrad_winograd_fused_upsample(b, h, w, cin, cout):
     """The decoder convs that follow nn.Upsample(2) (dream/models.py:691-710): x at half resolution, upsample fused into the loads."""
     err = pc.check_wgrad_winograd(DEV, b, h, w, cin, cout, seed=h + cin, ups=True)
     print("winograd wgrad after upsample %dx%dx%d %d->%d: err / sum|terms| %.2e" % (b, h, w, cin, cout, err))
+
+
+@pytest.mark.parametrize("algorithm", ["winograd", "direct"])
+def test_skip_connections_fold_into_the_producing_conv(monkeypatch, algorithm):
+    """K13 (dream/models.py:774-799): in inference the skip-connection sums x + x_0_k_d are made by the producing conv's epilogue
+    (DREAM_CONV_RES_AFTER_RELU) -- no stand-alone add launch -- and the reference's golden maps still hold; training keeps the add."""
+    monkeypatch.setenv("DREAM_CONV_ALGORITHM", algorithm)
+    adds = []
+    real = ops.add
+    monkeypatch.setattr(ops, "add", lambda *a, **k: (adds.append(1), real(*a, **k))[1])
+    for name in ("vgg_q_skip", "vgg_f_skip"):
+        pc.check_variant(DEV, name, train=False)
+    assert not adds
