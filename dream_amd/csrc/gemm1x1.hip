@@ -48,7 +48,8 @@ struct GemmParams {
     StatTree st;             // one row of partial sums per 64-row block (stat_tree.h)
     BnFwdOut st_fwd;         // EPI 1: statistics -> scale / shift of the following BatchNorm (st_fwd.mean / invstd: outputs)
     const float *st_z;       // EPI 2: [M][N]
-    const float *st_zab;     // EPI 2: [2][N]
+    const float *st_zab;     // EPI 2: [2][N], or null when the mask comes from st_yact
+    const float *st_yact;    // EPI 2: stored activation [M][N] whose sign is the ReLU mask (Bottleneck outputs: relu(BN(z) + identity)), or null
     const float *st_mean, *st_invstd;  // EPI 2: of the masked BatchNorm
     float *st_dgamma, *st_dbeta;       // EPI 2 out
 };
@@ -165,9 +166,12 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
     double st0[4] = {0.0, 0.0, 0.0, 0.0}, st1[4] = {0.0, 0.0, 0.0, 0.0};      // EPI: this lane's sums over its rows
     f32x4 za = {0.0f, 0.0f, 0.0f, 0.0f}, zb = za, zmu = za, zis = za;
+    const bool mask_y = EPI == 2 && p.st_yact != nullptr;
     if (EPI == 2 && cok) {
-        za = *(const f32x4 *)(p.st_zab + c0);
-        zb = *(const f32x4 *)(p.st_zab + p.N + c0);
+        if (!mask_y) {
+            za = *(const f32x4 *)(p.st_zab + c0);
+            zb = *(const f32x4 *)(p.st_zab + p.N + c0);
+        }
         zmu = *(const f32x4 *)(p.st_mean + c0);
         zis = *(const f32x4 *)(p.st_invstd + c0);
     }
@@ -191,9 +195,12 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
                 }
                 if (EPI == 2) {
                     const f32x4 z = *(const f32x4 *)(p.st_z + o);
+                    f32x4 ya = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (mask_y) ya = *(const f32x4 *)(p.st_yact + o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f ? v[e] : 0.0f;
+                        const bool on = mask_y ? ya[e] > 0.0f : __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f;
+                        v[e] = on ? v[e] : 0.0f;
                         const float xh = (z[e] - zmu[e]) * zis[e];
                         st0[e] += (double)v[e];
                         st1[e] += (double)v[e] * (double)xh;
@@ -501,23 +508,26 @@ extern "C" int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_pac
     return gemm1x1_launch(p, M, K, N, x_stride, pre_ab != nullptr, 1, stream);
 }
 
-// Data gradient of a 1x1 conv whose INPUT was relu(BatchNorm(z)) (never stored):  g = (dy . w) * [ab[0] z + ab[1] > 0], written to
-// g_out, and -- finished inside the launch -- dbeta = sum g, dgamma = sum g * (z - mean) * invstd of that BatchNorm.
-// w_packed_t: mode-1 packing; K = channels of dy, N = channels of z.
-extern "C" int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, float *g_out, long M, int K, int N,
-                                                 int dy_stride, const float *z, const float *ab, const float *mean,
-                                                 const float *invstd, float *dgamma, float *dbeta, void *workspace,
+// Data gradient of a 1x1 conv whose INPUT was the output of a BatchNorm + ReLU, with that BatchNorm's backward reductions in the
+// epilogue:  g = (dy . w (+ residual)) * mask, written to g_out, and -- finished inside the launch -- dbeta = sum g,
+// dgamma = sum g * (z - mean) * invstd.  mask = [ab[0] z + ab[1] > 0] (the input relu(BN(z)) was never stored: gemm1x1 PRE), or
+// [y_act > 0] when y_act is given (a Bottleneck output relu(BN(z) + identity), which IS stored; `residual` then carries the
+// gradient of the other branch that meets it: the downsample's or the identity's).  w_packed_t: mode-1 packing; K = channels of
+// dy, N = channels of z.
+extern "C" int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, const float *residual, float *g_out, long M,
+                                                 int K, int N, int dy_stride, const float *z, const float *ab, const float *y_act,
+                                                 const float *mean, const float *invstd, float *dgamma, float *dbeta, void *workspace,
                                                  unsigned *counters, void *stream) {
-    DREAM_REQUIRE(dy && w_packed_t && g_out && z && ab && mean && invstd && dgamma && dbeta && workspace && counters,
+    DREAM_REQUIRE(dy && w_packed_t && g_out && z && (ab || y_act) && mean && invstd && dgamma && dbeta && workspace && counters,
                   "conv1x1_bwd_bnmask: null pointer");
     DREAM_REQUIRE(M > 0 && K > 0 && N > 0 && dy_stride >= K, "conv1x1_bwd_bnmask: bad shape M=%ld K=%d N=%d stride=%d", M, K, N, dy_stride);
     DREAM_REQUIRE(K % 32 == 0 && N % 4 == 0 && dy_stride % 4 == 0, "conv1x1_bwd_bnmask: K %% 32, N %% 4, stride %% 4 (got %d, %d, %d)", K, N, dy_stride);
     DREAM_REQUIRE((size_t)M * (size_t)dy_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
                   "conv1x1_bwd_bnmask: tensor too large for 32-bit offsets");
     GemmParams p = {};
-    p.x = dy; p.w = w_packed_t; p.y = g_out;
+    p.x = dy; p.w = w_packed_t; p.y = g_out; p.residual = residual;
     p.st = stat_tree_make(workspace, counters, (int)((M + 63) / 64), N);
-    p.st_z = z; p.st_zab = ab; p.st_mean = mean; p.st_invstd = invstd;
+    p.st_z = z; p.st_zab = ab; p.st_yact = y_act; p.st_mean = mean; p.st_invstd = invstd;
     p.st_dgamma = dgamma; p.st_dbeta = dbeta;
     return gemm1x1_launch(p, M, K, N, dy_stride, false, 2, stream);
 }

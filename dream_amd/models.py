@@ -1400,7 +1400,7 @@ class ResnetSimple(nn.Module):
         if isinstance(dy, tuple):
             _, g, dgam, dbet = dy
             dz, _ = ops.bn_bwd_apply(rec["z"], g, bn.weight, rec["mean"], rec["invstd"], dgam, dbet)
-            return dz, None, dgam, dbet
+            return dz, g, dgam, dbet
         y_act = rec["y"] if rec["relu"] else None
         ab = rec["ab"] if (rec["relu"] and y_act is None) else None
         dgam, dbet = ops.bn_bwd_stats(rec["z"], dy, rec["mean"], rec["invstd"], self._ctr(dev), y_act=y_act, ab=ab)
@@ -1415,7 +1415,8 @@ class ResnetSimple(nn.Module):
         side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= 96 * 400 * 400)
         g = None
         block = None
-        for rec in reversed(tape):
+        for idx in range(len(tape) - 1, -1, -1):
+            rec = tape[idx]
             kind = rec["kind"]
             if kind == "final":
                 m = rec["conv"]
@@ -1485,7 +1486,19 @@ class ResnetSimple(nn.Module):
             elif kind == "block_begin":
                 name1, conv1, dz, cin, k, stride, in_hw = block["dz1"]
                 other = block["g_ds"] if rec["ds"] else block["g_idt"]
-                g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
+                # the block's input is the previous Bottleneck's output relu(BN3(z3) + identity): that BatchNorm's ReLU mask and its
+                # two backward reductions ride in the epilogue of this data-gradient GEMM (one full pass over three 4x-wide tensors
+                # and one launch fewer per Bottleneck)
+                prev = tape[idx - 2] if idx >= 2 and tape[idx - 1]["kind"] == "block_end" else None
+                if (prev is not None and prev["kind"] == "conv" and prev["has_res"] and prev["relu"] and prev["y"] is not None
+                        and self.conv1x1_algorithm == "gemm" and k == 1 and stride == 1 and int(dz.shape[3]) == int(conv1.weight.shape[0])
+                        and ops.conv1x1_applies(dz, cin) and tuple(prev["y"].shape) == tuple(dz.shape[:3]) + (cin,)):
+                    packed_t, rows = self._cached(("g1", name1), [conv1.weight], lambda: ops.pack_conv1x1_weight(conv1.weight.detach(), 1))
+                    gmask, dg3, db3 = ops.conv1x1_bwd_bnmask(dz, packed_t, cin, prev["z"], None, prev["mean"], prev["invstd"],
+                                                            self._ctr(dz.device), y_act=prev["y"], residual=other)
+                    g = ("masked", gmask, dg3, db3)
+                else:
+                    g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
                 block = None
             elif kind == "pool":
                 g = ops.maxpool3s2_bwd(g, rec["x"])

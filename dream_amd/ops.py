@@ -830,8 +830,9 @@ def conv1x1_bn(x_nhwc, packed, cout, bn, counters, pre_ab=None, shift=None):
     return z, ab, mean, invstd
 
 
-def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counters):
-    """Data gradient of a 1x1 conv whose input was relu(BN(z)): -> (g = (dy . w) masked, dgamma, dbeta of that BN)."""
+def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counters, y_act=None, residual=None):
+    """Data gradient of a 1x1 conv whose input was the output of a BN + ReLU: -> (g = (dy . w (+ residual)) masked, dgamma, dbeta of
+    that BN).  The mask is recomputed from (z, ab) -- the input relu(BN(z)) was never stored -- or read from ``y_act`` (> 0)."""
     dy = _f32(dy_nhwc)
     b, h, w, k = (int(v) for v in dy.shape)
     m = b * h * w
@@ -842,8 +843,10 @@ def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counter
     dbeta = torch.empty_like(dgamma)
     ws = _workspace(_hip.lib().dream_conv1x1_bn_workspace(m, cin), dy.device)
     ctr = _ctr_words(counters, _hip.lib().dream_conv1x1_bn_counters(m, cin))
-    call("dream_conv1x1_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_t), ptr(g), m, k, cin, k, ptr(_f32(z_nhwc)), ptr(ab), ptr(mean),
-         ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(ctr), stream())
+    if residual is not None and tuple(residual.shape) != tuple(g.shape):
+        raise RuntimeError("conv1x1_bwd_bnmask: residual shape %s != %s" % (tuple(residual.shape), tuple(g.shape)))
+    call("dream_conv1x1_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_t), ptr(residual), ptr(g), m, k, cin, k, ptr(_f32(z_nhwc)),
+         None if y_act is not None else ptr(ab), ptr(y_act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(ctr), stream())
     return g, dgamma, dbeta
 
 

@@ -430,12 +430,14 @@ int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_packed, const 
                                    float *running_mean, float *running_var, long long *num_batches_tracked, float eps,
                                    float momentum, float *out_ab, float *save_mean, float *save_invstd, void *workspace,
                                    unsigned *counters, void *stream);
-/* data gradient of a 1x1 conv whose input was relu(BN(z)) (never stored): g_out = (dy . w) * [ab[0] z + ab[1] > 0] and, finished in
- * the launch, dbeta = sum g, dgamma = sum g * (z - mean) * invstd of that BN.  w_packed_t: mode-1 packing, K = channels of dy,
- * N = channels of z. */
-int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, float *g_out, long M, int K, int N, int dy_stride,
-                                      const float *z, const float *ab, const float *mean, const float *invstd, float *dgamma,
-                                      float *dbeta, void *workspace, unsigned *counters, void *stream);
+/* data gradient of a 1x1 conv whose input was the output of a BN + ReLU, with that BN's backward reductions in the epilogue:
+ * g_out = (dy . w (+ residual)) * mask and, finished in the launch, dbeta = sum g, dgamma = sum g * (z - mean) * invstd.
+ * mask = [ab[0] z + ab[1] > 0] (input never stored), or [y_act > 0] when y_act is given (a Bottleneck output relu(BN(z) + identity);
+ * residual = the gradient of the other branch meeting there).  w_packed_t: mode-1 packing, K = channels of dy, N = channels of z. */
+int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, const float *residual, float *g_out, long M, int K,
+                                      int N, int dy_stride, const float *z, const float *ab, const float *y_act, const float *mean,
+                                      const float *invstd, float *dgamma, float *dbeta, void *workspace, unsigned *counters,
+                                      void *stream);
 /* weight gradient of a 1x1 conv whose input was relu(pre_ab[0][ci] x + pre_ab[1][ci]) (x = the BN input) */
 int dream_conv1x1_wgrad_pre_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout,
                                      int Cdy, const float *pre_ab, void *stream);

@@ -4,6 +4,7 @@
 #include <thread>
 #include <vector>
 #include <atomic>
+#include <mutex>
 
 namespace emu {
 thread_local Block *tb = nullptr;
@@ -89,6 +90,24 @@ static void run_block(Block *b) {
     }
 }
 
+// Fiber stacks are recycled across launches: a launch used to malloc / free 256 KB per emulated thread and worker (an mmap +
+// munmap + page faults each: ~20 ms per launch with 512-thread workgroups on 8 workers, more than the kernels themselves for the
+// ~1 700 small launches of a ResNet-101 training step).
+static std::mutex g_stack_mu;
+static std::vector<char *> g_stack_pool;
+static char *stack_get() {
+    {
+        std::lock_guard<std::mutex> lock(g_stack_mu);
+        if (!g_stack_pool.empty()) { char *s = g_stack_pool.back(); g_stack_pool.pop_back(); return s; }
+    }
+    return (char *)malloc(kStack);
+}
+static void stack_put(char *s) {
+    std::lock_guard<std::mutex> lock(g_stack_mu);
+    if (g_stack_pool.size() < 8192) g_stack_pool.push_back(s);
+    else free(s);
+}
+
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem) {
     const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
     const int nthreads = (int)block.x;
@@ -99,7 +118,7 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shm
     auto worker = [&]() {
         Block *b = new Block();
         b->fibers = new Fiber[nthreads];
-        for (int t = 0; t < nthreads; ++t) b->fibers[t].stack = (char *)malloc(kStack);
+        for (int t = 0; t < nthreads; ++t) b->fibers[t].stack = stack_get();
         b->nthreads = nthreads;
         b->bdim = block; b->gdim = grid;
         b->dyn_lds = (char *)aligned_alloc(64, ((shmem + 63) / 64 + 1) * 64);
@@ -112,7 +131,7 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shm
             memset(b->dyn_lds, 0xFF, shmem);      // poison: uninitialised LDS reads show up as NaNs
             run_block(b);
         }
-        for (int t = 0; t < nthreads; ++t) free(b->fibers[t].stack);
+        for (int t = 0; t < nthreads; ++t) stack_put(b->fibers[t].stack);
         delete[] b->fibers;
         free(b->dyn_lds);
         delete b;

@@ -1165,6 +1165,10 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
                 _hip.call("dream_conv1x1_set_ksplit", ks)
                 try:
                     gm, dg_p, db_p = ops.conv1x1_bwd_bnmask(dz, packed_t, Cin, zp_d, pre_ab, pre_mean, pre_invstd, ctr)
+                    if ks == 0:      # the same with the mask read from the stored activation (+ a second gradient meeting there)
+                        extra = to(dev, _nhwc(torch.zeros_like(zp.detach())))
+                        gm2, dg2, db2 = ops.conv1x1_bwd_bnmask(dz, packed_t, Cin, zp_d, None, pre_mean, pre_invstd, ctr, y_act=ops.bn_apply_ab(zp_d, pre_ab, None, True), residual=extra)
+                        assert torch.equal(gm2, gm) and torch.equal(dg2, dg_p) and torch.equal(db2, db_p)
                 finally:
                     _hip.call("dream_conv1x1_set_ksplit", 0)
                 assert float((dg_p.cpu() - bn_p.weight.grad).abs().max()) < 3e-4 * max(1.0, float(bn_p.weight.grad.abs().max())), (Cin, ks)

@@ -6,6 +6,7 @@ on the real device in the -m gpu suite."""
 import os
 
 import pytest
+import torch
 
 import cases
 from dream_amd import ops
