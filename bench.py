@@ -19,7 +19,8 @@ launch stream inside the timed region; achieved = algorithmic FLOPs of those lau
   * N == 1: `secondary` = the other single-GPU configurations of BASELINE.json under the same clock: configs[2] (vgg_q
     training b=128) and one GPU's share of configs[3] (resnet_h training, 16 frames) and configs[4] (resnet_f inference, 32
     frames), two timed steps each, every one with its executed-multiplication roofline fraction; `cpu_baseline` times the CPU
-    oracle (torch-CPU restatement of the reference + NumPy peak path) on a bounded sample of the main workload.
+    oracle by the protocol of BASELINE.md section 3 (torch-CPU restatement: forward B=1 / B=16, train() step B=8, resnet_h
+    forward B=1 on all host threads; plain-C peak extraction on one core; median of the timed iterations after the warm-ups).
   * N > 1: `scale` = the sharded configurations BASELINE.json names: configs[3] (resnet_h training, 128 frames split over the
     N GPUs, RCCL all-reduce of the gradients every step) and configs[4] (resnet_f inference, 256 frames split over the N
     GPUs), each with whole-job and per-GPU frames/s (strong scaling), next to the weak-scaling vgg_q metric in `value`.

@@ -28,4 +28,14 @@ w4pin)
   DREAM_W4_YMAP=0 line dflt_walked2
   DREAM_W4_YMAP=1 line dflt_pinned2
   ;;
+bn3)
+  echo "== pytest (new + touched)"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "bn_fused or resnet_h_train_step or reference_golden or resnet_training_ops or data_parallel or conv1x1 or skip_connections or variant" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in 1 2; do
+    DREAM_BN_FUSION=1 line rt16_fused_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_BN_FUSION=0 line rt16_three_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  DREAM_BN_FUSION=1 line rt128_fused --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  DREAM_BN_FUSION=0 line rt128_three --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 30 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_fused.txt; sed -n 2,24p $O/layer_profile_fused.txt | cut -c1-120
+  ;;
 esac

@@ -17,7 +17,7 @@ def main():
         for name, n, tot, avg, mn, mx in rows:
             f.write('"%s",%d,%.3f,%.1f,%.1f,%.1f,%.2f\n' % (name, n, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total))
         # template families (what bench.py's roofline.avg_launch_ms averages over)
-        for fam in ("conv_wino4_kernel<", "conv_wino_kernel<", "conv_mfma_kernel<", "conv_f16x3_kernel<", "wgrad_kernel<", "wgrad_wino", "bn_"):
+        for fam in ("conv_wino4_kernel<", "conv_wino_kernel<", "conv_mfma_kernel<", "conv_f16x3_kernel<", "gemm1x1_kernel<", "wgrad1x1", "wgrad_kernel<", "wgrad_wino", "bn_"):
             sel = [r for r in rows if fam in r[0]]
             if sel:
                 n = sum(r[1] for r in sel)
