@@ -59,6 +59,9 @@
 #ifndef DREAM_W4_STORE
 #define DREAM_W4_STORE buffer_store_f32
 #endif
+#ifndef DREAM_W4_MIDBARRIER
+#define DREAM_W4_MIDBARRIER 0
+#endif
 
 namespace {
 
@@ -407,7 +410,11 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                 pair(3);
             }
             if (s == S1 + 2 && !(DREAM_W4_DIAG & 4)) {                       // pass 1 of the next chunk is staged
-                __syncthreads();
+                // No workgroup barrier is needed here: the (tile, quad, row) items of pass 1 and the (tile, quad, column) items
+                // of pass 2 of one wavefront cover the SAME tiles (wide: tiles 2w, 2w + 1; narrow: 4w .. 4w + 3), so a
+                // wavefront's pass 2 reads only what that wavefront's pass 1 wrote, and a wavefront's LDS instructions execute
+                // in order.  (DREAM_W4_MIDBARRIER=1 restores the barrier of round 3 for A/B runs.)
+                if (DREAM_W4_MIDBARRIER) __syncthreads();
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -38,4 +38,19 @@ bn3)
   DREAM_BN_FUSION=0 line rt128_three --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
   timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 30 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_fused.txt; sed -n 2,24p $O/layer_profile_fused.txt | cut -c1-120
   ;;
+full)
+  echo "== pytest gpu (all)"; timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head -20
+  echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-200
+  echo "== default bench"; /usr/bin/time -f "%e s wall" timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-1500; tail -1 $O/bench_default.err
+  ;;
+ks)
+  timeout 300 python tools/sweep_conv1x1_ks.py 2>&1 | grep -v amdgpu.ids | tee $O/sweep_conv1x1_ks_b16.txt
+  timeout 300 python tools/sweep_conv1x1_ks.py --batch 128 --reps 3 2>&1 | grep -v amdgpu.ids | tee $O/sweep_conv1x1_ks_b128.txt
+  ;;
+midbar)
+  echo "== pytest (F(4x4) kernels, fixtures)"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "winograd4 or wino4 or structured or convT4 or golden or pinned" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  DREAM_W4_DIAG_KS=2101 timeout 300 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/wino4_midbarrier.txt
+  line dflt_a
+  line dflt_b
+  ;;
 esac

@@ -15,9 +15,9 @@ if os.environ.get("DREAM_W4_DIAG_KS"):          # a subset of the variants: DREA
 OUT = os.path.join(ROOT, "build", "diag")             # travels with the snapshot only while it exists: `rm -rf build/diag` after the measurement
 VARIANTS = {3001: ["-DDREAM_W4_STORE=buffer_store_f32_nt"], 2001: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 2002: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
             2003: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 2004: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
-            2005: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"]}
+            2005: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"], 2101: ["-DDREAM_W4_MIDBARRIER=1"], 2100: ["-DDREAM_W4_MIDBARRIER=0"]}
 NAMES = {0: "product", 3001: "non-temporal stores", 128: "no epilogue", 256: "epilogue without stores", 143: "MFMAs + operand reads only, no epilogue", 32: "weights from L1 (one position)", 64: "patches: chunk 0 only", 96: "weights from L1 + patches chunk 0", 48: "weights from L1 + patches out of range", 2001: "S1 6 S2 9", 2002: "S1 8 S2 13", 2003: "S1 10 S2 13, loads in slot 0", 2004: "S1 11 S2 14",
-         2005: "S1 4 S2 8, loads in slot 0", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
+         2005: "S1 4 S2 8, loads in slot 0", 2101: "with the mid-chunk workgroup barrier (round 3)", 2100: "without the mid-chunk barrier", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
          11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 1006: "weight ring 6 (4 ahead; the product has 8)", 1112: "narrow shape: weight ring 12 (product 18)"}
 
 
