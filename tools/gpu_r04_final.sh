@@ -8,7 +8,6 @@ export TMPDIR=/tmp
 R="$PWD"
 echo "== pytest gpu (all)"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-200
-echo "== default bench"; timeout 900 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log | cut -c1-300
 echo "== two ranks on this one GPU over gloo (rehearsal of the torchrun path; the numbers mean nothing)"
 DREAM_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-split-leg > $O/rehearsal_2ranks_selflaunch.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_2ranks_selflaunch.log | cut -c1-200
 DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 32 --no-cpu-baseline > $O/rehearsal_single_process_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_train.log | cut -c1-200
