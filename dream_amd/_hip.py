@@ -52,6 +52,7 @@ _SIGNATURES = {
     "dream_channel_sum_nhwc_f32": (_I, [_P, _P, _P, _SZ, _I, _P]),
     "dream_bn_stats_workspace": (_SZ, [_I]),
     "dream_bn_stats_counters": (_I, [_I]),
+    "dream_bn_stats_set_pixels_per_row": (_I, [_I]),
     "dream_bn_stats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _SZ, _I, _P]),
     "dream_bn_apply_ab_nhwc_f32": (_I, [_P, _P, _P, _P, _SZ, _I, _I, _P]),
     "dream_bn_bwd_stats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _SZ, _I, _I, _P]),

@@ -462,9 +462,15 @@ extern "C" int dream_bn_train_bwd_nhwc_f32(const float *x, const float *dy, cons
 extern "C" size_t dream_bn_stats_workspace(int C) { return stat_tree_doubles(kStatRows, C) * sizeof(double); }
 extern "C" int dream_bn_stats_counters(int C) { return stat_tree_counters(kStatRows, C); }
 
+static int g_stat_px_per_row = 128;     // A/B hook (dream_bn_stats_set_pixels_per_row): pixels a workgroup sums into its partial row
 static inline int host_stat_rows(size_t npix) {
-    size_t nb = (npix + 127) / 128;
+    size_t nb = (npix + g_stat_px_per_row - 1) / g_stat_px_per_row;
     return (int)(nb < 1 ? 1 : (nb > (size_t)kStatRows ? (size_t)kStatRows : nb));
+}
+extern "C" int dream_bn_stats_set_pixels_per_row(int px) {
+    DREAM_REQUIRE(px >= 16 && px <= (1 << 20), "bn_stats: %d pixels per partial row", px);
+    g_stat_px_per_row = px;
+    return 0;
 }
 
 // Batch statistics of z [npix][C] in ONE launch: save_mean, save_invstd, out_ab = (gamma * invstd, beta - mean * gamma * invstd),

@@ -403,6 +403,7 @@ int dream_channel_sum_nhwc_f32(const float *x, float *out, void *workspace, size
  * bytes (dream_conv1x1_bn_workspace(M, N) for the GEMM forms). */
 size_t dream_bn_stats_workspace(int C);
 int dream_bn_stats_counters(int C);
+int dream_bn_stats_set_pixels_per_row(int px);           /* A/B hook: pixels one workgroup sums into a partial row (default 128) */
 /* batch statistics of z [npix][C] in one launch (+ running statistics update as nn.BatchNorm2d in train mode) */
 int dream_bn_stats_nhwc_f32(const float *z, const float *gamma, const float *beta, float *running_mean, float *running_var,
                             long long *num_batches_tracked, float eps, float momentum, float *out_ab, float *save_mean,

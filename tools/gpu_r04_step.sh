@@ -53,4 +53,7 @@ midbar)
   line dflt_a
   line dflt_b
   ;;
+bnrows)
+  timeout 300 python tools/sweep_bn_stats.py 2>&1 | grep -v amdgpu.ids | tee $O/sweep_bn_stats_b16.txt
+  ;;
 esac
