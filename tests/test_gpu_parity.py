@@ -712,6 +712,45 @@ def test_conv1x1_wgrad_gemm(b, h, w, cin, cout, pad):
     print("conv1x1 wgrad %dx%dx%d %d->%d: err / sum|terms| %.2e" % (b, h, w, cin, cout, err))
 
 
+def test_resnet_batchnorm_paths_agree_at_the_benchmark_shape(monkeypatch):
+    """One GPU's share of configs[3] (resnet_h, 16 frames of 400x400): a training step with BatchNorm folded into its neighbours
+    (round 4: statistics finished by the ticket tree inside 2 500-row launches, BN + ReLU in the 1x1 convs' loaders, reductions in the
+    data-gradient epilogues) against the three-launch kernels of rounds 1-3 -- two correct fp32 evaluations of the same step: the
+    loss agrees to 1e-5, the BatchNorm running statistics to 1e-5 of their scale, the gradient in direction (the 101 train-mode
+    BatchNorms amplify summation-order differences; parity_checks.check_resnet_train_step holds each path against the fp64 oracle).
+    The fused step repeated gives the same bits (the tree's fixed summation order)."""
+    k = 7
+    wts = om.recipe_weights(om.build_model("resnet_h", k).state_dict(), cases.TRAIN_FINAL_KEYS, cases.TRAIN_FINAL_SCALE)
+    x = torch.from_numpy(cases.image_batch(16, 400, 400, seed=8)).to(DEV)
+    runs = {}
+    for tag, env in (("fused", "1"), ("fused_again", "1"), ("three_launch", "0")):
+        monkeypatch.setenv("DREAM_BN_FUSION", env)
+        net = pc.build_network("resnet_h", DEV, weights=wts, optimizer="sgd", lr=1e-5, in_res=(400, 400))
+        assert net.model.module.bn_fusion == (env == "1")
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(16, k, (ow, oh), in_wh=(400, 400), seed=8)).to(DEV)
+        net.optimizer.zero_grad()
+        loss = net.loss([x], t)
+        loss.backward()
+        runs[tag] = (float(loss.detach()), {n: p.grad.detach().clone() for n, p in net.model.named_parameters()},
+                     {n: b.detach().clone() for n, b in net.model.named_buffers() if n.endswith(("running_mean", "running_var"))})
+        del net
+    assert runs["fused"][0] == runs["fused_again"][0]
+    assert all(torch.equal(runs["fused"][1][n], runs["fused_again"][1][n]) for n in runs["fused"][1])
+    la, lb = runs["fused"][0], runs["three_launch"][0]
+    assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)
+    for n, b in runs["three_launch"][2].items():
+        assert float((runs["fused"][2][n] - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max())), n
+    ga, gb = runs["fused"][1], runs["three_launch"][1]
+    names = [n for n in ga if not (n.startswith("module.upsample") and n.endswith(".bias") and n != "module.upsample.12.bias")]
+    dot = sum(float((ga[n].double() * gb[n].double()).sum()) for n in names)
+    na = sum(float(ga[n].double().pow(2).sum()) for n in names) ** 0.5
+    nb = sum(float(gb[n].double().pow(2).sum()) for n in names) ** 0.5
+    print("fused vs three-launch BatchNorm at 16x400x400: loss %.7f / %.7f, gradient cosine %.6f, norm ratio %.5f" % (la, lb, dot / (na * nb), na / nb))
+    assert dot / (na * nb) >= 0.99 and abs(na / nb - 1.0) <= 0.02
+
+
 def test_resnet_conv1x1_algorithms_agree():
     """ResnetSimple with the 1x1 convs on the GEMM kernel vs on the direct conv kernel: evaluation maps agree to fp32
     round-off; one training step's gradient agrees in direction (cosine >= 0.99) -- the two kernels sum in different orders;

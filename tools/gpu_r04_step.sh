@@ -56,4 +56,7 @@ midbar)
 bnrows)
   timeout 300 python tools/sweep_bn_stats.py 2>&1 | grep -v amdgpu.ids | tee $O/sweep_bn_stats_b16.txt
   ;;
+bnfull)
+  timeout 900 python -m pytest tests -m gpu -q -x -s --timeout 600 -k "batchnorm_paths_agree" 2>&1 | grep -v "Warning\|warn" | tail -6
+  ;;
 esac
