@@ -59,4 +59,16 @@ bnrows)
 bnfull)
   timeout 900 python -m pytest tests -m gpu -q -x -s --timeout 600 -k "batchnorm_paths_agree" 2>&1 | grep -v "Warning\|warn" | tail -6
   ;;
+conc)
+  summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" "$3" "$4" > $O/summ.log 2>&1; echo "summary $2 rc=$?"; tail -9 $O/summ.log; rm -rf "$1"; }
+  R="$PWD"
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 5 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
+  summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 2
+  (cd /tmp && DREAM_BN_FUSION=0 timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain3" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 5 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain3.log" 2>&1); echo "rc=$?"
+  summ $O/prof_rtrain3 $O/bench_resnet_h_train16_three_launch_bn adam_kernel 2
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_vtrain" -o vtrain -- python "$R/bench.py" --mode train --steps 3 --warmup 2 --no-cpu-baseline > "$R/$O/rocprof_vtrain.log" 2>&1); echo "rc=$?"
+  summ $O/prof_vtrain $O/bench_train adam_kernel 1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_dflt" -o dflt -- python "$R/bench.py" --no-cpu-baseline --no-secondary > "$R/$O/rocprof_dflt.log" 2>&1); echo "rc=$?"
+  summ $O/prof_dflt $O/bench_default peaks_kernel 2
+  ;;
 esac
