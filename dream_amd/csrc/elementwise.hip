@@ -323,6 +323,36 @@ __global__ void __launch_bounds__(256) im2col_nchw_kernel(const float *x, float 
     }
 }
 
+// The same for the one shape the path uses -- ResNet-101's stem, Conv2d(3, 64, 7, stride 2, pad 3) (dream/models.py:22 via
+// torchvision) -- with every divisor a compile-time constant and 32-bit indices (the generic kernel spends ~6 64-bit divisions per
+// float: 1.1 TB/s of stores at 16 frames, 2.5 % of a ResNet-101 step and 4.5 % of its evaluation at 128 frames).  Workgroup =
+// one output row of one image; a thread produces four consecutive k of one output pixel (one 16-byte store, 4 gathers from the
+// L2-resident image).
+template <int C, int KH, int KW, int STRIDE, int PAD>
+__global__ void __launch_bounds__(256) im2col_nchw_fixed_kernel(const float *x, float *y, int H, int W, int Ho, int Wo, int Kpad) {
+    constexpr int K = C * KH * KW;
+    const int oy = (int)blockIdx.x, b = (int)blockIdx.y;
+    const int K4 = Kpad >> 2;
+    const float *img = x + (size_t)b * C * H * W;
+    f32x4 *row = (f32x4 *)(y + ((size_t)b * Ho + oy) * (size_t)Wo * Kpad);
+    const int n = Wo * K4;
+    for (int i = (int)threadIdx.x; i < n; i += 256) {
+        const int ox = (int)((unsigned)i / (unsigned)K4);                 // one 32-bit division per four outputs
+        const int k0 = (i - ox * K4) * 4;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = k0 + e;
+            if (k < K) {
+                const int kx = k % KW, ky = (k / KW) % KH, c = k / (KW * KH);
+                const int iy = oy * STRIDE - PAD + ky, ix = ox * STRIDE - PAD + kx;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v[e] = img[(c * H + iy) * W + ix];
+            }
+        }
+        row[i] = v;
+    }
+}
+
 // nn.MaxPool2d(kernel 3, stride 2, padding 1) on NHWC (ResNet stem); padding never wins (-inf)
 __global__ void __launch_bounds__(256) maxpool3s2_kernel(const f32x4 *x, f32x4 *y, int B, int H, int W, int C4, int Ho, int Wo) {
     const size_t total = (size_t)B * Ho * Wo * C4;
@@ -584,6 +614,13 @@ extern "C" int dream_im2col_nchw_f32(const float *x, float *y, int B, int C, int
     DREAM_REQUIRE(x && y && B > 0 && C > 0 && KH > 0 && KW > 0 && stride > 0 && Kpad >= C * KH * KW, "im2col: bad arguments");
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     DREAM_REQUIRE(Ho > 0 && Wo > 0, "im2col: empty output");
+    if (C == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Kpad % 4 == 0 && (size_t)Wo * (Kpad / 4) < ((size_t)1 << 30) &&
+        (size_t)C * H * W < ((size_t)1 << 30) && B <= 65535) {
+        hipLaunchKernelGGL((im2col_nchw_fixed_kernel<3, 7, 7, 2, 3>), dim3((unsigned)Ho, (unsigned)B), dim3(256), 0, (hipStream_t)stream,
+                           x, y, H, W, Ho, Wo, Kpad);
+        DREAM_LAUNCH_OK();
+        return 0;
+    }
     hipLaunchKernelGGL(im2col_nchw_kernel, dim3(grid_for((size_t)B * Ho * Wo * Kpad)), dim3(256), 0, (hipStream_t)stream,
                        x, y, B, C, H, W, KH, KW, stride, pad, Ho, Wo, Kpad);
     DREAM_LAUNCH_OK();
@@ -621,6 +658,38 @@ extern "C" int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, fl
     DREAM_LAUNCH_OK();
     return 0;
 }
+// Many tensors gathered into one flat buffer by ONE launch (the optimizer's flat gradient buffer: torch hands every parameter its
+// own gradient tensor, and 318 hipMemcpyAsync calls cost a ResNet-101 step 1.4 ms at its very end -- 3 % -- for 216 MB).  The
+// destination side (where each tensor lives in the flat buffer, cut into chunks of at most 64 K floats) never changes and sits in
+// a device-resident table; the source pointers of the step travel as one small array.
+namespace {
+__global__ void __launch_bounds__(256) multi_copy_kernel(const float *const *srcs, const dream_copy_chunk *chunks) {
+    const dream_copy_chunk c = chunks[blockIdx.x];
+    const float *src = srcs[c.job] + c.src_off;
+    float *dst = c.dst;
+    const unsigned n = c.n;
+    if ((((size_t)src | (size_t)dst) & 15) == 0) {
+        const unsigned n4 = n >> 2;
+        for (unsigned i = threadIdx.x; i < n4; i += 256) ((f32x4 *)dst)[i] = ((const f32x4 *)src)[i];
+        for (unsigned i = (n4 << 2) + threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    } else {
+        for (unsigned i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
+    }
+}
+}  // namespace
+
+extern "C" size_t dream_copy_chunk_bytes(void) { return sizeof(dream_copy_chunk); }
+
+// chunks[c] = {dst, src_off, n, job}: copy n floats from srcs[job] + src_off to dst; srcs: device array of device pointers
+extern "C" int dream_multi_copy_f32(const void *srcs, const void *chunks, int nchunks, void *stream) {
+    DREAM_REQUIRE(srcs && chunks && nchunks >= 0, "multi_copy: bad arguments");
+    if (nchunks == 0) return 0;
+    hipLaunchKernelGGL(multi_copy_kernel, dim3((unsigned)nchunks), dim3(256), 0, (hipStream_t)stream, (const float *const *)srcs,
+                       (const dream_copy_chunk *)chunks);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream) {
     DREAM_REQUIRE(dst && src, "add_inplace: null pointer");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dst, src, n);

@@ -63,6 +63,55 @@ def pack_weights_batched(table, njobs, workgroups_per_job=16):
     call("dream_pack_weights_batched", ptr(table), int(njobs), int(workgroups_per_job), stream())
 
 
+class MultiCopyPlan:
+    """Gathers a fixed list of fp32 tensors into fixed views of one flat buffer with ONE launch per call (csrc/elementwise.hip,
+    dream_multi_copy_f32) -- what ``torch._foreach_copy_(views, tensors)`` does with one hipMemcpyAsync per tensor.  The
+    destination table is built once (device-resident); a call ships the sources' pointers (one small pinned array)."""
+    CHUNK = 1 << 16
+
+    def __init__(self, views):
+        import numpy as np
+        dt = np.dtype([("dst", np.uint64), ("src_off", np.uint32), ("n", np.uint32), ("job", np.int32), ("reserved", np.int32)])
+        if int(_hip.lib().dream_copy_chunk_bytes()) != dt.itemsize:
+            raise RuntimeError("dream_copy_chunk layout mismatch")
+        self.device = views[0].device
+        self.numels = [int(v.numel()) for v in views]
+        rows = []
+        for job, v in enumerate(views):
+            if v.dtype != torch.float32 or not v.is_contiguous() or v.device != self.device:
+                raise RuntimeError("MultiCopyPlan: destinations must be contiguous fp32 views on one device")
+            base, n = ptr(v), int(v.numel())
+            for off in range(0, n, self.CHUNK):
+                rows.append((base + 4 * off, off, min(self.CHUNK, n - off), job, 0))
+        arr = np.array(rows, dtype=dt) if rows else np.zeros(0, dt)
+        self.nchunks = len(rows)
+        self.chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+        self.views = views                      # keeps the flat buffer alive
+        # the pointer array is staged through a small ring of pinned host buffers: the host may run a step or more ahead of the
+        # GPU, and a buffer must not be rewritten before its asynchronous copy has been consumed (an event per slot guards it)
+        pin = self.device.type == "cuda"
+        self._ring = [[torch.empty((len(views),), dtype=torch.int64, pin_memory=pin),
+                       torch.empty((len(views),), dtype=torch.int64, device=self.device), None] for _ in range(4)]
+        self._slot = 0
+
+    def matches(self, tensors):
+        return (len(tensors) == len(self.numels) and all(t is not None and t.dtype == torch.float32 and t.device == self.device
+                and t.is_contiguous() and int(t.numel()) == n for t, n in zip(tensors, self.numels)))
+
+    def run(self, tensors):
+        slot = self._ring[self._slot]
+        self._slot = (self._slot + 1) % len(self._ring)
+        host, dev, done = slot
+        if done is not None:
+            done.synchronize()                      # (four launches ago: normally long complete)
+        host.copy_(torch.tensor([ptr(t) for t in tensors], dtype=torch.int64))
+        dev.copy_(host, non_blocking=True)
+        call("dream_multi_copy_f32", ptr(dev), ptr(self.chunks), self.nchunks, stream())
+        if self.device.type == "cuda":
+            slot[2] = torch.cuda.Event()
+            slot[2].record()
+
+
 def pack_weight(w_oihw, mode=0):
     """OIHW [Cout,Cin,3,3] -> tap-major packed tensor (see dream_pack_conv3x3_weight).
     Returns (packed, rows, rows_pad, cols_pad)."""

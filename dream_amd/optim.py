@@ -98,7 +98,18 @@ class _FlatStepMixin:
         gspan = _flat_span(grads)
         if gspan is not None and gspan[1] == plan["span"][1] and gspan[0].numel() == plan["span"][0].numel():
             return gspan[0]                                   # already laid out like the parameters: use in place
-        torch._foreach_copy_(plan["grad_views"], grads)       # one multi-tensor copy (padding between tensors stays zero)
+        # gather into the flat buffer (padding between tensors stays zero): ONE launch of our own when the gradients are plain
+        # contiguous fp32 tensors (torch._foreach_copy_ issues one hipMemcpyAsync per tensor: 318 of them for resnet_h, 1.4 ms)
+        mc = plan.get("multi_copy")
+        if mc is None:
+            try:                                                # (CPU tensors outside the test emulator: ptr() refuses them)
+                mc = plan["multi_copy"] = ops.MultiCopyPlan(plan["grad_views"])
+            except RuntimeError:
+                mc = plan["multi_copy"] = False
+        if mc and mc.matches(grads):
+            mc.run(grads)
+        else:
+            torch._foreach_copy_(plan["grad_views"], grads)
         return plan["grad"]
 
 

@@ -444,6 +444,18 @@ int dream_conv1x1_wgrad_pre_nhwc_f32(const float *x, const float *dy, float *dw,
                                      int Cdy, const float *pre_ab, void *stream);
 /* MaxPool2d(3,2,1) backward (ATen first-max semantics; overlapping windows accumulate) */
 int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
+/* many tensors gathered into one flat buffer by one launch (the optimizer's flat gradient buffer, torch.optim's per-parameter
+ * gradients: network.py:335 -> :337).  chunks: device array, chunk c = copy n floats from srcs[job] + src_off to dst (<= 65536 floats
+ * per chunk keeps the workgroups even); srcs: device array of the step's source pointers. */
+typedef struct dream_copy_chunk {
+    float *dst;
+    unsigned src_off;
+    unsigned n;
+    int job;
+    int reserved;
+} dream_copy_chunk;
+size_t dream_copy_chunk_bytes(void);
+int dream_multi_copy_f32(const void *srcs, const void *chunks, int nchunks, void *stream);
 /* dst += src (gradient accumulation where two branches meet) */
 int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream);
 

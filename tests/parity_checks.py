@@ -331,6 +331,10 @@ def check_resnet_stem(dev, B, H, W):
     w = torch.randn(64, 3, 7, 7) * 0.1
     ref = F.conv2d(x, w, None, stride=2, padding=3)
     col = ops.im2col_nchw(to(dev, x), 7, 7, 2, 3, 160)
+    # the patch matrix itself, bit for bit: k = (c * 7 + ky) * 7 + kx as F.unfold orders it, zeros beyond k = 147 and outside the image
+    ho, wo = ref.shape[2], ref.shape[3]
+    unf = F.unfold(x, 7, padding=3, stride=2).reshape(B, 147, ho, wo).permute(0, 2, 3, 1)
+    assert torch.equal(col.cpu()[..., :147], unf) and float(col.cpu()[..., 147:].abs().max()) == 0.0
     packed, rows, _ = ops.pack_matrix_weight(to(dev, w.reshape(64, 147)), 160)
     y = ops.conv2d(col, packed, 64, 1, 1)
     assert float((y.cpu().permute(0, 3, 1, 2) - ref).abs().max()) <= tol(ref.numpy())

@@ -373,3 +373,29 @@ def test_skip_connections_fold_into_the_producing_conv(emu, monkeypatch, algorit
     for name in ("vgg_q_skip", "vgg_f_skip"):
         pc.check_variant("cpu", name, train=False)
     assert not adds
+
+
+def test_multi_copy_gathers_many_tensors_with_one_launch(emu):
+    """ops.MultiCopyPlan (dream_multi_copy_f32): the optimizer's gather of per-parameter gradients into its flat buffer -- aligned and
+    unaligned sources, tensors longer than one 64 K chunk, the padding between the views untouched, repeated calls (the pointer ring)."""
+    torch.manual_seed(0)
+    sizes = [1, 3, 64, 65537, 200000, 7, 131072, 5]
+    flat = torch.zeros(sum((n + 63) // 64 * 64 for n in sizes))
+    views, o = [], 0
+    for n in sizes:
+        views.append(flat[o:o + n])
+        o += (n + 63) // 64 * 64
+    plan = ops.MultiCopyPlan(views)
+    assert plan.nchunks == sum((n + 65535) // 65536 for n in sizes)
+    for rep in range(6):
+        srcs = [torch.randn(n + 1)[1:] if (i + rep) % 2 else torch.randn(n) for i, n in enumerate(sizes)]    # every other source 4 bytes off
+        assert plan.matches(srcs)
+        plan.run(srcs)
+        for v, s_ in zip(views, srcs):
+            assert torch.equal(v, s_)
+        o = 0
+        for n in sizes:                                                   # the padding between the views stays zero
+            pad = (n + 63) // 64 * 64
+            assert float(flat[o + n:o + pad].abs().sum()) == 0.0
+            o += pad
+    assert not plan.matches(srcs[:-1]) and not plan.matches([t.double() for t in srcs])
