@@ -71,4 +71,12 @@ conc)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_dflt" -o dflt -- python "$R/bench.py" --no-cpu-baseline --no-secondary > "$R/$O/rocprof_dflt.log" 2>&1); echo "rc=$?"
   summ $O/prof_dflt $O/bench_default peaks_kernel 2
   ;;
+mc)
+  echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "resnet or train or adam or optimizer or abi or general_conv or variant" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  line rt16_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt16_b --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rh128 --arch resnet_h --batch 128
+  line rf32 --arch resnet_f --batch 32
+  line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  ;;
 esac
