@@ -63,6 +63,8 @@ _SIGNATURES = {
     "dream_conv1x1_bwd_bnmask_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dream_conv1x1_wgrad_pre_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P]),
     "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_maxpool3s2_idx_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_maxpool3s2_idx_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
     "dream_copy_chunk_bytes": (_SZ, []),
     "dream_multi_copy_f32": (_I, [_P, _P, _I, _P]),

@@ -428,6 +428,69 @@ __global__ void __launch_bounds__(256) maxpool3s2_bwd_kernel(const f32x4 *dy, co
     }
 }
 
+// Training form of the stem's pool: the forward pass also stores WHICH element of the 3x3 window won (0..8 = 3 dy + dx, the first
+// maximum in scan order: ATen's max_pool2d_with_indices semantics), one byte per output; the backward pass then visits the <= 4
+// windows that contain an input pixel and compares ONE byte each, where maxpool3s2_bwd_kernel recomputes every window's arg-max from
+// nine loads (20 loads per input float4 on average: 0.46 ms of a ResNet-101 step at 16 frames, 0.8 TB/s).  Workgroup = one row of
+// one image (no 64-bit division chains).
+typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) maxpool3s2_idx_kernel(const f32x4 *x, f32x4 *y, u8x4 *idx, int H, int W, int C4, int Ho, int Wo) {
+    const int oy = (int)blockIdx.x, b = (int)blockIdx.y;
+    const f32x4 *img = x + (size_t)b * H * W * C4;
+    const size_t orow = ((size_t)b * Ho + oy) * (size_t)Wo * C4;
+    const int n = Wo * C4;
+    for (int i = (int)threadIdx.x; i < n; i += 256) {
+        const int ox = (int)((unsigned)i / (unsigned)C4), c = i - ox * C4;
+        const float ninf = -__builtin_huge_valf();
+        f32x4 best = {ninf, ninf, ninf, ninf};
+        int arg[4] = {-1, -1, -1, -1};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = 2 * oy - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = 2 * ox - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = img[(iy * W + ix) * C4 + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (v[k] > best[k] || arg[k] < 0) { best[k] = v[k]; arg[k] = 3 * dy + dx; }
+            }
+        }
+        y[orow + i] = best;
+        idx[orow + i] = u8x4{(unsigned char)arg[0], (unsigned char)arg[1], (unsigned char)arg[2], (unsigned char)arg[3]};
+    }
+}
+
+__global__ void __launch_bounds__(256) maxpool3s2_idx_bwd_kernel(const f32x4 *dy, const u8x4 *idx, f32x4 *dx, int H, int W, int C4,
+                                                                 int Ho, int Wo) {
+    const int iy = (int)blockIdx.x, b = (int)blockIdx.y;
+    const size_t obase = (size_t)b * Ho * Wo * C4;
+    f32x4 *row = dx + ((size_t)b * H + iy) * (size_t)W * C4;
+    const int n = W * C4;
+    for (int i = (int)threadIdx.x; i < n; i += 256) {
+        const int ix = (int)((unsigned)i / (unsigned)C4), c = i - ix * C4;
+        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
+        // windows oy with 2 oy - 1 <= iy <= 2 oy + 1, in the order the recomputing kernel adds them (same bits)
+        const int oy_lo = iy >> 1, oy_hi = (iy + 1) >> 1, ox_lo = ix >> 1, ox_hi = (ix + 1) >> 1;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                if (ox >= Wo) continue;
+                const size_t w = obase + ((size_t)oy * Wo + ox) * C4 + c;
+                const u8x4 a = idx[w];
+                const int me = 3 * (iy - (2 * oy - 1)) + (ix - (2 * ox - 1));          // this pixel's position inside that window
+                const f32x4 g = dy[w];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if ((int)a[k] == me) o[k] += g[k];
+            }
+        }
+        row[i] = o;
+    }
+}
+
 __global__ void __launch_bounds__(256) add_inplace_kernel(float *dst, const float *src, size_t n) {
     const size_t n4 = n / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -690,6 +753,25 @@ extern "C" int dream_multi_copy_f32(const void *srcs, const void *chunks, int nc
     return 0;
 }
 
+// MaxPool2d(3,2,1) for training: y and the winner's position inside its window (uint8, 0..8) / the backward pass from those
+extern "C" int dream_maxpool3s2_idx_nhwc_f32(const float *x, float *y, unsigned char *idx, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(x && y && idx && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool3s2_idx: bad arguments");
+    DREAM_REQUIRE((size_t)H * W * C < ((size_t)1 << 31), "maxpool3s2_idx: image too large for 32-bit offsets");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_idx_kernel, dim3((unsigned)Ho, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x,
+                       (f32x4 *)y, (u8x4 *)idx, H, W, C / 4, Ho, Wo);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_maxpool3s2_idx_bwd_nhwc_f32(const float *dy, const unsigned char *idx, float *dx, int B, int H, int W, int C,
+                                                 void *stream) {
+    DREAM_REQUIRE(dy && idx && dx && B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool3s2_idx_bwd: bad arguments");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3s2_idx_bwd_kernel, dim3((unsigned)H, (unsigned)B), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)dy,
+                       (const u8x4 *)idx, (f32x4 *)dx, H, W, C / 4, Ho, Wo);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
 extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream) {
     DREAM_REQUIRE(dst && src, "add_inplace: null pointer");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dst, src, n);

@@ -15,6 +15,9 @@ __global__ void __launch_bounds__(256) pack_batched_kernel(const dream_pack_job 
         case DREAM_PACK_CONV1X1: dream_pack::conv1x1(j.src, j.dst, j.cout, j.cin, j.mode, (int)blockIdx.x, (int)gridDim.x); break;
         case DREAM_PACK_WINOGRAD2: dream_pack::winograd2(j.src, j.dst, j.cout, j.cin, j.mode, (int)blockIdx.x, (int)gridDim.x); break;
         case DREAM_PACK_WINOGRAD4: dream_pack::winograd4(j.src, j.dst, j.cout, j.cin, j.mode, (int)blockIdx.x, (int)gridDim.x); break;
+        // one phase of a transposed conv (the ResNet decoder): straight from wT, no materialised 3x3 kernels
+        case DREAM_PACK_CONVT_WINOGRAD2: dream_pack::winograd2<true>(j.src, j.dst, j.cout, j.cin, j.mode, (int)blockIdx.x, (int)gridDim.x); break;
+        case DREAM_PACK_CONVT_WINOGRAD4: dream_pack::winograd4<true>(j.src, j.dst, j.cout, j.cin, j.mode, (int)blockIdx.x, (int)gridDim.x); break;
         default: break;
     }
 }

@@ -40,10 +40,41 @@ DREAM_DEVICE void filter3x3(const float *w, int Cin, int rows, int mode, int n, 
         }
 }
 
+// The same for phase (a, b) of nn.ConvTranspose2d(k4, s2, p1), written as a 3x3 conv with a zero-padded kernel (conv_wino.hip,
+// convT4x4_phase_kernels: the four OIHW kernels w3[phase] it materialises -- here read straight from wT [CinT][CoutT][4][4]).
+// pm = phase | (bwd << 2).  Forward (bwd 0): row n = output channel co, k = input channel ci, tap (r, c) = offset (r - 1, c - 1):
+// ky = a + 1 - 2 dy, kx = b + 1 - 2 dx, used where the offset points up / left for a (b) = 0, down / right for 1.  Data gradient
+// (bwd 1): row n = ci (the gradient conv's output channel), k = co: ky = a - 1 + 2 r, kx = b - 1 + 2 c.
+DREAM_DEVICE void filterT3x3(const float *wT, int rows, int cols, int pm, int n, int k, double g[3][3]) {
+    const int a = (pm >> 1) & 1, b = pm & 1, bwd = (pm >> 2) & 1;
+    const int CoutT = bwd ? cols : rows;
+    const int ci = bwd ? n : k, co = bwd ? k : n;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int ky, kx;
+            bool used;
+            if (!bwd) {
+                const int dy = r - 1, dx = c - 1;
+                ky = a + 1 - 2 * dy; kx = b + 1 - 2 * dx;
+                used = (a == 0 ? dy <= 0 : dy >= 0) && (b == 0 ? dx <= 0 : dx >= 0);
+            } else {
+                ky = a - 1 + 2 * r; kx = b - 1 + 2 * c;
+                used = (a == 0 ? r >= 1 : r <= 1) && (b == 0 ? c >= 1 : c <= 1);
+            }
+            float v = 0.0f;
+            if (used && n < rows) v = wT[(((size_t)ci * CoutT + co) * 4 + ky) * 4 + kx];
+            g[r][c] = (double)v;
+        }
+}
+
 // Winograd F(2x2,3x3) (conv_wino.hip): U = G g G^T in fp64, rounded once, [cols/16][16 positions][RowsPad][16]; RowsPad = rows
 // rounded up to 128; position row 3 negated (the kernel computes -V[3][.])
+// CONVT: w is a transposed conv's weight, (Cout, Cin) = the phase conv's (rows, cols), mode = phase | (bwd << 2) (filterT3x3)
+template <bool CONVT = false>
 DREAM_DEVICE void winograd2(const float *w, float *u, int Cout, int Cin, int mode, int blk, int nblk) {
-    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
+    const int rows = CONVT ? Cout : (mode == 0 ? Cout : Cin), cols = CONVT ? Cin : (mode == 0 ? Cin : Cout);
     const int RowsPad = (rows + 127) / 128 * 128;
     const size_t total = (size_t)(cols / 16) * RowsPad * 16;
     for (size_t i = (size_t)blk * 256 + threadIdx.x; i < total; i += (size_t)nblk * 256) {
@@ -52,7 +83,8 @@ DREAM_DEVICE void winograd2(const float *w, float *u, int Cout, int Cin, int mod
         const int n = (int)(rest % RowsPad);
         const int ch = (int)(rest / RowsPad);
         double g[3][3];
-        filter3x3(w, Cin, rows, mode, n, ch * 16 + kk, g);
+        if (CONVT) filterT3x3(w, rows, cols, mode, n, ch * 16 + kk, g);
+        else filter3x3(w, Cin, rows, mode, n, ch * 16 + kk, g);
         double t[4][3];                                             // G g
 #pragma unroll
         for (int b = 0; b < 3; ++b) {
@@ -73,6 +105,7 @@ DREAM_DEVICE void winograd2(const float *w, float *u, int Cout, int Cin, int mod
 
 // Winograd F(4x4,3x3) (conv_wino4.hip), interpolation points (0, 1, -1, 1/2, -2, inf): [cols/K][36 positions][RowsPad][K] with
 // (K, RowsPad) = (16, rows up to a multiple of 128), or (8, 64) when rows <= 64 (the kernel's narrow workgroup shape)
+template <bool CONVT = false>
 DREAM_DEVICE void winograd4(const float *w, float *u, int Cout, int Cin, int mode, int blk, int nblk) {
     const double G[6][3] = {{1.0, 0.0, 0.0},
                             {1.0 / 3.0, 1.0 / 3.0, 1.0 / 3.0},
@@ -80,7 +113,7 @@ DREAM_DEVICE void winograd4(const float *w, float *u, int Cout, int Cin, int mod
                             {-16.0 / 15.0, -8.0 / 15.0, -4.0 / 15.0},
                             {1.0 / 15.0, -2.0 / 15.0, 4.0 / 15.0},
                             {0.0, 0.0, 1.0}};
-    const int rows = mode == 0 ? Cout : Cin, cols = mode == 0 ? Cin : Cout;
+    const int rows = CONVT ? Cout : (mode == 0 ? Cout : Cin), cols = CONVT ? Cin : (mode == 0 ? Cin : Cout);
     const int K = rows <= 64 ? 8 : 16;
     const int RowsPad = rows <= 64 ? 64 : (rows + 127) / 128 * 128;
     const size_t total = (size_t)(cols / K) * RowsPad * K;
@@ -90,7 +123,8 @@ DREAM_DEVICE void winograd4(const float *w, float *u, int Cout, int Cin, int mod
         const int n = (int)(rest % RowsPad);
         const int ch = (int)(rest / RowsPad);
         double g[3][3];
-        filter3x3(w, Cin, rows, mode, n, ch * K + kk, g);
+        if (CONVT) filterT3x3(w, rows, cols, mode, n, ch * K + kk, g);
+        else filter3x3(w, Cin, rows, mode, n, ch * K + kk, g);
         double t[6][3];                                             // G g
 #pragma unroll
         for (int a = 0; a < 6; ++a)

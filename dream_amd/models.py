@@ -1342,8 +1342,8 @@ class ResnetSimple(nn.Module):
         ab, mean, invstd = ops.bn_stats(z, self.bn1, self._ctr(z.device))
         y = ops.bn_apply_ab(z, ab, None, True)
         tape.append(dict(kind="stem", conv=self.conv1, bn=self.bn1, relu=True, x=col, z=z, y=y, ab=ab, mean=mean, invstd=invstd))
-        yp = ops.maxpool3s2(y)
-        tape.append(dict(kind="pool", x=y))
+        yp, pidx = ops.maxpool3s2_idx(y)               # the backward pass compares one stored byte per window
+        tape.append(dict(kind="pool", x=y, idx=pidx))
         y = yp
         for li in (1, 2, 3, 4):
             for bi, blk in enumerate(getattr(self, "layer%d" % li)):
@@ -1501,7 +1501,7 @@ class ResnetSimple(nn.Module):
                     g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
                 block = None
             elif kind == "pool":
-                g = ops.maxpool3s2_bwd(g, rec["x"])
+                g = ops.maxpool3s2_idx_bwd(g, rec["idx"], rec["x"].shape)
             elif kind == "stem":
                 bn = rec["bn"]
                 dz, _, dgam, dbet = self._bn_bwd_fused(rec, g)

@@ -25,7 +25,7 @@ def round_up(v, m):
 
 
 _pack_log = threading.local()
-PACK_CONV1X1, PACK_WINOGRAD2, PACK_WINOGRAD4 = 0, 1, 2
+PACK_CONV1X1, PACK_WINOGRAD2, PACK_WINOGRAD4, PACK_CONVT_WINOGRAD2, PACK_CONVT_WINOGRAD4 = 0, 1, 2, 3, 4
 
 
 class record_packs:
@@ -251,6 +251,8 @@ def pack_convT4x4_winograd_weight(wT, mode=0):
     u4 = torch.empty(n, dtype=torch.float32, device=w.device)
     scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
     call("dream_pack_convT4x4_winograd_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, mode, stream())
+    for ph in range(4):                                  # what a batched re-pack needs: one job per phase, straight from wT
+        _log_pack(PACK_CONVT_WINOGRAD2, w, u4[ph * (n // 4):(ph + 1) * (n // 4)], rows, cols, ph | (mode << 2))
     return u4, rows
 
 
@@ -330,6 +332,8 @@ def pack_convT4x4_winograd4_weight(wT, mode=0):
     u4 = torch.empty(n, dtype=torch.float32, device=w.device)
     scratch = torch.empty(4 * cout * cin * 9, dtype=torch.float32, device=w.device)
     call("dream_pack_convT4x4_winograd4_weight", ptr(w), ptr(u4), ptr(scratch), cin, cout, mode, stream())
+    for ph in range(4):
+        _log_pack(PACK_CONVT_WINOGRAD4, w, u4[ph * (n // 4):(ph + 1) * (n // 4)], rows, cols, ph | (mode << 2))
     return u4, rows
 
 
@@ -980,6 +984,24 @@ def conv2d_bwd_data(dy_nhwc, packed_t, cin, ksize, stride, in_hw, residual=None)
     call("dream_conv2d_nhwc_f32", ptr(dy), ptr(packed_t), None, None, ptr(residual), ptr(y), b, h, w, c, cin,
          int(packed_t.shape[-2]), ksize, 1, CONV_ZEROSTUFF2X, stream())
     return y
+
+
+def maxpool3s2_idx(x_nhwc):
+    """MaxPool2d(3,2,1) for training -> (y, idx): idx [B,Ho,Wo,C] uint8, the winner's position inside its 3x3 window."""
+    x = _f32(x_nhwc)
+    b, h, w, c = (int(v) for v in x.shape)
+    y = torch.empty((b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    idx = torch.empty(tuple(y.shape), dtype=torch.uint8, device=x.device)
+    call("dream_maxpool3s2_idx_nhwc_f32", ptr(x), ptr(y), ptr(idx), b, h, w, c, stream())
+    return y, idx
+
+
+def maxpool3s2_idx_bwd(dy, idx, in_shape):
+    """Backward of maxpool3s2_idx: dy [B,Ho,Wo,C], idx from the forward pass -> dx of ``in_shape`` = (B,H,W,C)."""
+    b, h, w, c = (int(v) for v in in_shape)
+    dx = torch.empty((b, h, w, c), dtype=torch.float32, device=dy.device)
+    call("dream_maxpool3s2_idx_bwd_nhwc_f32", ptr(_f32(dy)), ptr(idx), ptr(dx), b, h, w, c, stream())
+    return dx
 
 
 def maxpool3s2_bwd(dy, x):

@@ -140,7 +140,10 @@ int dream_conv3x3_winograd4_set_channel_block_pinning(int on);   /* A/B hook: ou
  * jobs: DEVICE array of njobs entries; src = the weight tensor as the reference stores it (OIHW), dst = the packed copy
  * (dream_conv1x1_weight_floats / dream_conv3x3_winograd_weight_floats / dream_conv3x3_winograd4_weight_floats floats; the zero tail
  * the Winograd kernels over-read is written by the one-tensor entry points and not touched here), mode as theirs. */
-enum { DREAM_PACK_CONV1X1 = 0, DREAM_PACK_WINOGRAD2 = 1, DREAM_PACK_WINOGRAD4 = 2 };
+enum { DREAM_PACK_CONV1X1 = 0, DREAM_PACK_WINOGRAD2 = 1, DREAM_PACK_WINOGRAD4 = 2,
+       /* one output phase of nn.ConvTranspose2d(k4,s2,p1) (src = wT [Cin][Cout][4][4]): cout / cin = rows / columns of the phase's
+        * conv, mode = phase | (bwd << 2), dst = that phase's slice of the u4 tensor of dream_pack_convT4x4_winograd[4]_weight */
+       DREAM_PACK_CONVT_WINOGRAD2 = 3, DREAM_PACK_CONVT_WINOGRAD4 = 4 };
 typedef struct dream_pack_job {
     const float *src;
     float *dst;
@@ -442,6 +445,11 @@ int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, 
 /* weight gradient of a 1x1 conv whose input was relu(pre_ab[0][ci] x + pre_ab[1][ci]) (x = the BN input) */
 int dream_conv1x1_wgrad_pre_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout,
                                      int Cdy, const float *pre_ab, void *stream);
+/* the same pool for training: also stores which element of its 3x3 window won (uint8 0..8 = 3 dy + dx, the first maximum in scan
+ * order: ATen's max_pool2d_with_indices), so that the backward pass compares one byte per window instead of recomputing nine-way
+ * arg-maxima; idx: [B,Ho,Wo,C] bytes */
+int dream_maxpool3s2_idx_nhwc_f32(const float *x, float *y, unsigned char *idx, int B, int H, int W, int C, void *stream);
+int dream_maxpool3s2_idx_bwd_nhwc_f32(const float *dy, const unsigned char *idx, float *dx, int B, int H, int W, int C, void *stream);
 /* MaxPool2d(3,2,1) backward (ATen first-max semantics; overlapping windows accumulate) */
 int dream_maxpool3s2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
 /* many tensors gathered into one flat buffer by one launch (the optimizer's flat gradient buffer, torch.optim's per-parameter

@@ -856,6 +856,11 @@ def check_resnet_training_ops(dev):
         y.backward(dy)
         dx = ops.maxpool3s2_bwd(to(dev, _nhwc(dy)), to(dev, _nhwc(xin.detach())))
         assert torch.equal(nchw(dx.cpu()), xin.grad)
+        # the training pair: the forward pass stores the winner's window position, the backward pass gathers with it -- same bits
+        yi, idx = ops.maxpool3s2_idx(to(dev, _nhwc(xin.detach())))
+        assert torch.equal(nchw(yi.cpu()), y.detach()) and idx.dtype == torch.uint8 and int(idx.max()) <= 8
+        dxi = ops.maxpool3s2_idx_bwd(to(dev, _nhwc(dy)), idx, tuple(_nhwc(xin.detach()).shape))
+        assert torch.equal(dxi.cpu(), dx.cpu())
     a, b = torch.randn(1003), torch.randn(1003)
     c = to(dev, a.clone())
     ops.add_(c, to(dev, b))

@@ -333,6 +333,26 @@ def test_batched_weight_packing(emu):
         out[:n_body] = float("nan")                           # the batched kernel must rewrite the body (not the zero tail)
         jobs.append((kind, w, out, cout, cin, mode))
         singles.append(ref)
+    # the decoder's transposed convs: four jobs (one per output phase) straight from wT, forward and data-gradient operators,
+    # F(2x2) and F(4x4) -- against the two-step one-tensor path (materialised zero-padded 3x3 kernels, then the conv's pack)
+    for kind, fn, cin_t, cout_t, mode in [(ops.PACK_CONVT_WINOGRAD2, ops.pack_convT4x4_winograd_weight, 32, 48, 0),
+                                         (ops.PACK_CONVT_WINOGRAD2, ops.pack_convT4x4_winograd_weight, 48, 32, 1),
+                                         (ops.PACK_CONVT_WINOGRAD4, ops.pack_convT4x4_winograd4_weight, 32, 160, 0),
+                                         (ops.PACK_CONVT_WINOGRAD4, ops.pack_convT4x4_winograd4_weight, 160, 32, 1)]:
+        wT = torch.randn(cin_t, cout_t, 4, 4, generator=g)
+        with ops.record_packs() as descs:
+            ref = fn(wT, mode)[0]
+        assert len(descs) == 4 and all(d[0] == kind for d in descs)
+        out = ref.clone()
+        per = out.numel() // 4
+        rows = cout_t if mode == 0 else cin_t
+        k_, pad_ = (16, (rows + 127) // 128 * 128) if (kind == ops.PACK_CONVT_WINOGRAD2 or rows > 64) else (8, 64)
+        ahead = 6 if kind == ops.PACK_CONVT_WINOGRAD2 else (6 if rows > 64 else 16)
+        for ph, d in enumerate(descs):
+            body = per - ahead * pad_ * k_
+            out[ph * per:ph * per + body] = float("nan")          # the batched kernel rewrites the body; the zero tail stays
+            jobs.append((kind, wT, out[ph * per:(ph + 1) * per], d[3], d[4], d[5]))
+            singles.append(ref[ph * per:(ph + 1) * per])
     table = ops.pack_job_table(jobs, "cpu")
     ops.pack_weights_batched(table, len(jobs), workgroups_per_job=3)
     for (kind, w, out, cout, cin, mode), ref in zip(jobs, singles):
