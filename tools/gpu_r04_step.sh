@@ -79,4 +79,11 @@ mc)
   line rf32 --arch resnet_f --batch 32
   line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
   ;;
+mp)
+  echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "resnet or repack or batched or training_ops or data_parallel" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  line rt16_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt16_b --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  line rft16 --arch resnet_f --mode train --batch 16 --steps 5 --warmup 3
+  ;;
 esac
