@@ -43,37 +43,46 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const f32x4 *x, f32x4 *y,
 
 // backward: the gradient goes to the first maximal element in (row-major) window order, which is
 // what ATen's max_pool2d_with_indices records.  Rows/cols beyond 2*floor(H/2) get zero.
+// One thread per 2x2 WINDOW (and channel quad): its four inputs are loaded once, the window's gradient goes to the first maximum, the
+// other three outputs are zeros (round 4: one thread per INPUT pixel loaded every window four times over: 3.9 TB/s on 64 x 400 x 400).
+// The thread of the last window of a row / column also zeroes the odd extent's leftover column / row.
 template <bool RELU>
 __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const f32x4 *dy, const f32x4 *x, f32x4 *dx,
                                                            int B, int H, int W, int C4) {
     const int Ho = H / 2, Wo = W / 2;
-    const size_t total = (size_t)B * H * W * C4;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int c = (int)(i % C4);
         size_t r = i / C4;
-        const int ix = (int)(r % W);
-        r /= W;
-        const int iy = (int)(r % H);
-        const int b = (int)(r / H);
-        f32x4 o = {0.0f, 0.0f, 0.0f, 0.0f};
-        const int oy = iy >> 1, ox = ix >> 1;
-        if (oy < Ho && ox < Wo) {
-            const f32x4 *s = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * C4 + c;
-            const f32x4 v[4] = {s[0], s[C4], s[(size_t)W * C4], s[(size_t)W * C4 + C4]};
-            const f32x4 g = dy[(((size_t)b * Ho + oy) * Wo + ox) * C4 + c];
-            const int me = (iy & 1) * 2 + (ix & 1);
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const size_t base = (((size_t)b * H + 2 * oy) * W + 2 * ox) * C4 + c, row = (size_t)W * C4;
+        const f32x4 v[4] = {x[base], x[base + C4], x[base + row], x[base + row + C4]};
+        const f32x4 g = dy[i];
+        f32x4 o[4] = {zero, zero, zero, zero};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int arg = 0;
-                float best = v[0][k];
+        for (int k = 0; k < 4; ++k) {
+            int arg = 0;
+            float best = v[0][k];
 #pragma unroll
-                for (int j = 1; j < 4; ++j)
-                    if (v[j][k] > best) { best = v[j][k]; arg = j; }
-                // RELU: x is a ReLU output, and the gradient continues through that ReLU (mask x > 0) in the same pass
-                o[k] = (arg == me && (!RELU || best > 0.0f)) ? g[k] : 0.0f;
-            }
+            for (int j = 1; j < 4; ++j)
+                if (v[j][k] > best) { best = v[j][k]; arg = j; }
+            // RELU: x is a ReLU output, and the gradient continues through that ReLU (mask x > 0) in the same pass
+            const float gk = (!RELU || best > 0.0f) ? g[k] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j][k] = arg == j ? gk : 0.0f;
         }
-        dx[i] = o;
+        dx[base] = o[0];
+        dx[base + C4] = o[1];
+        dx[base + row] = o[2];
+        dx[base + row + C4] = o[3];
+        const bool last_x = (ox == Wo - 1) && (W & 1), last_y = (oy == Ho - 1) && (H & 1);
+        if (last_x) { dx[base + 2 * C4] = zero; dx[base + row + 2 * C4] = zero; }
+        if (last_y) { dx[base + 2 * row] = zero; dx[base + 2 * row + C4] = zero; }
+        if (last_x && last_y) dx[base + 2 * row + 2 * C4] = zero;
     }
 }
 
@@ -581,7 +590,7 @@ extern "C" int dream_maxpool2_nhwc_f32(const float *x, float *y, int B, int H, i
 }
 extern "C" int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream) {
     DREAM_REQUIRE(dy && x && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0, "maxpool2_bwd: bad arguments");
-    const size_t total = (size_t)B * H * W * (C / 4);
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4);
     DREAM_LAUNCH_OK();
@@ -589,7 +598,7 @@ extern "C" int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, floa
 }
 extern "C" int dream_maxpool2_relu_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream) {
     DREAM_REQUIRE(dy && x && dx && B > 0 && H >= 2 && W >= 2 && C % 4 == 0, "maxpool2_relu_bwd: bad arguments");
-    const size_t total = (size_t)B * H * W * (C / 4);
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4);
     DREAM_LAUNCH_OK();
