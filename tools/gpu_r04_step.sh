@@ -86,4 +86,10 @@ mp)
   line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
   line rft16 --arch resnet_f --mode train --batch 16 --steps 5 --warmup 3
   ;;
+vt)
+  echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "backward_ops or train_step or train_steps or vgg or variant or first" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  line vt_a --mode train --steps 4 --warmup 2
+  line vt_b --mode train --steps 4 --warmup 2
+  line vft --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
+  ;;
 esac
