@@ -145,6 +145,8 @@ _SIGNATURES = {
     "dream_conv3x3_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_wgrad_winograd_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "dream_conv3x3_wgrad_winograd_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_wgrad_winograd_fuses_bias": (_I, [_I, _I, _I]),
+    "dream_conv3x3_wgrad_winograd_bias_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv3x3_wgrad_winograd_set_version": (_I, [_I]),
     "dream_conv3x3_first_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "dream_conv3x3_first_wgrad_f32": (_I, [_P, _P, _P, _P, _P, _SZ, _I, _I, _I, _I, _I, _P]),

@@ -372,7 +372,14 @@ __global__ void __launch_bounds__(256) wgrad1x1_reduce_kernel(const float *parti
     for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 256 * 4) {
         f32x4 s = *(const f32x4 *)(partial + i);
         int k = 1;
-        for (; k + 4 <= nsplit; k += 4) {           // four loads in flight, summed in index order (same bits as one by one)
+        for (; k + 8 <= nsplit; k += 8) {           // eight loads in flight, summed in index order (same bits as one by one)
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = *(const f32x4 *)(partial + (size_t)(k + j) * n + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = s + v[j];
+        }
+        for (; k + 4 <= nsplit; k += 4) {
             f32x4 v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = *(const f32x4 *)(partial + (size_t)(k + j) * n + i);

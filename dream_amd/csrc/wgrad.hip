@@ -241,7 +241,14 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float *part, fl
         f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
         const f32x4 *src = (const f32x4 *)part + i;
         int k = 0;
-        for (; k + 4 <= splitk; k += 4) {           // four independent loads in flight, summed in index order
+        for (; k + 8 <= splitk; k += 8) {           // eight independent loads in flight, summed in index order
+            f32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(size_t)(k + j) * n4];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k + 4 <= splitk; k += 4) {
             const f32x4 v0 = src[(size_t)k * n4], v1 = src[(size_t)(k + 1) * n4];
             const f32x4 v2 = src[(size_t)(k + 2) * n4], v3 = src[(size_t)(k + 3) * n4];
             s += v0;

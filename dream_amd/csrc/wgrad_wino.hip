@@ -264,6 +264,7 @@ struct WgWinoLdsParams {
     const float *x;          // [B,H,W,Cin]
     const float *dy;         // [B,H,W,Cdy]
     float *partial;          // [nsplit][16][Cout][Cin]
+    float *bias_partial;     // BIAS: [nsplit][Cout] column sums of dy over the split's tiles (behind `partial` in the workspace)
     int B, H, W, Cin, Cout, Cdy;
     int TY, TX, ntiles;
     unsigned long long magic_tpi, magic_tx;
@@ -273,7 +274,12 @@ struct WgWinoLdsParams {
 
 // UPS: x is stored at half resolution and the conv ran on its nearest x2 upsample (compile-time: the run-time form of the few
 // extra selects cost 19 spilled registers)
-template <bool UPS>
+// BIAS: the bias gradient (column sums of dy) rides in the dy loader.  Every dy element of the split's tiles passes through the
+// registers of exactly one (wave, dy row, channel quad) of each workgroup, so the workgroups of input-channel block 0 add it up
+// on the way (two packed additions per stage and lane next to 64 MFMAs) -- the stand-alone pass over every gradient tensor
+// (1.8 % of a vgg_q training step, at the HBM roofline) is not launched.  Fixed order: lane, then (wave, row) through LDS, then the
+// splits in the reduction kernel.
+template <bool UPS, bool BIAS>
 __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsParams p) {
     DREAM_DYNAMIC_LDS(float, smem);
     const int lane = threadIdx.x & 63;
@@ -308,6 +314,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
 
     f32x4 xr[2][4];                                          // [register set][column]
     f32x4 yr[2][2];                                          // [register set][column]
+    const bool bias_wg = BIAS && cig == 0;                   // workgroup-uniform
+    f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};                   // dy of (wave's tiles, row yr2, quad yq); lanes yh = 0 / 1 hold the same
 
     // one load of stage st into register set `set`: n = 0..3 the patch row's columns, 4..5 the dy row's columns.
     // VALU instructions share the SIMD's issue slots with the MFMAs (measured: every VALU instruction in this loop shows up
@@ -351,6 +359,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
             // along the dy row: (y0, y1) -> y0, y0 + y1, y0 - y1, y1 (the minus sign of the fourth column is applied at the end)
             const int jj = k - 4;
             const f32x4 y0 = yr[set][0], y1 = yr[set][1];
+            if (BIAS && jj == 0 && bias_wg) bsum = bsum + (y0 + y1);           // out-of-range pixels and tiles were loaded as zeros
             f32x4 m, mixed;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -432,33 +441,70 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
                 const f32x4 v = {acc[pl][m][0][r], acc[pl][m][1][r], acc[pl][m][2][r], acc[pl][m][3][r]};
                 *(f32x4 *)(out + ((size_t)(2 * wave + pl) * p.Cout + co) * p.Cin + ci0 + 4 * li) = v;
             }
+    if (BIAS && bias_wg) {                                   // the stage loop ended with a barrier: LDS is free
+        if (yh == 0) *(f32x4 *)(smem + (2 * wave + yr2) * 64 + 4 * yq) = bsum;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            float s = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += smem[r * 64 + threadIdx.x];
+            p.bias_partial[(size_t)split * p.Cout + co0 + threadIdx.x] = s;
+        }
+    }
 }
 
-// dw_oihw[co][ci][3][3] = G^T (sum over splits, fixed order, of dU) G with the deferred signs (fourth column of the positions)
-__global__ void __launch_bounds__(256) wgrad_wino_lds_reduce_kernel(const float *partial, float *dw, int nsplit, int Cout, int Cin) {
-    const size_t n = (size_t)Cout * Cin;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float u[16];
+// dw_oihw[co][ci][3][3] = G^T (sum over splits, fixed order, of dU) G with the deferred signs (fourth column of the positions).
+// One thread per weight summed 16 positions x nsplit partials, one workgroup per CU: 79 us for the 67 MB of a 256 x 256-channel
+// layer of ResNet-101 at 16 frames (0.85 TB/s, 3 % of that training step).  Now a weight's four COLUMNS of positions go to the four
+// waves of a workgroup (lane = weight: 256 contiguous bytes per load), sixteen loads in flight per thread, G^T applied per column,
+// the columns exchanged through LDS, G applied by the first three waves (row a each).  Same additions in the same order: same bits.
+// db (optional): the bias gradient = sum over splits of the main kernel's column sums.
+__global__ void __launch_bounds__(256) wgrad_wino_lds_reduce_kernel(const float *partial, float *dw, const float *bias_partial, float *db,
+                                                                    int nsplit, int Cout, int Cin) {
+    __shared__ float t_s[4][3][64];
+    const size_t n = (size_t)Cout * Cin;                     // a multiple of 64 * 64
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;
+    if (db != nullptr) {
+        const int co = (int)blockIdx.x * 256 + (int)threadIdx.x;
+        if (co < Cout) db[co] = sum_splits(bias_partial + co, (size_t)Cout, nsplit);
+    }
+    // column j of dU: positions j, 4 + j, 8 + j, 12 + j
+    const float *src = partial + (size_t)j * n + i;
+    const size_t rs = (size_t)4 * n, ss = (size_t)16 * n;    // row and split strides
+    float u[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+        float v[4][4];
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            const float s = sum_splits(partial + (size_t)pp * n + i, (size_t)16 * n, nsplit);
-            u[pp] = ((pp & 3) == 3) ? -s : s;
-        }
-        float t[3][4];                              // G^T dU, G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float hs = 0.5f * (u[4 + j] + u[8 + j]), hd = 0.5f * (u[4 + j] - u[8 + j]);
-            t[0][j] = u[j] + hs;
-            t[1][j] = hd;
-            t[2][j] = hs + u[12 + j];
-        }
+            for (int r = 0; r < 4; ++r) v[kk][r] = src[(size_t)(k + kk) * ss + (size_t)r * rs];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const float hs = 0.5f * (t[a][1] + t[a][2]), hd = 0.5f * (t[a][1] - t[a][2]);
-            dw[i * 9 + a * 3 + 0] = t[a][0] + hs;
-            dw[i * 9 + a * 3 + 1] = hd;
-            dw[i * 9 + a * 3 + 2] = hs + t[a][3];
-        }
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[r] += v[kk][r];
+    }
+    for (; k < nsplit; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] += src[(size_t)k * ss + (size_t)r * rs];
+    if (j == 3) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[r] = -u[r];
+    }
+    {                                               // G^T dU, G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
+        const float hs = 0.5f * (u[1] + u[2]), hd = 0.5f * (u[1] - u[2]);
+        t_s[j][0][lane] = u[0] + hs;
+        t_s[j][1][lane] = hd;
+        t_s[j][2][lane] = hs + u[3];
+    }
+    __syncthreads();
+    if (j < 3) {                                    // row a = j of (G^T dU) G
+        const float t0 = t_s[0][j][lane], t1 = t_s[1][j][lane], t2 = t_s[2][j][lane], t3 = t_s[3][j][lane];
+        const float hs = 0.5f * (t1 + t2), hd = 0.5f * (t1 - t2);
+        dw[i * 9 + j * 3 + 0] = t0 + hs;
+        dw[i * 9 + j * 3 + 1] = hd;
+        dw[i * 9 + j * 3 + 2] = hs + t3;
     }
 }
 
@@ -512,7 +558,7 @@ extern "C" size_t dream_conv3x3_wgrad_winograd_workspace(int B, int H, int W, in
     size_t bytes = (size_t)pl.nsplit * 9 * Cout * Cin * sizeof(float);
     if (Cout % 64 == 0) {                               // the LDS version keeps all 16 positions per split
         const PlanLds pl2 = make_plan_lds(B, H, W, Cin, Cout);
-        const size_t b2 = (size_t)pl2.nsplit * 16 * Cout * Cin * sizeof(float);
+        const size_t b2 = (size_t)pl2.nsplit * (16 * (size_t)Cout * Cin + Cout) * sizeof(float);      // + the bias partials
         if (b2 > bytes) bytes = b2;
     }
     return bytes;
@@ -527,9 +573,15 @@ extern "C" int dream_conv3x3_wgrad_winograd_set_version(int version) {
 
 // x [B,H,W,Cin] (or [B,H/2,W/2,Cin] with DREAM_CONV_UPSAMPLE2X: the conv that follows nn.Upsample(2)), dy [B,H,W,Cdy]
 // (Cdy >= Cout) NHWC -> dw_oihw [Cout,Cin,3,3] (overwritten).  Cin % 64 == 0, Cout % 16 == 0.
-// workspace: dream_conv3x3_wgrad_winograd_workspace() bytes.  (The bias gradient is dream_channel_sum_nhwc_f32(dy).)
-extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
-                                                     int W, int Cin, int Cout, int Cdy, int flags, void *stream) {
+// workspace: dream_conv3x3_wgrad_winograd_workspace() bytes.
+// dbias [Cout] (optional): the bias gradient = column sums of dy, accumulated in the dy loader of the LDS kernel -- only where
+// dream_conv3x3_wgrad_winograd_fuses_bias() says so; elsewhere it is dream_channel_sum_nhwc_f32(dy) and a non-null dbias is an error.
+extern "C" int dream_conv3x3_wgrad_winograd_fuses_bias(int Cin, int Cout, int Cdy) {
+    return Cin > 0 && Cout > 0 && Cdy >= Cout && use_lds_version(Cin, Cout, Cdy) ? 1 : 0;
+}
+
+extern "C" int dream_conv3x3_wgrad_winograd_bias_nhwc_f32(const float *x, const float *dy, float *dw_oihw, float *dbias, void *workspace,
+                                                          int B, int H, int W, int Cin, int Cout, int Cdy, int flags, void *stream) {
     DREAM_REQUIRE(x && dy && dw_oihw && workspace, "winograd wgrad: null pointer");
     DREAM_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cdy >= Cout, "winograd wgrad: bad shape");
     DREAM_REQUIRE(Cin % 64 == 0 && Cout % 16 == 0 && Cdy % 16 == 0, "winograd wgrad: Cin %% 64, Cout %% 16, Cdy %% 16 (got %d, %d, %d)", Cin, Cout, Cdy);
@@ -542,24 +594,27 @@ extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float
         DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd wgrad: too many tiles");
         WgWinoLdsParams p;
         p.x = x; p.dy = dy; p.partial = (float *)workspace;
+        p.bias_partial = p.partial + (size_t)pl.nsplit * 16 * Cout * Cin;
         p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Cdy = Cdy;
         p.TY = pl.TY; p.TX = pl.TX; p.ntiles = pl.ntiles;
         p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(pl.TY * pl.TX) - 1) / (unsigned long long)(pl.TY * pl.TX);
         p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)pl.TX - 1) / (unsigned long long)pl.TX;
         p.tiles_per_split = pl.tiles_per_split;
         p.ncog = Cout / 64;
-        if (dream_allow_full_lds((const void *)wgrad_wino_lds_kernel<false>) || dream_allow_full_lds((const void *)wgrad_wino_lds_kernel<true>)) return 2;
+        void (*const kernels[4])(WgWinoLdsParams) = {wgrad_wino_lds_kernel<false, false>, wgrad_wino_lds_kernel<true, false>,
+                                                     wgrad_wino_lds_kernel<false, true>, wgrad_wino_lds_kernel<true, true>};
+        for (int v = 0; v < 4; ++v)
+            if (dream_allow_full_lds((const void *)kernels[v])) return 2;
         const dim3 grid((unsigned)(p.ncog * (Cin / 64)), (unsigned)pl.nsplit);
-        if (ups) hipLaunchKernelGGL(wgrad_wino_lds_kernel<true>, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(wgrad_wino_lds_kernel<false>, grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(kernels[(ups ? 1 : 0) + (dbias ? 2 : 0)], grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
         DREAM_LAUNCH_OK();
-        size_t rgrid = ((size_t)Cout * Cin + 255) / 256;
-        if (rgrid > 2048) rgrid = 2048;
-        hipLaunchKernelGGL(wgrad_wino_lds_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, (hipStream_t)stream,
-                           (const float *)workspace, dw_oihw, pl.nsplit, Cout, Cin);
+        // one workgroup per 64 weights; the first ceil(Cout / 256) of them also sum the bias partials
+        hipLaunchKernelGGL(wgrad_wino_lds_reduce_kernel, dim3((unsigned)((size_t)Cout * Cin / 64)), dim3(256), 0, (hipStream_t)stream,
+                           (const float *)workspace, dw_oihw, (const float *)p.bias_partial, dbias, pl.nsplit, Cout, Cin);
         DREAM_LAUNCH_OK();
         return 0;
     }
+    DREAM_REQUIRE(dbias == nullptr, "winograd wgrad: the bias gradient is fused in the LDS kernel only (see dream_conv3x3_wgrad_winograd_fuses_bias)");
     const Plan pl = make_plan(B, H, W, Cin, Cout);
     DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd wgrad: too many tiles");
     WgWinoParams p;
@@ -579,4 +634,9 @@ extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float
                        dw_oihw, pl.nsplit, Cout, Cin);
     DREAM_LAUNCH_OK();
     return 0;
+}
+
+extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
+                                                     int W, int Cin, int Cout, int Cdy, int flags, void *stream) {
+    return dream_conv3x3_wgrad_winograd_bias_nhwc_f32(x, dy, dw_oihw, nullptr, workspace, B, H, W, Cin, Cout, Cdy, flags, stream);
 }

@@ -519,6 +519,10 @@ def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
     return dw, dbias[:cout].contiguous()
 
 
+# A/B switch: DREAM_WGRAD_BIAS_FUSION=0 restores the stand-alone channel_sum pass for the bias gradients
+WGRAD_BIAS_FUSION = _os.environ.get("DREAM_WGRAD_BIAS_FUSION", "1") != "0"
+
+
 def wgrad_winograd_pays(pixels, cin, cout):
     """Where the Winograd-domain weight gradient beats the direct kernel (profiles/r02_microbench_wgrad_wino_b128.txt:
     1.2-2.1x on the layers with >= 128 x 64 channel pairs or >= 4 M pixels; it loses on small 64 x 64-channel maps, whose
@@ -529,16 +533,24 @@ def wgrad_winograd_pays(pixels, cin, cout):
 def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True, flags=0):
     """Weight (+ bias) gradient of a 3x3 stride-1 conv in the Winograd F(2x2,3x3) domain -> (dW OIHW [cout,cin,3,3], dbias
     [cout] or None).  cin % 64 == 0, cout % 16 == 0; dy may carry padded channels (>= cout).  flags: CONV_UPSAMPLE2X when x is
-    the half-resolution input of a conv that followed a nearest x2 upsample (channels a multiple of 64)."""
+    the half-resolution input of a conv that followed a nearest x2 upsample (channels a multiple of 64).  The bias gradient
+    is summed in the kernel's dy loader where the LDS kernel runs (channels multiples of 64; WGRAD_BIAS_FUSION), by a
+    channel_sum pass elsewhere."""
     x, dy = _f32(x_nhwc), _f32(dy_nhwc)
     b, h, w, cdy = (int(v) for v in dy.shape)
     if int(x.shape[3]) != cin:
         raise RuntimeError("wgrad: x has %d channels, expected %d" % (x.shape[3], cin))
-    nbytes = int(_hip.lib().dream_conv3x3_wgrad_winograd_workspace(b, h, w, cin, cout))
+    lib = _hip.lib()
+    nbytes = int(lib.dream_conv3x3_wgrad_winograd_workspace(b, h, w, cin, cout))
     ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    call("dream_conv3x3_wgrad_winograd_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(ws), b, h, w, cin, cout, cdy, flags, stream())
-    db = channel_sum(dy)[:cout].contiguous() if want_bias else None
+    db = None
+    if want_bias and WGRAD_BIAS_FUSION and lib.dream_conv3x3_wgrad_winograd_fuses_bias(cin, cout, cdy):
+        db = torch.empty((cout,), dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_wgrad_winograd_bias_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), b, h, w, cin, cout, cdy, flags,
+         stream())
+    if want_bias and db is None:
+        db = channel_sum(dy)[:cout].contiguous()
     return dw, db
 
 

@@ -366,6 +366,12 @@ int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float
                                           int W, int Cin, int Cout, int Cdy, int flags, void *stream);
 /* flags: 0 or DREAM_CONV_UPSAMPLE2X (x is [B,H/2,W/2,Cin]: weight gradient of the conv that follows nn.Upsample(2),
  * dream/models.py:691-710; channels a multiple of 64) */
+/* ... with the bias gradient dbias [Cout] = column sums of dy accumulated in the kernel's dy loader (no separate pass over dy).
+ * Only where dream_conv3x3_wgrad_winograd_fuses_bias(Cin, Cout, Cdy) returns 1 (Cin, Cout multiples of 64); dbias == NULL: as
+ * dream_conv3x3_wgrad_winograd_nhwc_f32.  Same workspace. */
+int dream_conv3x3_wgrad_winograd_fuses_bias(int Cin, int Cout, int Cdy);
+int dream_conv3x3_wgrad_winograd_bias_nhwc_f32(const float *x, const float *dy, float *dw_oihw, float *dbias, void *workspace,
+                                               int B, int H, int W, int Cin, int Cout, int Cdy, int flags, void *stream);
 int dream_conv3x3_wgrad_winograd_set_version(int version);   /* test / A-B hook: 0 = by shape (default), 1 = register-only kernel */
 /* general forms for the ResNet path (1x1 / 3x3, stride 1 / 2) and the 4x4 transposed conv */
 size_t dream_conv2d_wgrad_workspace(int B, int H, int W, int Cin, int CoutPad, int ksize, int stride);

@@ -274,6 +274,18 @@ def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0, ups=False):
     err = float(((dw.cpu().double() - wref.grad).abs() / aref.grad).max())
     assert dw.shape == (Cout, Cin, 3, 3) and err <= 3e-6, (B, H, W, Cin, Cout, err)
     assert float((db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())
+    if ops.WGRAD_BIAS_FUSION and Cin % 64 == 0 and Cout % 64 == 0:
+        # the bias gradient rode in the kernel's dy loader: the weight gradient must not notice (same bits as without it), padded dy
+        # channels (garbage here) must not leak into it, and it agrees with the stand-alone column sums
+        junk = torch.cat([_nhwc(dy), torch.full((B, H, W, 16), 1e6)], dim=3).contiguous()
+        dwj, dbj = ops.conv3x3_wgrad_winograd(to(dev, _nhwc(x)), to(dev, junk), Cout, Cin, flags=ops.CONV_UPSAMPLE2X if ups else 0)
+        ops.WGRAD_BIAS_FUSION = False
+        try:
+            dw2, db2 = ops.conv3x3_wgrad_winograd(to(dev, _nhwc(x)), to(dev, dyn), Cout, Cin, flags=ops.CONV_UPSAMPLE2X if ups else 0)
+        finally:
+            ops.WGRAD_BIAS_FUSION = True
+        assert torch.equal(dw, dw2) and torch.equal(dw, dwj) and torch.equal(db, dbj)
+        assert float((db - db2).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())
     return err
 
 

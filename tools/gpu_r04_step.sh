@@ -92,4 +92,13 @@ vt)
   line vt_b --mode train --steps 4 --warmup 2
   line vft --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
   ;;
+wb)
+  echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "wgrad or backward_ops or train_step or train_steps or reference_golden or variant or general_conv or convT" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  DREAM_WGRAD_BIAS_FUSION=0 line vt_sum_a --mode train --steps 4 --warmup 2
+  DREAM_WGRAD_BIAS_FUSION=1 line vt_fused_a --mode train --steps 4 --warmup 2
+  DREAM_WGRAD_BIAS_FUSION=0 line vt_sum_b --mode train --steps 4 --warmup 2
+  DREAM_WGRAD_BIAS_FUSION=1 line vt_fused_b --mode train --steps 4 --warmup 2
+  line rt16_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt16_b --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  ;;
 esac
