@@ -183,6 +183,11 @@ class DreamDataParallel(nn.Module):
         object.__setattr__(self, "_opt_state", {})        # replica index -> optimizer state buffers on that replica's device
         object.__setattr__(self, "_tick", [0])            # use counter for the LRU of captured graphs
         object.__setattr__(self, "_grad_version", None)   # version of the master's flat gradient buffer right after the all-reduce
+        # Opt-in (DreamNetwork.hip_graph / DREAM_TRAIN_GRAPH=1): a training step on ONE device also runs as two hipGraph replays
+        # (forward, backward) instead of ~2000 launches from Python -- what every replica of a multi-device step already does.  A
+        # ResNet-101 step at 16 frames leaves the GPU idle 11 % of the time waiting for the host between its small kernels
+        # (profiles/r04_bench_resnet_h_train16_concurrency.txt).  Same kernels in the same order: bit-identical.
+        self.single_device_graphs = os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
         # statistics of the last step (tests, bench): hipGraph replays / eager replica runs / captures
         object.__setattr__(self, "stats", {"replays": 0, "eager": 0, "captures": 0, "param_copies": 0, "replica_steps": 0})
 
@@ -213,9 +218,11 @@ class DreamDataParallel(nn.Module):
         return max(1, -(-int(batch) // per))
 
     def use_graphs(self):
-        """Replica launch sequences as hipGraphs: real GPUs, more than one replica, not switched off (DREAM_DP_GRAPHS=0)."""
+        """Replica launch sequences as hipGraphs: real GPUs, more than one replica (or ``single_device_graphs``), not switched
+        off (DREAM_DP_GRAPHS=0)."""
         devs = self.devices()
-        return len(devs) > 1 and devs[0].type == "cuda" and os.environ.get("DREAM_DP_GRAPHS", "1") != "0"
+        return ((len(devs) > 1 or self.single_device_graphs) and devs[0].type == "cuda"
+                and os.environ.get("DREAM_DP_GRAPHS", "1") != "0")
 
     # ---- replicas ---------------------------------------------------------------------------------------------------------
     def flatten_parameters(self):
@@ -531,11 +538,16 @@ class DreamDataParallel(nn.Module):
 
     # ---- nn.Module interface ------------------------------------------------------------------------------------------------
     def forward(self, x, *args, **kwargs):
-        if self.n_devices(x.shape[0]) == 1 or args or kwargs:
+        if args or kwargs:
             return self.module(x, *args, **kwargs)
+        one = self.n_devices(x.shape[0]) == 1
+        if one and not (self.single_device_graphs and self.module.training and torch.is_grad_enabled()):
+            return self.module(x)
         params = self.module.dp_parameters()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params) and self.module.dp_trainable():
             outs = list(_DataParallelFunction.apply(self, x, *params))
+        elif one:
+            return self.module(x)
         else:
             outs, _, _ = self._forward_shards(x, save=False)
             outs = self._gather(outs)

@@ -208,7 +208,9 @@ class DreamNetwork:
         # captures the whole launch sequence of one input shape -- CNN + peak extraction, 30-140 kernel launches -- into
         # a hipGraph and replays it, so a frame costs one graph launch + one 56-byte D2H copy instead of one Python /
         # ctypes round trip per kernel.  Results are bit-identical (same kernels, same order).  Off by default.
-        self.hip_graph = False
+        # train() with hip_graph set runs the step as two replays (forward, backward; DreamDataParallel.single_device_graphs):
+        # the second step of a batch shape captures, later ones replay.
+        self._hip_graph = False
         self._graphs = {}
 
         out_res = list(self.net_output_resolution_from_input_resolution(self.trained_net_input_resolution()))
@@ -217,6 +219,16 @@ class DreamNetwork:
                 "Network model and config file disagree for trained network output resolution."
         else:
             tcfg["net_output_resolution"] = out_res
+
+    @property
+    def hip_graph(self):
+        return self._hip_graph
+
+    @hip_graph.setter
+    def hip_graph(self, on):
+        self._hip_graph = bool(on)
+        if isinstance(self.model, models.DreamDataParallel):
+            self.model.single_device_graphs = bool(on) or os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
 
     # ---- small getters (network.py:319-326) ------------------------------------------------------------
     def trained_net_input_resolution(self):

@@ -395,6 +395,35 @@ def test_eight_devices_uneven_chunks(emu, monkeypatch):
     assert reduced == [6, 8] and len(tdp._replicas) == 7
 
 
+def test_one_device_step_through_the_replica_path(emu):
+    """``single_device_graphs`` (DreamNetwork.hip_graph on a training network): a one-device step takes the replica path -- flat
+    gradient buffer, no all-reduce, no replica update -- so that it can be replayed as hipGraphs on a GPU.  Here on CPU tensors
+    (nothing to capture): gradients and Adam steps equal the direct path's, accumulation over two backwards included."""
+    a, oa = _tiny_dp("adam")
+    b, ob = _tiny_dp("adam")
+    a.single_device_graphs = True
+    assert len(a.devices()) == 1 and not a.use_graphs()
+    for step in range(3):
+        x, t = _tiny_batch(6, 50 + step)
+        for dp, optim in ((a, oa), (b, ob)):
+            optim.zero_grad()
+            _tiny_loss(dp, x, t).backward()
+            if step == 2:                                  # a second backward before the step
+                _tiny_loss(dp, x, t).backward()
+        base = a.module._dream_flat["grads"]
+        if step < 2:
+            assert all(base.data_ptr() <= p.grad.data_ptr() < base.data_ptr() + 4 * base.numel() for p in a.parameters())
+        for ga, gb in zip(_grads(a), _grads(b)):
+            assert torch.allclose(ga, gb, rtol=1e-6, atol=1e-7)
+        oa.step()
+        ob.step()
+        for pa, pb in zip(a.parameters(), b.parameters()):
+            assert torch.allclose(pa, pb, rtol=1e-6, atol=1e-7)
+    assert not a._replicas and a.stats["replica_steps"] == 0
+    with torch.no_grad():                                  # evaluation and no-grad forwards stay on the direct path
+        assert torch.equal(a(x)[0], a.module(x)[0])
+
+
 def _tiny_reference_at(dp, x, t):
     """Whole-batch gradient of the tiny module at the data-parallel master's current parameters (plain autograd)."""
     ref = _TinyReplica()

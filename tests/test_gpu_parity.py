@@ -945,6 +945,47 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch):
         assert torch.equal(m, ref[0]) and torch.equal(k, ref[1])
 
 
+@pytest.mark.parametrize("arch,res", [("resnet_h", (64, 64)), ("vgg_q", (64, 48))])
+def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
+    """DreamNetwork.hip_graph on a training network with ONE device: from the second step of a batch shape train() is two
+    hipGraph replays (forward, backward) + the loss and the optimizer launch.  Four Adam steps must equal the eager steps bit for
+    bit (losses, parameters, BatchNorm running statistics), the host must spend a fraction of the eager enqueue time on a replayed
+    step, and switching the flag off again returns to the eager path on the same parameters."""
+    import time
+    wts = om.recipe_weights(om.build_model(arch, 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1) if arch == "resnet_h" \
+        else None                                          # _dp_network's default recipe
+    x = torch.from_numpy(cases.image_batch(4, res[1], res[0], seed=47)).to(DEV)        # res = (width, height)
+
+    def run(graph):
+        net = _dp_network(arch, [0], optimizer="adam", lr=1e-5, in_res=res, weights=wts)
+        net.enable_training()
+        net.hip_graph = graph
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=res, seed=47)).to(DEV)
+        losses, host = [], []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = net.train([x], t)
+            host.append(time.perf_counter() - t0)
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        return net, losses, host, t
+
+    g, lg, hg, t = run(True)
+    e, le, he, _ = run(False)
+    st = g.model.stats
+    assert st["captures"] == 2 and st["replays"] == 2 * 3 and e.model.stats["replays"] == 0, st
+    assert lg == le, (lg, le)
+    for (k, a), (_, b) in zip(g.model.state_dict().items(), e.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    print("%s host seconds per step: graph %s, eager %s" % (arch, ["%.4f" % v for v in hg], ["%.4f" % v for v in he]))
+    assert hg[3] < 0.5 * he[3], (hg, he)
+    g.hip_graph = False                                    # back to the eager path, same parameters, same optimizer state
+    assert g.train([x], t).item() == e.train([x], t).item()
+    assert st["replays"] == 2 * 3
+
+
 def test_resnet_batched_packing_equals_lazy_packing(monkeypatch):
     """ResnetSimple._repack_weights: from the second training step on the packed weight copies are refreshed by ONE launch
     (dream_pack_weights_batched).  Four Adam steps and an evaluation in between must equal the same with DREAM_PACK_BATCHED=0

@@ -92,6 +92,17 @@ vt)
   line vt_b --mode train --steps 4 --warmup 2
   line vft --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
   ;;
+tg)
+  echo "== pytest"; timeout 600 python -m pytest tests -m gpu -q -x -s --timeout 400 -k "one_device_training_step_as_graph or graph_replay_equals_eager" 2>&1 | grep -v "Warning\|warn" | tail -6
+  line rt16_eager_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  DREAM_TRAIN_GRAPH=1 line rt16_graph_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt16_eager_b --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  DREAM_TRAIN_GRAPH=1 line rt16_graph_b --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt128_eager --arch resnet_h --mode train --batch 128 --steps 3 --warmup 3
+  DREAM_TRAIN_GRAPH=1 line rt128_graph --arch resnet_h --mode train --batch 128 --steps 3 --warmup 3
+  line vt_eager --mode train --steps 4 --warmup 3
+  DREAM_TRAIN_GRAPH=1 line vt_graph --mode train --steps 4 --warmup 3
+  ;;
 wb)
   echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "wgrad or backward_ops or train_step or train_steps or reference_golden or variant or general_conv or convT" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
   DREAM_WGRAD_BIAS_FUSION=0 line vt_sum_a --mode train --steps 4 --warmup 2
