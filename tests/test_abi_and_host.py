@@ -29,6 +29,19 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc != 0
 
 
+def test_host_side_planning_queries_need_no_gpu():
+    """Workspace sizes and the 'does this launch carry the bias gradient' query are pure host functions of the shape."""
+    lib = _hip.lib()
+    assert lib.dream_conv3x3_wgrad_winograd_fuses_bias(64, 64, 64) == 1 and lib.dream_conv3x3_wgrad_winograd_fuses_bias(512, 256, 272) == 1
+    assert lib.dream_conv3x3_wgrad_winograd_fuses_bias(64, 48, 48) == 0            # the register-only kernel: no fused bias
+    assert lib.dream_conv3x3_wgrad_winograd_fuses_bias(64, 64, 48) == 0            # fewer dy channels than outputs
+    small, big = (int(lib.dream_conv3x3_wgrad_winograd_workspace(b, 100, 100, 256, 256)) for b in (2, 128))
+    assert small > 0 and big >= small and big % 4 == 0
+    assert int(lib.dream_conv3x3_wgrad_winograd_workspace(2, 100, 100, 60, 64)) == 0   # input channels not a multiple of 64
+    rc = lib.dream_conv3x3_wgrad_winograd_bias_nhwc_f32(None, None, None, None, None, 1, 8, 8, 64, 64, 64, 0, None)
+    assert rc != 0 and b"null" in lib.dream_hip_last_error()
+
+
 # ---- the reference's own resolution KATs (test/test_image_proc.py:20-91) -----------------------------
 def test_shrink_resolution():
     assert image_proc.shrink_resolution((640, 480), (400, 400)) == (533, 400)
