@@ -868,8 +868,10 @@ class ResnetSimple(nn.Module):
         # decoder ConvTranspose2d(k4,s2,p1) forward: "winograd" = minimal filtering on the Winograd kernel (9/16 of the direct
         # multiplications, conv_wino.hip), "direct" = sub-pixel phases on conv_mfma
         self.convT_algorithm = os.environ.get("DREAM_CONVT_ALGORITHM", "winograd")
-        # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order)
+        # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order), up to
+        # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
+        self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "96"))
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
@@ -1206,7 +1208,7 @@ class ResnetSimple(nn.Module):
         # every kernel already fills the chip and the two streams only disturb each other's L2.
         stem_x = tape[0]["x"]                                  # im2col of the input: [B, H/2, W/2, 160]
         input_px = 4 * int(stem_x.shape[0]) * int(stem_x.shape[1]) * int(stem_x.shape[2])
-        side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= 96 * 400 * 400)
+        side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= self.overlap_max_frames * 400 * 400)
         g = None                 # gradient w.r.t. the output of the unit being processed
         block = None             # state of the Bottleneck being unwound
         for rec in reversed(tape):
@@ -1412,7 +1414,7 @@ class ResnetSimple(nn.Module):
         grads = _GradDict(reducer)
         stem_x = tape[1]["x"]
         input_px = 4 * int(stem_x.shape[0]) * int(stem_x.shape[1]) * int(stem_x.shape[2])
-        side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= 96 * 400 * 400)
+        side = _SideStream.create(grad_out_nchw, self.overlap_wgrad and input_px <= self.overlap_max_frames * 400 * 400)
         g = None
         block = None
         for idx in range(len(tape) - 1, -1, -1):
