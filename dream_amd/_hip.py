@@ -60,6 +60,10 @@ _SIGNATURES = {
     "dream_conv1x1_bn_workspace": (_SZ, [_c.c_long, _I]),
     "dream_conv1x1_bn_counters": (_I, [_c.c_long, _I]),
     "dream_conv1x1_bnstats_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "dream_conv3x3_winograd_bn_workspace": (_SZ, [_I, _I, _I, _I]),
+    "dream_conv3x3_winograd_bn_counters": (_I, [_I, _I, _I, _I]),
+    "dream_conv3x3_winograd_bnstats_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P]),
+    "dream_conv3x3_winograd_bwd_bnmask_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dream_conv1x1_bwd_bnmask_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dream_conv1x1_wgrad_pre_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P, _P]),
     "dream_maxpool3s2_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),

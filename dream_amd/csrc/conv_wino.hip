@@ -45,6 +45,7 @@
 #include <dream_cdna4.h>
 #include "common.h"
 #include "pack_device.h"
+#include "stat_tree.h"
 #include "../../include/dream_hip.h"
 
 // Timing diagnostics only (tools/wino_diag.py builds separate libraries with -DDREAM_WINO_DIAG=k; never the product
@@ -75,6 +76,22 @@ struct WinoParams {
                                      // gradient in the transposed conv's data gradient; the stored tensor is in_scale H x in_scale W
     unsigned long long magic_tpi, magic_tx;   // ceil(2^40 / (TY * TX)), ceil(2^40 / TX): tile -> (image, row, column) without divides
     int flags;
+};
+
+// STAT != 0: a train-mode BatchNorm folded into this launch (csrc/stat_tree.h; the 1x1 convs' form is in gemm1x1.hip).
+//   1: batch statistics of y (sum, sum of squares per output channel over the `count` stored outputs of ALL launches that share
+//      the tree -- one conv, or the four phase launches of a transposed conv) -> scale / shift of the FOLLOWING BatchNorm;
+//   2: with MODE 3 and `residual` = the masked BatchNorm's INPUT z: y = g * [fmaf(a, z, b) > 0] (the ReLU mask recomputed
+//      exactly as the forward pass evaluated it), per-channel sums of y (dbeta) and y * xhat (dgamma).
+// A persistent workgroup is one producer row (row0 + blockIdx.x) of each 64-channel column block it covers.
+// (A second kernel argument of the STAT kernels only: inside WinoParams the extra fields cost the plain kernels scalar registers.)
+struct WinoStat {
+    StatTree st;
+    int row0;
+    double count;
+    BnFwdOut fwd;                           // STAT 1
+    const float *zab, *mean, *invstd;       // STAT 2: [2][Cout], [Cout], [Cout] of the masked BatchNorm
+    float *dgamma, *dbeta;                  // STAT 2 out
 };
 
 constexpr int WT = 32;       // tiles per workgroup
@@ -114,352 +131,44 @@ DREAM_DEVICE constexpr int pat_pos(int pat, int k) {          // k-th active pos
     return 0;
 }
 
-template <int NW, int MODE, int PAT>
-__global__ void __launch_bounds__(64 * NW, 2) conv_wino_kernel(const WinoParams p) {
-    constexpr int NT = 64 * NW;                        // threads
-    constexpr int NPOS = pat_count(PAT);               // positions this kernel multiplies
-    constexpr int RING = NPOS == 16 ? B_RING : NPOS;   // operand ring of the weight stream: a divisor of NPOS (slots carry over chunks)
-    constexpr int ITEMS = 512 / NT;                    // (tile, quad, row) items per thread and chunk: 2 (NW 4) or 1 (NW 8)
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    DREAM_DYNAMIC_LDS(float, sV);                      // 2 x V buffer (16 skewed planes of [32 tiles][16 channels]), then the offset table
-    u32x4 *sG = (u32x4 *)(sV + 2 * VB);                // [ITEMS][NT]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = wave_index();
-
-    // PERSISTENT workgroups: the grid is what the chip holds at once (host side); a workgroup walks over tile blocks
-    // tb, tb + J, tb + 2J .. of its XCD's contiguous range (XCD-aware placement, see conv_mfma.hip: workgroup g runs on XCD
-    // g % 8; the J workgroups of an XCD work on J neighbouring blocks at any time and meet in its L2).  What this buys: the
-    // first chunk of the NEXT block is loaded and transformed during the last chunk of the current one, so only the very
-    // first block of a workgroup pays the load latency of a prologue (~2.5 us of a 14-56 us block).
-    const int xcd = (int)(blockIdx.x & 7), J = (int)(gridDim.x >> 3);
-    const int blk_hi = (xcd + 1) * p.blk_per_xcd;
-    const int blk_end = blk_hi < p.nblk ? blk_hi : p.nblk;
-    int tb = xcd * p.blk_per_xcd + (int)(blockIdx.x >> 3);
-    if (tb >= blk_end) return;
-    const int n0 = blockIdx.y * (16 * NW);
-    const int tiles_per_img = p.TY * p.TX;
-    const size_t img_floats = (size_t)(p.in_scale * p.H) * (p.in_scale * p.W) * p.Cin;     // stored input image
-
-    // ---- input-transform plan: thread -> ITEMS items (tile t, channel quad q, patch row r); r = the lane's index in its quad
-    // Loads go through buffer descriptors (dream_cdna4.h): a 32-bit byte offset per (item, column) relative to the first image
-    // the BLOCK touches, BUFFER_OOB where the patch leaves the image (the hardware returns zeros: no compare / select per
-    // load), the chunk's channel offset in the scalar operand.  The offsets are parked in LDS ([ITEMS][NT] uint4, each entry
-    // private to its thread, conflict-free b128 access) and re-read per chunk: VGPRs that accumulators + weight ring + patch
-    // cannot spare.
-    int soff[ITEMS];                                   // LDS float offset of V[p = 4r][t][slot q]; + j * 512 for p = 4r + j
-    const int qr = lane & 3;                           // patch row of this lane's items (e & 3 with NT a multiple of 4)
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const int e = tid + it * NT;
-        const int q = (e >> 2) & 3, t = (e >> 4) & 31;
-        soff[it] = v_plane(4 * qr) + t * WKC + 4 * v_slot(q, t);
+// The end of a STAT workgroup: its per-lane sums (channel n0 + 16 wave + (lane & 15), the lane's share of the tiles) -> one fp64
+// row per 64-channel column block, then the ticket tree; the wavefront that finishes a column block writes the BatchNorm's results.
+template <int NW, int STAT>
+DREAM_DEVICE void wino_stat_finish(const WinoParams &p, const WinoStat &q, int n0, int wave, int lane, double s0, double s1) {
+    // the four lanes l, l + 16, l + 32, l + 48 hold the same channel on different tiles: (0 + 1) + (2 + 3) in every lane
+    s0 += lane_xor(s0, 16);
+    s1 += lane_xor(s1, 16);
+    s0 += lane_xor(s0, 32);
+    s1 += lane_xor(s1, 32);
+    const int col = n0 + wave * 16 + (lane & 15);
+    const int row = q.row0 + (int)blockIdx.x;
+    if ((lane >> 4) == 0 && col < p.Cout) {
+        double *dst = q.st.rows + ((size_t)row * p.Cout + col) * 2;
+        coherent_store(dst, s0);
+        coherent_store(dst + 1, s1);
     }
-    auto plan_item = [&](int it, int tile0, int b0) -> u32x4 {
-        const int e = tid + it * NT;
-        const int q = (e >> 2) & 3, t = (e >> 4) & 31;
-        const int tau = (DREAM_WINO_DIAG & 8) ? tile0 : tile0 + t;
-        const bool tv = tau < p.ntiles;
-        const int b = div_magic40(tau, p.magic_tpi), rem = tau - b * tiles_per_img;
-        const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
-        const int gy = 2 * ty - 1 + qr, x0 = 2 * tx - 1;
-        const bool rok = tv & ((unsigned)gy < (unsigned)p.H);          // bitwise: no short-circuit branches inside a chunk
-        const int Si = p.in_scale;                                    // conv position -> stored pixel (WinoParams)
-        const unsigned off0 = (unsigned)(((((b - b0) * (Si * p.H) + Si * gy + p.in_oy) * (Si * p.W) + Si * x0 + p.in_ox) * p.Cin + 4 * q) * 4);   // column 0 (wraps when outside)
-        const unsigned px = (unsigned)(Si * p.Cin * 4);
-        u32x4 g;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const bool ok = rok & ((unsigned)(x0 + c) < (unsigned)p.W);
-            g[c] = ok ? off0 + (unsigned)c * px : BUFFER_OOB;
-        }
-        sG[it * NT + tid] = g;
-        return g;
-    };
-    // first tile / first image / input descriptor of a block; a block past the end of the range reads nothing (all OOB)
-    auto block_tile0 = [&](int blk) { return blk < blk_end ? blk * WT : p.ntiles; };
-    auto block_xbuf = [&](int b0) {
-        return make_buffer(p.x + (size_t)b0 * img_floats, ((size_t)(p.B - b0) * img_floats) * sizeof(float));
-    };
-    // column transform across the quad: row r of B^T (u_0..u_3) = u_r + sb * u_partner(r), partner = {2, 2, 1, 1}, for
-    // r = 0, 1, 2; the lane of r = 3 computes u_3 - u_1 = MINUS row 3 -- the packed weights carry the matching sign in their
-    // positions 12..15 (wino_pack_kernel), so the product is unchanged and every lane needs one fma per value.
-    const float sb = (qr == 1) ? 1.0f : -1.0f;
-
-    // ---- MFMA operand addresses ------------------------------------------------------------------------------------------
-    // A: lane l -> tile row (l & 15) (+16 for the second block), k = 4 (l >> 4) .. +3 (one float4, feeds 4 MFMAs)
-    const int lt = lane & 15, lg = lane >> 4;
-    int a_off[2];
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk) {
-        const int t = blk * 16 + lt;
-        a_off[blk] = t * WKC + 4 * v_slot(lg, t);
-    }
-    // B: lane l -> output channel n0 + 16 wave + (l & 15), k = 4 (l >> 4) .. +3; position s at scalar offset s * stride
-    const unsigned b_lane = (unsigned)(((wave * 16 + lt) * WKC + 4 * lg) * 4);
-    const unsigned u_pos_stride = (unsigned)(p.CoutPad * WKC * 4);          // bytes between consecutive positions
-    const BufferRsrc ubuf = make_buffer(p.u + (size_t)n0 * WKC, ((size_t)((p.Cin / WKC) * 16 + B_AHEAD) * p.CoutPad - (size_t)n0) * WKC * sizeof(float));
-
-    f32x4 acc[16][2];
-    const int nchunks = p.Cin / WKC;
-
-    // weight stream: ring of B_RING operand registers, position s lives in bq[s % B_RING] (16 positions per chunk: the
-    // register depends on the position inside the chunk only).  Unconditional and branch-free, so the compiler can count
-    // outstanding loads exactly (s_waitcnt vmcnt(N) instead of vmcnt(0) at merge points); in the last chunk of a block the
-    // stream wraps around to the first positions of the next block (same weights).
-    f32x4 bq[RING];
-#pragma unroll
-    for (int k = 0; k < B_AHEAD; ++k) bq[k] = buffer_load_x4(ubuf, b_lane, (unsigned)pat_pos(PAT, k) * u_pos_stride);
-
-    // patch row of an item: its four loads / row transform, quad exchange, column transform, four V stores
-    f32x4 d[ITEMS][4];
-    u32x4 goff[ITEMS];
-    // piece j (0..3) of an item's transform: column j of the row transform u = d B (B^T d B = B^T (d B)), the quad exchange
-    // for the column transform, one b128 store -- ~8 VALU instructions, placed after ONE pair of MFMAs each, so that the
-    // wave's next MFMA is never more than the other wave's MFMA time away
-    auto item_piece = [&](int it, int j, float *vbuf) {
-        const f32x4 u = j == 0 ? d[it][0] - d[it][2] : j == 1 ? d[it][1] + d[it][2] : j == 2 ? d[it][2] - d[it][1] : d[it][1] - d[it][3];
-        f32x4 v;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = __builtin_fmaf(sb, quad_perm_2211(u[k]), u[k]);     // exact: sb = +-1
-        *(f32x4 *)(vbuf + soff[it] + j * (WT * WKC)) = v;
-    };
-    auto item_store = [&](int it, float *vbuf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) item_piece(it, j, vbuf);
-    };
-
-    // MFMA operands of position pp from V buffer vbuf: read one position ahead of their use into the register set of the
-    // other parity (no copies).  The schedule is pinned in groups of two MFMAs (sched_barrier): at ~200 VGPRs hipcc
-    // schedules for register pressure -- it sinks every load to its use (a full LDS / memory latency with no MFMA of this
-    // wave in flight) and issues the four MFMAs of one accumulator back to back (40-cycle dependent latency vs 32 issue).
-    f32x4 a[2][2];
-    auto read_a = [&](int set, int pp, const float *vbuf) {
-        a[set][0] = *(const f32x4 *)(vbuf + v_plane(pp) + a_off[0]);
-        a[set][1] = *(const f32x4 *)(vbuf + v_plane(pp) + a_off[1]);
-    };
-
-    // ---- first block of this workgroup: plan, chunk 0 into buffer 0 (the only exposed load latency of the workgroup) --------
-    int tile0 = block_tile0(tb);
-    int b0 = div_magic40(tile0, p.magic_tpi);
-    BufferRsrc xbuf = block_xbuf(b0);
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        goff[it] = plan_item(it, tile0, b0);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) d[it][c] = buffer_load_x4(xbuf, goff[it][c], 0u);
-    }
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) item_store(it, sV);
+    publish_wait();                                    // this wave's part of the row is out before the barrier releases the arriver
     __syncthreads();
-    int par = 0;                                       // V buffer holding the chunk about to be multiplied
-
-    // One chunk: 16 positions x (2 tile blocks x 4 k-steps) MFMAs on V buffer `par`, while the NEXT chunk is loaded,
-    // transformed and stored into the other buffer.  Patch loads: ONE per pair of MFMAs (a load touches 16 separate 64-byte
-    // segments and the texture-address unit takes tens of cycles to accept it; issued back to back they stall the wave's
-    // in-order instruction stream, MFMAs included); item it loads during position it, is transformed and stored ten
-    // positions later.  FIRST: the block's first chunk starts the accumulators from zero (no clearing pass).  LAST: the
-    // next chunk is chunk 0 of the NEXT block -- its plan is computed here (a few dozen VALU instructions per item) and
-    // kept in the offset table, the weight stream wraps around.
-    auto chunk = [&](auto first_tag, auto last_tag, int c, const BufferRsrc &xnext, int tile0n, int b0n) {
-        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
-        const float *cur = sV + par * VB;
-        float *nxt = sV + (par ^ 1) * VB;
-        const unsigned coff = LAST ? 0u : (unsigned)((c + 1) * WKC * 4);
-        read_a(0, pat_pos(PAT, 0), cur);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NPOS; ++k) {                                    // k-th active position pp
-            constexpr int SP = NPOS == 16 ? 10 : 5;                         // item it is transformed during slot SP + it
-            const int pp = pat_pos(PAT, k);
-            const bool tf = !(DREAM_WINO_DIAG & 1);
-            const int li = (k < ITEMS) ? k : -1;                            // item loaded during this slot
-            const int si = (k >= SP && k < SP + ITEMS) ? k - SP : -1;
-            auto load_b = [&]() {
-                if (DREAM_WINO_DIAG & 2) return;
-                const int kn = k + B_AHEAD;                                 // slot the load is for: this chunk's, or the next one's
-                const int s = kn >= NPOS ? (LAST ? 0 : (c + 1) * 16) + pat_pos(PAT, kn - NPOS) : c * 16 + pat_pos(PAT, kn);
-                bq[kn % RING] = buffer_load_x4(ubuf, b_lane, (unsigned)s * u_pos_stride);
-            };
-            auto load_one = [&](int col) {
-                d[li][col] = buffer_load_x4(LAST ? xnext : xbuf, goff[li][col], (DREAM_WINO_DIAG & 16) ? 0u : coff);
-            };
-            auto pair = [&](int r) {
-                if (FIRST && r == 0) {
-                    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-                    acc[pp][0] = mfma_f32_16x16x4(a[k & 1][0][r], bq[k % RING][r], zero);
-                    acc[pp][1] = mfma_f32_16x16x4(a[k & 1][1][r], bq[k % RING][r], zero);
-                } else {
-                    acc[pp][0] = mfma_f32_16x16x4(a[k & 1][0][r], bq[k % RING][r], acc[pp][0]);
-                    acc[pp][1] = mfma_f32_16x16x4(a[k & 1][1][r], bq[k % RING][r], acc[pp][1]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            };
-            // Two instruction orders, chosen by measurement (profiles/r02_wino_diag.txt; DIAG bit 6 swaps them): the 4-wave
-            // kernel (two items per thread, two workgroups per CU) is ~3 % faster with its loads ahead of the position's first
-            // MFMAs and the transform in one piece, the 8-wave kernel ~2 % faster the other way round.
-            if ((NW == 4) != ((DREAM_WINO_DIAG & 64) != 0)) {
-                load_b();
-                if (tf && li >= 0) {
-                    if (LAST) goff[li] = plan_item(li, tile0n, b0n);
-                    else goff[li] = sG[li * NT + tid];
-                    load_one(0);
-                }
-                pair(0);
-                if (k + 1 < NPOS) read_a((k + 1) & 1, pat_pos(PAT, k + 1), cur);
-                if (tf && li >= 0) load_one(1);
-                pair(1);
-                if (tf && li >= 0) load_one(2);
-                if (tf && si >= 0) item_store(si, nxt);
-                pair(2);
-                if (tf && li >= 0) load_one(3);
-                pair(3);
-            } else {
-                // every position STARTS with MFMAs (operands were read during the previous position); everything else --
-                // the weight load, the operand reads of the next position, one patch load or one transform piece -- follows
-                // a pair, never more than one memory instruction and ~8 VALU instructions between two pairs
-                pair(0);
-                load_b();
-                if (k + 1 < NPOS) read_a((k + 1) & 1, pat_pos(PAT, k + 1), cur);
-                if (tf && li >= 0) {
-                    if (LAST) goff[li] = plan_item(li, tile0n, b0n);
-                    else goff[li] = sG[li * NT + tid];                      // written by this thread: no barrier
-                    load_one(0);
-                }
-                if (tf && si >= 0) item_piece(si, 0, nxt);
-                pair(1);
-                if (tf && li >= 0) load_one(1);
-                if (tf && si >= 0) item_piece(si, 1, nxt);
-                pair(2);
-                if (tf && li >= 0) load_one(2);
-                if (tf && si >= 0) item_piece(si, 2, nxt);
-                pair(3);
-                if (tf && li >= 0) load_one(3);
-                if (tf && si >= 0) item_piece(si, 3, nxt);
-                if (k == NPOS - 1) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (!(DREAM_WINO_DIAG & 4)) __syncthreads();
-        par ^= 1;
-    };
-    const std::true_type yes{};
-    const std::false_type no{};
-
-    // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ----------------
-    // Output addresses are 32-bit byte offsets from the first image of the block, BUFFER_OOB for everything that must not be
-    // written (tile beyond the batch, channel beyond Cout, odd-extent overhang): masked stores without branches.
-    const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
-    constexpr bool pool = MODE == 1, has_res = MODE >= 2, mask = MODE == 3;
-    const bool late = MODE == 2 && (p.flags & DREAM_CONV_RES_AFTER_RELU) != 0;      // the residual is a skip connection: added after the ReLU
-    const int col = n0 + wave * 16 + lt;
-    const bool cok = col < p.Cout;
-    const float sc = (p.scale != nullptr && cok) ? p.scale[col] : 1.0f;
-    const float sh = (p.shift != nullptr && cok) ? p.shift[col] : 0.0f;
-    const int Ho = pool ? p.H / 2 : p.H, Wo = pool ? p.W / 2 : p.W;           // grid of conv positions that are stored
-    const int S = pool ? 1 : p.out_scale;                                     // conv position -> output pixel (see WinoParams)
-    const int Wy = S * Wo;
-    const size_t out_img = (size_t)(S * Ho) * Wy * p.Cout;
-    const unsigned px_b = (unsigned)(S * p.Cout * 4), row_b = (unsigned)(S * Wy * p.Cout * 4);
-    const unsigned phase_b = pool ? 0u : (unsigned)((p.out_oy * Wy + p.out_ox) * p.Cout * 4);
-    auto epilogue = [&](int tile0e, int b0e) {
-        const BufferRsrc ybuf = make_buffer(p.y + (size_t)b0e * out_img, (size_t)(p.B - b0e) * out_img * sizeof(float));
-        const BufferRsrc rbuf = make_buffer(has_res ? p.residual + (size_t)b0e * out_img : p.y,
-                                            has_res ? (size_t)(p.B - b0e) * out_img * sizeof(float) : 0);
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk) {
-            // the lane's four tiles of this block are consecutive: decompose the first, step the others
-            const int tau0 = tile0e + blk * 16 + lg * 4;                // C/D layout: row = 4 (l >> 4) + reg, col = l & 15
-            int b = div_magic40(tau0, p.magic_tpi);
-            const int rem = tau0 - b * tiles_per_img;
-            int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
-            // per tile: the byte offsets of its 2x2 outputs (or of its pooled output), BUFFER_OOB where nothing may be written
-            auto tile_offsets = [&](int r, unsigned *o) {
-                // pooled output (floor(H/2) x floor(W/2)): the window of a tile with ty < Ho, tx < Wo lies entirely inside the image
-                const bool tok = cok & ((tau0 + r) < p.ntiles) & (!pool | ((ty < Ho) & (tx < Wo)));
-                const int oy = pool ? ty : 2 * ty, ox = pool ? tx : 2 * tx;
-                const unsigned base = (unsigned)(((((b - b0e) * (S * Ho) + S * oy) * Wy + S * ox) * p.Cout + col) * 4) + phase_b;
-                if (pool) {
-                    o[0] = tok ? base : BUFFER_OOB;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < 2; ++jj) {
-                            const bool inb = tok & ((oy + i) < Ho) & ((ox + jj) < Wo);
-                            o[2 * i + jj] = inb ? base + i * row_b + jj * px_b : BUFFER_OOB;
-                        }
-                }
-                const bool wrap_x = (tx + 1 == p.TX);                   // step to the next tile
-                const bool wrap_y = wrap_x & (ty + 1 == p.TY);
-                tx = wrap_x ? 0 : tx + 1;
-                ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
-                b += wrap_y ? 1 : 0;
-            };
-            unsigned off[4][4];                                         // [tile][2 i + jj]
-            float rv[4][4];
-            if (has_res) {                                              // all 16 mask / residual loads of the block in flight
-#pragma unroll                                                          // before the first inverse transform
-                for (int r = 0; r < 4; ++r) {
-                    tile_offsets(r, off[r]);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) rv[r][e] = buffer_load_f32(rbuf, off[r][e], 0);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (!has_res) tile_offsets(r, off[r]);
-                // positions without weights (PAT) were never multiplied: they are zeros of the sums
-                auto M = [&](int pp) { return pat_active(PAT, pp) ? acc[pp][blk][r] : 0.0f; };
-                float s[2][4];                                          // A^T M : rows [1,1,1,0], [0,1,-1,-1]
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    s[0][j] = M(j) + M(4 + j) + M(8 + j);
-                    s[1][j] = M(4 + j) - M(8 + j) - M(12 + j);
-                }
-                float out[2][2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    out[i][0] = s[i][0] + s[i][1] + s[i][2];
-                    out[i][1] = s[i][1] - s[i][2] - s[i][3];
-                }
-                float best = -__builtin_huge_valf();
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        float v = out[i][jj] * sc + sh;                 // sc = 1 / sh = 0 when absent (exact)
-                        if (has_res) v = mask ? (rv[r][2 * i + jj] > 0.0f ? v : 0.0f) : (late ? v : v + rv[r][2 * i + jj]);
-                        const float vr = fmaxf(v, 0.0f);
-                        v = relu ? vr : v;
-                        if (MODE == 2) v = late ? v + rv[r][2 * i + jj] : v;
-                        if (pool) best = fmaxf(best, v);
-                        else buffer_store_f32(ybuf, v, off[r][2 * i + jj], 0);
-                    }
-                if (pool) buffer_store_f32(ybuf, best, off[r][0], 0);
-            }
-        }
-    };
-
-    // ---- the blocks of this workgroup -----------------------------------------------------------------------------------
-    // Written out twice (first block, then the loop): at a control-flow join hipcc takes the more pessimistic of the incoming
-    // s_waitcnt states, and the state after the prologue (a handful of loads in flight) differs from the one after an
-    // epilogue (its stores still in flight); joined, every block would start by waiting for the previous block's stores.
-    auto block = [&]() {
-        const int tile0n = block_tile0(tb + J);
-        const int b0n = div_magic40(tile0n, p.magic_tpi);
-        const BufferRsrc xnext = block_xbuf(b0n);
-        chunk(yes, no, 0, xnext, tile0n, b0n);                     // nchunks >= 2 (host side)
-        for (int c = 1; c < nchunks - 1; ++c) chunk(no, no, c, xnext, tile0n, b0n);
-        chunk(no, yes, nchunks - 1, xnext, tile0n, b0n);
-        epilogue(tile0, b0);
-        tb += J;
-        tile0 = tile0n;
-        b0 = b0n;
-        xbuf = xnext;
-    };
-    block();
-    while (tb < blk_end) block();
+    if ((wave & 3) != 0) return;                       // one wavefront per 64-channel column block carries on
+    const int cb = (n0 >> 6) + (wave >> 2);
+    if (cb * 64 >= p.Cout) return;
+    double t0, t1;
+    if (!stat_tree_arrive(q.st, cb, row, lane, &t0, &t1)) return;
+    const int c = cb * 64 + lane;
+    if (STAT == 1) {
+        bn_finish_forward(q.fwd, c, p.Cout, q.count, t0, t1);
+    } else if (c < p.Cout) {
+        q.dbeta[c] = (float)t0;
+        q.dgamma[c] = (float)t1;
+    }
 }
+
+#define WINO_STAT 0
+#include "conv_wino_body.inc"
+#undef WINO_STAT
+#define WINO_STAT 1
+#include "conv_wino_body.inc"
+#undef WINO_STAT
 
 // OIHW (mode 0) or, for the data-gradient operator, IOHW with flipped taps (mode 1: rows = Cin_fwd, cols = Cout_fwd)
 // -> U = G g G^T in fp64, rounded once to fp32, laid out [cols/16][16 positions][RowsPad][16]: pack_device.h (dream_pack::winograd2)
@@ -471,25 +180,47 @@ __global__ void __launch_bounds__(256) wino_pack_kernel(const float *w, float *u
 constexpr int kCUs = 256;     // MI355X
 int g_max_workgroups = 0;     // test hook: cap on resident workgroups (0 = the chip's capacity)
 
+// persistent grid: as many workgroups as the 256 CUs hold at once (2 of the 4-wave, 1 of the 8-wave kind per CU), a
+// multiple of 8 (XCDs), split over the output-channel blocks; fewer when there are fewer tile blocks than that
+int wino_grid_x(int nw, int Cout, int nblk) {
+    const int ny = (Cout + 16 * nw - 1) / (16 * nw);
+    int resident = g_max_workgroups > 0 ? g_max_workgroups : kCUs * (nw == 4 ? 2 : 1);
+    int gx = resident / ny / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > (nblk + 7) / 8 * 8) gx = (nblk + 7) / 8 * 8;
+    return gx;
+}
+
 template <int NW, int MODE, int PAT = 0>
 int launch_wino(const WinoParams &p, void *stream) {
     void (*kernel)(const WinoParams) = conv_wino_kernel<NW, MODE, PAT>;
     const size_t lds = (size_t)2 * VB * sizeof(float) + (size_t)512 * 16;          // V buffers + the offset table
     if (dream_allow_full_lds((const void *)kernel)) return 2;
-    // persistent grid: as many workgroups as the 256 CUs hold at once (2 of the 4-wave, 1 of the 8-wave kind per CU), a
-    // multiple of 8 (XCDs), split over the output-channel blocks; fewer when there are fewer tile blocks than that
     const int ny = (p.Cout + 16 * NW - 1) / (16 * NW);
-    int resident = g_max_workgroups > 0 ? g_max_workgroups : kCUs * (NW == 4 ? 2 : 1);
-    int gx = resident / ny / 8 * 8;
-    if (gx < 8) gx = 8;
-    if (gx > (p.nblk + 7) / 8 * 8) gx = (p.nblk + 7) / 8 * 8;
+    const int gx = wino_grid_x(NW, p.Cout, p.nblk);
     const dim3 grid((unsigned)gx, (unsigned)ny);
     hipLaunchKernelGGL(kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }
+template <int NW, int MODE, int STAT>
+int launch_wino_stat(const WinoParams &p, const WinoStat &q, void *stream) {
+    void (*kernel)(const WinoParams, const WinoStat) = conv_wino_stat_kernel<NW, MODE, STAT>;
+    const size_t lds = (size_t)2 * VB * sizeof(float) + (size_t)512 * 16;
+    if (dream_allow_full_lds((const void *)kernel)) return 2;
+    const int ny = (p.Cout + 16 * NW - 1) / (16 * NW);
+    const dim3 grid((unsigned)wino_grid_x(NW, p.Cout, p.nblk), (unsigned)ny);
+    hipLaunchKernelGGL(kernel, grid, dim3(64 * NW), lds, (hipStream_t)stream, p, q);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
 
 int g_variant = 0;
+int wino_nw(int Cout) { return g_variant ? g_variant : (Cout > 64 ? 8 : 4); }
+int wino_stat_rows(int B, int H, int W, int Cout) {       // = the persistent grid's x extent: one producer row per workgroup (STAT)
+    const long ntiles = (long)B * ((H + 1) / 2) * ((W + 1) / 2);
+    return wino_grid_x(wino_nw(Cout), Cout, (int)((ntiles + WT - 1) / WT));
+}
 
 }  // namespace
 
@@ -607,7 +338,7 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
     DREAM_REQUIRE(!(flags & DREAM_CONV_RELUMASK) || residual != nullptr, "winograd conv: ReLU mask without a mask tensor");
     WinoParams p;
     if (int rc = wino_setup(p, x, u_packed, scale, shift, residual, y, B, H, W, Cin, Cout, flags, 1)) return rc;
-    const int nw = g_variant ? g_variant : (Cout > 64 ? 8 : 4);
+    const int nw = wino_nw(Cout);
     const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
     switch (mode + (nw == 8 ? 4 : 0)) {
         case 0: return launch_wino<4, 0>(p, stream);
@@ -619,6 +350,62 @@ extern "C" int dream_conv3x3_winograd_nhwc_f32(const float *x, const float *u_pa
         case 6: return launch_wino<8, 2>(p, stream);
         default: return launch_wino<8, 3>(p, stream);
     }
+}
+
+// ---- train-mode BatchNorm folded into the 3x3 conv's launches (the ResNet-101 Bottlenecks' conv2; the 1x1 form: gemm1x1.hip) ----
+// bytes of the partial-sum workspace / zero words of counters of the two entry points below (the counters are left zero).
+// NOTE: they depend on dream_conv3x3_winograd_set_variant / _set_max_workgroups (test hooks): query after setting those.
+extern "C" size_t dream_conv3x3_winograd_bn_workspace(int B, int H, int W, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 64 != 0) return 0;
+    return stat_tree_doubles(wino_stat_rows(B, H, W, Cout), Cout) * sizeof(double);
+}
+extern "C" int dream_conv3x3_winograd_bn_counters(int B, int H, int W, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout % 64 != 0) return 0;
+    return stat_tree_counters(wino_stat_rows(B, H, W, Cout), Cout);
+}
+
+// y = conv3x3(x, pad 1) + shift, and the batch statistics of y for the BatchNorm that follows, finished inside the launch (the
+// last workgroup to arrive per 64-channel block sums the workgroups' fp64 rows in a fixed order): save_mean / save_invstd,
+// out_ab[0] = gamma * invstd, out_ab[1] = beta - mean * out_ab[0], running statistics as nn.BatchNorm2d updates them.
+// Replaces conv2 -> bn2 (statistics pass) of torchvision's Bottleneck behind /root/reference/dream/models.py:22-32 in training.
+extern "C" int dream_conv3x3_winograd_bnstats_nhwc_f32(const float *x, const float *u_packed, const float *shift, float *y, int B, int H,
+                                                       int W, int Cin, int Cout, const float *gamma, const float *beta,
+                                                       float *running_mean, float *running_var, long long *num_batches_tracked,
+                                                       float eps, float momentum, float *out_ab, float *save_mean, float *save_invstd,
+                                                       void *workspace, unsigned *counters, void *stream) {
+    DREAM_REQUIRE(gamma && beta && out_ab && save_mean && save_invstd && workspace && counters, "winograd conv + BatchNorm statistics: null pointer");
+    DREAM_REQUIRE(Cout % 64 == 0, "winograd conv + BatchNorm statistics: %d output channels, must be a multiple of 64", Cout);
+    WinoParams p = {};
+    if (int rc = wino_setup(p, x, u_packed, nullptr, shift, nullptr, y, B, H, W, Cin, Cout, 0, 1)) return rc;
+    const int nw = wino_nw(Cout);
+    WinoStat q = {};
+    q.st = stat_tree_make(workspace, counters, wino_grid_x(nw, Cout, p.nblk), Cout);
+    q.row0 = 0;
+    q.count = (double)B * H * W;
+    q.fwd.gamma = gamma; q.fwd.beta = beta; q.fwd.running_mean = running_mean; q.fwd.running_var = running_var;
+    q.fwd.nbt = num_batches_tracked; q.fwd.eps = eps; q.fwd.momentum = momentum;
+    q.fwd.ab = out_ab; q.fwd.mean = save_mean; q.fwd.invstd = save_invstd;
+    return nw == 8 ? launch_wino_stat<8, 0, 1>(p, q, stream) : launch_wino_stat<4, 0, 1>(p, q, stream);
+}
+
+// Data gradient of a 3x3 conv whose INPUT was relu(BatchNorm(z)), with that BatchNorm's backward reductions in the epilogue:
+// g = conv3x3(dy; mode-1 weights) * [ab[0] z + ab[1] > 0] -> g_out, and -- finished inside the launch -- dbeta = sum g,
+// dgamma = sum g * (z - mean) * invstd.  dy [B,H,W,Cin], z / g_out [B,H,W,Cout] (Cout = the forward conv's input channels).
+extern "C" int dream_conv3x3_winograd_bwd_bnmask_nhwc_f32(const float *dy, const float *u_packed_t, const float *z, float *g_out, int B,
+                                                          int H, int W, int Cin, int Cout, const float *ab, const float *mean,
+                                                          const float *invstd, float *dgamma, float *dbeta, void *workspace,
+                                                          unsigned *counters, void *stream) {
+    DREAM_REQUIRE(z && ab && mean && invstd && dgamma && dbeta && workspace && counters, "winograd data gradient + BatchNorm mask: null pointer");
+    DREAM_REQUIRE(Cout % 64 == 0, "winograd data gradient + BatchNorm mask: %d channels, must be a multiple of 64", Cout);
+    WinoParams p = {};
+    if (int rc = wino_setup(p, dy, u_packed_t, nullptr, nullptr, z, g_out, B, H, W, Cin, Cout, DREAM_CONV_RELUMASK, 1)) return rc;
+    const int nw = wino_nw(Cout);
+    WinoStat q = {};
+    q.st = stat_tree_make(workspace, counters, wino_grid_x(nw, Cout, p.nblk), Cout);
+    q.row0 = 0;
+    q.count = (double)B * H * W;
+    q.zab = ab; q.mean = mean; q.invstd = invstd; q.dgamma = dgamma; q.dbeta = dbeta;
+    return nw == 8 ? launch_wino_stat<8, 3, 2>(p, q, stream) : launch_wino_stat<4, 3, 2>(p, q, stream);
 }
 
 // nn.ConvTranspose2d(k4, s2, p1) (+ folded BatchNorm / bias, ReLU) of the ResNet decoder (dream/models.py:37-136) by minimal

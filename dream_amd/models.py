@@ -872,6 +872,9 @@ class ResnetSimple(nn.Module):
         # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "96"))
+        # opt-in until measured on the GPU (round 4, last hours): the 3x3 convs' BatchNorm statistics / masked backward reductions in
+        # the Winograd F(2x2) kernel's epilogue (csrc/conv_wino.hip WINO_STAT) -- 66 launches fewer per ResNet-101 step
+        self.bn_fusion_3x3 = os.environ.get("DREAM_BN_FUSION_3X3", "0") == "1"
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
@@ -1318,15 +1321,21 @@ class ResnetSimple(nn.Module):
                 x, packed, rows, bn, self._ctr(x.device), pre_ab=None if pre is None else pre["ab"], shift=bias)
         else:
             assert pre is None
+            z = None
             if self._wino_train(conv):
                 tile = ops.winograd_tile(int(x.shape[1]), int(x.shape[2]), int(conv.weight.shape[1]), cout, int(x.shape[0]))
                 u, rows = self._cached(("wino", name, tile), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 0, tile))
-                z = ops.conv3x3_winograd_tile(tile, x, u, rows, None, bias, None, 0)
+                if self.bn_fusion_3x3 and tile == 2 and cout % 64 == 0:
+                    # the statistics ride in the F(2x2) kernel's epilogue: no separate pass over z
+                    rec["z"], rec["ab"], rec["mean"], rec["invstd"] = ops.conv3x3_winograd_bn(x, u, rows, bn, self._ctr(x.device), shift=bias)
+                else:
+                    z = ops.conv3x3_winograd_tile(tile, x, u, rows, None, bias, None, 0)
             else:
                 packed, rows, _ = self._packed_w(name, conv, 0)
                 z = ops.conv2d(x, packed, rows, k, stride, None, bias, None, 0)
-            rec["z"] = z
-            rec["ab"], rec["mean"], rec["invstd"] = ops.bn_stats(z, bn, self._ctr(x.device))
+            if z is not None:
+                rec["z"] = z
+                rec["ab"], rec["mean"], rec["invstd"] = ops.bn_stats(z, bn, self._ctr(x.device))
         tape.append(rec)
         if not materialize:
             return rec
@@ -1484,7 +1493,18 @@ class ResnetSimple(nn.Module):
                                                             self._ctr(dz.device))
                     g = ("masked", gmask, dg2, db2)
                 else:
-                    g = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
+                    prod = tape[idx - 1]
+                    if (self.bn_fusion_3x3 and self._wino_train(conv) and cin % 64 == 0 and int(dz.shape[3]) == cout
+                            and prod["kind"] == "conv" and prod["y"] is rec["x"] and prod["relu"] and not prod["has_res"]
+                            and ops.winograd_tile(int(dz.shape[1]), int(dz.shape[2]), cout, cin, int(dz.shape[0])) == 2):
+                        # data gradient + the ReLU mask and the two reductions of the producer's BatchNorm in ONE launch of the
+                        # F(2x2) kernel (the mask is recomputed from the producer's (z, ab) exactly as its apply pass evaluated it)
+                        u_t, _ = self._cached(("wino1", name, 2), [conv.weight], lambda: ops.pack_weight_winograd_tile(conv.weight.detach(), 1, 2))
+                        gmask, dg1, db1 = ops.conv3x3_winograd_bwd_bnmask(dz, u_t, cin, prod["z"], prod["ab"], prod["mean"], prod["invstd"],
+                                                                         self._ctr(dz.device))
+                        g = ("masked", gmask, dg1, db1)
+                    else:
+                        g = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
             elif kind == "block_begin":
                 name1, conv1, dz, cin, k, stride, in_hw = block["dz1"]
                 other = block["g_ds"] if rec["ds"] else block["g_idt"]

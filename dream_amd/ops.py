@@ -915,6 +915,40 @@ def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counter
     return g, dgamma, dbeta
 
 
+def conv3x3_winograd_bn(x_nhwc, packed_u, cout, bn, counters, shift=None):
+    """Stride-1 3x3 conv on the Winograd F(2x2,3x3) kernel -> (z, ab, save_mean, save_invstd) with the batch statistics of z summed
+    in the kernel's epilogue and finished inside the launch (cout a multiple of 64); updates bn's running statistics."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    lib = _hip.lib()
+    z = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    ab, mean, invstd = _bn_outputs(cout, x.device)
+    ws = _workspace(lib.dream_conv3x3_winograd_bn_workspace(b, h, w, cout), x.device)
+    ctr = _ctr_words(counters, lib.dream_conv3x3_winograd_bn_counters(b, h, w, cout))
+    call("dream_conv3x3_winograd_bnstats_nhwc_f32", ptr(x), ptr(packed_u), ptr(shift), ptr(z), b, h, w, cin, cout, *_bn_args(bn),
+         ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(ctr), stream())
+    _bn_bump(bn)
+    return z, ab, mean, invstd
+
+
+def conv3x3_winograd_bwd_bnmask(dy_nhwc, packed_u_t, cin, z_nhwc, ab, mean, invstd, counters):
+    """Data gradient of a stride-1 3x3 conv whose input was relu(BN(z)): -> (g = conv3x3(dy; mode-1 weights) masked by
+    [ab[0] z + ab[1] > 0], dgamma, dbeta of that BN), one launch of the Winograd F(2x2,3x3) kernel (cin a multiple of 64)."""
+    dy = _f32(dy_nhwc)
+    b, h, w, k = (int(v) for v in dy.shape)
+    if tuple(z_nhwc.shape) != (b, h, w, cin):
+        raise RuntimeError("conv3x3_winograd_bwd_bnmask: z shape %s != %s" % (tuple(z_nhwc.shape), (b, h, w, cin)))
+    lib = _hip.lib()
+    g = torch.empty((b, h, w, cin), dtype=torch.float32, device=dy.device)
+    dgamma = torch.empty((cin,), dtype=torch.float32, device=dy.device)
+    dbeta = torch.empty_like(dgamma)
+    ws = _workspace(lib.dream_conv3x3_winograd_bn_workspace(b, h, w, cin), dy.device)
+    ctr = _ctr_words(counters, lib.dream_conv3x3_winograd_bn_counters(b, h, w, cin))
+    call("dream_conv3x3_winograd_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_u_t), ptr(_f32(z_nhwc)), ptr(g), b, h, w, k, cin, ptr(ab),
+         ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(ctr), stream())
+    return g, dgamma, dbeta
+
+
 def channel_sum(x_nhwc):
     x = _f32(x_nhwc)
     c = int(x.shape[-1])

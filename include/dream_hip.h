@@ -448,6 +448,21 @@ int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w_packed_t, 
                                       int N, int dy_stride, const float *z, const float *ab, const float *y_act, const float *mean,
                                       const float *invstd, float *dgamma, float *dbeta, void *workspace, unsigned *counters,
                                       void *stream);
+/* The same two foldings for the stride-1 3x3 convs on the Winograd F(2x2,3x3) kernel (conv2 of torchvision's Bottleneck behind
+ * dream/models.py:22-32): the batch statistics of y = conv3x3(x) + shift summed in the kernel's epilogue, and the data gradient
+ * g_out = conv3x3(dy; mode-1 weights) * [ab[0] z + ab[1] > 0] with dbeta / dgamma of the masked BatchNorm -- one persistent
+ * workgroup = one fp64 partial row, finished in the launch by the ticket tree.  Cout % 64 == 0.  Workspace / counters depend on the
+ * kernel's grid: query AFTER dream_conv3x3_winograd_set_variant / _set_max_workgroups. */
+size_t dream_conv3x3_winograd_bn_workspace(int B, int H, int W, int Cout);
+int dream_conv3x3_winograd_bn_counters(int B, int H, int W, int Cout);
+int dream_conv3x3_winograd_bnstats_nhwc_f32(const float *x, const float *u_packed, const float *shift, float *y, int B, int H, int W,
+                                            int Cin, int Cout, const float *gamma, const float *beta, float *running_mean,
+                                            float *running_var, long long *num_batches_tracked, float eps, float momentum,
+                                            float *out_ab, float *save_mean, float *save_invstd, void *workspace, unsigned *counters,
+                                            void *stream);
+int dream_conv3x3_winograd_bwd_bnmask_nhwc_f32(const float *dy, const float *u_packed_t, const float *z, float *g_out, int B, int H,
+                                               int W, int Cin, int Cout, const float *ab, const float *mean, const float *invstd,
+                                               float *dgamma, float *dbeta, void *workspace, unsigned *counters, void *stream);
 /* weight gradient of a 1x1 conv whose input was relu(pre_ab[0][ci] x + pre_ab[1][ci]) (x = the BN input) */
 int dream_conv1x1_wgrad_pre_nhwc_f32(const float *x, const float *dy, float *dw, void *workspace, long M, int Cin, int Cout,
                                      int Cdy, const float *pre_ab, void *stream);

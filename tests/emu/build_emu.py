@@ -12,7 +12,7 @@ def build(force=False):
     srcs = [os.path.join(HERE, "emu_runtime.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
             os.path.join(HERE, "dream_cdna4.h")]
     csrc = os.path.join(ROOT, "dream_amd", "csrc")
-    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".inc"))]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(s) <= os.path.getmtime(OUT) for s in srcs):
         return OUT
     clang = "/opt/rocm/lib/llvm/bin/clang++"

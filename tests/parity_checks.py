@@ -1091,6 +1091,82 @@ def check_wgrad(dev, B, H, W, Cin, Cout, k=3, stride=1, seed=0):
     assert float((db.cpu() - dy.sum((0, 2, 3))).abs().max()) <= tol(dy.sum((0, 2, 3)).numpy())
 
 
+def check_conv3x3_bn_fused(dev, cases=None):
+    """Train-mode BatchNorm folded into the stride-1 3x3 conv's launches on the Winograd F(2x2,3x3) kernel (csrc/conv_wino.hip
+    WINO_STAT): conv -> statistics of the FOLLOWING BatchNorm in the epilogue; data gradient -> ReLU mask of the PRECEDING BatchNorm
+    recomputed from (z, ab) + its two backward reductions.  Against the unfused launches (same conv bits, same mask) and against
+    torch's conv2d / BatchNorm2d / autograd on CPU; the ticket words are left zero."""
+    def nchw(t):
+        return t.permute(0, 3, 1, 2)
+
+    def make_bn(C):
+        bn = torch.nn.BatchNorm2d(C)
+        bn.weight.data.uniform_(0.5, 1.5)
+        bn.bias.data.normal_(0.0, 0.5)
+        twin = torch.nn.BatchNorm2d(C)
+        twin.load_state_dict(bn.state_dict())
+        return bn, (twin.to(dev) if dev != "cpu" else twin)
+
+    torch.manual_seed(23)
+    # (B, H, W, Cin, Cout): one and two column blocks, the 4- and the 8-wave kernel, odd extents (half tiles), more tile blocks than
+    # workgroups (several blocks per producer row) and fewer (producer rows of zeros)
+    cases = cases or [(2, 9, 11, 64, 64), (1, 13, 13, 64, 128), (3, 6, 5, 128, 256), (2, 25, 25, 64, 128), (1, 4, 4, 64, 64)]
+    for (B, H, W, Cin, Cout) in cases:
+        bn_p, bn_p2 = make_bn(Cin)               # the BatchNorm in front of the conv (bn1 of a Bottleneck)
+        bn_n, bn_n2 = make_bn(Cout)              # the one behind it (bn2)
+        z1 = (torch.randn(B, Cin, H, W) + 0.2).requires_grad_()
+        w = (torch.randn(Cout, Cin, 3, 3) * (2.0 / (9 * Cin)) ** 0.5).requires_grad_()
+        y1 = bn_p(z1).relu()
+        z2_ref = F.conv2d(y1, w, None, padding=1)
+        y2_ref = bn_n(z2_ref).relu()
+        dy2 = torch.randn_like(y2_ref)
+        y2_ref.backward(dy2)
+        ctr = to(dev, torch.zeros(4096, dtype=torch.int32))
+        z1_d = to(dev, _nhwc(z1.detach()))
+        ab1, mean1, invstd1 = ops.bn_stats(z1_d, bn_p2, ctr)
+        y1_d = ops.bn_apply_ab(z1_d, ab1, None, True)
+        u, rows = ops.pack_weight_winograd_tile(to(dev, w.detach()), 0, 2)
+        # ---- forward: conv + statistics in one launch
+        z2, ab2, mean2, invstd2 = ops.conv3x3_winograd_bn(y1_d, u, rows, bn_n2, ctr)
+        z2_plain = ops.conv3x3_winograd(y1_d, u, rows)
+        assert torch.equal(z2, z2_plain), (B, H, W, Cin, Cout)
+        assert float((nchw(z2.cpu()) - z2_ref.detach()).abs().max()) < 2e-5 * float(z2_ref.abs().max())
+        assert float((mean2.cpu() - z2_ref.detach().mean((0, 2, 3))).abs().max()) < 1e-5
+        var_ref = z2_ref.detach().var((0, 2, 3), unbiased=False)
+        assert float((invstd2.cpu() - (var_ref + bn_n.eps).rsqrt()).abs().max()) < 1e-4 * float((var_ref + bn_n.eps).rsqrt().max())
+        assert float((ab2[0].cpu() - bn_n.weight.detach() * invstd2.cpu()).abs().max()) < 1e-6
+        assert float((ab2[1].cpu() - (bn_n.bias.detach() - mean2.cpu() * ab2[0].cpu())).abs().max()) < 1e-6
+        assert float((bn_n.running_mean - bn_n2.running_mean.cpu()).abs().max()) < 1e-6
+        assert float((bn_n.running_var - bn_n2.running_var.cpu()).abs().max()) < 1e-5
+        assert int(bn_n2.num_batches_tracked.item()) == 1
+        # the stand-alone statistics of the same tensor agree to round-off (fp64 rows of different shapes)
+        twin = torch.nn.BatchNorm2d(Cout)
+        twin.load_state_dict(bn_n.state_dict())
+        twin.running_mean.zero_(); twin.running_var.fill_(1.0); twin.num_batches_tracked.zero_()
+        twin = twin.to(dev) if dev != "cpu" else twin
+        ab_s, mean_s, invstd_s = ops.bn_stats(z2, twin, ctr)
+        assert float((mean_s - mean2).abs().max()) < 1e-6 and float((invstd_s / invstd2 - 1).abs().max()) < 1e-5
+        # ---- backward: data gradient of the conv + mask and reductions of bn_p in one launch
+        y2 = ops.bn_apply_ab(z2, ab2, None, True)
+        dy2_d = to(dev, _nhwc(dy2))
+        dgam2, dbet2 = ops.bn_bwd_stats(z2, dy2_d, mean2, invstd2, ctr, y_act=y2)
+        dz2, _ = ops.bn_bwd_apply(z2, dy2_d, bn_n2.weight, mean2, invstd2, dgam2, dbet2, y_act=y2)
+        u_t, rows_t = ops.pack_weight_winograd_tile(to(dev, w.detach()), 1, 2)
+        g, dgam1, dbet1 = ops.conv3x3_winograd_bwd_bnmask(dz2, u_t, Cin, z1_d, ab1, mean1, invstd1, ctr)
+        g_raw = ops.conv3x3_winograd(dz2, u_t, rows_t)
+        dgam_u, dbet_u = ops.bn_bwd_stats(z1_d, g_raw, mean1, invstd1, ctr, ab=ab1)
+        dz1_u, g_u = ops.bn_bwd_apply(z1_d, g_raw, bn_p2.weight, mean1, invstd1, dgam_u, dbet_u, ab=ab1, want_g=True)
+        assert torch.equal(g, g_u), (B, H, W, Cin, Cout)                      # same conv bits, same recomputed mask
+        scale = max(float(dgam_u.abs().max()), float(dbet_u.abs().max()), 1e-3)
+        assert float((dgam1 - dgam_u).abs().max()) < 1e-5 * scale and float((dbet1 - dbet_u).abs().max()) < 1e-5 * scale
+        dz1, _ = ops.bn_bwd_apply(z1_d, g, bn_p2.weight, mean1, invstd1, dgam1, dbet1)     # g is masked already: no mask source
+        assert float((nchw(dz1.cpu()) - z1.grad).abs().max()) < 2e-5 * max(1.0, float(z1.grad.abs().max()))
+        assert float((dgam1.cpu() - bn_p.weight.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.weight.grad.abs().max()))
+        assert float((dbet1.cpu() - bn_p.bias.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.bias.grad.abs().max()))
+        assert int(ctr.cpu().abs().sum()) == 0       # every launch leaves its ticket words zero
+    return True
+
+
 def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
     """Round 4: train-mode BatchNorm without its separate passes (csrc/bn.hip "round 4", csrc/gemm1x1.hip PRE / EPI) against
     torch's BatchNorm2d / conv2d / autograd on CPU: statistics finished inside the launch (stand-alone and in the GEMM epilogue),

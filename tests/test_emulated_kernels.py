@@ -212,6 +212,33 @@ def test_bn_fused_ops(emu):
     pc.check_bn_fused_ops("cpu")
 
 
+def test_conv3x3_bn_fused_ops(emu):
+    """The 3x3 convs' BatchNorm in the Winograd F(2x2) kernel's epilogue (csrc/conv_wino.hip WINO_STAT): forward statistics, backward
+    mask + reductions; one-level trees under the suite's grid cap, then the chip's grid (24 producer rows: both levels of the tree,
+    idle workgroups arriving with rows of zeros)."""
+    pc.check_conv3x3_bn_fused("cpu")
+    emu.dream_conv3x3_winograd_set_max_workgroups(0)
+    try:
+        pc.check_conv3x3_bn_fused("cpu", cases=[(4, 25, 25, 64, 64), (1, 7, 9, 64, 128)])
+    finally:
+        emu.dream_conv3x3_winograd_set_max_workgroups(16)
+
+
+def test_resnet_h_train_step_bn_in_the_3x3_kernels(emu, monkeypatch):
+    """DREAM_BN_FUSION_3X3=1 (opt-in): conv2's statistics and bn1's backward reductions ride in the Winograd kernel -- the step still
+    meets the reference goldens, and the launches it removes are really gone."""
+    monkeypatch.setenv("DREAM_BN_FUSION_3X3", "1")
+    seen = []
+    real_stats, real_fwd, real_bwd = ops.bn_stats, ops.conv3x3_winograd_bn, ops.conv3x3_winograd_bwd_bnmask
+    monkeypatch.setattr(ops, "bn_stats", lambda *a, **k: (seen.append("bn_stats"), real_stats(*a, **k))[1])
+    monkeypatch.setattr(ops, "conv3x3_winograd_bn", lambda *a, **k: (seen.append("fwd"), real_fwd(*a, **k))[1])
+    monkeypatch.setattr(ops, "conv3x3_winograd_bwd_bnmask", lambda *a, **k: (seen.append("bwd"), real_bwd(*a, **k))[1])
+    pc.check_resnet_train_step("cpu", "resnet_h", (2, 64, 64))
+    # ResNet-101: 33 Bottlenecks; the three stride-2 conv2's (layers 2-4, first block) are not Winograd convs
+    assert seen.count("fwd") >= 30 and seen.count("bwd") >= 30, (seen.count("fwd"), seen.count("bwd"))
+    assert seen.count("bn_stats") <= 12, seen.count("bn_stats")
+
+
 def test_resnet_h_train_step_three_launch_batchnorm(emu, monkeypatch):
     """The round-1..3 BatchNorm kernels (DREAM_BN_FUSION=0) stay selectable and correct."""
     monkeypatch.setenv("DREAM_BN_FUSION", "0")

@@ -945,6 +945,34 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch):
         assert torch.equal(m, ref[0]) and torch.equal(k, ref[1])
 
 
+def test_conv3x3_bn_fused_ops():
+    """The 3x3 convs' train-mode BatchNorm inside the Winograd F(2x2) kernel's launches (csrc/conv_wino.hip WINO_STAT), small shapes
+    and the two benchmark shapes of ResNet-101 at 16 frames (256 producer rows: both levels of the ticket tree; 64 channels: the
+    4-wave kernel), against the unfused launches bit for bit where the arithmetic is the same and against torch on CPU."""
+    pc.check_conv3x3_bn_fused(DEV)
+    pc.check_conv3x3_bn_fused(DEV, cases=[(16, 25, 25, 256, 256), (8, 100, 100, 64, 64)])
+
+
+def test_resnet_training_with_batchnorm_in_the_3x3_kernels(monkeypatch):
+    """DREAM_BN_FUSION_3X3=1 (opt-in): the reference goldens hold, and two runs give the same bits (fixed summation order)."""
+    monkeypatch.setenv("DREAM_BN_FUSION_3X3", "1")
+    pc.check_resnet_train_step(DEV, "resnet_h", (2, 64, 64))
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(4, 64, 96, seed=51)).to(DEV)
+    runs = []
+    for _ in range(2):
+        net = _dp_network("resnet_h", [0], optimizer="sgd", lr=0.0, in_res=(96, 64), weights=wts)
+        net.enable_training()
+        assert net.model.module.bn_fusion_3x3
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=(96, 64), seed=51)).to(DEV)
+        loss = net.train([x], t).item()
+        runs.append((loss, [p.grad.clone() for p in net.model.parameters()]))
+    assert runs[0][0] == runs[1][0]
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("arch,res", [("resnet_h", (64, 64)), ("vgg_q", (64, 48))])
 def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
     """DreamNetwork.hip_graph on a training network with ONE device: from the second step of a batch shape train() is two
