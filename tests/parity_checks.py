@@ -1160,7 +1160,10 @@ def check_conv3x3_bn_fused(dev, cases=None):
         scale = max(float(dgam_u.abs().max()), float(dbet_u.abs().max()), 1e-3)
         assert float((dgam1 - dgam_u).abs().max()) < 1e-5 * scale and float((dbet1 - dbet_u).abs().max()) < 1e-5 * scale
         dz1, _ = ops.bn_bwd_apply(z1_d, g, bn_p2.weight, mean1, invstd1, dgam1, dbet1)     # g is masked already: no mask source
-        assert float((nchw(dz1.cpu()) - z1.grad).abs().max()) < 2e-5 * max(1.0, float(z1.grad.abs().max()))
+        # against autograd through torch's own conv / BatchNorm: two Winograd convs and two BatchNorm backward passes of round-off
+        # (a wrong mask or sum is an O(1) error)
+        err = float((nchw(dz1.cpu()) - z1.grad).abs().max()) / max(1.0, float(z1.grad.abs().max()))
+        assert err < 2e-4, ((B, H, W, Cin, Cout), err)
         assert float((dgam1.cpu() - bn_p.weight.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.weight.grad.abs().max()))
         assert float((dbet1.cpu() - bn_p.bias.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.bias.grad.abs().max()))
         assert int(ctr.cpu().abs().sum()) == 0       # every launch leaves its ticket words zero
