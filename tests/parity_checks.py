@@ -1161,11 +1161,17 @@ def check_conv3x3_bn_fused(dev, cases=None):
         assert float((dgam1 - dgam_u).abs().max()) < 1e-5 * scale and float((dbet1 - dbet_u).abs().max()) < 1e-5 * scale
         dz1, _ = ops.bn_bwd_apply(z1_d, g, bn_p2.weight, mean1, invstd1, dgam1, dbet1)     # g is masked already: no mask source
         # against autograd through torch's own conv / BatchNorm: two Winograd convs and two BatchNorm backward passes of round-off
-        # (a wrong mask or sum is an O(1) error)
-        err = float((nchw(dz1.cpu()) - z1.grad).abs().max()) / max(1.0, float(z1.grad.abs().max()))
-        assert err < 2e-4, ((B, H, W, Cin, Cout), err)
-        assert float((dgam1.cpu() - bn_p.weight.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.weight.grad.abs().max()))
-        assert float((dbet1.cpu() - bn_p.bias.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.bias.grad.abs().max()))
+        # (a wrong mask or sum is an O(1) error).  The mask sits on a*z + b > 0 evaluated in two arithmetics: among millions of
+        # elements one may land within round-off of zero and flip (measured on the GPU: one element of 5.1 M, an error of 1.7e-2 of
+        # the maximum there and an O(1) term in dbeta) -- so on large tensors the bound is on all but a 1e-5 fraction of the
+        # elements, and the sums are held to the unfused launches above (same mask) instead of to torch.
+        rel = (nchw(dz1.cpu()) - z1.grad).abs() / max(1.0, float(z1.grad.abs().max()))
+        if B * H * W <= 20000:
+            assert float(rel.max()) < 2e-4, ((B, H, W, Cin, Cout), float(rel.max()))
+            assert float((dgam1.cpu() - bn_p.weight.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.weight.grad.abs().max()))
+            assert float((dbet1.cpu() - bn_p.bias.grad).abs().max()) < 1e-4 * max(1.0, float(bn_p.bias.grad.abs().max()))
+        else:
+            assert float((rel > 2e-4).float().mean()) < 1e-5, ((B, H, W, Cin, Cout), float((rel > 2e-4).float().mean()))
         assert int(ctr.cpu().abs().sum()) == 0       # every launch leaves its ticket words zero
     return True
 
