@@ -92,6 +92,16 @@ vt)
   line vt_b --mode train --steps 4 --warmup 2
   line vft --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
   ;;
+b3)
+  # first measurement of round 5: the 3x3 convs' BatchNorm inside the Winograd kernel (opt-in) against the default, alternating
+  echo "== pytest"; timeout 600 python -m pytest tests -m gpu -q -x --timeout 400 -k "conv3x3_bn_fused_ops or batchnorm_in_the_3x3 or resnet_h_train_step" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for r in a b; do
+    DREAM_BN_FUSION_3X3=0 line rt16_off_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_BN_FUSION_3X3=1 line rt16_on_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  DREAM_BN_FUSION_3X3=0 line rt128_off --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  DREAM_BN_FUSION_3X3=1 line rt128_on --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
 tg)
   echo "== pytest"; timeout 600 python -m pytest tests -m gpu -q -x -s --timeout 400 -k "one_device_training_step_as_graph or graph_replay_equals_eager" 2>&1 | grep -v "Warning\|warn" | tail -6
   line rt16_eager_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
