@@ -62,6 +62,13 @@
 #ifndef DREAM_W4_MIDBARRIER
 #define DREAM_W4_MIDBARRIER 0
 #endif
+#ifndef DREAM_W4_RUNNING_WOFF
+#define DREAM_W4_RUNNING_WOFF 1
+#endif
+// static priority for the second-dispatched half of the workgroup's wavefronts (MI355X_MICROARCH.md "two waves per SIMD", item 4)
+#ifndef DREAM_W4_SETPRIO
+#define DREAM_W4_SETPRIO 0
+#endif
 
 namespace {
 
@@ -271,6 +278,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
 
     f32x4 acc[W4P];
     const int nchunks = p.Cin / W4K;
+    if (DREAM_W4_SETPRIO && wave >= W4NW / 2) __builtin_amdgcn_s_setprio(1);
 
     // weight stream: the k-th position of the chunk sequence (k counted from the start of the block, 36 per chunk) lives in
     // bq[k % 8]; the chunk loop is unrolled by two so that the ring index is a compile-time constant (72 % 8 == 0)
@@ -281,6 +289,12 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     };
 #pragma unroll
     for (int k = 0; k < W4_AHEAD; ++k) bq[k] = load_u((unsigned)pat4_pos(PAT, k) * u_pos_stride);
+    // The full kernel's weight stream is SEQUENTIAL in memory (position k of chunk c sits at (36 c + k) positions): one running
+    // wave-uniform byte offset, bumped after every load and reset where the stream wraps around to the next block's chunk 0.  (As
+    // `(36 c + k) * stride` hipcc kept the 36 products k * stride in scalar registers it does not have: 18 v_readlane_b32 + their
+    // hazard s_nops per chunk in the MFMA loop.)  The phase patterns skip positions and keep the table form.
+    unsigned woff = (unsigned)W4_AHEAD * u_pos_stride;
+    asm volatile("" : "+s"(woff));
 
     // LDS addresses: one per-lane base register per (role, V buffer), everything else in the instructions' 16-bit immediate
     // offsets (every plane / row offset below is < 64 KB from its base).  `opaque` keeps the compiler from folding the buffer
@@ -364,8 +378,15 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
             auto load_b = [&](int half) {                                    // weight operands of active position k0 + half + AHEAD
                 if ((DREAM_W4_DIAG & 2) || (half && !two)) return;
                 const int kn = k0 + half + W4_AHEAD;
-                const int spos = kn >= NPOS ? cnext + pat4_pos(PAT, kn - NPOS) : c * W4P + pat4_pos(PAT, kn);
-                bq[(PH * NPOS + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
+                if constexpr (PAT == 0 && DREAM_W4_RUNNING_WOFF && !(DREAM_W4_DIAG & 32)) {
+                    if (kn == NPOS && last) woff = 0u;                        // wave-uniform: s_cselect
+                    bq[(PH * NPOS + kn) % W4_RING] = load_u(woff);
+                    woff += u_pos_stride;
+                    asm volatile("" : "+s"(woff));                            // opaque: no re-derivation from the chunk counter
+                } else {
+                    const int spos = kn >= NPOS ? cnext + pat4_pos(PAT, kn - NPOS) : c * W4P + pat4_pos(PAT, kn);
+                    bq[(PH * NPOS + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
+                }
             };
             auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), (DREAM_W4_DIAG & 64) ? 0u : coff); };
             auto pair = [&](int r) {
