@@ -872,9 +872,10 @@ class ResnetSimple(nn.Module):
         # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
         self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "96"))
-        # opt-in until measured on the GPU (round 4, last hours): the 3x3 convs' BatchNorm statistics / masked backward reductions in
-        # the Winograd F(2x2) kernel's epilogue (csrc/conv_wino.hip WINO_STAT) -- 66 launches fewer per ResNet-101 step
-        self.bn_fusion_3x3 = os.environ.get("DREAM_BN_FUSION_3X3", "0") == "1"
+        # the 3x3 convs' BatchNorm statistics / masked backward reductions in the Winograd F(2x2) kernel's epilogue (csrc/conv_wino.hip
+        # WINO_STAT) -- 66 launches fewer per ResNet-101 step; measured round 5 (profiles/r05_ab_bn_fusion_3x3.txt, alternating on one
+        # box): 350.4 -> 358.5 frames/s at 16 frames (+2.3 %), so on by default; "0" = the stand-alone bn_stats / bn_bwd_stats passes
+        self.bn_fusion_3x3 = os.environ.get("DREAM_BN_FUSION_3X3", "1") == "1"
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
