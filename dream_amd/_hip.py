@@ -104,6 +104,7 @@ _SIGNATURES = {
     "dream_conv3x3_winograd4_weight_floats": (_SZ, [_I, _I]),
     "dream_conv3x3_winograd4_set_max_workgroups": (_I, [_I]),
     "dream_conv3x3_winograd4_set_channel_block_pinning": (_I, [_I]),
+    "dream_conv3x3_winograd4_set_stagger": (_I, [_I, _I]),
     "dream_pack_conv3x3_winograd4_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "dream_conv3x3_winograd4_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_pack_job_bytes": (_SZ, []),

@@ -62,6 +62,10 @@
 #ifndef DREAM_W4_MIDBARRIER
 #define DREAM_W4_MIDBARRIER 0
 #endif
+#ifndef DREAM_W4_STAGGER_N
+#define DREAM_W4_STAGGER_N 0
+#define DREAM_W4_STAGGER_PCT 0
+#endif
 #ifndef DREAM_W4_RUNNING_WOFF
 #define DREAM_W4_RUNNING_WOFF 1
 #endif
@@ -89,6 +93,8 @@ struct Wino4Params {
                                      // conv, (2, a, b) for phase (a, b) of a stride-2 transposed conv (y: [B, out_scale H, out_scale W, Cout])
     int in_scale, in_oy, in_ox;      // stored input pixel of conv position (y, x), likewise: (2, a, b) for the phase views of the gradient in the
                                      // transposed conv's data gradient (x: [B, in_scale H, in_scale W, Cin]); read by the PAT kernels only
+    int stagger_n, stagger_unit;     // start-up stagger: workgroup w sleeps (hash(w) % stagger_n) * stagger_unit x s_sleep(127) before its first
+                                     // block, so that the workgroups' epilogues (a burst of 128 KB of stores per CU) stop coinciding (0: off)
     int ymap;                        // 0: output-channel block = blockIdx.y, every XCD walks all of them over its own eighth of the tile blocks;
                                      // ny (2 | 4): 1-D grid, XCD k owns channel block k % ny and shares the tile blocks with the other 8 / ny - 1
                                      // XCDs of that block (blk_per_xcd = their share): an XCD's L2 then streams ONE block's transformed weights
@@ -219,6 +225,14 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     int tb = part * p.blk_per_xcd + (int)(blockIdx.x >> 3);
     if (tb >= blk_end) return;
     const int n0 = (p.ymap ? xcd % p.ymap : (int)blockIdx.y) * (16 * W4NW);
+    if (p.stagger_n > 1) {
+        // The persistent workgroups start together and take the same time per block, so all 256 CUs reach their epilogues together:
+        // 32 MB of stores at once drain at the HBM write rate (~9 us), and on gfx9 the next block's weight loads count behind them in
+        // the in-order vmcnt.  Spread over a fraction of a block time, a CU's 128 KB leave in ~2 us.
+        const unsigned w = blockIdx.x + blockIdx.y * gridDim.x;
+        const int naps = (int)((w * 2654435761u >> 16) % (unsigned)p.stagger_n) * p.stagger_unit;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int tiles_per_img = p.TY * p.TX;
     const int Si = PAT ? p.in_scale : 1;                                      // spacing of the conv positions in the stored input
     const size_t img_floats = (size_t)(Si * p.H) * (Si * p.W) * p.Cin;
@@ -294,7 +308,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     // `(36 c + k) * stride` hipcc kept the 36 products k * stride in scalar registers it does not have: 18 v_readlane_b32 + their
     // hazard s_nops per chunk in the MFMA loop.)  The phase patterns skip positions and keep the table form.
     unsigned woff = (unsigned)W4_AHEAD * u_pos_stride;
-    asm volatile("" : "+s"(woff));
+    DREAM_OPAQUE_SGPR(woff);
 
     // LDS addresses: one per-lane base register per (role, V buffer), everything else in the instructions' 16-bit immediate
     // offsets (every plane / row offset below is < 64 KB from its base).  `opaque` keeps the compiler from folding the buffer
@@ -382,7 +396,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                     if (kn == NPOS && last) woff = 0u;                        // wave-uniform: s_cselect
                     bq[(PH * NPOS + kn) % W4_RING] = load_u(woff);
                     woff += u_pos_stride;
-                    asm volatile("" : "+s"(woff));                            // opaque: no re-derivation from the chunk counter
+                    DREAM_OPAQUE_SGPR(woff);                            // opaque: no re-derivation from the chunk counter
                 } else {
                     const int spos = kn >= NPOS ? cnext + pat4_pos(PAT, kn - NPOS) : c * W4P + pat4_pos(PAT, kn);
                     bq[(PH * NPOS + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
@@ -606,6 +620,8 @@ __global__ void __launch_bounds__(256) wino4_pack_kernel(const float *w, float *
 }
 
 int g_max_workgroups4 = 0;     // test hook: cap on resident workgroups (0 = the chip's 256 CUs, two narrow workgroups on each)
+int g_stagger_n4 = -1, g_stagger_pct4 = 0;   // start-up stagger (Wino4Params::stagger_n): phases and spread in per cent of a block's time; -1 = by
+                               // the environment (DREAM_W4_STAGGER="<phases>,<per cent>", default off)
 int g_ymap4 = -1;              // channel blocks pinned to XCDs (Wino4Params::ymap): -1 = by the environment (DREAM_W4_YMAP=0 switches it off).
                                // Measured round 4 (tools/ab_wino4_pinning.py, b=128): 0.5-1.3 % faster on every layer with 2 or 4 channel
                                // blocks, headline +0.6 %: an XCD's L2 streams one block's transformed weights instead of all four
@@ -668,6 +684,15 @@ extern "C" int dream_conv3x3_winograd4_set_channel_block_pinning(int on) {
     return 0;
 }
 
+// A/B hook: start-up stagger of the persistent workgroups: `phases` (0 / 1 = off) spread over `percent` of one block's time; phases < 0 = by
+// DREAM_W4_STAGGER again.  Same results either way (bit for bit).
+extern "C" int dream_conv3x3_winograd4_set_stagger(int phases, int percent) {
+    DREAM_REQUIRE(phases <= 1024 && percent >= 0 && percent <= 400, "winograd F(4x4): stagger %d phases over %d %%", phases, percent);
+    g_stagger_n4 = phases < 0 ? -1 : (phases > 1 ? phases : 0);
+    g_stagger_pct4 = percent;
+    return 0;
+}
+
 extern "C" int dream_conv3x3_winograd4_set_max_workgroups(int n) {
     DREAM_REQUIRE(n >= 0, "winograd F(4x4): max workgroups %d", n);
     g_max_workgroups4 = n;
@@ -720,6 +745,21 @@ int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const flo
     p.out_scale = out_scale; p.out_oy = 0; p.out_ox = 0;
     p.in_scale = in_scale; p.in_oy = 0; p.in_ox = 0;
     p.ymap = 0;
+    if (g_stagger_n4 < 0) {
+        const char *e = getenv("DREAM_W4_STAGGER");
+        int n = DREAM_W4_STAGGER_N, pct = DREAM_W4_STAGGER_PCT;
+        if (e != nullptr && sscanf(e, "%d,%d", &n, &pct) != 2) { n = DREAM_W4_STAGGER_N; pct = DREAM_W4_STAGGER_PCT; }
+        g_stagger_n4 = n > 1 ? n : 0;
+        g_stagger_pct4 = pct;
+    }
+    // a chunk takes ~13.5 k cycles (wide; the narrow shape's half-size chunks ~7 k), one s_sleep(127) 8128: naps per phase step
+    {
+        const double chunk_cycles = narrow_rows(Cout) ? 7000.0 : 13500.0;
+        const double block_naps = (double)(Cin / ps.k) * chunk_cycles / 8128.0;
+        p.stagger_n = g_stagger_n4;
+        p.stagger_unit = g_stagger_n4 > 1 ? (int)(block_naps * g_stagger_pct4 / 100.0 / g_stagger_n4 + 0.5) : 0;
+        if (p.stagger_n > 1 && p.stagger_unit < 1) p.stagger_unit = 1;
+    }
     if (g_ymap4 < 0) {
         const char *e = getenv("DREAM_W4_YMAP");
         g_ymap4 = (e != nullptr && e[0] == '0') ? 0 : 1;

@@ -29,6 +29,8 @@ DREAM_DEVICE const __attribute__((address_space(4))) T *kernarg_again(const T &)
     return kp;
 }
 #define DREAM_KERNARG(arg) kernarg_again(arg)
+// a wave-uniform value the optimiser may not see through (kept in a scalar register)
+#define DREAM_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
 
 DREAM_DEVICE f32x16 mfma_f32_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -134,6 +134,7 @@ int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, cons
                                      const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                      void *stream);
 int dream_conv3x3_winograd4_set_max_workgroups(int n);
+int dream_conv3x3_winograd4_set_stagger(int phases, int percent);   /* A/B hook: start-up stagger of the persistent workgroups (phases <= 1: off; < 0: by DREAM_W4_STAGGER) */
 int dream_conv3x3_winograd4_set_channel_block_pinning(int on);   /* A/B hook: output-channel blocks pinned to XCDs (1) or walked by every XCD (0); -1: by DREAM_W4_YMAP (default: pinned) */     /* test hook, as dream_conv3x3_winograd_set_max_workgroups */
 
 /* ---- all packed weight copies of a network in one launch (training: every conv weight changes every step) ----------------------

@@ -30,4 +30,7 @@ ab1)
     DREAM_BN_FUSION_3X3=1 line rt16_bn3on_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
   done
   ;;
+stagger)
+  timeout 600 python tools/ab_wino4_stagger.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/ab_wino4_stagger.txt
+  ;;
 esac
