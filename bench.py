@@ -67,6 +67,11 @@ def parse():
                     "product) on the same workload and report it beside the exact-fp32 value (off by default since round 3: with the "
                     "F(4x4,3x3) kernel the exact path is the faster one)")
     ap.add_argument("--no-split-leg", action="store_true", help="(accepted for older command lines; the leg is off by default)")
+    ap.add_argument("--dp-check", action="store_true", help="training: add `dp_check` to the line -- the per-step loss averaged over the "
+                    "ranks and the largest difference of any parameter between ranks after the last step (tests/test_gpu_parity.py: the "
+                    "first multi-GPU contact is a test, not a bench)")
+    ap.add_argument("--concat-ranks", type=int, default=0, help="one process, one GPU: the batch is the concatenation of what ranks 0..N-1 "
+                    "of a `--gpus N` run would see (the single-device reference of --dp-check)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` (N = 1) / `scale` (N > 1) blocks")
     ap.add_argument("--secondary-steps", type=int, default=3)
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline block (each CNN leg gets a quarter; a leg whose 3 + 5 iterations do not fit falls back to 1 + 3)")
@@ -237,7 +242,10 @@ def self_launch(args):
     import torch
     n_visible = torch.cuda.device_count()
     if n_visible < args.gpus and not os.environ.get("DREAM_BENCH_BACKEND"):
-        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_visible))
+        print(json.dumps({"metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
+                          "value": None, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "error": "bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_visible)}), flush=True)
+        raise SystemExit(2)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -341,12 +349,17 @@ def build_network(ctx, spec):
     net.model.module.conv_algorithm = "direct" if spec["conv_algorithm"] == "direct" else "winograd"
     ops.set_winograd_tile(2 if spec["conv_algorithm"] == "winograd2" else 0)
     frames = spec["batch"] * (len(ctx.single_ids) if ctx.single else 1)               # frames this PROCESS handles per step
-    x = torch.from_numpy(cases.image_batch(frames, spec["res"], spec["res"], seed=ctx.rank)).cuda()
+    seeds = list(range(spec["concat_ranks"])) if spec.get("concat_ranks") else [ctx.rank]
+    if len(seeds) > 1:
+        frames = spec["batch"] * len(seeds)
+    per = frames // len(seeds)
+    x = torch.cat([torch.from_numpy(cases.image_batch(per, spec["res"], spec["res"], seed=sd)) for sd in seeds]).cuda()
     tgt = None
     if spec["mode"] == "train":
         net.enable_training()
         ow, oh = net.trained_net_output_resolution()
-        tgt = torch.from_numpy(cases.target_batch(frames, n_kp, (ow, oh), in_wh=(spec["res"], spec["res"]), seed=ctx.rank)).cuda()
+        tgt = torch.cat([torch.from_numpy(cases.target_batch(per, n_kp, (ow, oh), in_wh=(spec["res"], spec["res"]), seed=sd))
+                         for sd in seeds]).cuda()
     else:
         net.enable_evaluation()
         net.hip_graph = bool(spec.get("graph"))
@@ -366,7 +379,10 @@ def timed_region(ctx, net, x, tgt, spec):
 
     def step():
         if spec["mode"] == "train":
-            return net.train([x], tgt)
+            loss = net.train([x], tgt)
+            if spec.get("dp_check"):
+                ctx.losses.append(loss.detach().double().reshape(1).clone())
+            return loss
         with torch.no_grad():
             return net.inference(x)
 
@@ -461,8 +477,43 @@ def run_side_workload(ctx, spec, label, baseline_index, sharded_total=None):
     return block
 
 
+def dp_check(ctx, net):
+    """--dp-check: per-step losses averaged over the ranks, and the largest difference of any parameter between the ranks."""
+    import torch
+    import torch.distributed as dist
+    losses = torch.cat(ctx.losses) if ctx.losses else torch.zeros(0, dtype=torch.float64, device="cuda")
+    flat = torch.cat([p.detach().reshape(-1) for p in net.model.parameters()])
+    hi, lo = flat.clone(), flat.clone()
+    if ctx.world > 1:
+        dist.all_reduce(losses, op=dist.ReduceOp.SUM)
+        losses /= ctx.world
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return {"losses": [float(v) for v in losses.cpu()], "param_spread_between_ranks": float((hi - lo).abs().max()),
+            "param_l2": float(flat.double().norm()), "ranks": ctx.world}
+
+
 def main():
+    """A failure (RCCL initialisation on a multi-GPU node, a device that is missing ...) leaves ONE JSON line with an `error` field on
+    rank 0 and a non-zero exit status instead of N interleaved tracebacks, so that a SCALE record is diagnosable."""
     args = parse()
+    stage = ["start"]
+    try:
+        return _main(args, stage)
+    except SystemExit:
+        raise
+    except BaseException as e:  # noqa: BLE001
+        import traceback
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
+                              "value": None, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                              "error": "%s during %s: %s" % (type(e).__name__, stage[0], str(e)[:600]),
+                              "world_size": int(os.environ.get("WORLD_SIZE", "1"))}), flush=True)
+        traceback.print_exc(file=sys.stderr)
+        raise SystemExit(1)
+
+
+def _main(args, stage):
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.single_process:
         self_launch(args)
     import torch
@@ -491,21 +542,28 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29555")
         dist.init_process_group("gloo", rank=0, world_size=1)
+    stage[0] = "process-group initialisation (%s, %d ranks)" % ("RCCL" if backend == "nccl" else backend, ctx.world)
     if ctx.world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", ctx.device_index))
         else:
             dist.init_process_group(backend)
+    ctx.losses = []
     if args.global_batch:
         assert args.global_batch % ctx.n_gpus == 0, "--global-batch must divide evenly over the GPUs"
         args.batch = args.global_batch // ctx.n_gpus
     ctx.timer = ConvTimer(ops, torch)
 
     spec = {"arch": args.arch, "mode": args.mode, "batch": args.batch, "res": args.res, "steps": args.steps,
-            "warmup": args.warmup, "precision": args.precision, "conv_algorithm": args.conv_algorithm, "graph": args.graph}
+            "warmup": args.warmup, "precision": args.precision, "conv_algorithm": args.conv_algorithm, "graph": args.graph,
+            "dp_check": args.dp_check and args.mode == "train", "concat_ranks": args.concat_ranks}
     n_kp, manip = ARCH_K[args.arch]
+    stage[0] = "network construction"
     net, x, tgt, frames = build_network(ctx, spec)
+    stage[0] = "the timed region (first RCCL collective in it for N > 1)"
     dt, conv, out_main = timed_region(ctx, net, x, tgt, spec)
+    check = dp_check(ctx, net) if spec["dp_check"] else None
+    stage[0] = "reporting"
     # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
     # fp16 MFMA MACs, so its ceiling in ALGORITHMIC flops is the dense fp16 MFMA peak / 3
     peak = PEAK_F32_MFMA_TFLOPS if args.precision == "fp32" or args.mode == "train" else PEAK_F16_MFMA_TFLOPS / 3.0
@@ -589,6 +647,8 @@ def main():
         }
         if split is not None:
             line["split_precision"] = split
+        if check is not None:
+            line["dp_check"] = check
         if side:
             line["secondary" if ctx.n_gpus == 1 else "scale"] = side
         if ctx.world == 1 and not ctx.single and not args.no_cpu_baseline and args.mode == "inference":

@@ -1300,6 +1300,8 @@ class ResnetSimple(nn.Module):
             self._ctr_pos = 0
 
         def take(n):
+            if n > buf.numel():                     # a short slice would let the kernel's ticket atomics run past the buffer
+                raise RuntimeError("dream_amd: a BatchNorm launch needs %d ticket words, the replica's buffer holds %d" % (n, buf.numel()))
             if self._ctr_pos + n > buf.numel():
                 self._ctr_pos = 0
             out = buf[self._ctr_pos:self._ctr_pos + n]
@@ -1367,7 +1369,12 @@ class ResnetSimple(nn.Module):
                 o = self._unit_fused(tape, name + ".1", y, blk.conv1, blk.bn1, relu=True)
                 # conv2's BatchNorm + ReLU is applied by conv3's loader when conv3 runs on the GEMM kernel (always, for ResNet-101)
                 r2 = self._unit_fused(tape, name + ".2", o, blk.conv2, blk.bn2, relu=True, materialize=False)
-                if self._gemm1x1(blk.conv3, r2["z"]):
+                # ... and when the BACKWARD GEMM applies too: conv3's data gradient (conv1x1_bwd_bnmask) reads dz3, which has 4x the
+                # channels of z2 and crosses the kernel's 2-GB offset limit first; relu(BN(z2)) is never stored on this path, so the
+                # decision has to be made here (round-4 advice: ~210 frames of 400x400 per GPU would pass the forward and raise in the backward)
+                z2 = r2["z"]
+                dz3_fits = int(z2.shape[0]) * int(z2.shape[1]) * int(z2.shape[2]) * int(blk.conv3.weight.shape[0]) * 4 < (1 << 31)
+                if self._gemm1x1(blk.conv3, r2["z"]) and dz3_fits:
                     y = self._unit_fused(tape, name + ".3", r2["z"], blk.conv3, blk.bn3, relu=True, residual=idt, pre=r2)
                 else:
                     r2["y"] = ops.bn_apply_ab(r2["z"], r2["ab"], None, True)

@@ -208,9 +208,12 @@ class DreamNetwork:
         # captures the whole launch sequence of one input shape -- CNN + peak extraction, 30-140 kernel launches -- into
         # a hipGraph and replays it, so a frame costs one graph launch + one 56-byte D2H copy instead of one Python /
         # ctypes round trip per kernel.  Results are bit-identical (same kernels, same order).  Off by default.
-        # train() with hip_graph set runs the step as two replays (forward, backward; DreamDataParallel.single_device_graphs):
-        # the second step of a batch shape captures, later ones replay.
+        # hip_graph is INFERENCE-only.  The one-device training step as hipGraph replays (forward, backward;
+        # DreamDataParallel.single_device_graphs: the second step of a batch shape captures, later ones replay) has its own switch,
+        # hip_graph_train (or DREAM_TRAIN_GRAPH=1): it keeps a private memory pool per batch shape (several GB for ResNet-101), which
+        # a user who sets hip_graph for evaluation and later fine-tunes should not get implicitly (round-4 advice).
         self._hip_graph = False
+        self._hip_graph_train = os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
         self._graphs = {}
 
         out_res = list(self.net_output_resolution_from_input_resolution(self.trained_net_input_resolution()))
@@ -227,8 +230,16 @@ class DreamNetwork:
     @hip_graph.setter
     def hip_graph(self, on):
         self._hip_graph = bool(on)
+
+    @property
+    def hip_graph_train(self):
+        return self._hip_graph_train
+
+    @hip_graph_train.setter
+    def hip_graph_train(self, on):
+        self._hip_graph_train = bool(on)
         if isinstance(self.model, models.DreamDataParallel):
-            self.model.single_device_graphs = bool(on) or os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
+            self.model.single_device_graphs = bool(on)
 
     # ---- small getters (network.py:319-326) ------------------------------------------------------------
     def trained_net_input_resolution(self):

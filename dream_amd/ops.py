@@ -807,14 +807,22 @@ def bn_counter_buffer(device, words=1 << 17):
 def _ctr_words(counters, n):
     """``counters``: a zero int32 tensor of at least n words (tests), or an allocator n -> slice (a model's per-replica buffer)."""
     if callable(counters):
-        return counters(int(n))
+        out = counters(int(n))
+        if out.numel() != n:
+            raise RuntimeError("dream_amd: %d ticket words needed, the allocator returned %d" % (n, out.numel()))
+        return out
     if counters.numel() < n:
         raise RuntimeError("dream_amd: %d ticket words needed, %d given" % (n, counters.numel()))
     return counters
 
 
 def _bn_args(bn):
-    momentum = 0.1 if bn.momentum is None else bn.momentum
+    # nn.BatchNorm2d(momentum=None) means a cumulative moving average (factor 1 / num_batches_tracked), which the kernels' running-
+    # statistics update does not implement; the reference's models use 0.1 (dream/models.py:45-47 and torchvision's default)
+    if bn.momentum is None:
+        raise NotImplementedError("dream_amd: BatchNorm2d(momentum=None) (cumulative moving average) is not supported by the HIP "
+                                  "BatchNorm kernels; use a numeric momentum (the reference's models use 0.1)")
+    momentum = bn.momentum
     return (ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked),
             float(bn.eps), float(momentum))
 

@@ -277,6 +277,50 @@ def recipe_weights(state_dict, final_keys=(), final_scale=1.0):
     return out
 
 
+def smooth_weights(state_dict):
+    """Weights for the round-5 structured VGG fixtures (tests/golden/structured_vgg_q_400.npz, structured_vgg_f.npz): every conv is a
+    three-input NON-NEGATIVE channel mix (rows summing to one) times the binomial kernel [1,2,1] x [1,2,1] / 16, without bias -- a smoothing,
+    mean-preserving layer; the 3-channel first conv carries signed colour filters with a small positive bias, so its ReLU outputs are
+    colour-selective; stride-2 transposed convs (vgg_f) carry the bilinear kernel [1,2,1] x [1,2,1] / 4.  A blob in the frame then comes
+    out as ONE smooth bump in every belief map, with a height that depends on its colour and the keypoint's channel mix: most maps
+    have a clear winner (a detection), two comparable blobs give a rejection by the 0.25 rule.  (The recipe weights give ripples
+    around every blob -- several local maxima within 0.25 of each other -- and 2 detections out of 14 at 400 x 400.)  The last
+    layer is calibrated and stored by make_golden.py."""
+    import zlib
+    import numpy as np
+    out = {}
+    binom = np.outer([1.0, 2.0, 1.0], [1.0, 2.0, 1.0])
+    for key, t in state_dict.items():
+        rs = np.random.RandomState(zlib.crc32(("smooth:" + key).encode()) & 0x7FFFFFFF)
+        shape = tuple(t.shape)
+        if t.dim() == 4:
+            transposed = "deconv" in key
+            ci = shape[0] if transposed else shape[1]
+            co = shape[1] if transposed else shape[0]
+            if ci <= 4:                                     # first conv: signed colour filters of four TYPES (channel o: type o % 4)
+                types = rs.uniform(-1.0, 1.0, (4, ci))
+                mix = types[np.arange(co) % 4] * rs.uniform(0.8, 1.2, (co, 1))
+            else:
+                # output o mixes inputs o, o + 4, o + 8 (mod ci): channels of one colour type only, so the colour preference of the
+                # first layer survives the depth
+                mix = np.zeros((co, ci))
+                for j, wgt in enumerate((0.6, 0.25, 0.15)):
+                    mix[np.arange(co), (np.arange(co) + 4 * j) % ci] += wgt * rs.uniform(0.8, 1.2, co)
+                mix = mix / mix.sum(1, keepdims=True)
+            assert shape[2:] == (3, 3), (key, shape)
+            kern = binom / (4.0 if transposed else 16.0)
+            v = mix[:, :, None, None] * kern[None, None]
+            if transposed:
+                v = v.transpose(1, 0, 2, 3)
+        elif key.endswith(".bias") and any(k2 == key[:-len("bias")] + "weight" and tuple(t2.shape)[1] <= 4 and t2.dim() == 4
+                                           for k2, t2 in state_dict.items()):
+            v = rs.uniform(0.05, 0.3, shape)                 # first conv
+        else:
+            v = np.zeros(shape)
+        out[key] = torch.as_tensor(np.ascontiguousarray(v), dtype=t.dtype)
+    return out
+
+
 def structured_weights(state_dict):
     """Variant of recipe_weights for the structured end-to-end fixture of ResnetSimple (tests/golden/structured_resnet_h.npz):
     recipe weights, except that (i) every additive term is removed (conv / BN biases and BN running means are zero), so a

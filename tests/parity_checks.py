@@ -540,7 +540,7 @@ def check_structured(dev, arch, precision="fp32"):
     arch, manip, k, last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[case]
     g = np.load(os.path.join(GOLD, "structured_%s.npz" % case))
     sd = om.build_model(arch, k).state_dict()
-    weights = om.structured_weights(sd) if recipe == "structured" else om.recipe_weights(sd)
+    weights = {"structured": om.structured_weights, "smooth": om.smooth_weights, "recipe": om.recipe_weights}[recipe](sd)
     weights[last + ".weight"] = torch.from_numpy(g["final_weight"])
     weights[last + ".bias"] = torch.from_numpy(g["final_bias"])
     net = build_network(arch, dev, weights=weights, in_res=(w, h))

@@ -396,7 +396,7 @@ def test_eight_devices_uneven_chunks(emu, monkeypatch):
 
 
 def test_one_device_step_through_the_replica_path(emu):
-    """``single_device_graphs`` (DreamNetwork.hip_graph on a training network): a one-device step takes the replica path -- flat
+    """``single_device_graphs`` (DreamNetwork.hip_graph_train): a one-device step takes the replica path -- flat
     gradient buffer, no all-reduce, no replica update -- so that it can be replayed as hipGraphs on a GPU.  Here on CPU tensors
     (nothing to capture): gradients and Adam steps equal the direct path's, accumulation over two backwards included."""
     a, oa = _tiny_dp("adam")

@@ -1,5 +1,7 @@
 """GPU suite (-m gpu): parity of the real libdream_hip.so (through the C ABI, on an MI355X) with the CPU
 oracle and with the committed golden outputs of the real reference.  Nothing here reads /root/reference."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -872,6 +874,50 @@ def test_single_process_data_parallel_on_two_physical_gpus():
     assert torch.equal(rep._dream_flat["params"].to(devs[0]), dp.model.module._dream_flat["params"])
 
 
+def _bench_line(args, env=None, timeout=900):
+    """Run bench.py (a subprocess, as the driver does) and return its JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, cwd=root, env=e, capture_output=True, text=True, timeout=timeout)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert lines, "bench.py printed no JSON line (rc %d)\n%s\n%s" % (out.returncode, out.stdout[-2000:], out.stderr[-4000:])
+    return json.loads(lines[-1]), out.returncode
+
+
+def test_bench_two_ranks_over_rccl_on_two_physical_gpus():
+    """The torchrun twin of the test above (skipped on the one-GPU test box): `bench.py --gpus 2` launches its own two RCCL ranks, as
+    the driver's SCALE run does.  After 3 Adam steps both ranks hold the same parameters, and the per-step loss averaged over the
+    ranks equals the loss of ONE GPU on the concatenated batch within 1e-5 -- to tolerance, not bit for bit: the conv algorithm
+    depends on the per-GPU batch (dream_amd/ops.py winograd_tile), see INTEGRATION.md."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two physical GPUs")
+    common = ["--mode", "train", "--arch", "vgg_q", "--res", "128", "--steps", "3", "--warmup", "0", "--dp-check", "--no-secondary", "--no-cpu-baseline"]
+    two, rc2 = _bench_line(["--gpus", "2", "--batch", "4"] + common)
+    assert rc2 == 0 and "error" not in two, two
+    one, rc1 = _bench_line(["--gpus", "1", "--batch", "4", "--concat-ranks", "2"] + common)
+    assert rc1 == 0 and "error" not in one, one
+    assert two["rccl_ranks"] == 2 and two["n_gpus"] == 2 and two["dp_check"]["ranks"] == 2
+    assert two["dp_check"]["param_spread_between_ranks"] == 0.0, two["dp_check"]
+    l2, l1 = np.array(two["dp_check"]["losses"]), np.array(one["dp_check"]["losses"])
+    assert l2.shape == l1.shape == (3,) and np.allclose(l2, l1, rtol=1e-5, atol=1e-7), (l2, l1)
+    assert abs(two["dp_check"]["param_l2"] - one["dp_check"]["param_l2"]) <= 1e-5 * one["dp_check"]["param_l2"]
+
+
+def test_bench_dp_check_and_error_line_on_one_gpu():
+    """What the twin above needs and a one-GPU box can exercise: --dp-check / --concat-ranks on one rank (losses recorded, zero spread),
+    and the `error` field -- `--gpus 64` on this box must leave ONE diagnosable JSON line and a non-zero exit status, not a traceback."""
+    common = ["--mode", "train", "--arch", "vgg_q", "--res", "64", "--steps", "2", "--warmup", "0", "--dp-check", "--no-secondary", "--no-cpu-baseline"]
+    a, rc = _bench_line(["--gpus", "1", "--batch", "2", "--concat-ranks", "2"] + common)
+    assert rc == 0 and a["dp_check"]["ranks"] == 1 and len(a["dp_check"]["losses"]) == 2 and a["dp_check"]["param_spread_between_ranks"] == 0.0
+    assert a["dp_check"]["losses"][1] != a["dp_check"]["losses"][0]
+    bad, rc = _bench_line(["--gpus", "64"] + common)
+    assert rc != 0 and bad["value"] is None and "only" in bad["error"] and bad["n_gpus"] == 64, bad
+
+
 def test_single_process_data_parallel_resnet_batchnorm_semantics():
     """ResNet under gpu_ids = [0, 0]: per-replica batch statistics (as nn.DataParallel), running statistics of replica 0 kept
     in the master module: one training step on 4 frames = the average of the gradients of two independent 2-frame steps."""
@@ -975,7 +1021,7 @@ def test_resnet_training_with_batchnorm_in_the_3x3_kernels(monkeypatch):
 
 @pytest.mark.parametrize("arch,res", [("resnet_h", (64, 64)), ("vgg_q", (64, 48))])
 def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
-    """DreamNetwork.hip_graph on a training network with ONE device: from the second step of a batch shape train() is two
+    """DreamNetwork.hip_graph_train on a training network with ONE device: from the second step of a batch shape train() is two
     hipGraph replays (forward, backward) + the loss and the optimizer launch.  Four Adam steps must equal the eager steps bit for
     bit (losses, parameters, BatchNorm running statistics), the host must spend clearly less than the eager enqueue time on a replayed
     step, and switching the flag off again returns to the eager path on the same parameters."""
@@ -987,7 +1033,7 @@ def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
     def run(graph):
         net = _dp_network(arch, [0], optimizer="adam", lr=1e-5, in_res=res, weights=wts)
         net.enable_training()
-        net.hip_graph = graph
+        net.hip_graph_train = graph
         ow, oh = net.trained_net_output_resolution()
         t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=res, seed=47)).to(DEV)
         losses, host = [], []
@@ -1009,7 +1055,7 @@ def test_one_device_training_step_as_graph_replay_equals_eager(arch, res):
         assert torch.equal(a, b), k
     print("%s host seconds per step: graph %s, eager %s" % (arch, ["%.4f" % v for v in hg], ["%.4f" % v for v in he]))
     assert hg[3] < 0.7 * he[3], (hg, he)                 # measured: resnet_h 8 ms against 25, vgg_q 1.6 against 3.9
-    g.hip_graph = False                                    # back to the eager path, same parameters, same optimizer state
+    g.hip_graph_train = False                              # back to the eager path, same parameters, same optimizer state
     assert g.train([x], t).item() == e.train([x], t).item()
     assert st["replays"] == 2 * 3
 

@@ -33,4 +33,83 @@ ab1)
 stagger)
   timeout 600 python tools/ab_wino4_stagger.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/ab_wino4_stagger.txt
   ;;
+final)
+  # The round's measurement set (one GPU call): full GPU suite, smoke(), rehearsals of both multi-GPU paths on this one GPU, rocprofv3
+  # kernel tables, the calibrated HBM-traffic and SQ PMC passes, ResNet training traffic, the secondary lines, layer profiles,
+  # micro-benchmarks, and the default line LAST (it picks up this bench.py's PMC traffic).  `collect` (dev container) copies the
+  # summaries into profiles/r05_*.
+  R="$PWD"
+  summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" $3 $4 > $O/summ.log 2>&1; echo "summary $2 rc=$?"; rm -rf "$1"; }
+  lraw() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | cut -c1-160; }
+  if [ "$2" != "notests" ]; then
+    echo "== pytest gpu (all)"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
+    echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-200
+  fi
+  echo "== two ranks on this one GPU over gloo / four replicas in one process (rehearsals: the numbers mean nothing)"
+  DREAM_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-secondary > $O/rehearsal_2ranks_selflaunch.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_2ranks_selflaunch.log | cut -c1-200
+  DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 32 --no-cpu-baseline > $O/rehearsal_single_process_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_train.log | cut -c1-200
+  echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline --no-secondary > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; grep -h '^{"metric' $O/rocprof_default.log | cut -c1-200
+  summ $O/prof_default $O/bench_default peaks_kernel 2
+  for C in FETCH_SIZE WRITE_SIZE; do
+    echo "== pmc $C"; (cd /tmp && DREAM_BENCH_PMC_CALIBRATE=1 timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_$C" -o pmc -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > "$R/$O/pmc_$C.log" 2>&1); echo "rc=$?"
+  done
+  python tools/pmc_traffic.py $(ls $O/pmc_FETCH_SIZE/*/*.db $O/pmc_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_WRITE_SIZE/*/*.db $O/pmc_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic.json | grep -i "ratio\|raw_to" | head
+  rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
+  C1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+  C2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE"
+  for pass in 1 2; do
+    if [ $pass = 1 ]; then C="$C1"; else C="$C2"; fi
+    (cd /tmp && timeout 400 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_sq_$pass" -o p -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > "$R/$O/pmc_sq_$pass.log" 2>&1); echo "pmc sq pass $pass rc=$?"
+  done
+  python tools/pmc_mfma.py $O/pmc_sq_1 $O/pmc_sq_2 > $O/pmc_mfma.json 2> $O/pmc_mfma.err; python -c "
+import json; d=json.load(open('$O/pmc_mfma.json'))['kernels']
+for k,v in d.items(): print(k, {a: round(b,3) for a,b in v.items() if a in ('mfma_util','lds_conflict_frac','wait_frac','issue_stall_frac','valu_insts_per_mfma')})"
+  rm -rf $O/pmc_sq_1 $O/pmc_sq_2
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_rt_$C" -o pmc -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 --no-cpu-baseline > "$R/$O/pmc_rt_$C.log" 2>&1); echo "resnet train pmc $C rc=$?"
+  done
+  python tools/pmc_traffic.py $(ls $O/pmc_rt_FETCH_SIZE/*/*.db $O/pmc_rt_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_rt_WRITE_SIZE/*/*.db $O/pmc_rt_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic_resnet_train.json "bn_,gemm1x1_kernel,wgrad1x1,conv_mfma_kernel,conv_wino_kernel,conv_wino_stat_kernel,conv_wino4_kernel,wgrad_kernel<,wgrad_wino,adam,pack" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 | head -40
+  rm -rf $O/pmc_rt_FETCH_SIZE $O/pmc_rt_WRITE_SIZE
+  lraw train --mode train --steps 4 --warmup 1
+  lraw resnet_h_train16 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  lraw resnet_h_train128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  lraw resnet_f_b32 --arch resnet_f --batch 32
+  lraw resnet_h_b128 --arch resnet_h --batch 128
+  lraw vgg_f_b32 --arch vgg_f --batch 32
+  echo "== rocprof train"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_train" -o train -- python "$R/bench.py" --mode train --steps 3 --warmup 2 --no-cpu-baseline > "$R/$O/rocprof_train.log" 2>&1); echo "rc=$?"
+  summ $O/prof_train $O/bench_train adam_kernel 1
+  echo "== rocprof resnet_h train16"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 5 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
+  summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 2
+  echo "== layer profiles"
+  for cfg in "resnet_h train 16" "vgg_q infer 128" "vgg_q train 128"; do set -- $cfg
+    timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-200
+  done
+  echo "== microbenches"; timeout 300 python tools/microbench_wino4.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino4_b128.txt; tail -1 $O/microbench_wino4_b128.txt
+  timeout 400 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/wino4_diag.txt; tail -2 $O/wino4_diag.txt | cut -c1-300
+  cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json
+  echo "== default bench (with the PMC traffic of this bench.py)"; /usr/bin/time -f "%e s wall" timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-1800; tail -1 $O/bench_default.err
+  du -sh $O
+  ;;
+collect)
+  # dev container: gpurun_out/r05_final -> profiles/r05_*
+  O=gpurun_out/r05_final
+  for n in default train resnet_h_train16; do
+    cp $O/bench_${n}_kernel_stats.csv profiles/r05_bench_${n}_kernel_stats.csv
+    cp $O/bench_${n}_conv_dispatches.csv profiles/r05_bench_${n}_conv_dispatches.csv
+    [ -f $O/bench_${n}_concurrency.txt ] && cp $O/bench_${n}_concurrency.txt profiles/r05_bench_${n}_concurrency.txt
+  done
+  cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json
+  cp $O/pmc_traffic_resnet_train.json profiles/r05_pmc_traffic_resnet_train.json
+  cp $O/pmc_mfma.json profiles/r05_pmc_mfma.json
+  for n in default train resnet_h_train16 resnet_h_train128 resnet_f_b32 resnet_h_b128 vgg_f_b32; do tail -1 $O/bench_$n.log > profiles/r05_bench_${n}_line.json; done
+  grep -h '^{"metric' $O/rocprof_default.log > profiles/r05_bench_default_under_rocprof_line.json
+  grep -E "passed|failed" $O/pytest_gpu.log | tail -1 > profiles/r05_pytest_gpu_tail.txt
+  for f in $O/layer_profile_*.txt; do cp $f profiles/r05_$(basename $f); done
+  cp $O/microbench_wino4_b128.txt profiles/r05_microbench_wino4_b128.txt
+  cp $O/wino4_diag.txt profiles/r05_wino4_diag.txt
+  tail -1 $O/rehearsal_2ranks_selflaunch.log > profiles/r05_rehearsal_2ranks_gloo_selflaunch_line.json
+  tail -1 $O/rehearsal_single_process_train.log > profiles/r05_rehearsal_single_process_4replicas_train_line.json
+  tail -3 $O/smoke.log > profiles/r05_smoke_tail.txt
+  ls profiles/r05_*
+  ;;
 esac
