@@ -633,8 +633,29 @@ class _SideStream:
             return None
         dev = like.device.index
         if dev not in cls._streams:
-            cls._streams[dev] = torch.cuda.Stream(device=like.device)
+            cls._streams[dev] = cls._new_stream(like.device)
         return cls(cls._streams[dev])
+
+    @staticmethod
+    def _new_stream(device):
+        """DREAM_SIDE_STREAM_PRIORITY=low: the weight-gradient stream at the LOWEST HIP stream priority (hipStreamCreateWithPriority;
+        torch.cuda.Stream only offers normal / high), so that the dispatcher prefers the main stream's dependent chain -- the step's
+        critical path -- wherever both have workgroups pending; "high": the opposite (A/B); default: a normal-priority stream."""
+        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "default")
+        if want == "high":
+            return torch.cuda.Stream(device=device, priority=-1)
+        if want != "low":
+            return torch.cuda.Stream(device=device)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+        with torch.cuda.device(device):
+            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+                raise RuntimeError("hipDeviceGetStreamPriorityRange failed")
+            handle = ctypes.c_void_p()
+            if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0:   # 1 = hipStreamNonBlocking
+                raise RuntimeError("hipStreamCreateWithPriority failed")
+        return torch.cuda.ExternalStream(handle.value, device=device)
 
     def __init__(self, stream):
         self.side, self.main = stream, torch.cuda.current_stream()

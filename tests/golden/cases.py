@@ -148,19 +148,22 @@ STRUCTURED_BLOBS = {"vgg_q_400": 4, "vgg_f": 4, "resnet_h": 4}     # blobs per f
 STRUCTURED_BLOB_GAINS = {
     "vgg_q_400": [[1.0, 0.4, 0.35, 0.3], [1.0, 0.9, 0.35, 0.3]],
     "vgg_f": [[1.0, 0.8, 0.6, 0.5]],
-    "resnet_h": [[1.0, 0.4, 0.35, 0.3], [1.0, 0.72, 0.35, 0.3]],
+    "resnet_h": [[1.0, 0.4, 0.35, 0.3], [1.0, 0.62, 0.35, 0.3]],
 }
+# background grey level where not 96: at 128 the normalised background is ~0, i.e. what the convs' zero padding supplies -- the smooth
+# networks' maps then have no dark frame along the borders
+STRUCTURED_BG_LEVEL = {"vgg_q_400": 128.0, "vgg_f": 128.0}
 STRUCTURED_MIN_REJECTIONS = {"vgg_q_400": 2, "vgg_f": 2, "resnet_h": 2}
 # least fraction of (frame, keypoint) maps with a detection the generator accepts (default 0.25); at 400 x 400 the random
 # network gives most maps several comparable peaks, which the 0.25 rule rejects
-STRUCTURED_MIN_DETECTIONS = {"vgg_q_400": 0.7, "vgg_f": 0.55, "resnet_h": 0.7}
+STRUCTURED_MIN_DETECTIONS = {"vgg_q_400": 0.7, "vgg_f": 0.55, "resnet_h": 0.64}
 
 
 def structured_input(case):
     """Frames of a structured case -> (NCHW float32, blob centres)."""
     _, _, _, _, (b, h, w), _, zero_bg = STRUCTURED_CASES[case]
     return blob_image_batch(b, h, w, seed=91, n_blobs=STRUCTURED_BLOBS.get(case, 3), zero_background=zero_bg,
-                            gains=STRUCTURED_BLOB_GAINS.get(case))
+                            gains=STRUCTURED_BLOB_GAINS.get(case), bg_level=STRUCTURED_BG_LEVEL.get(case, 96.0))
 
 
 RESNET_TRAIN_CASES = {
@@ -171,7 +174,7 @@ RESNET_TRAIN_LR = 1e-6                     # SGD
 RESNET_DECODER_PREFIXES = ("upsample.", "upsample2.")
 
 
-def blob_image_batch(b, h, w, seed=0, n_blobs=3, zero_background=False, gains=None):
+def blob_image_batch(b, h, w, seed=0, n_blobs=3, zero_background=False, gains=None, bg_level=96.0):
     """RGB frames with n_blobs coloured Gaussian blobs (sigma 8-14 px).  Default: background level + noise, quantised to uint8,
     then ToTensor + Normalize(0.5, 0.5) as image_batch().  zero_background: float frames, exactly 0 away from the blobs.
     Returns (NCHW float32, blob centres [b, n_blobs, 2] (x, y))."""
@@ -180,7 +183,7 @@ def blob_image_batch(b, h, w, seed=0, n_blobs=3, zero_background=False, gains=No
     imgs = np.zeros((b, h, w, 3))
     centres = np.zeros((b, n_blobs, 2))
     for i in range(b):
-        img = np.zeros((h, w, 3)) if zero_background else np.full((h, w, 3), 96.0) + rs.normal(0, 2.0, (h, w, 3))
+        img = np.zeros((h, w, 3)) if zero_background else np.full((h, w, 3), bg_level) + rs.normal(0, 2.0, (h, w, 3))
         for j in range(n_blobs):
             cx, cy = rs.uniform(0.15 * w, 0.85 * w), rs.uniform(0.15 * h, 0.85 * h)
             sg = rs.uniform(8, 14)

@@ -206,7 +206,9 @@ def structured(dream):
             flat = (z - bg[None, :, None, None]).transpose(1, 0, 2, 3).reshape(k, -1)
             ext = flat[np.arange(k), np.abs(flat).argmax(1)]                # strongest deviation, with its sign
             if recipe == "smooth":
-                ext = flat.max(1)                                           # the bumps are positive; the zero padding darkens the borders
+                # the bumps (blobs a channel's colour filter likes) are positive and scaled to 1; blobs it dislikes clamp the first
+                # layer's ReLU and leave dips below the background, several times deeper for some mixes: the maps span [-6, 1]
+                ext = flat.max(1)
             scale = 1.0 / ext
             w[wk] = (w[wk].double() * torch.as_tensor(scale).view(k, 1, 1, 1)).float()
             w[bk] = torch.as_tensor(-bg * scale).float()

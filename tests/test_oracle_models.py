@@ -65,7 +65,7 @@ def test_structured_fixture_regenerates_from_the_oracle(arch):
     arch, manip, k, last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[case]
     g = np.load(os.path.join(GOLD, "structured_%s.npz" % case))
     m = om.build_model(arch, k)
-    wts = om.structured_weights(m.state_dict()) if recipe == "structured" else om.recipe_weights(m.state_dict())
+    wts = {"structured": om.structured_weights, "smooth": om.smooth_weights, "recipe": om.recipe_weights}[recipe](m.state_dict())
     wts[last + ".weight"], wts[last + ".bias"] = torch.from_numpy(g["final_weight"]), torch.from_numpy(g["final_bias"])
     m.load_state_dict(wts)
     m.eval()
@@ -73,7 +73,10 @@ def test_structured_fixture_regenerates_from_the_oracle(arch):
     assert np.array_equal(centres, g["centres"])
     with torch.no_grad():
         y = m(torch.from_numpy(x))[0].numpy()
-    assert np.abs(y - g["maps"]).max() <= 1e-5 and 0.99 <= np.abs(g["maps"]).max() <= 1.0 + 1e-6
+    # magnitude 1: the strongest response is scaled to 1 (smooth recipe: the strongest POSITIVE one; its maps dip to -6 where a blob's colour
+    # clamps the first layer's ReLU -- the absolute 1e-4 bound of the GPU test is the harder for it)
+    top = g["maps"].max() if recipe == "smooth" else np.abs(g["maps"]).max()
+    assert np.abs(y - g["maps"]).max() <= 1e-5 and 0.99 <= top <= 1.0 + 1e-6 and np.abs(g["maps"]).max() <= 8.0
     kps = op.keypoints_from_belief_maps(y, op.upsampling_offset(y.shape[3], y.shape[2]))
     det = g["keypoints"][..., 0] > -999
     assert np.array_equal(kps[..., 0] > -999, det) and 0 < det.sum() < det.size

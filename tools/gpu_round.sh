@@ -30,6 +30,17 @@ ab1)
     DREAM_BN_FUSION_3X3=1 line rt16_bn3on_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
   done
   ;;
+prio)
+  # weight-gradient side stream at the lowest / highest / normal HIP stream priority (resnet_h training), + the tests this round touched
+  echo "== pytest (touched)"; timeout 1200 python -m pytest tests -m gpu -q -x --timeout 900 -k "structured or bench_dp_check or graph_replay_equals_eager or two_physical or resnet_h_train_step or batchnorm_in_the_3x3" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in a b; do for pr in default low high; do
+    DREAM_SIDE_STREAM_PRIORITY=$pr line rt16_${pr}_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done; done
+  for pr in default low; do
+    DREAM_SIDE_STREAM_PRIORITY=$pr DREAM_OVERLAP_MAX_FRAMES=128 line rt128_overlap_${pr} --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  done
+  line rt128_inorder --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
 stagger)
   timeout 600 python tools/ab_wino4_stagger.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/ab_wino4_stagger.txt
   ;;
