@@ -522,6 +522,20 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
             auto fm = [](float c, f32x2 x, f32x2 y) { return __builtin_elementwise_fma(f32x2{c, c}, x, y); };
             // A^T M A in two lane-local steps that shrink the live set: rows first (6 x 6 -> 6 x 4, in place of the
             // accumulator values just read), then one output column at a time, stored as soon as it exists
+            float r0[2][4];                              // residual / mask values of column 0: in flight during the row transforms
+            if (has_res) {
+                if (all_interior) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r0[h][i] = buffer_load_f32(rbuf, base[h], (unsigned)i * row_b);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) r0[h][i] = buffer_load_f32(rbuf, out_off(h, i, 0), 0u);
+                }
+            }
             f32x2 sA[6][4];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -535,58 +549,71 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                 sA[i][2] = fm(4.0f, m[4], fm(0.25f, m[3], t2));
                 sA[i][3] = fm(-8.0f, m[4], fm(0.125f, m[3], t1)) + m[5];
             }
-            auto finish = [&](float v, unsigned o, unsigned so) {     // residual or mask, ReLU (scale / shift applied before)
-                float rv = 0.0f;
-                if (has_res) {
-                    rv = buffer_load_f32(rbuf, o, so);
-                    v = mask ? (rv > 0.0f ? v : 0.0f) : (late ? v : v + rv);
-                }
+            // The residual / ReLU-mask values of a column are loaded as a GROUP, one column ahead of their use: the loads of column
+            // jj + 1 are issued before the stores of column jj.  (Loaded where they are used -- round 3-4 -- every one of the 64 was
+            // followed by s_waitcnt vmcnt(0) and its store: the compiler cannot move a load above the previous store, the two buffers
+            // may alias (they DO in the transposed conv's data gradient, which accumulates its phases in place) -- 64 serialised
+            // memory round trips per wavefront and block in the data-gradient launches.  Safe under aliasing: a thread reads exactly the
+            // elements it writes, and the loads of column jj + 1 touch other elements than the stores of column jj.)
+            auto finish = [&](float v, float rv) {                    // residual or mask, ReLU (scale / shift applied before)
+                if (has_res) v = mask ? (rv > 0.0f ? v : 0.0f) : (late ? v : v + rv);
                 const float vr = fmaxf(v, 0.0f);
                 v = relu ? vr : v;
                 return (MODE == 2 && late) ? v + rv : v;
             };
-            float keep[2][2];                                         // pool: the even column's values wait for the odd one
+            // `interior` (wave-uniform) -- every tile of the wavefront lies wholly inside the image: the lane's offset is the tile's base
+            // and the position inside the tile rides in the scalar offset; otherwise per-element masks
+            auto columns = [&](auto interior_tag, auto &rcur) {
+                constexpr bool interior = decltype(interior_tag)::value;
+                auto voff = [&](int h, int i, int j2) { return interior ? base[h] : out_off(h, i, j2); };
+                auto soff = [&](int i, int j2) { return interior ? (unsigned)i * row_b + (unsigned)j2 * px_b : 0u; };
+                float keep[2][2];                                     // pool: the even column's values wait for the odd one
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const f32x2 t1 = pk_sub2(sA[1][jj], sA[2][jj]), t2 = sA[1][jj] + sA[2][jj];
-                f32x2 o4[4];
-                o4[0] = (sA[0][jj] + t2) + (sA[3][jj] + sA[4][jj]);
-                o4[1] = fm(-2.0f, sA[4][jj], fm(0.5f, sA[3][jj], t1));
-                o4[2] = fm(4.0f, sA[4][jj], fm(0.25f, sA[3][jj], t2));
-                o4[3] = fm(-8.0f, sA[4][jj], fm(0.125f, sA[3][jj], t1)) + sA[5][jj];
+                for (int jj = 0; jj < 4; ++jj) {
+                    float rnext[2][4];
+                    if (has_res && jj + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o4[i] = o4[i] * f32x2{sc, sc} + f32x2{sh, sh};
-                // stores of this column: `interior` (wave-uniform) -- every tile of the wavefront lies wholly inside the image: the
-                // lane's offset is the tile's base and the position inside the tile rides in the scalar offset; otherwise per-element masks
-                auto store_column = [&](auto interior_tag) {
-                    constexpr bool interior = decltype(interior_tag)::value;
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rnext[h][i] = buffer_load_f32(rbuf, voff(h, i, jj + 1), soff(i, jj + 1));
+                    }
+                    const f32x2 t1 = pk_sub2(sA[1][jj], sA[2][jj]), t2 = sA[1][jj] + sA[2][jj];
+                    f32x2 o4[4];
+                    o4[0] = (sA[0][jj] + t2) + (sA[3][jj] + sA[4][jj]);
+                    o4[1] = fm(-2.0f, sA[4][jj], fm(0.5f, sA[3][jj], t1));
+                    o4[2] = fm(4.0f, sA[4][jj], fm(0.25f, sA[3][jj], t2));
+                    o4[3] = fm(-8.0f, sA[4][jj], fm(0.125f, sA[3][jj], t1)) + sA[5][jj];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o4[i] = o4[i] * f32x2{sc, sc} + f32x2{sh, sh};
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        auto voff = [&](int i, int j2) { return interior ? base[h] : out_off(h, i, j2); };
-                        auto soff = [&](int i, int j2) { return interior ? (unsigned)i * row_b + (unsigned)j2 * px_b : 0u; };
                         if (pool) {
                             float v[4];
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = finish(o4[i][h], 0u, 0u);
+                            for (int i = 0; i < 4; ++i) v[i] = finish(o4[i][h], 0.0f);
                             if ((jj & 1) == 0) {
                                 keep[h][0] = fmaxf(v[0], v[1]);
                                 keep[h][1] = fmaxf(v[2], v[3]);
                             } else {
-                                DREAM_W4_STORE(ybuf, fmaxf(keep[h][0], fmaxf(v[0], v[1])), voff(0, jj >> 1), soff(0, jj >> 1));
-                                DREAM_W4_STORE(ybuf, fmaxf(keep[h][1], fmaxf(v[2], v[3])), voff(1, jj >> 1), soff(1, jj >> 1));
+                                DREAM_W4_STORE(ybuf, fmaxf(keep[h][0], fmaxf(v[0], v[1])), voff(h, 0, jj >> 1), soff(0, jj >> 1));
+                                DREAM_W4_STORE(ybuf, fmaxf(keep[h][1], fmaxf(v[2], v[3])), voff(h, 1, jj >> 1), soff(1, jj >> 1));
                             }
                         } else {
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const unsigned vo = voff(i, jj), so = soff(i, jj);
-                                DREAM_W4_STORE(ybuf, finish(o4[i][h], vo, so), vo, so);
-                            }
+                            for (int i = 0; i < 4; ++i)
+                                DREAM_W4_STORE(ybuf, finish(o4[i][h], has_res ? rcur[h][i] : 0.0f), voff(h, i, jj), soff(i, jj));
                         }
                     }
-                };
-                if (all_interior) store_column(std::true_type{});
-                else store_column(std::false_type{});
-            }
+                    if (has_res && jj + 1 < 4) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) rcur[h][i] = rnext[h][i];
+                    }
+                }
+            };
+            if (all_interior) columns(std::true_type{}, r0);
+            else columns(std::false_type{}, r0);
         }
     };
 

@@ -81,7 +81,7 @@ class _PackedCache:
 class DreamHourglass(nn.Module):
     # input pixels per step up to which weight gradients run on a second stream: +1.4 % at 16 frames of 400x400, -0.2 % at
     # 32 (the VGG layers are large enough to fill the chip on their own; see ResnetSimple for the case where it pays)
-    OVERLAP_MAX_PIXELS = 16 * 400 * 400
+    OVERLAP_MAX_PIXELS = int(os.environ.get("DREAM_VGG_OVERLAP_MAX_FRAMES", "16")) * 400 * 400
 
     def __init__(self, n_keypoints, n_image_input_channels=3, internalize_spatial_softmax=True,
                  learned_beta=True, initial_beta=1.0, skip_connections=False, deconv_decoder=False,
@@ -641,21 +641,27 @@ class _SideStream:
         """DREAM_SIDE_STREAM_PRIORITY=low: the weight-gradient stream at the LOWEST HIP stream priority (hipStreamCreateWithPriority;
         torch.cuda.Stream only offers normal / high), so that the dispatcher prefers the main stream's dependent chain -- the step's
         critical path -- wherever both have workgroups pending; "high": the opposite (A/B); default: a normal-priority stream."""
-        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "default")
+        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "low")
         if want == "high":
             return torch.cuda.Stream(device=device, priority=-1)
         if want != "low":
             return torch.cuda.Stream(device=device)
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-        with torch.cuda.device(device):
-            if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
-                raise RuntimeError("hipDeviceGetStreamPriorityRange failed")
-            handle = ctypes.c_void_p()
-            if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0:   # 1 = hipStreamNonBlocking
-                raise RuntimeError("hipStreamCreateWithPriority failed")
-        return torch.cuda.ExternalStream(handle.value, device=device)
+        # Measured round 5 (profiles/r05_ab_side_stream_priority.txt, resnet_h training, one box, alternating): 16 frames 356.7 (normal) /
+        # 358.0 (low) / 353.7 (high) frames/s; at 128 frames with the overlap forced the low-priority stream reaches 446-450 against the
+        # in-order 434-436, but one run in three still drops to 300 (as in round 4), so the 96-frame threshold stays.
+        try:
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            least, greatest = ctypes.c_int(0), ctypes.c_int(0)
+            with torch.cuda.device(device):
+                if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
+                    raise OSError("hipDeviceGetStreamPriorityRange failed")
+                handle = ctypes.c_void_p()
+                if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0:   # 1 = hipStreamNonBlocking
+                    raise OSError("hipStreamCreateWithPriority failed")
+            return torch.cuda.ExternalStream(handle.value, device=device)
+        except OSError:                                  # no HIP runtime library to call directly: a normal-priority torch stream
+            return torch.cuda.Stream(device=device)
 
     def __init__(self, stream):
         self.side, self.main = stream, torch.cuda.current_stream()

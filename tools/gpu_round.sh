@@ -41,6 +41,24 @@ prio)
   done
   line rt128_inorder --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   ;;
+prio2)
+  # is the b=128 gain of the low-priority weight-gradient stream stable?  (round 4: forced overlap at 128 frames scattered 311..450)
+  for r in a b c; do
+    DREAM_SIDE_STREAM_PRIORITY=low DREAM_OVERLAP_MAX_FRAMES=128 line rt128_overlap_low_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+    line rt128_inorder_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  done
+  for r in a b; do
+    DREAM_SIDE_STREAM_PRIORITY=low DREAM_VGG_OVERLAP_MAX_FRAMES=128 line vt_overlap_low_$r --mode train --steps 3 --warmup 2
+    line vt_inorder_$r --mode train --steps 3 --warmup 2
+  done
+  DREAM_SIDE_STREAM_PRIORITY=low DREAM_OVERLAP_MAX_FRAMES=128 line rt64_overlap_low --arch resnet_h --mode train --batch 64 --steps 4 --warmup 2
+  DREAM_SIDE_STREAM_PRIORITY=low line rt64_default_low --arch resnet_h --mode train --batch 64 --steps 4 --warmup 2
+  line rt64_default --arch resnet_h --mode train --batch 64 --steps 4 --warmup 2
+  timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
+  ;;
+mask)
+  timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
+  ;;
 stagger)
   timeout 600 python tools/ab_wino4_stagger.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/ab_wino4_stagger.txt
   ;;
