@@ -492,50 +492,63 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         const int rem = tau0 - b * tiles_per_img;
         int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         constexpr int NS = pool ? 2 : 4;               // stored positions of a tile: a 4x4 block of outputs, or its 2x2 block of pooled outputs
+        // stored-position bases and bounds of the lane's four tiles (two pairs), up front: the second pair's residual / mask loads start
+        // while the first pair is still being stored
+        unsigned base4[2][2];
+        int lim4[2][2];                                // bits 0..3: stored row i inside the image, bits 4..7: stored column jj (0 for a tile that stores nothing)
+        constexpr int FULL = pool ? 0x33 : 0xff;
 #pragma unroll
-        for (int rp = 0; rp < 2; ++rp) {
-            unsigned base[2];
-            int lim[2];                                // bits 0..3: stored row i inside the image, bits 4..7: stored column jj (0 for a tile that stores nothing)
+        for (int rp = 0; rp < 2; ++rp)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const bool tok = cok & ((tau0 + 2 * rp + h) < p.ntiles);
                 const int oy = NS * ty, ox = NS * tx;
-                base[h] = (unsigned)(((((b - b0e) * So * Ho + So * oy + e.out_oy) * (So * Wo) + So * ox + e.out_ox) * e.Cout + col) * 4);
+                base4[rp][h] = (unsigned)(((((b - b0e) * So * Ho + So * oy + e.out_oy) * (So * Wo) + So * ox + e.out_ox) * e.Cout + col) * 4);
                 int m = 0;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) m |= ((oy + i) < Ho ? 1 << i : 0) | ((ox + i) < Wo ? 16 << i : 0);
-                lim[h] = tok ? m : 0;
+                lim4[rp][h] = tok ? m : 0;
                 const bool wrap_x = (tx + 1 == p.TX);
                 const bool wrap_y = wrap_x & (ty + 1 == p.TY);
                 tx = wrap_x ? 0 : tx + 1;
                 ty = wrap_y ? 0 : (wrap_x ? ty + 1 : ty);
                 b += wrap_y ? 1 : 0;
             }
-            // byte offset of stored position (i, jj) of tile h of the pair, BUFFER_OOB where nothing may be written -- computed where
-            // it is used (the accumulators leave no registers for a table)
-            auto out_off = [&](int h, int i, int jj) {
-                const bool inb = ((lim[h] >> i) & (lim[h] >> (4 + jj)) & 1) != 0;
-                return inb ? base[h] + (unsigned)i * row_b + (unsigned)jj * px_b : BUFFER_OOB;
-            };
-            constexpr int FULL = pool ? 0x33 : 0xff;
-            const bool all_interior = wave_all((lim[0] == FULL) & (lim[1] == FULL));
+        // byte offset of stored position (i, jj) of tile h of pair rp, BUFFER_OOB where nothing may be written -- computed where it is
+        // used (the accumulators leave no registers for a table)
+        auto out_off4 = [&](int rp, int h, int i, int jj) {
+            const bool inb = ((lim4[rp][h] >> i) & (lim4[rp][h] >> (4 + jj)) & 1) != 0;
+            return inb ? base4[rp][h] + (unsigned)i * row_b + (unsigned)jj * px_b : BUFFER_OOB;
+        };
+        // `interior` (wave-uniform) -- every tile of the wavefront's pair lies wholly inside the image: the lane's offset is the tile's base
+        // and the position inside the tile rides in the scalar offset; otherwise per-element masks
+        bool interior4[2];
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) interior4[rp] = wave_all((lim4[rp][0] == FULL) & (lim4[rp][1] == FULL));
+        // residual / mask values of column 0 of a pair (8 loads): in flight during the row transforms (pair 0) / the last column of pair 0
+        auto load_col0 = [&](int rp, float (&r)[2][4]) {
+            if (interior4[rp]) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[h][i] = buffer_load_f32(rbuf, base4[rp][h], (unsigned)i * row_b);
+            } else {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[h][i] = buffer_load_f32(rbuf, out_off4(rp, h, i, 0), 0u);
+            }
+        };
+        float r0[2][4], r0n[2][4];
+        if (has_res) load_col0(0, r0);
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp) {
+            const unsigned (&base)[2] = base4[rp];
+            auto out_off = [&](int h, int i, int jj) { return out_off4(rp, h, i, jj); };
+            const bool all_interior = interior4[rp];
             auto fm = [](float c, f32x2 x, f32x2 y) { return __builtin_elementwise_fma(f32x2{c, c}, x, y); };
             // A^T M A in two lane-local steps that shrink the live set: rows first (6 x 6 -> 6 x 4, in place of the
             // accumulator values just read), then one output column at a time, stored as soon as it exists
-            float r0[2][4];                              // residual / mask values of column 0: in flight during the row transforms
-            if (has_res) {
-                if (all_interior) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) r0[h][i] = buffer_load_f32(rbuf, base[h], (unsigned)i * row_b);
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) r0[h][i] = buffer_load_f32(rbuf, out_off(h, i, 0), 0u);
-                }
-            }
             f32x2 sA[6][4];
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -571,6 +584,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     float rnext[2][4];
+                    if (has_res && jj == 3 && rp == 0) load_col0(1, r0n);
                     if (has_res && jj + 1 < 4) {
 #pragma unroll
                         for (int h = 0; h < 2; ++h)
@@ -614,6 +628,12 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
             };
             if (all_interior) columns(std::true_type{}, r0);
             else columns(std::false_type{}, r0);
+            if (has_res && rp == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r0[h][i] = r0n[h][i];
+            }
         }
     };
 

@@ -64,6 +64,9 @@ DREAM_DEVICE f32x4 bn_relu4(f32x4 x, f32x4 a, f32x4 b) {
 }
 
 template <int KS, bool PRE = false, int EPI = 0>
+#ifndef DREAM_G1_PIPELINED
+#define DREAM_G1_PIPELINED 1
+#endif
 __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     __shared__ float s_part[KS > 1 ? 4 * 64 * 64 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
     __shared__ double s_stat[(KS > 1 && EPI != 0) ? 4 * 16 * 8 : 1];      // [wave][lane & 15][4 channels][2]: the waves' sums
@@ -175,6 +178,61 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
         zmu = *(const f32x4 *)(p.st_mean + c0);
         zis = *(const f32x4 *)(p.st_invstd + c0);
     }
+    if constexpr (KS == 1 && DREAM_G1_PIPELINED) {
+        // One wavefront owns all 16 rows of its lanes: the residual / mask operands of row i + 1 are loaded BEFORE row i is stored.  (In the
+        // loop below every row is its own predicated block -- load, s_waitcnt vmcnt(0), compute, store: 16 serialised memory round trips
+        // per wavefront and tile.)  Loads are unconditional on a clamped row (a row past M is never stored), so the body is straight-line
+        // code under ONE branch; safe if the output aliases an operand: a thread reads exactly the elements it writes, one row ahead.
+        if (cok) {
+            const int row0 = rb * 64 + 4 * lg;
+            const long last = p.M - 1;
+            auto offset_of = [&](int i) {
+                const long row = row0 + 16 * (i >> 2) + (i & 3);
+                return (size_t)(row < last ? row : last) * p.N + c0;
+            };
+            f32x4 nres = {0.0f, 0.0f, 0.0f, 0.0f}, nz = nres, nya = nres;
+            auto load_row = [&](int i) {
+                const size_t o = offset_of(i);
+                if (p.residual != nullptr) nres = *(const f32x4 *)(p.residual + o);
+                if (EPI == 2) {
+                    nz = *(const f32x4 *)(p.st_z + o);
+                    if (mask_y) nya = *(const f32x4 *)(p.st_yact + o);
+                }
+            };
+            load_row(0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = i >> 2, r = i & 3;
+                const f32x4 res = nres, z = nz, ya = nya;
+                if (i + 1 < 16) load_row(i + 1);
+                f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+                v = v * sc + sh;
+                if (p.residual != nullptr) v = v + res;
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                }
+                const bool rok = row0 + 16 * m + r < p.M;
+                if (EPI == 1 && rok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { st0[e] += (double)v[e]; st1[e] += (double)v[e] * (double)v[e]; }
+                }
+                if (EPI == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool on = mask_y ? ya[e] > 0.0f : __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f;
+                        v[e] = on ? v[e] : 0.0f;
+                        const float xh = (z[e] - zmu[e]) * zis[e];
+                        if (rok) {
+                            st0[e] += (double)v[e];
+                            st1[e] += (double)v[e] * (double)xh;
+                        }
+                    }
+                }
+                if (rok) *(f32x4 *)(p.y + (size_t)(row0 + 16 * m + r) * p.N + c0) = v;
+            }
+        }
+    } else
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll

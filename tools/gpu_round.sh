@@ -56,6 +56,34 @@ prio2)
   line rt64_default --arch resnet_h --mode train --batch 64 --steps 4 --warmup 2
   timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
   ;;
+mask2)
+  # after the epilogue fix (residual / mask loads grouped one column ahead): parity, the microbench again, the training lines
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "winograd4 or wino4 or structured or backward_ops or train_step or train_steps or reference_golden or variant or skip or convT or conv4x4 or general_conv" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
+  line vt_a --mode train --steps 4 --warmup 2
+  line vt_b --mode train --steps 4 --warmup 2
+  line rt16_a --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  line vft32 --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
+  line dflt
+  ;;
+g1)
+  # gemm1x1 epilogue: residual / mask operands one row ahead (product) vs the predicated per-row form (build/libG0.so), resnet paths; then the
+  # F(4x4) mask microbench with the cross-pair prefetch
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv1x1 or resnet or bn_fused or winograd4 or wino4 or backward_ops or convT" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
+  for r in a b; do
+    line rt16_pipe_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    withlib G0 line rt16_G0_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    line rh128_pipe_$r --arch resnet_h --batch 128
+    withlib G0 line rh128_G0_$r --arch resnet_h --batch 128
+  done
+  line rf32_pipe --arch resnet_f --batch 32
+  withlib G0 line rf32_G0 --arch resnet_f --batch 32
+  line rt128_pipe --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  withlib G0 line rt128_G0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  line vt --mode train --steps 4 --warmup 2
+  ;;
 mask)
   timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
   ;;
