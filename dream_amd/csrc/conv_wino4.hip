@@ -66,6 +66,10 @@
 #define DREAM_W4_STAGGER_N 0
 #define DREAM_W4_STAGGER_PCT 0
 #endif
+// patch loads of wavefronts 4-7 (wide shape, plain 3x3 conv) this many slots later than those of wavefronts 0-3 (0: same slots)
+#ifndef DREAM_W4_STAG_LX
+#define DREAM_W4_STAG_LX 0
+#endif
 #ifndef DREAM_W4_RUNNING_WOFF
 #define DREAM_W4_RUNNING_WOFF 1
 #endif
@@ -366,8 +370,9 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     // the block (chunks run in pairs: the ring index of the weight stream is a compile-time constant, 72 % 8 == 0).  `last`
     // (wave-uniform; only the odd chunk can be the last one): the next chunk is chunk 0 of the NEXT block -- its plan is
     // computed here, the weight stream wraps around.  One instantiation per parity, one call site each: the loop below.
-    auto chunk = [&](auto ph_tag, bool last, int c, int tile0n, int b0n) __attribute__((always_inline)) {
+    auto chunk = [&](auto ph_tag, auto stag_tag, bool last, int c, int tile0n, int b0n) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
+        constexpr int STAG = decltype(stag_tag)::value;
 #ifndef DREAM_W4_S1
 #define DREAM_W4_S1 10
 #define DREAM_W4_S2 13
@@ -378,7 +383,13 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         // issues its six patch loads in slot 0, so that they have four slots to arrive.
         constexpr int NSLOT = (NPOS + 1) / 2;
         constexpr int S1 = PAT ? NSLOT - DREAM_W4_PAT_S1OFF : DREAM_W4_S1, S2 = PAT ? S1 + 3 : DREAM_W4_S2; // pass 1 in slots S1 .. S1 + 2; staging reads in slot S2, pass 2 in S2 + 1 .. S2 + 3
-        constexpr int LX = PAT ? 1 : DREAM_W4_LX;         // patch loads in slots 0 .. LX - 1 (6 / LX per slot)
+        constexpr int LX = PAT ? 1 : DREAM_W4_LX;         // patch loads in slots LX0 .. LX0 + LX - 1 (6 / LX per slot)
+        // STAG (wavefronts 4-7 of the wide shape: the SECOND wavefront of every SIMD): the patch loads come DREAM_W4_STAG_LX slots later.  A
+        // patch load misses to HBM, loads return in order, so the weight operands issued behind it stall the wavefront three slots
+        // later -- both wavefronts of a SIMD at the same slots, matrix pipe idle.  Shifted, one wavefront's MFMAs cover the other's stall.
+        // (The whole block loop is instantiated twice, chosen once per wavefront: no branch and no control-flow join inside it.)
+        constexpr int LX0 = STAG ? DREAM_W4_STAG_LX : 0;
+        static_assert(LX0 + LX <= S1, "the patch loads must be issued before pass 1");
         const unsigned coff = last ? 0u : (unsigned)((c + 1) * W4K * 4);
         const int cnext = last ? 0 : (c + 1) * W4P;                          // first position of the next chunk in the weight stream
         if (PH == 1 && last) xbuf = block_xbuf(b0n);                        // this block's loads are all issued: from here on the next block's
@@ -415,13 +426,13 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                     load_b(0);
                     if (s + 1 < NSLOT) read_a((s + 1) & 1, k0 + 2, PH);
                     if (PH == 1 && s == 0 && last) plan_item(tile0n, b0n);
-                    if (s < LX) { for (int c2 = 0; c2 < 3 / LX; ++c2) load_x((6 / LX) * s + c2); }
+                    if (s >= LX0 && s < LX0 + LX) { for (int c2 = 0; c2 < 3 / LX; ++c2) load_x((6 / LX) * (s - LX0) + c2); }
                     if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1));
                     if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(0); pass2_read(1); }
                     if (!(DREAM_W4_DIAG & 8) && s > S2 && s <= S2 + 3) pass2_piece(2 * (s - S2 - 1), 1 - PH);
                 } else if (k == 1) {
                     load_b(1);
-                    if (s < LX) { for (int c2 = 3 / LX; c2 < 6 / LX; ++c2) load_x((6 / LX) * s + c2); }
+                    if (s >= LX0 && s < LX0 + LX) { for (int c2 = 3 / LX; c2 < 6 / LX; ++c2) load_x((6 / LX) * (s - LX0) + c2); }
                     if (!(DREAM_W4_DIAG & 8) && s == S2) { pass2_read(2); pass2_read(3); }
                 } else if (k == 2) {
                     if (!(DREAM_W4_DIAG & 8) && s >= S1 && s < S1 + 3) pass1_piece(2 * (s - S1) + 1);
@@ -460,7 +471,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
 
     // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ------------------------
     constexpr bool pool = MODE == 1, has_res = MODE >= 2, mask = MODE == 3;
-    auto epilogue = [&](int tile0e, int b0e) {
+    auto epilogue = [&](auto site_tag, int tile0e, int b0e) {
         // Everything the epilogue needs is read again from the kernel-argument segment (scalar loads, once per block): kept in
         // SGPRs across the MFMA phases these values push the kernel past its scalar register file (spills through VGPR lanes).
         if (DREAM_W4_DIAG & 128) {                     // diagnostics: no epilogue (the accumulators stay live)
@@ -469,7 +480,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                 if (pat4_active(PAT, pp)) asm volatile("" :: "v"(acc[pp]));
             return;
         }
-        const auto &e = *DREAM_KERNARG(p);
+        const auto &e = *DREAM_KERNARG_SITE(p, decltype(site_tag)::value);
         const bool relu = (e.flags & DREAM_CONV_RELU) != 0;
         const bool late = MODE == 2 && (e.flags & DREAM_CONV_RES_AFTER_RELU) != 0;    // the residual is a skip connection: added after the ReLU
         // Ho x Wo: grid of stored conv positions; So: their spacing in the stored tensor (2 for a transposed conv's phase)
@@ -638,22 +649,30 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     };
 
     // ---- the blocks of this workgroup (chunks in pairs: nchunks is even, host side) ----------------------------------------------
-    while (true) {
-        const int tile0n = block_tile0(tb + J);
-        const int b0n = div_magic40(tile0n, p.magic_tpi);
-        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    auto run_blocks = [&](auto stag_tag) __attribute__((always_inline)) {
+        while (true) {
+            const int tile0n = block_tile0(tb + J);
+            const int b0n = div_magic40(tile0n, p.magic_tpi);
+            const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int pp = 0; pp < W4P; ++pp)
-            if (pat4_active(PAT, pp)) acc[pp] = zero;
-        for (int c = 0; c < nchunks; c += 2) {
-            chunk(ph0, false, c, tile0n, b0n);
-            chunk(ph1, c + 2 == nchunks, c + 1, tile0n, b0n);
+            for (int pp = 0; pp < W4P; ++pp)
+                if (pat4_active(PAT, pp)) acc[pp] = zero;
+            for (int c = 0; c < nchunks; c += 2) {
+                chunk(ph0, stag_tag, false, c, tile0n, b0n);
+                chunk(ph1, stag_tag, c + 2 == nchunks, c + 1, tile0n, b0n);
+            }
+            epilogue(stag_tag, tile0, b0);
+            tb += J;
+            if (tb >= blk_end) break;
+            tile0 = tile0n;
+            b0 = b0n;
         }
-        epilogue(tile0, b0);
-        tb += J;
-        if (tb >= blk_end) break;
-        tile0 = tile0n;
-        b0 = b0n;
+    };
+    if constexpr (!NARROW && PAT == 0 && DREAM_W4_STAG_LX > 0) {
+        if (wave >= W4NW / 2) run_blocks(std::integral_constant<int, 1>{});
+        else run_blocks(std::integral_constant<int, 0>{});
+    } else {
+        run_blocks(std::integral_constant<int, 0>{});
     }
 }
 

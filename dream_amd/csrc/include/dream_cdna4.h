@@ -20,15 +20,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // values that are needed once per tile block and would otherwise sit in SGPRs across the main loop (the empty asm makes the
 // pointer opaque, so the loads cannot be merged with the kernel's initial argument loads and hoisted).  `arg` must be the
 // kernel's single by-value struct.
-template <class T>
+// TAG: distinct call sites in the two arms of a branch get distinct asm strings (identical statements are merged into the join block, and
+// the merged pointer then lives in a VGPR: "illegal VGPR to SGPR copy").
+template <int TAG = 0, class T>
 DREAM_DEVICE const __attribute__((address_space(4))) T *kernarg_again(const T &) {
     // constant address space: the reads become s_load (a generic pointer would make them flat loads into VGPRs -- VMEM latency, and
     // every buffer descriptor built from them non-uniform: a waterfall loop around each access)
     const __attribute__((address_space(4))) T *kp = (const __attribute__((address_space(4))) T *)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
+    asm volatile("; kernarg pointer, site %1" : "+s"(kp) : "n"(TAG));
     return kp;
 }
 #define DREAM_KERNARG(arg) kernarg_again(arg)
+#define DREAM_KERNARG_SITE(arg, tag) kernarg_again<tag>(arg)
 // a wave-uniform value the optimiser may not see through (kept in a scalar register)
 #define DREAM_OPAQUE_SGPR(x) asm volatile("" : "+s"(x))
 

@@ -10,6 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define DREAM_DEVICE inline __attribute__((always_inline))
 #define DREAM_KERNARG(arg) (&(arg))
+#define DREAM_KERNARG_SITE(arg, tag) (&(arg))
 #define DREAM_OPAQUE_SGPR(x) asm volatile("" : "+r"(x))
 #define DREAM_DYNAMIC_LDS(type, var) type *var = (type *)emu::tb->dyn_lds
 

@@ -84,6 +84,14 @@ g1)
   withlib G0 line rt128_G0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   line vt --mode train --steps 4 --warmup 2
   ;;
+diag)
+  DREAM_W4_DIAG_KS=${2:-128,256,15,2,16,8} timeout 600 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/wino4_diag.txt
+  ;;
+lp)
+  for cfg in "vgg_q train 128" "resnet_h train 16" "resnet_h infer 128"; do set -- $cfg
+    timeout 400 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -12 $O/layer_profile_$1_$2$3.txt | cut -c1-200
+  done
+  ;;
 mask)
   timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
   ;;
