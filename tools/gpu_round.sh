@@ -84,15 +84,6 @@ g1)
   withlib G0 line rt128_G0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   line vt --mode train --steps 4 --warmup 2
   ;;
-vt)
-  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "batched_packing or train_step or train_steps or reference_golden or data_parallel or graph_replay" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
-  for r in a b; do
-    DREAM_PACK_BATCHED=1 line vt_batched_$r --mode train --steps 4 --warmup 2
-    DREAM_PACK_BATCHED=0 line vt_lazy_$r --mode train --steps 4 --warmup 2
-  done
-  DREAM_PACK_BATCHED=1 line vft_batched --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
-  DREAM_PACK_BATCHED=0 line vft_lazy --arch vgg_f --mode train --batch 32 --steps 4 --warmup 2
-  ;;
 diag)
   DREAM_W4_DIAG_KS=${2:-128,256,15,2,16,8} timeout 600 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/wino4_diag.txt
   ;;
