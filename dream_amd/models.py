@@ -51,39 +51,6 @@ class _PackedCache:
 
     def __init__(self):
         self._store = {}
-        # batched re-packing of a training step (repack_batched): key -> (weight, packed, job descriptions), noted while `recording`
-        self.records = {}
-        self.recording = False
-        self.table = None
-        self.steps = 0
-
-    def repack_batched(self, device):
-        """A vgg_q training step re-packs its ~60 Winograd weight copies with one tiny launch each (1.3 ms of a 185-ms step).  As
-        ResnetSimple._repack_weights: the FIRST training step records which batchable copies are built from which parameter; from the
-        second on ONE launch (dream_pack_weights_batched) rewrites all of them in place at the start of the step and stamps the cache
-        entries with the parameters' new versions.  Copies the table does not cover (tap-major ones for the direct kernel, the
-        upsample-fused convs' derived weights) stay lazy.  Not during a hipGraph capture (the replicas capture packing with the step)."""
-        if device.type != "cuda" and not os.environ.get("DREAM_PACK_BATCHED_ON_CPU"):
-            return
-        if (device.type == "cuda" and torch.cuda.is_current_stream_capturing()) or os.environ.get("DREAM_PACK_BATCHED", "1") == "0":
-            self.recording = False
-            return
-        if self.table is not None and any(ds[0][1].data_ptr() != w.data_ptr() for _, (w, _, ds) in self.keys):
-            self.table, self.records, self.steps = None, {}, 0         # the parameters moved (.to(), a new flat buffer): record again
-        if self.table is None:
-            self.steps += 1
-            if self.steps == 1 or not self.records:
-                self.recording = True
-                return
-            self.recording = False
-            self.keys = list(self.records.items())
-            descs = [d for _, (_, _, ds) in self.keys for d in ds]
-            self.table, self.njobs = ops.pack_job_table(descs, device), len(descs)
-        tags = {key: (w._version, w.data_ptr(), w.device) for key, (w, _, _) in self.keys}
-        if any(self._store.get(key, (None,))[0] != tag or self._store[key][1] is not self.records[key][1] for key, tag in tags.items()):
-            ops.pack_weights_batched(self.table, self.njobs)
-            for key, tag in tags.items():
-                self._store[key] = (tag, self.records[key][1])
 
     def get(self, weight, mode, f16x3=False):
         """mode 0 / 1: forward / transposed tap-major packing; "ups": the conv that follows a nearest x2 upsample, as the
@@ -92,7 +59,7 @@ class _PackedCache:
         tag = (weight._version, weight.data_ptr(), weight.device)
         hit = self._store.get(key)
         if hit is None or hit[0] != tag:
-            with torch.no_grad(), ops.record_packs() as descs:
+            with torch.no_grad():
                 if mode in ("wino0", "wino1"):                    # Winograd F(2x2,3x3) transformed weights (fwd / data gradient)
                     packed = ops.pack_weight_winograd(weight.detach(), int(mode[-1]))
                 elif mode in ("wino4_0", "wino4_1"):              # Winograd F(4x4,3x3)
@@ -108,9 +75,6 @@ class _PackedCache:
                     packed = ops.pack_conv_weight_f16x3(weight.detach(), mode) if f16x3 else ops.pack_weight(weight.detach(), mode)
                 hit = (tag, packed)
             self._store[key] = hit
-            # batchable: every pack made here is one of the table's kinds and reads the parameter itself (not a derived copy)
-            if self.recording and descs and all(d[1].data_ptr() == weight.data_ptr() for d in descs):
-                self.records[key] = (weight, packed, list(descs))
         return hit[1]
 
 
@@ -346,8 +310,6 @@ class DreamHourglass(nn.Module):
             return self.run_forward_f16x3(x, params, x_is_nhwc, x_amax), []
         if self.precision not in ("fp32", "fp16x3"):
             raise ValueError("unknown precision %r" % (self.precision,))
-        if save:
-            self._packed.repack_batched(x.device)
         saved = []
         keep = {}
         act = x

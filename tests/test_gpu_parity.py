@@ -1090,34 +1090,6 @@ def test_resnet_batched_packing_equals_lazy_packing(monkeypatch):
         assert torch.equal(pa, pb), k
 
 
-def test_hourglass_batched_packing_equals_lazy_packing(monkeypatch):
-    """_PackedCache.repack_batched (round 5): the same for the VGG hourglass -- from the second training step on ONE launch refreshes
-    the Winograd weight copies; four Adam steps with an evaluation in between equal DREAM_PACK_BATCHED=0 bit for bit."""
-    x = torch.from_numpy(cases.image_batch(4, 64, 96, seed=44)).to(DEV)
-
-    def run(flag):
-        monkeypatch.setenv("DREAM_PACK_BATCHED", flag)
-        net = _dp_network("vgg_q", [0], optimizer="adam", lr=1e-5, in_res=(96, 64))
-        net.enable_training()
-        ow, oh = net.trained_net_output_resolution()
-        t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=(96, 64), seed=44)).to(DEV)
-        losses = [net.train([x], t).item() for _ in range(3)]
-        net.enable_evaluation()
-        with torch.no_grad():
-            maps = net.inference(x)[0].clone()
-        net.enable_training()
-        losses.append(net.train([x], t).item())
-        return net, losses, maps
-
-    a, la, ma = run("1")
-    b, lb, mb = run("0")
-    pc = a.model.module._packed
-    assert pc.table is not None and pc.njobs >= 20 and b.model.module._packed.table is None, getattr(pc, "njobs", None)
-    assert la == lb and torch.equal(ma, mb), (la, lb)
-    for (k, pa), (_, pb) in zip(a.model.named_parameters(), b.model.named_parameters()):
-        assert torch.equal(pa, pb), k
-
-
 def test_allreduce_entry_point(monkeypatch):
     """dream_allreduce_sum_f32: buffers that share the one GPU of this box are summed locally; with DREAM_FORCE_RCCL=1 a
     one-device list goes through RCCL itself (dlopen, ncclCommInitAll, group call) -- the sequence an 8-GPU node runs."""
