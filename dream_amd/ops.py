@@ -816,6 +816,29 @@ def _ctr_words(counters, n):
     return counters
 
 
+# DREAM_BN_DEBUG=1 (round-4 advice): the "last arriver finishes" launches write their per-channel outputs from ONE wavefront that draws
+# the last ticket; if a ticket word were ever left non-zero (an aborted launch) or the hand-ordered visibility failed, nobody would finish
+# and the outputs -- torch.empty tensors -- would silently keep garbage.  The debug mode NaN-fills them before the launch, synchronises
+# after it and raises unless every output is finite and every ticket word is zero again.  (Slow: one synchronisation per launch.)
+BN_DEBUG = _os.environ.get("DREAM_BN_DEBUG", "0") == "1"
+
+
+def _bn_debug_begin(*outs):
+    if BN_DEBUG:
+        for o in outs:
+            o.fill_(float("nan"))
+
+
+def _bn_debug_end(name, ctr, *outs):
+    if BN_DEBUG:
+        torch.cuda.synchronize(ctr.device) if ctr.is_cuda else None
+        if int(ctr.abs().max()) != 0:
+            raise RuntimeError("dream_amd (DREAM_BN_DEBUG): %s left non-zero ticket words" % name)
+        for o in outs:
+            if not bool(torch.isfinite(o).all()):
+                raise RuntimeError("dream_amd (DREAM_BN_DEBUG): %s did not finish its per-channel outputs (the last-arriver wavefront never ran)" % name)
+
+
 def _bn_args(bn):
     # nn.BatchNorm2d(momentum=None) means a cumulative moving average (factor 1 / num_batches_tracked), which the kernels' running-
     # statistics update does not implement; the reference's models use 0.1 (dream/models.py:45-47 and torchvision's default)
@@ -845,8 +868,10 @@ def bn_stats(z_nhwc, bn, counters):
     ab, mean, invstd = _bn_outputs(c, z.device)
     ws = _workspace(_hip.lib().dream_bn_stats_workspace(c), z.device)
     ctr = _ctr_words(counters, _hip.lib().dream_bn_stats_counters(c))
+    _bn_debug_begin(ab, mean, invstd)
     call("dream_bn_stats_nhwc_f32", ptr(z), *_bn_args(bn), ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(ctr), z.numel() // c, c,
          stream())
+    _bn_debug_end("bn_stats", ctr, ab, mean, invstd)
     _bn_bump(bn)
     return ab, mean, invstd
 
@@ -871,8 +896,10 @@ def bn_bwd_stats(z_nhwc, dy, mean, invstd, counters, y_act=None, ab=None):
     dbeta = torch.empty_like(dgamma)
     ws = _workspace(_hip.lib().dream_bn_stats_workspace(c), z.device)
     ctr = _ctr_words(counters, _hip.lib().dream_bn_stats_counters(c))
+    _bn_debug_begin(dgamma, dbeta)
     call("dream_bn_bwd_stats_nhwc_f32", ptr(z), ptr(_f32(dy)), ptr(y_act), ptr(ab), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta),
          ptr(ws), ptr(ctr), z.numel() // c, c, _mask_mode(y_act, ab), stream())
+    _bn_debug_end("bn_bwd_stats", ctr, dgamma, dbeta)
     return dgamma, dbeta
 
 
@@ -897,8 +924,10 @@ def conv1x1_bn(x_nhwc, packed, cout, bn, counters, pre_ab=None, shift=None):
     ab, mean, invstd = _bn_outputs(cout, x.device)
     ws = _workspace(_hip.lib().dream_conv1x1_bn_workspace(m, cout), x.device)
     ctr = _ctr_words(counters, _hip.lib().dream_conv1x1_bn_counters(m, cout))
+    _bn_debug_begin(ab, mean, invstd)
     call("dream_conv1x1_bnstats_nhwc_f32", ptr(x), ptr(packed), ptr(shift), ptr(pre_ab), ptr(z), m, cin, cout, cin, *_bn_args(bn),
          ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(ctr), stream())
+    _bn_debug_end("conv1x1_bn", ctr, ab, mean, invstd)
     _bn_bump(bn)
     return z, ab, mean, invstd
 
@@ -918,8 +947,10 @@ def conv1x1_bwd_bnmask(dy_nhwc, packed_t, cin, z_nhwc, ab, mean, invstd, counter
     ctr = _ctr_words(counters, _hip.lib().dream_conv1x1_bn_counters(m, cin))
     if residual is not None and tuple(residual.shape) != tuple(g.shape):
         raise RuntimeError("conv1x1_bwd_bnmask: residual shape %s != %s" % (tuple(residual.shape), tuple(g.shape)))
+    _bn_debug_begin(dgamma, dbeta)
     call("dream_conv1x1_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_t), ptr(residual), ptr(g), m, k, cin, k, ptr(_f32(z_nhwc)),
          None if y_act is not None else ptr(ab), ptr(y_act), ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(ctr), stream())
+    _bn_debug_end("conv1x1_bwd_bnmask", ctr, dgamma, dbeta)
     return g, dgamma, dbeta
 
 
@@ -933,8 +964,10 @@ def conv3x3_winograd_bn(x_nhwc, packed_u, cout, bn, counters, shift=None):
     ab, mean, invstd = _bn_outputs(cout, x.device)
     ws = _workspace(lib.dream_conv3x3_winograd_bn_workspace(b, h, w, cout), x.device)
     ctr = _ctr_words(counters, lib.dream_conv3x3_winograd_bn_counters(b, h, w, cout))
+    _bn_debug_begin(ab, mean, invstd)
     call("dream_conv3x3_winograd_bnstats_nhwc_f32", ptr(x), ptr(packed_u), ptr(shift), ptr(z), b, h, w, cin, cout, *_bn_args(bn),
          ptr(ab), ptr(mean), ptr(invstd), ptr(ws), ptr(ctr), stream())
+    _bn_debug_end("conv3x3_winograd_bn", ctr, ab, mean, invstd)
     _bn_bump(bn)
     return z, ab, mean, invstd
 
@@ -952,8 +985,10 @@ def conv3x3_winograd_bwd_bnmask(dy_nhwc, packed_u_t, cin, z_nhwc, ab, mean, invs
     dbeta = torch.empty_like(dgamma)
     ws = _workspace(lib.dream_conv3x3_winograd_bn_workspace(b, h, w, cin), dy.device)
     ctr = _ctr_words(counters, lib.dream_conv3x3_winograd_bn_counters(b, h, w, cin))
+    _bn_debug_begin(dgamma, dbeta)
     call("dream_conv3x3_winograd_bwd_bnmask_nhwc_f32", ptr(dy), ptr(packed_u_t), ptr(_f32(z_nhwc)), ptr(g), b, h, w, k, cin, ptr(ab),
          ptr(mean), ptr(invstd), ptr(dgamma), ptr(dbeta), ptr(ws), ptr(ctr), stream())
+    _bn_debug_end("conv3x3_winograd_bwd_bnmask", ctr, dgamma, dbeta)
     return g, dgamma, dbeta
 
 

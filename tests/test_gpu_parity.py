@@ -190,6 +190,59 @@ def test_bn_fused_statistics_are_deterministic_and_tickets_rearm():
     assert float((runs[0][2].double() - zz.mean((0, 1, 2))).abs().max()) < 1e-5 * float(zz.abs().max())
 
 
+def test_bn_fused_launches_stress_mixed_shapes_two_streams(monkeypatch):
+    """Stress of the "last arriver finishes" launches (round-4 advice; the ordering they rely on -- relaxed agent-scope atomics, an
+    inline s_waitcnt, sc1 loads -- is outside the formal memory model and cannot be exercised by the CPU emulator): 60 rounds of mixed
+    shapes (few rows / many rows per channel block, one- and two-level ticket trees, the K splits of the GEMM) issued on TWO streams
+    at once from one shared ticket buffer, under DREAM_BN_DEBUG=1 -- outputs NaN-filled before every launch, finite afterwards, ticket
+    words zero again.  Every result must equal the first round's bit for bit and torch's batch statistics to round-off."""
+    monkeypatch.setattr(ops, "BN_DEBUG", True)
+    torch.manual_seed(11)
+    shapes = [(2, 13, 13, 512), (16, 25, 25, 256), (4, 100, 100, 64), (16, 50, 50, 128), (1, 7, 9, 64), (16, 104, 104, 256)]
+    zs = [torch.randn(*sh, device=DEV) * 1.5 + 0.25 for sh in shapes]
+    bns = [torch.nn.BatchNorm2d(sh[3]).to(DEV) for sh in shapes]
+    gemm_in = zs[1]
+    w = torch.randn(1024, 256, 1, 1, device=DEV) * 0.05
+    packed, rows = ops.pack_conv1x1_weight(w, 0)
+    bn_g = torch.nn.BatchNorm2d(1024).to(DEV)
+    buf = ops.bn_counter_buffer(torch.device(DEV), words=1 << 14)
+    pos = [0]
+
+    def take(n):                                           # as ResnetSimple._ctr: every launch its own slice, the cursor wraps
+        if pos[0] + n > buf.numel():
+            pos[0] = 0
+        out = buf[pos[0]:pos[0] + n]
+        pos[0] += n
+        return out
+
+    side = torch.cuda.Stream()
+    first = None
+    for rnd in range(60):
+        res = []
+        for i, (z, bn) in enumerate(zip(zs, bns)):
+            if i % 2:                                      # odd shapes on the side stream, concurrently with the even ones
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    res.append(ops.bn_stats(z, bn, take))
+            else:
+                res.append(ops.bn_stats(z, bn, take))
+        torch.cuda.current_stream().wait_stream(side)
+        zg, ab, mean, invstd = ops.conv1x1_bn(gemm_in, packed, rows, bn_g, take, pre_ab=res[1][0])
+        dy = zs[1]
+        dgam, dbet = ops.bn_bwd_stats(zs[1], dy, res[1][1], res[1][2], take, ab=res[1][0])
+        flat = [t for r in res for t in r] + [ab, mean, invstd, dgam, dbet]
+        torch.cuda.synchronize()
+        if first is None:
+            first = [t.clone() for t in flat]
+            for z, r in zip(zs, res):
+                zd = z.double()
+                assert float((r[1].double() - zd.mean((0, 1, 2))).abs().max()) < 1e-5
+        else:
+            for a, b in zip(flat, first):
+                assert torch.equal(a, b), rnd
+    assert int(buf.abs().max()) == 0
+
+
 def test_resnet_h_train_step():
     pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
 

@@ -98,6 +98,11 @@ mask)
 stagger)
   timeout 600 python tools/ab_wino4_stagger.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/ab_wino4_stagger.txt
   ;;
+dflt)
+  # the default line alone, into the final set's directory (after a change that touches nothing measured there)
+  O=gpurun_out/r05_final; mkdir -p $O
+  T0=$SECONDS; timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-2500; echo "$((SECONDS - T0)) s wall"
+  ;;
 final)
   # The round's measurement set (one GPU call): full GPU suite, smoke(), rehearsals of both multi-GPU paths on this one GPU, rocprofv3
   # kernel tables, the calibrated HBM-traffic and SQ PMC passes, ResNet training traffic, the secondary lines, layer profiles,
@@ -152,7 +157,7 @@ for k,v in d.items(): print(k, {a: round(b,3) for a,b in v.items() if a in ('mfm
   echo "== microbenches"; timeout 300 python tools/microbench_wino4.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino4_b128.txt; tail -1 $O/microbench_wino4_b128.txt
   timeout 400 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/wino4_diag.txt; tail -2 $O/wino4_diag.txt | cut -c1-300
   cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json
-  echo "== default bench (with the PMC traffic of this bench.py)"; /usr/bin/time -f "%e s wall" timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-1800; tail -1 $O/bench_default.err
+  echo "== default bench (with the PMC traffic of this bench.py)"; T0=$SECONDS; timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-1800; echo "$((SECONDS - T0)) s wall"
   du -sh $O
   ;;
 collect)

@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [1006, 1112, 3001, 128, 256, 143, 15, 11, 9, 16, 32, 64, 96, 48]          # 1000 + r: product code with weight-ring size r; 2001..: schedule variants
+KS = [128, 256, 15, 2, 32, 64, 96]          # 1000 + r: product code with weight-ring size r; 2001..: schedule variants
 if os.environ.get("DREAM_W4_DIAG_KS"):          # a subset of the variants: DREAM_W4_DIAG_KS=1008,128
     KS = [int(v) for v in os.environ["DREAM_W4_DIAG_KS"].split(",")]
 OUT = os.path.join(ROOT, "build", "diag")             # travels with the snapshot only while it exists: `rm -rf build/diag` after the measurement
