@@ -107,6 +107,7 @@ _SIGNATURES = {
     "dream_conv3x3_winograd4_set_stagger": (_I, [_I, _I]),
     "dream_pack_conv3x3_winograd4_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "dream_conv3x3_winograd4_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_conv3x3_winograd4_pool_both_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_pack_job_bytes": (_SZ, []),
     "dream_pack_weights_batched": (_I, [_P, _I, _I, _P]),
     "dream_convT4x4_winograd_weight_floats": (_SZ, [_I, _I]),

@@ -87,6 +87,7 @@ struct Wino4Params {
     const float *shift;      // per-channel addend (bias / BN shift) or null
     const float *residual;   // ReLU mask source (DREAM_CONV_RELUMASK) or addend of the output's shape, or null
     float *y;                // [B,H,W,Cout]  (or [B,H/2,W/2,Cout] with DREAM_CONV_POOL2)
+    float *y_full;           // MODE 4 (training forward of a conv that feeds a 2x2 max-pool): the un-pooled [B,H,W,Cout] as well, else null
     int B, H, W, Cin, Cout, CoutPad;
     int TY, TX;              // 4x4 tiles per image
     int ntiles;              // B * TY * TX  (< 2^24)
@@ -203,7 +204,7 @@ template <int PAT>
 struct Pat4 { static constexpr Pat4Table table = pat4_table(PAT); };
 #define pat4_pos(PAT, k) (Pat4<PAT>::table.pos[k])
 
-// MODE: 0 plain, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask (conv_wino.hip)
+// MODE: 0 plain, 1 fused 2x2 max-pool, 2 residual add, 3 ReLU mask (conv_wino.hip), 4 fused 2x2 max-pool AND the un-pooled tensor (training)
 template <int MODE, bool NARROW, int PAT = 0>
 __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(const Wino4Params p) {
     using C = W4Cfg<NARROW>;
@@ -470,7 +471,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     const std::integral_constant<int, 1> ph1{};
 
     // ---- inverse transform Y = A^T M A (lane-local), scale / shift / residual / ReLU / 2x2 max-pool, store ------------------------
-    constexpr bool pool = MODE == 1, has_res = MODE >= 2, mask = MODE == 3;
+    constexpr bool pool = MODE == 1 || MODE == 4, both = MODE == 4, has_res = MODE == 2 || MODE == 3, mask = MODE == 3;
     auto epilogue = [&](auto site_tag, int tile0e, int b0e) {
         // Everything the epilogue needs is read again from the kernel-argument segment (scalar loads, once per block): kept in
         // SGPRs across the MFMA phases these values push the kernel past its scalar register file (spills through VGPR lanes).
@@ -496,6 +497,11 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         const BufferRsrc ybuf = make_buffer(e.y + (size_t)b0e * out_img, (DREAM_W4_DIAG & 256) ? 0 : (size_t)(e.B - b0e) * out_img * sizeof(float));
         const BufferRsrc rbuf = make_buffer(has_res ? e.residual + (size_t)b0e * out_img : e.y,
                                             has_res ? (size_t)(e.B - b0e) * out_img * sizeof(float) : 0);
+        // MODE 4: the un-pooled tensor [B, H, W, Cout] as well (the training forward pass keeps it for the backward pass: ReLU mask, pool
+        // routing), stored from the same registers the pooled maxima are taken from -- no separate max-pool pass over it
+        const size_t full_img = (size_t)e.H * e.W * e.Cout;
+        const unsigned fpx_b = (unsigned)(e.Cout * 4), frow_b = (unsigned)(e.W * e.Cout * 4);
+        const BufferRsrc fbuf = make_buffer(both ? e.y_full + (size_t)b0e * full_img : e.y, both ? (size_t)(e.B - b0e) * full_img * sizeof(float) : 0);
         // C/D layout: reg r of lane l is tile 4 (l >> 4) + r of the block: the lane's four tiles are consecutive.  They go through the
         // inverse transform in PAIRS (regs 2 rp, 2 rp + 1: an aligned register pair of every accumulator), on packed fp32 operations.
         const int tau0 = tile0e + lg * 4;
@@ -505,6 +511,8 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
         constexpr int NS = pool ? 2 : 4;               // stored positions of a tile: a 4x4 block of outputs, or its 2x2 block of pooled outputs
         // stored-position bases and bounds of the lane's four tiles (two pairs), up front: the second pair's residual / mask loads start
         // while the first pair is still being stored
+        unsigned basef[2][2];                          // MODE 4: the same for the un-pooled tensor (4x4 stored positions per tile)
+        int limf[2][2];
         unsigned base4[2][2];
         int lim4[2][2];                                // bits 0..3: stored row i inside the image, bits 4..7: stored column jj (0 for a tile that stores nothing)
         constexpr int FULL = pool ? 0x33 : 0xff;
@@ -519,6 +527,13 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
 #pragma unroll
                 for (int i = 0; i < NS; ++i) m |= ((oy + i) < Ho ? 1 << i : 0) | ((ox + i) < Wo ? 16 << i : 0);
                 lim4[rp][h] = tok ? m : 0;
+                if (both) {
+                    basef[rp][h] = (unsigned)(((((b - b0e) * e.H + 4 * ty) * e.W + 4 * tx) * e.Cout + col) * 4);
+                    int mf = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) mf |= ((4 * ty + i) < e.H ? 1 << i : 0) | ((4 * tx + i) < e.W ? 16 << i : 0);
+                    limf[rp][h] = tok ? mf : 0;
+                }
                 const bool wrap_x = (tx + 1 == p.TX);
                 const bool wrap_y = wrap_x & (ty + 1 == p.TY);
                 tx = wrap_x ? 0 : tx + 1;
@@ -616,6 +631,13 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                             float v[4];
 #pragma unroll
                             for (int i = 0; i < 4; ++i) v[i] = finish(o4[i][h], 0.0f);
+                            if (both) {
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    const bool inb = ((limf[rp][h] >> i) & (limf[rp][h] >> (4 + jj)) & 1) != 0;
+                                    DREAM_W4_STORE(fbuf, v[i], inb ? basef[rp][h] + (unsigned)i * frow_b + (unsigned)jj * fpx_b : BUFFER_OOB, 0u);
+                                }
+                            }
                             if ((jj & 1) == 0) {
                                 keep[h][0] = fmaxf(v[0], v[1]);
                                 keep[h][1] = fmaxf(v[2], v[3]);
@@ -731,6 +753,7 @@ int launch_wino4_mode(const Wino4Params &p, int mode, void *stream) {
         case 0: return launch_wino4<0, NARROW>(p, stream);
         case 1: return launch_wino4<1, NARROW>(p, stream);
         case 2: return launch_wino4<2, NARROW>(p, stream);
+        case 4: return launch_wino4<4, NARROW>(p, stream);
         default: return launch_wino4<3, NARROW>(p, stream);
     }
 }
@@ -795,7 +818,7 @@ int wino4_setup(Wino4Params &p, const float *x, const float *u_packed, const flo
     DREAM_REQUIRE(span_imgs * in_scale * in_scale * H * W * (size_t)Cin * sizeof(float) < ((size_t)1 << 31) &&
                   span_imgs * out_scale * out_scale * H * W * (size_t)Cout * sizeof(float) < ((size_t)1 << 31),
                   "winograd F(4x4) conv: image too large for 32-bit offsets");
-    p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
+    p.x = x; p.u = u_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y; p.y_full = nullptr;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
     p.CoutPad = Cout <= ps.rows_pad ? ps.rows_pad : (Cout + ps.rows_pad - 1) / ps.rows_pad * ps.rows_pad;
     DREAM_REQUIRE(((size_t)(Cin / ps.k) * W4P + ps.ahead) * (size_t)p.CoutPad * ps.k * sizeof(float) < ((size_t)1 << 31), "winograd F(4x4) conv: weights too large");
@@ -850,6 +873,20 @@ extern "C" int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_p
     if (int rc = wino4_setup(p, x, u_packed, scale, shift, residual, y, B, H, W, Cin, Cout, flags, 1)) return rc;
     const int mode = (flags & DREAM_CONV_POOL2) ? 1 : (flags & DREAM_CONV_RELUMASK) ? 3 : (residual != nullptr ? 2 : 0);
     return narrow_rows(Cout) ? launch_wino4_mode<true>(p, mode, stream) : launch_wino4_mode<false>(p, mode, stream);
+}
+
+// Training forward of a conv that feeds nn.MaxPool2d(2) (dream/models.py:589,765-771): y_full = relu(conv3x3(x) * scale + shift)
+// [B,H,W,Cout] AND y_pool = maxpool2x2(y_full) [B,H/2,W/2,Cout] from one launch -- the pooled maxima are taken from the registers the
+// un-pooled values are stored from, so the stand-alone max-pool pass (a read of y_full) disappears.  Same values as the two launches, bit for bit.
+extern "C" int dream_conv3x3_winograd4_pool_both_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                                          float *y_full, float *y_pool, int B, int H, int W, int Cin, int Cout, int flags,
+                                                          void *stream) {
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "winograd F(4x4) conv + pool: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE(y_full != nullptr && y_pool != nullptr && H >= 2 && W >= 2, "winograd F(4x4) conv + pool: null output or map too small");
+    Wino4Params p;
+    if (int rc = wino4_setup(p, x, u_packed, scale, shift, nullptr, y_pool, B, H, W, Cin, Cout, flags, 1)) return rc;
+    p.y_full = y_full;
+    return narrow_rows(Cout) ? launch_wino4_mode<true>(p, 4, stream) : launch_wino4_mode<false>(p, 4, stream);
 }
 
 // nn.ConvTranspose2d(k4, s2, p1) (+ folded BatchNorm / bias, ReLU) by minimal filtering on the F(4x4) kernel: every output phase

@@ -176,6 +176,9 @@ class DreamHourglass(nn.Module):
         # implicit-GEMM kernel everywhere (csrc/conv_mfma.hip, the reference form)
         self.conv_algorithm = os.environ.get("DREAM_CONV_ALGORITHM", "winograd")
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
+        # training forward: a conv that feeds MaxPool2d(2) stores the pooled tensor from its own epilogue (csrc/conv_wino4.hip MODE 4)
+        # instead of a stand-alone max-pool pass over the un-pooled one; "0": the separate pass (A/B, tests)
+        self.pool_in_training_conv = os.environ.get("DREAM_POOL_IN_TRAINING_CONV", "1") != "0"
         self._aux = {}
         # the reference builds every hourglass on vgg19(pretrained=True).features (models.py:587): ImageNet weights for all
         # encoder convs but the first when they can be had, one loud warning otherwise (dream_amd/pretrained.py)
@@ -316,11 +319,14 @@ class DreamHourglass(nn.Module):
         pi = 0
         layers = self.plan_layers()
         pool_done = add_done = False
+        pooled_by_conv = None
         for li, (kind, mod, flags) in enumerate(layers):
             inp = act
             skip = None
             if kind == "pool":
-                if not pool_done:
+                if pooled_by_conv is not None:             # training: the conv's own launch stored the pooled tensor beside the un-pooled one
+                    act, pooled_by_conv = pooled_by_conv, None
+                elif not pool_done:
                     act = ops.maxpool2(inp)
                 pool_done = False
             elif kind == "add":
@@ -364,7 +370,12 @@ class DreamHourglass(nn.Module):
                         u, rows = self._packed.get(mod.weight, "wino4_0" if tile == 4 else "wino0")
                         if skip is not None:
                             self._join(tuple(inp.shape[:3]) + (rows,), skip)
-                        act = ops.conv3x3_winograd_tile(tile, inp, u, rows, None, bias, skip, flags | (ops.CONV_RES_AFTER_RELU if skip is not None else 0))
+                        if (save and tile == 4 and skip is None and self.pool_in_training_conv and flags == CONV_RELU
+                                and li + 1 < len(layers) and layers[li + 1][0] == "pool"):
+                            # training: un-pooled tensor (kept for the backward pass) AND pooled tensor from one launch
+                            act, pooled_by_conv = ops.conv3x3_winograd4_pool_both(inp, u, rows, bias, flags)
+                        else:
+                            act = ops.conv3x3_winograd_tile(tile, inp, u, rows, None, bias, skip, flags | (ops.CONV_RES_AFTER_RELU if skip is not None else 0))
                         add_done = skip is not None
                     elif skip is not None:
                         packed, rows, _, _ = self._packed.get(mod.weight, 0)
@@ -648,7 +659,7 @@ class _SideStream:
             return torch.cuda.Stream(device=device)
         # Measured round 5 (profiles/r05_ab_side_stream_priority.txt, resnet_h training, one box, alternating): 16 frames 356.7 (normal) /
         # 358.0 (low) / 353.7 (high) frames/s; at 128 frames with the overlap forced the low-priority stream reaches 446-450 against the
-        # in-order 434-436, but one run in three still drops to 300 (as in round 4), so the 96-frame threshold stays.
+        # in-order 434-436 (two early runs dropped to 300 as in round 4; none of the twelve later ones did: overlap_max_frames is 128 now).
         try:
             import ctypes
             hip = ctypes.CDLL("libamdhip64.so")
@@ -665,17 +676,28 @@ class _SideStream:
 
     def __init__(self, stream):
         self.side, self.main = stream, torch.cuda.current_stream()
+        # DREAM_SIDE_KEEP=1: the leaves' inputs are kept referenced until join() instead of record_stream()-ed.  A recorded block cannot be
+        # reused by the main stream until an event on the side stream has passed; holding the references until the main stream has
+        # been ordered behind the side stream needs no events at all (at the price of the inputs' memory until the end of backward).
+        # Measured round 5 (profiles/r05_ab_side_stream_keep.txt, alternating on one box): resnet_h training at 16 frames 359.2 / 359.9 / 360.3
+        # (record_stream) -> 364.5 / 364.9 / 363.8 frames/s; at 128 frames equal (451-453).  "0" restores record_stream().
+        self.keep = [] if os.environ.get("DREAM_SIDE_KEEP", "1") == "1" else None
 
     def run(self, fn, *inputs):
         self.side.wait_stream(self.main)
         with torch.cuda.stream(self.side):
             out = fn()
-        for t in inputs:
-            t.record_stream(self.side)
+        if self.keep is not None:
+            self.keep.append(inputs)
+        else:
+            for t in inputs:
+                t.record_stream(self.side)
         return out
 
     def join(self):
         self.main.wait_stream(self.side)
+        if self.keep is not None:
+            del self.keep[:]
 
 
 def _on_side(side, fn, *inputs):
@@ -896,9 +918,11 @@ class ResnetSimple(nn.Module):
         # multiplications, conv_wino.hip), "direct" = sub-pixel phases on conv_mfma
         self.convT_algorithm = os.environ.get("DREAM_CONVT_ALGORITHM", "winograd")
         # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order), up to
-        # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own)
+        # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own).  Round 5: 128 (was 96) -- with the
+        # weight-gradient stream at the lowest HIP priority the overlap is worth +3.3 % at 128 frames (437.8 in order, 447-453 in twelve
+        # runs on four boxes, two of them the first process on a cold box; at normal priority round 4 had seen 300-450)
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
-        self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "96"))
+        self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "128"))
         # the 3x3 convs' BatchNorm statistics / masked backward reductions in the Winograd F(2x2) kernel's epilogue (csrc/conv_wino.hip
         # WINO_STAT) -- 66 launches fewer per ResNet-101 step; measured round 5 (profiles/r05_ab_bn_fusion_3x3.txt, alternating on one
         # box): 350.4 -> 358.5 frames/s at 16 frames (+2.3 %), so on by default; "0" = the stand-alone bn_stats / bn_bwd_stats passes

@@ -144,6 +144,18 @@ def conv3x3(x_nhwc, packed, bias, cout, flags=0, relu_mask=None):
     return y
 
 
+def conv3x3_winograd4_pool_both(x_nhwc, packed_u, cout, shift=None, flags=0):
+    """Training forward of a conv followed by MaxPool2d(2): -> (y_full [B,H,W,cout], y_pool [B,H/2,W/2,cout]) from one launch of the
+    F(4x4,3x3) kernel (csrc/conv_wino4.hip MODE 4); flags: CONV_RELU.  Same contract on the input as conv3x3_winograd4."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    yp = torch.empty((b, h // 2, w // 2, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv3x3_winograd4_pool_both_nhwc_f32", ptr(x), ptr(packed_u), None, ptr(shift), ptr(y), ptr(yp), b, h, w, cin, cout,
+         flags, stream())
+    return y, yp
+
+
 def pack_weight_winograd(w_oihw, mode=0):
     """OIHW [Cout,Cin,3,3] -> the transformed weights U = G g G^T of the Winograd F(2x2,3x3) kernel
     ([cols/16][16][rows_pad][16]).  mode 0: forward (rows = Cout); mode 1: data-gradient operator (rows = Cin).

@@ -133,6 +133,10 @@ int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u, int Cout,
 int dream_conv3x3_winograd4_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
                                      const float *residual, float *y, int B, int H, int W, int Cin, int Cout, int flags,
                                      void *stream);
+/* Training forward of a conv that feeds nn.MaxPool2d(2) (dream/models.py:589,765-771): y_full = relu(conv * scale + shift) [B,H,W,Cout] AND
+ * y_pool = maxpool2x2(y_full) [B,H/2,W/2,Cout] from ONE launch (the same values as conv + dream_maxpool2, bit for bit).  flags: DREAM_CONV_RELU. */
+int dream_conv3x3_winograd4_pool_both_nhwc_f32(const float *x, const float *u_packed, const float *scale, const float *shift,
+                                               float *y_full, float *y_pool, int B, int H, int W, int Cin, int Cout, int flags, void *stream);
 int dream_conv3x3_winograd4_set_max_workgroups(int n);
 int dream_conv3x3_winograd4_set_stagger(int phases, int percent);   /* A/B hook: start-up stagger of the persistent workgroups (phases <= 1: off; < 0: by DREAM_W4_STAGGER) */
 int dream_conv3x3_winograd4_set_channel_block_pinning(int on);   /* A/B hook: output-channel blocks pinned to XCDs (1) or walked by every XCD (0); -1: by DREAM_W4_YMAP (default: pinned) */     /* test hook, as dream_conv3x3_winograd_set_max_workgroups */

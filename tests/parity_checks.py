@@ -103,6 +103,24 @@ def check_conv_winograd(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_s
     return err
 
 
+def check_conv_winograd4_pool_both(dev, B, H, W, Cin, Cout, seed=0):
+    """csrc/conv_wino4.hip MODE 4 (the training forward of a conv that feeds MaxPool2d(2)): the un-pooled and the pooled tensor from ONE
+    launch equal the plain launch and a max-pool over its output bit for bit (odd extents: the pool floors, as nn.MaxPool2d)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = ((torch.rand(Cout, Cin, 3, 3, generator=g) * 2 - 1) * (6.0 / (9 * Cin)) ** 0.5).to(dev)
+    bias = (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    u, rows = ops.pack_weight_winograd4(w, 0)
+    y_ref = ops.conv3x3_winograd4(x, u, rows, None, bias, None, ops.CONV_RELU)
+    p_ref = ops.maxpool2(y_ref)
+    p_fused = ops.conv3x3_winograd4(x, u, rows, None, bias, None, ops.CONV_RELU | ops.CONV_POOL2)
+    y, p = ops.conv3x3_winograd4_pool_both(x, u, rows, bias, ops.CONV_RELU)
+    assert tuple(p.shape) == (B, H // 2, W // 2, Cout) and tuple(y.shape) == (B, H, W, Cout)
+    assert torch.equal(y, y_ref), float((y - y_ref).abs().max())
+    assert torch.equal(p, p_ref) and torch.equal(p, p_fused)
+    return 0.0
+
+
 def check_conv_winograd4(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=False, residual=None, max_workgroups=(8,), tol=1e-5):
     """Winograd F(4x4,3x3) conv (csrc/conv_wino4.hip) vs an fp64 direct convolution: error relative to the output maximum
     <= 1e-5 (measured 1e-6 .. 6.5e-6 on these unit-variance inputs with the interpolation points 0, +-1, 1/2, -2 -- 512 input

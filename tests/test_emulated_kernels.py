@@ -73,6 +73,9 @@ def test_conv_winograd4(emu):
              pc.check_conv_winograd4("cpu", 2, 7, 9, 32, 128, 0, seed=7, mode=1, max_workgroups=()),
              pc.check_conv_winograd4("cpu", 2, 40, 40, 32, 128, ops.CONV_RELU | ops.CONV_POOL2, seed=9)]
     print("winograd F(4x4) max rel err", max(errs))
+    # MODE 4: un-pooled + pooled tensor from one launch (training forward), narrow and wide shape, odd extents, several blocks per workgroup
+    for (b, h, w, cin, cout) in [(2, 13, 9, 16, 64), (1, 8, 12, 32, 48), (2, 12, 20, 32, 144), (2, 25, 25, 32, 128), (2, 40, 40, 32, 64)]:
+        pc.check_conv_winograd4_pool_both("cpu", b, h, w, cin, cout, seed=b + h)
 
 
 def test_conv_transpose4x4_winograd(emu):

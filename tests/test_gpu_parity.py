@@ -689,6 +689,35 @@ def test_conv_winograd(b, h, w, cin, cout, flags, kw):
     print("winograd %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
 
 
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 13, 9, 16, 64), (2, 12, 20, 32, 144), (2, 13, 9, 32, 128), (2, 25, 25, 512, 512),
+                                            (2, 400, 400, 64, 64), (2, 200, 200, 128, 128), (4, 100, 100, 256, 256), (4, 50, 50, 512, 512)])
+def test_conv_winograd4_pool_both(b, h, w, cin, cout):
+    """MODE 4 of the F(4x4) kernel (both workgroup shapes, odd extents, the four pooled vgg_q layers): un-pooled + pooled tensor from one
+    launch, bit for bit the plain launch and a max-pool over it."""
+    pc.check_conv_winograd4_pool_both(DEV, b, h, w, cin, cout, seed=b + h)
+
+
+def test_hourglass_pool_in_the_training_conv_same_bits(monkeypatch):
+    """DreamHourglass training forward with the pooled tensors stored by the convs' own launches (default) against the stand-alone
+    max-pool passes (DREAM_POOL_IN_TRAINING_CONV=0): three Adam steps, losses and parameters bit for bit."""
+    x = torch.from_numpy(cases.image_batch(8, 64, 96, seed=45)).to(DEV)
+
+    def run(flag):
+        monkeypatch.setenv("DREAM_POOL_IN_TRAINING_CONV", flag)
+        net = _dp_network("vgg_q", [0], optimizer="adam", lr=1e-5, in_res=(96, 64))
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(8, 7, (ow, oh), in_wh=(96, 64), seed=45)).to(DEV)
+        return net, [net.train([x], t).item() for _ in range(3)]
+
+    a, la = run("1")
+    b, lb = run("0")
+    assert a.model.module.pool_in_training_conv and not b.model.module.pool_in_training_conv
+    assert la == lb, (la, lb)
+    for (k, pa), (_, pb) in zip(a.model.named_parameters(), b.model.named_parameters()):
+        assert torch.equal(pa, pb), k
+
+
 @pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
     # narrow workgroup shape (up to 64 output channels)
     (1, 8, 8, 32, 16, 0, {}), (2, 13, 25, 32, 64, ops.CONV_RELU, {}), (3, 5, 3, 48, 7, 0, {}),

@@ -84,6 +84,35 @@ g1)
   withlib G0 line rt128_G0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   line vt --mode train --steps 4 --warmup 2
   ;;
+pool)
+  # the pooled tensor stored by the training conv's own launch (MODE 4) against the stand-alone max-pool pass
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "pool_both or pool_in_the_training or train_step or train_steps or reference_golden or variant or data_parallel" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in a b c; do
+    DREAM_POOL_IN_TRAINING_CONV=1 line vt_fused_$r --mode train --steps 4 --warmup 2
+    DREAM_POOL_IN_TRAINING_CONV=0 line vt_separate_$r --mode train --steps 4 --warmup 2
+  done
+  line rt16 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
+cold)
+  # first bench on a cold box: the forced overlap at 128 frames with record_stream() (arg rec) or kept references (arg keep)
+  K=0; [ "$2" = keep ] && K=1
+  DREAM_SIDE_KEEP=$K DREAM_OVERLAP_MAX_FRAMES=128 line rt128_$2_cold --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  DREAM_SIDE_KEEP=$K DREAM_OVERLAP_MAX_FRAMES=128 line rt128_$2_second --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
+keep)
+  # the weight-gradient stream's inputs kept referenced until the join (DREAM_SIDE_KEEP=1) against record_stream(): is the 300-frames/s mode
+  # of the forced overlap at 128 frames the allocator?
+  for r in a b c d; do
+    DREAM_SIDE_KEEP=1 DREAM_OVERLAP_MAX_FRAMES=128 line rt128_keep_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+    DREAM_SIDE_KEEP=0 DREAM_OVERLAP_MAX_FRAMES=128 line rt128_rec_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  done
+  line rt128_inorder --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  for r in a b c; do
+    DREAM_SIDE_KEEP=1 line rt16_keep_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_SIDE_KEEP=0 line rt16_rec_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  ;;
 diag)
   DREAM_W4_DIAG_KS=${2:-128,256,15,2,16,8} timeout 600 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/wino4_diag.txt
   ;;
