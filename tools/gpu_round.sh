@@ -94,6 +94,13 @@ pool)
   line rt16 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
   line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   ;;
+sbatch)
+  for r in a b; do for n in 1 4 8 16; do
+    DREAM_SIDE_BATCH=$n line rt16_batch${n}_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done; done
+  for n in 1 8; do DREAM_SIDE_BATCH=$n line rt128_batch${n} --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2; done
+  echo "== pytest"; DREAM_SIDE_BATCH=8 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "resnet_h_train_step or resnet_f_train_step or vgg_f_train or reference_golden" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  ;;
 cold)
   # first bench on a cold box: the forced overlap at 128 frames with record_stream() (arg rec) or kept references (arg keep)
   K=0; [ "$2" = keep ] && K=1
