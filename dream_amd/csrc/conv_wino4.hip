@@ -67,6 +67,13 @@
 #define DREAM_W4_STAGGER_PCT 0
 #endif
 // patch loads of wavefronts 4-7 (wide shape, plain 3x3 conv) this many slots later than those of wavefronts 0-3 (0: same slots)
+// cache policy of the wide shape's weight stream / of the patch loads (aux bits: 1 sc0, 2 nt, 16 sc1): A/B builds (tools/wino4_diag.py 60xx)
+#ifndef DREAM_W4_WAUX
+#define DREAM_W4_WAUX 0
+#endif
+#ifndef DREAM_W4_XAUX
+#define DREAM_W4_XAUX 0
+#endif
 #ifndef DREAM_W4_STAG_LX
 #define DREAM_W4_STAG_LX 0
 #endif
@@ -304,7 +311,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
     vec bq[W4_RING];
     auto load_u = [&](unsigned soff) {
         if constexpr (NARROW) return buffer_load_x2(ubuf, b_lane, soff);
-        else return buffer_load_x4(ubuf, b_lane, soff);
+        else return buffer_load_x4_aux<DREAM_W4_WAUX>(ubuf, b_lane, soff);
     };
 #pragma unroll
     for (int k = 0; k < W4_AHEAD; ++k) bq[k] = load_u((unsigned)pat4_pos(PAT, k) * u_pos_stride);
@@ -414,7 +421,7 @@ __global__ void __launch_bounds__(64 * W4Cfg<NARROW>::NW, 2) conv_wino4_kernel(c
                     bq[(PH * NPOS + kn) % W4_RING] = load_u((DREAM_W4_DIAG & 32) ? 0u : (unsigned)spos * u_pos_stride);
                 }
             };
-            auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4(xbuf, item_offset(col), (DREAM_W4_DIAG & 64) ? 0u : coff); };
+            auto load_x = [&](int col) { if (!(DREAM_W4_DIAG & 1)) d[col] = buffer_load_x4_aux<DREAM_W4_XAUX>(xbuf, item_offset(col), (DREAM_W4_DIAG & 64) ? 0u : coff); };
             auto pair = [&](int r) {
                 const int i0 = (PH * NPOS + k0) % W4_RING, i1 = (PH * NPOS + k0 + 1) % W4_RING;
                 acc[pp] = mfma_f32_16x16x4(a[s & 1][0][r], bq[i0][r], acc[pp]);

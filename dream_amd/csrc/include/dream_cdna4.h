@@ -111,6 +111,14 @@ DREAM_DEVICE f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned
     return __builtin_bit_cast(f32x4, v);
 }
 
+// the same with a compile-time cache policy (aux bits on gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1) -- A/B builds only
+template <int AUX>
+DREAM_DEVICE f32x4 buffer_load_x4_aux(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(b.r, voffset_bytes, soffset_bytes, AUX);
+    return __builtin_bit_cast(f32x4, v);
+}
+
 DREAM_DEVICE f32x2 buffer_load_x2(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
     typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
     const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(b.r, voffset_bytes, soffset_bytes, 0);

@@ -81,6 +81,9 @@ constexpr unsigned BUFFER_OOB = 0x80000000u;
 inline BufferRsrc make_buffer(const void *base, size_t bytes) {
     return {(const char *)base, bytes > 0x7fffffffull ? 0x7fffffffu : (unsigned)bytes};
 }
+inline f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes);
+template <int AUX>
+inline f32x4 buffer_load_x4_aux(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) { return buffer_load_x4(b, voffset_bytes, soffset_bytes); }
 inline f32x4 buffer_load_x4(BufferRsrc b, unsigned voffset_bytes, unsigned soffset_bytes) {
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if ((unsigned long long)voffset_bytes + 16ull <= (unsigned long long)b.bytes)

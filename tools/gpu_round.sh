@@ -101,6 +101,10 @@ sbatch)
   for n in 1 8; do DREAM_SIDE_BATCH=$n line rt128_batch${n} --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2; done
   echo "== pytest"; DREAM_SIDE_BATCH=8 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "resnet_h_train_step or resnet_f_train_step or vgg_f_train or reference_golden" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
   ;;
+waux)
+  for r in a b c; do for l in W0 W1 W16; do withlib $l line dflt_${l}_$r; done; done
+  for l in W0 W16 W0 W16; do withlib $l line vt_$l --mode train --steps 4 --warmup 2; done
+  ;;
 cold)
   # first bench on a cold box: the forced overlap at 128 frames with record_stream() (arg rec) or kept references (arg keep)
   K=0; [ "$2" = keep ] && K=1

@@ -14,12 +14,13 @@ if os.environ.get("DREAM_W4_DIAG_KS"):          # a subset of the variants: DREA
     KS = [int(v) for v in os.environ["DREAM_W4_DIAG_KS"].split(",")]
 OUT = os.path.join(ROOT, "build", "diag")             # travels with the snapshot only while it exists: `rm -rf build/diag` after the measurement
 SCALAR = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DDREAM_PACKED_F32=0"]     # __graft_entry__.SCALAR_F32_FLAGS
-VARIANTS = {5003: SCALAR + ["-DDREAM_W4_STAG_LX=3"], 5004: SCALAR + ["-DDREAM_W4_STAG_LX=4"], 5005: SCALAR + ["-DDREAM_W4_STAG_LX=5"], 5006: SCALAR + ["-DDREAM_W4_STAG_LX=6"],
+VARIANTS = {6002: SCALAR + ["-DDREAM_W4_WAUX=2"], 6001: SCALAR + ["-DDREAM_W4_WAUX=1"], 6016: SCALAR + ["-DDREAM_W4_WAUX=16"], 6102: SCALAR + ["-DDREAM_W4_XAUX=2"],
+            6116: SCALAR + ["-DDREAM_W4_XAUX=16"], 6202: SCALAR + ["-DDREAM_W4_WAUX=2", "-DDREAM_W4_XAUX=2"], 5003: SCALAR + ["-DDREAM_W4_STAG_LX=3"], 5004: SCALAR + ["-DDREAM_W4_STAG_LX=4"], 5005: SCALAR + ["-DDREAM_W4_STAG_LX=5"], 5006: SCALAR + ["-DDREAM_W4_STAG_LX=6"],
             5007: SCALAR + ["-DDREAM_W4_STAG_LX=7"], 4001: SCALAR, 4002: SCALAR + ["-DDREAM_W4_SETPRIO=1"], 4003: ["-DDREAM_PACKED_F32=1", "-DDREAM_W4_RUNNING_WOFF=0"], 4004: ["-DDREAM_PACKED_F32=1", "-DDREAM_W4_SETPRIO=1"],
             4005: ["-DDREAM_PACKED_F32=1"], 3001: ["-DDREAM_W4_STORE=buffer_store_f32_nt"], 2001: ["-DDREAM_W4_S1=6", "-DDREAM_W4_S2=9", "-DDREAM_W4_LX=3"], 2002: ["-DDREAM_W4_S1=8", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=3"],
             2003: ["-DDREAM_W4_S1=10", "-DDREAM_W4_S2=13", "-DDREAM_W4_LX=1"], 2004: ["-DDREAM_W4_S1=11", "-DDREAM_W4_S2=14", "-DDREAM_W4_LX=3"],
             2005: ["-DDREAM_W4_S1=4", "-DDREAM_W4_S2=8", "-DDREAM_W4_LX=1"], 2101: ["-DDREAM_W4_MIDBARRIER=1"], 2100: ["-DDREAM_W4_MIDBARRIER=0"]}
-NAMES = {0: "product", 5003: "wavefronts 4-7: patch loads 3 slots later", 5004: "... 4 slots later", 5005: "... 5 slots later", 5006: "... 6 slots later", 5007: "... 7 slots later", 4001: "scalar fp32 VALU (no v_pk_*)", 4002: "scalar fp32 VALU + s_setprio 1 on waves 4-7", 4003: "round-4 code (packed, table weight offsets)",
+NAMES = {0: "product", 6002: "weights nt", 6001: "weights sc0", 6016: "weights sc1", 6102: "patches nt", 6116: "patches sc1", 6202: "weights + patches nt", 5003: "wavefronts 4-7: patch loads 3 slots later", 5004: "... 4 slots later", 5005: "... 5 slots later", 5006: "... 6 slots later", 5007: "... 7 slots later", 4001: "scalar fp32 VALU (no v_pk_*)", 4002: "scalar fp32 VALU + s_setprio 1 on waves 4-7", 4003: "round-4 code (packed, table weight offsets)",
          4004: "packed + s_setprio 1 on waves 4-7", 4005: "packed fp32 VALU", 3001: "non-temporal stores", 128: "no epilogue", 256: "epilogue without stores", 143: "MFMAs + operand reads only, no epilogue", 32: "weights from L1 (one position)", 64: "patches: chunk 0 only", 96: "weights from L1 + patches chunk 0", 48: "weights from L1 + patches out of range", 2001: "S1 6 S2 9", 2002: "S1 8 S2 13", 2003: "S1 10 S2 13, loads in slot 0", 2004: "S1 11 S2 14",
          2005: "S1 4 S2 8, loads in slot 0", 2101: "with the mid-chunk workgroup barrier (round 3)", 2100: "without the mid-chunk barrier", 16: "patch loads out of range", 18: "patch loads out of range, no weight stream", 1: "no patch loads", 2: "no weight stream", 4: "no barriers", 8: "no passes (loads kept)", 9: "no loads, no passes",
          11: "no loads / passes / weights", 15: "MFMAs + operand reads only", 1006: "weight ring 6 (4 ahead; the product has 8)", 1112: "narrow shape: weight ring 12 (product 18)"}
