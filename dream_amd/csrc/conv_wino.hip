@@ -182,6 +182,9 @@ int g_max_workgroups = 0;     // test hook: cap on resident workgroups (0 = the 
 
 // persistent grid: as many workgroups as the 256 CUs hold at once (2 of the 4-wave, 1 of the 8-wave kind per CU), a
 // multiple of 8 (XCDs), split over the output-channel blocks; fewer when there are fewer tile blocks than that
+// read per call (four launches per layer): tests and A/B runs switch it through the environment
+bool small_grid_nw4() { const char *e = getenv("DREAM_WINO_SMALL_GRID"); return !(e != nullptr && e[0] == '0'); }
+
 int wino_grid_x(int nw, int Cout, int nblk) {
     const int ny = (Cout + 16 * nw - 1) / (16 * nw);
     int resident = g_max_workgroups > 0 ? g_max_workgroups : kCUs * (nw == 4 ? 2 : 1);
@@ -478,11 +481,23 @@ extern "C" int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const
         p.u = u4 + ph * per_u;
         p.out_oy = ph >> 1; p.out_ox = ph & 1;
         int rc;
-        switch (ph) {
-            case 0: rc = launch_wino<8, 0, 1>(p, stream); break;
-            case 1: rc = launch_wino<8, 0, 2>(p, stream); break;
-            case 2: rc = launch_wino<8, 0, 3>(p, stream); break;
-            default: rc = launch_wino<8, 0, 4>(p, stream); break;
+        // a grid of fewer than ~160 eight-wavefront workgroups leaves CUs empty (ResNet's first decoder layer at 16 frames: 2048 -> 256 on
+        // 13x13 maps = 25 tile blocks x 2 channel blocks on 256 CUs, 1.2 ms): four-wavefront workgroups of 64 channels spread the same
+        // wavefronts over twice the CUs (DREAM_WINO_SMALL_GRID=0: always eight)
+        if (small_grid_nw4() && p.nblk * ((Cout + 127) / 128) < 160) {
+            switch (ph) {
+                case 0: rc = launch_wino<4, 0, 1>(p, stream); break;
+                case 1: rc = launch_wino<4, 0, 2>(p, stream); break;
+                case 2: rc = launch_wino<4, 0, 3>(p, stream); break;
+                default: rc = launch_wino<4, 0, 4>(p, stream); break;
+            }
+        } else {
+            switch (ph) {
+                case 0: rc = launch_wino<8, 0, 1>(p, stream); break;
+                case 1: rc = launch_wino<8, 0, 2>(p, stream); break;
+                case 2: rc = launch_wino<8, 0, 3>(p, stream); break;
+                default: rc = launch_wino<8, 0, 4>(p, stream); break;
+            }
         }
         if (rc) return rc;
     }

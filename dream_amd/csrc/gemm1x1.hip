@@ -178,16 +178,19 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
         zmu = *(const f32x4 *)(p.st_mean + c0);
         zis = *(const f32x4 *)(p.st_invstd + c0);
     }
-    if constexpr (KS == 1 && DREAM_G1_PIPELINED) {
-        // One wavefront owns all 16 rows of its lanes: the residual / mask operands of row i + 1 are loaded BEFORE row i is stored.  (In the
-        // loop below every row is its own predicated block -- load, s_waitcnt vmcnt(0), compute, store: 16 serialised memory round trips
-        // per wavefront and tile.)  Loads are unconditional on a clamped row (a row past M is never stored), so the body is straight-line
-        // code under ONE branch; safe if the output aliases an operand: a thread reads exactly the elements it writes, one row ahead.
-        if (cok) {
+    if constexpr (DREAM_G1_PIPELINED) {
+        // A wavefront owns 16 / KS rows of its lanes (block rows m = kpart, kpart + KS, ..): the residual / mask operands of row i + 1 are
+        // loaded BEFORE row i is stored.  (In the loop below every row is its own predicated block -- load, s_waitcnt vmcnt(0), compute,
+        // store: one serialised memory round trip per row.)  Loads are unconditional on a clamped row (a row past M is never stored), so
+        // the body is straight-line code under ONE branch; safe if the output aliases an operand: a thread reads exactly the elements it
+        // writes, one row ahead.  With a K split the block rows depend on the wavefront (kpart): one instantiation per value, chosen by a
+        // wave-uniform branch, so that the accumulator indices stay compile-time constants.
+        auto rows = [&](auto m0_tag) {
+            constexpr int M0 = decltype(m0_tag)::value, NR = 16 / KS;
             const int row0 = rb * 64 + 4 * lg;
             const long last = p.M - 1;
             auto offset_of = [&](int i) {
-                const long row = row0 + 16 * (i >> 2) + (i & 3);
+                const long row = row0 + 16 * (M0 + KS * (i >> 2)) + (i & 3);
                 return (size_t)(row < last ? row : last) * p.N + c0;
             };
             f32x4 nres = {0.0f, 0.0f, 0.0f, 0.0f}, nz = nres, nya = nres;
@@ -201,10 +204,11 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
             };
             load_row(0);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int m = i >> 2, r = i & 3;
+            for (int i = 0; i < NR; ++i) {
+                constexpr int dummy = 0;
+                const int m = M0 + KS * (i >> 2), r = i & 3;
                 const f32x4 res = nres, z = nz, ya = nya;
-                if (i + 1 < 16) load_row(i + 1);
+                if (i + 1 < NR) load_row(i + 1);
                 f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
                 v = v * sc + sh;
                 if (p.residual != nullptr) v = v + res;
@@ -230,6 +234,22 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
                     }
                 }
                 if (rok) *(f32x4 *)(p.y + (size_t)(row0 + 16 * m + r) * p.N + c0) = v;
+                (void)dummy;
+            }
+        };
+        if (cok && live) {
+            if constexpr (KS == 1) {
+                rows(std::integral_constant<int, 0>{});
+            } else if constexpr (KS == 2) {
+                if (kpart == 0) rows(std::integral_constant<int, 0>{});
+                else rows(std::integral_constant<int, 1>{});
+            } else {
+                switch (kpart) {
+                    case 0: rows(std::integral_constant<int, 0>{}); break;
+                    case 1: rows(std::integral_constant<int, 1>{}); break;
+                    case 2: rows(std::integral_constant<int, 2>{}); break;
+                    default: rows(std::integral_constant<int, 3>{}); break;
+                }
             }
         }
     } else

@@ -78,7 +78,13 @@ def test_conv_winograd4(emu):
         pc.check_conv_winograd4_pool_both("cpu", b, h, w, cin, cout, seed=b + h)
 
 
-def test_conv_transpose4x4_winograd(emu):
+def test_conv_transpose4x4_winograd(emu, monkeypatch):
+    # small grids run on four-wavefront workgroups since round 5 (csrc/conv_wino.hip small_grid_nw4): both forms on the same cases
+    monkeypatch.setenv("DREAM_WINO_SMALL_GRID", "0")
+    errs8 = [pc.check_convT4x4_winograd("cpu", 1, 6, 6, 32, 128, max_workgroups=()),
+             pc.check_convT4x4_winograd("cpu", 2, 13, 9, 48, 96, ops.CONV_RELU, seed=1, with_scale=True)]
+    monkeypatch.setenv("DREAM_WINO_SMALL_GRID", "1")
+    print("winograd convT (eight-wavefront workgroups forced) max rel err", max(errs8))
     errs = [pc.check_convT4x4_winograd("cpu", 1, 6, 6, 32, 128, max_workgroups=()),                        # one block per phase
             pc.check_convT4x4_winograd("cpu", 2, 13, 9, 48, 96, ops.CONV_RELU, seed=1, with_scale=True),    # odd extents, 3 chunks, ragged cout
             pc.check_convT4x4_winograd("cpu", 1, 26, 26, 32, 256, ops.CONV_RELU, seed=2)]                   # two channel blocks, several tile blocks per workgroup

@@ -761,9 +761,13 @@ def test_conv4x4s2_winograd4(b, h, w, cin, cout):
 @pytest.mark.parametrize("b,h,w,cin,cout,flags,kw", [
     (1, 6, 6, 32, 128, 0, {}), (2, 13, 9, 48, 96, 1, {"with_scale": True}), (1, 26, 26, 32, 256, 1, {}),
     (4, 13, 13, 2048, 256, 1, {"with_scale": True}), (4, 104, 104, 256, 256, 1, {"with_scale": True}), (2, 208, 208, 256, 256, 1, {})])
-def test_conv_transpose4x4_winograd(b, h, w, cin, cout, flags, kw):
-    """The ResNet decoder's ConvTranspose2d(k4,s2,p1) (dream/models.py:37-136) by minimal filtering on the Winograd kernel."""
+def test_conv_transpose4x4_winograd(b, h, w, cin, cout, flags, kw, monkeypatch):
+    """The ResNet decoder's ConvTranspose2d(k4,s2,p1) (dream/models.py:37-136) by minimal filtering on the Winograd kernel; small grids
+    on four-wavefront workgroups (round 5) and, forced, on eight-wavefront ones."""
     err = pc.check_convT4x4_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw)
+    if b * ((h + 1) // 2) * ((w + 1) // 2) // 32 * ((cout + 127) // 128) < 160:
+        monkeypatch.setenv("DREAM_WINO_SMALL_GRID", "0")
+        err = max(err, pc.check_convT4x4_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw))
     print("convT4x4 winograd %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))
 
 
