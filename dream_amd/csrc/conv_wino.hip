@@ -481,10 +481,12 @@ extern "C" int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const
         p.u = u4 + ph * per_u;
         p.out_oy = ph >> 1; p.out_ox = ph & 1;
         int rc;
-        // a grid of fewer than ~160 eight-wavefront workgroups leaves CUs empty (ResNet's first decoder layer at 16 frames: 2048 -> 256 on
+        // a grid of a few dozen eight-wavefront workgroups leaves most CUs empty (ResNet's first decoder layer at 16 frames: 2048 -> 256 on
         // 13x13 maps = 25 tile blocks x 2 channel blocks on 256 CUs, 1.2 ms): four-wavefront workgroups of 64 channels spread the same
-        // wavefronts over twice the CUs (DREAM_WINO_SMALL_GRID=0: always eight)
-        if (small_grid_nw4() && p.nblk * ((Cout + 127) / 128) < 160) {
+        // wavefronts over twice the CUs (DREAM_WINO_SMALL_GRID=0: always eight).  Measured (profiles/r05_ab_convT_small_grid.txt): 50 -> 100
+        // workgroups +0.8 % on the training step, +3.2 % on resnet_h inference at 16 frames; 98 -> 196 (resnet_f at 32 frames) LOSES 8-40 % (two
+        // four-wavefront workgroups may share a CU while others stay empty): the rule stops at 72.
+        if (small_grid_nw4() && p.nblk * ((Cout + 127) / 128) < 72) {
             switch (ph) {
                 case 0: rc = launch_wino<4, 0, 1>(p, stream); break;
                 case 1: rc = launch_wino<4, 0, 2>(p, stream); break;

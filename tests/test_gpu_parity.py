@@ -765,7 +765,7 @@ def test_conv_transpose4x4_winograd(b, h, w, cin, cout, flags, kw, monkeypatch):
     """The ResNet decoder's ConvTranspose2d(k4,s2,p1) (dream/models.py:37-136) by minimal filtering on the Winograd kernel; small grids
     on four-wavefront workgroups (round 5) and, forced, on eight-wavefront ones."""
     err = pc.check_convT4x4_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw)
-    if b * ((h + 1) // 2) * ((w + 1) // 2) // 32 * ((cout + 127) // 128) < 160:
+    if b * ((h + 1) // 2) * ((w + 1) // 2) // 32 * ((cout + 127) // 128) < 72:
         monkeypatch.setenv("DREAM_WINO_SMALL_GRID", "0")
         err = max(err, pc.check_convT4x4_winograd(DEV, b, h, w, cin, cout, flags, seed=h + cin, **kw))
     print("convT4x4 winograd %dx%dx%d %d->%d flags %d: rel err %.2e" % (b, h, w, cin, cout, flags, err))

@@ -81,6 +81,68 @@ g1)
   line rt128_pipe --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   withlib G0 line rt128_G0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   ;;
+pool)
+  # the pooled tensor stored by the training conv's own launch (MODE 4) against the stand-alone max-pool pass
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "pool_both or pool_in_the_training or train_step or train_steps or reference_golden or variant or data_parallel" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in a b c; do
+    DREAM_POOL_IN_TRAINING_CONV=1 line vt_fused_$r --mode train --steps 4 --warmup 2
+    DREAM_POOL_IN_TRAINING_CONV=0 line vt_separate_$r --mode train --steps 4 --warmup 2
+  done
+  line rt16 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  line rt128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
+sbatch)
+  for r in a b; do for n in 1 4 8 16; do
+    DREAM_SIDE_BATCH=$n line rt16_batch${n}_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done; done
+  for n in 1 8; do DREAM_SIDE_BATCH=$n line rt128_batch${n} --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2; done
+  echo "== pytest"; DREAM_SIDE_BATCH=8 timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "resnet_h_train_step or resnet_f_train_step or vgg_f_train or reference_golden" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  ;;
+waux)
+  for r in a b c; do for l in W0 W1 W16; do withlib $l line dflt_${l}_$r; done; done
+  for l in W0 W16 W0 W16; do withlib $l line vt_$l --mode train --steps 4 --warmup 2; done
+  ;;
+cold)
+  # first bench on a cold box: the forced overlap at 128 frames with record_stream() (arg rec) or kept references (arg keep)
+  K=0; [ "$2" = keep ] && K=1
+  DREAM_SIDE_KEEP=$K DREAM_OVERLAP_MAX_FRAMES=128 line rt128_$2_cold --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  DREAM_SIDE_KEEP=$K DREAM_OVERLAP_MAX_FRAMES=128 line rt128_$2_second --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
+keep)
+  # the weight-gradient stream's inputs kept referenced until the join (DREAM_SIDE_KEEP=1) against record_stream(): is the 300-frames/s mode
+  # of the forced overlap at 128 frames the allocator?
+  for r in a b c d; do
+    DREAM_SIDE_KEEP=1 DREAM_OVERLAP_MAX_FRAMES=128 line rt128_keep_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+    DREAM_SIDE_KEEP=0 DREAM_OVERLAP_MAX_FRAMES=128 line rt128_rec_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  done
+  line rt128_inorder --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  for r in a b c; do
+    DREAM_SIDE_KEEP=1 line rt16_keep_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_SIDE_KEEP=0 line rt16_rec_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  ;;
+diag)
+  DREAM_W4_DIAG_KS=${2:-128,256,15,2,16,8} timeout 600 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/wino4_diag.txt
+  ;;
+lp)
+  for cfg in "vgg_q train 128" "resnet_h train 16" "resnet_h infer 128"; do set -- $cfg
+    timeout 400 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -12 $O/layer_profile_$1_$2$3.txt | cut -c1-200
+  done
+  ;;
+sgrid)
+  # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
+  echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "conv_transpose4x4_winograd or resnet_h_train_step or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for r in a b c; do
+    DREAM_WINO_SMALL_GRID=1 line rt16_nw4_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_WINO_SMALL_GRID=0 line rt16_nw8_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  for r in a b; do
+    DREAM_WINO_SMALL_GRID=1 line rf32_nw4_$r --arch resnet_f --batch 32
+    DREAM_WINO_SMALL_GRID=0 line rf32_nw8_$r --arch resnet_f --batch 32
+    DREAM_WINO_SMALL_GRID=1 line rh16_nw4_$r --arch resnet_h --batch 16
+    DREAM_WINO_SMALL_GRID=0 line rh16_nw8_$r --arch resnet_h --batch 16
+  done
+  ;;
 mask)
   timeout 600 python tools/microbench_wino4_mask.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_wino4_mask.txt
   ;;
