@@ -659,7 +659,7 @@ class _SideStream:
             return torch.cuda.Stream(device=device)
         # Measured round 5 (profiles/r05_ab_side_stream_priority.txt, resnet_h training, one box, alternating): 16 frames 356.7 (normal) /
         # 358.0 (low) / 353.7 (high) frames/s; at 128 frames with the overlap forced the low-priority stream reaches 446-450 against the
-        # in-order 434-436 (two early runs dropped to 300 as in round 4; none of the twelve later ones did: overlap_max_frames is 128 now).
+        # in-order 434-436 -- but two early runs dropped to 300 as in round 4 and the final measurement run to 414: the threshold stays 96.
         try:
             import ctypes
             hip = ctypes.CDLL("libamdhip64.so")
@@ -937,11 +937,11 @@ class ResnetSimple(nn.Module):
         # multiplications, conv_wino.hip), "direct" = sub-pixel phases on conv_mfma
         self.convT_algorithm = os.environ.get("DREAM_CONVT_ALGORITHM", "winograd")
         # weight gradients on a second stream, concurrent with the data-gradient chain (DREAM_OVERLAP_WGRAD=0: in order), up to
-        # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own).  Round 5: 128 (was 96) -- with the
-        # weight-gradient stream at the lowest HIP priority the overlap is worth +3.3 % at 128 frames (437.8 in order, 447-453 in twelve
-        # runs on four boxes, two of them the first process on a cold box; at normal priority round 4 had seen 300-450)
+        # overlap_max_frames 400x400 frames per step (beyond, each kernel fills the chip on its own).  Round 5 tried 128: with the
+        # weight-gradient stream at the lowest HIP priority the overlap gave 447-453 frames/s at 128 frames in twelve runs on four boxes
+        # (in order: 435-438) -- and 414 in the round's final measurement run, 300 in two early ones: unreliable, so 96 stays
         self.overlap_wgrad = os.environ.get("DREAM_OVERLAP_WGRAD", "1") != "0"
-        self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "128"))
+        self.overlap_max_frames = int(os.environ.get("DREAM_OVERLAP_MAX_FRAMES", "96"))
         # the 3x3 convs' BatchNorm statistics / masked backward reductions in the Winograd F(2x2) kernel's epilogue (csrc/conv_wino.hip
         # WINO_STAT) -- 66 launches fewer per ResNet-101 step; measured round 5 (profiles/r05_ab_bn_fusion_3x3.txt, alternating on one
         # box): 350.4 -> 358.5 frames/s at 16 frames (+2.3 %), so on by default; "0" = the stand-alone bn_stats / bn_bwd_stats passes
