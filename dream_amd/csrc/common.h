@@ -29,8 +29,6 @@ char *dream_err_buf();            // thread-local, 512 bytes
 // hipFuncAttributeMaxDynamicSharedMemorySize (the full 160 KB of LDS) is a property of (device, kernel): set once per pair,
 // from whichever host thread launches the kernel on that device first (api.hip).  0 = ok, else the error text is set.
 int dream_allow_full_lds(const void *kernel);
-// fork (1): three per-device auxiliary streams ordered behind `stream` -> out[3]; join (0): `stream` ordered behind them (api.hip)
-int dream_aux_streams(void *stream, int fork, hipStream_t out[3]);
 
 #define DREAM_LAUNCH_OK() DREAM_HIP_OK(hipGetLastError())
 

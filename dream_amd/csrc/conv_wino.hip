@@ -183,7 +183,6 @@ int g_max_workgroups = 0;     // test hook: cap on resident workgroups (0 = the 
 // persistent grid: as many workgroups as the 256 CUs hold at once (2 of the 4-wave, 1 of the 8-wave kind per CU), a
 // multiple of 8 (XCDs), split over the output-channel blocks; fewer when there are fewer tile blocks than that
 // read per call (four launches per layer): tests and A/B runs switch it through the environment
-bool concurrent_phases() { const char *e = getenv("DREAM_CONVT_CONCURRENT"); return !(e != nullptr && e[0] == '0'); }
 bool small_grid_nw4() { const char *e = getenv("DREAM_WINO_SMALL_GRID"); return !(e != nullptr && e[0] == '0'); }
 
 int wino_grid_x(int nw, int Cout, int nblk) {
@@ -478,28 +477,16 @@ extern "C" int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const
     WinoParams p;
     if (int rc = wino_setup(p, x, u4, scale, shift, nullptr, y, B, H, W, Cin, Cout, flags, 2)) return rc;
     const size_t per_u = dream_conv3x3_winograd_weight_floats(Cout, Cin);
-    // The four output phases are independent launches (disjoint outputs, the same input).  Where one phase's grid cannot fill the chip
-    // (fewer than 200 eight-wavefront workgroups: ResNet's first decoder layers at <= 32 frames per GPU) they run CONCURRENTLY, phase 0
-    // on the caller's stream and phases 1-3 on three auxiliary streams forked from it and joined back (api.hip dream_aux_streams;
-    // DREAM_CONVT_CONCURRENT=0: one after the other).
-    const int wgs8 = p.nblk * ((Cout + 127) / 128);
-    const bool concurrent = concurrent_phases() && wgs8 < 200;
-    hipStream_t aux[3] = {nullptr, nullptr, nullptr};
-    if (concurrent) {
-        if (int rc = dream_aux_streams(stream, 1, aux)) return rc;
-    }
-    void *const caller_stream = stream;
     for (int ph = 0; ph < 4; ++ph) {
         p.u = u4 + ph * per_u;
         p.out_oy = ph >> 1; p.out_ox = ph & 1;
-        stream = (concurrent && ph > 0) ? (void *)aux[ph - 1] : caller_stream;
         int rc;
-        // (without the concurrent phases:) a grid of a few dozen eight-wavefront workgroups leaves most CUs empty (ResNet's first decoder layer at 16 frames: 2048 -> 256 on
+        // a grid of a few dozen eight-wavefront workgroups leaves most CUs empty (ResNet's first decoder layer at 16 frames: 2048 -> 256 on
         // 13x13 maps = 25 tile blocks x 2 channel blocks on 256 CUs, 1.2 ms): four-wavefront workgroups of 64 channels spread the same
         // wavefronts over twice the CUs (DREAM_WINO_SMALL_GRID=0: always eight).  Measured (profiles/r05_ab_convT_small_grid.txt): 50 -> 100
         // workgroups +0.8 % on the training step, +3.2 % on resnet_h inference at 16 frames; 98 -> 196 (resnet_f at 32 frames) LOSES 8-40 % (two
         // four-wavefront workgroups may share a CU while others stay empty): the rule stops at 72.
-        if (!concurrent && small_grid_nw4() && wgs8 < 72) {
+        if (small_grid_nw4() && p.nblk * ((Cout + 127) / 128) < 72) {
             switch (ph) {
                 case 0: rc = launch_wino<4, 0, 1>(p, stream); break;
                 case 1: rc = launch_wino<4, 0, 2>(p, stream); break;
@@ -516,6 +503,5 @@ extern "C" int dream_conv_transpose4x4s2_winograd_nhwc_f32(const float *x, const
         }
         if (rc) return rc;
     }
-    if (concurrent) return dream_aux_streams(caller_stream, 0, aux);
     return 0;
 }

@@ -97,8 +97,6 @@ inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullpt
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-constexpr unsigned hipStreamNonBlocking = 1;
-inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     strcpy(p->name, "SIMT emulator"); strcpy(p->gcnArchName, "host"); p->multiProcessorCount = 0; return hipSuccess;
 }
