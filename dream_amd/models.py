@@ -642,10 +642,14 @@ class _SideStream:
     def create(cls, like, enabled=True):
         if not (enabled and like.is_cuda):
             return None
-        dev = like.device.index
-        if dev not in cls._streams:
-            cls._streams[dev] = cls._new_stream(like.device)
-        return cls(cls._streams[dev])
+        # Under hipGraph capture (the replicas of the single-process data-parallel path, DREAM_TRAIN_GRAPH) the side branch is captured
+        # from a NORMAL-priority stream: a low-priority one captured into the graph slows the replayed step from 344 to 264 frames/s
+        # (resnet_h, 16 frames; profiles/r05_ab_train_graph.txt) -- the eager step is the one that gains from the low priority.
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (like.device.index, capturing)
+        if key not in cls._streams:
+            cls._streams[key] = torch.cuda.Stream(device=like.device) if capturing else cls._new_stream(like.device)
+        return cls(cls._streams[key])
 
     @staticmethod
     def _new_stream(device):

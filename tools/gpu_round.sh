@@ -10,7 +10,7 @@ line() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-se
 import json,sys
 try:
     d=json.loads(sys.stdin.read()); r=d.get('roofline',{})
-    print('$n', round(d['value'],1), 'fps', round(d['ms_per_step'],2), 'ms', 'frac', round(r.get('frac',0),4), 'exec', r.get('executed_frac'))
+    print('$n', round(d['value'],1), 'fps', round(d['ms_per_step'],2), 'ms', 'frac', round(r.get('frac') or 0,4), 'exec', r.get('executed_frac'))
 except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
@@ -128,6 +128,24 @@ lp)
   for cfg in "vgg_q train 128" "resnet_h train 16" "resnet_h infer 128"; do set -- $cfg
     timeout 400 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -12 $O/layer_profile_$1_$2$3.txt | cut -c1-200
   done
+  ;;
+tg)
+  # the one-device training step as two hipGraph replays (DREAM_TRAIN_GRAPH=1) against the eager step, on the round's last tree
+  for r in a b; do
+    DREAM_TRAIN_GRAPH=0 line rt16_eager_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+    DREAM_TRAIN_GRAPH=1 line rt16_graph_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  done
+  DREAM_TRAIN_GRAPH=0 line vt_eager --mode train --steps 4 --warmup 3
+  DREAM_TRAIN_GRAPH=1 line vt_graph --mode train --steps 4 --warmup 3
+  ;;
+tg2)
+  # which of the round's changes slowed the captured training step down?
+  DREAM_TRAIN_GRAPH=1 line g_all --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  DREAM_TRAIN_GRAPH=1 DREAM_SIDE_STREAM_PRIORITY=default line g_prio_default --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  DREAM_TRAIN_GRAPH=1 DREAM_SIDE_KEEP=0 line g_keep0 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  DREAM_TRAIN_GRAPH=1 DREAM_SIDE_STREAM_PRIORITY=default DREAM_SIDE_KEEP=0 line g_prio_default_keep0 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  DREAM_TRAIN_GRAPH=1 DREAM_BN_FUSION_3X3=0 line g_bn3off --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  DREAM_TRAIN_GRAPH=1 DREAM_OVERLAP_WGRAD=0 line g_nooverlap --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   ;;
 conc)
   # the four phases of a small transposed conv on four streams at once (DREAM_CONVT_CONCURRENT=1, default) vs one after the other (=0)
