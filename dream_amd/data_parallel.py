@@ -221,8 +221,12 @@ class DreamDataParallel(nn.Module):
         """Replica launch sequences as hipGraphs: real GPUs, more than one replica (or ``single_device_graphs``), not switched
         off (DREAM_DP_GRAPHS=0)."""
         devs = self.devices()
-        return ((len(devs) > 1 or self.single_device_graphs) and devs[0].type == "cuda"
-                and os.environ.get("DREAM_DP_GRAPHS", "1") != "0")
+        on = ((len(devs) > 1 or self.single_device_graphs) and devs[0].type == "cuda"
+              and os.environ.get("DREAM_DP_GRAPHS", "1") != "0")
+        if on:
+            from . import models
+            models._SideStream.forbid_low_priority()      # see there: low-priority streams and replayed graphs do not mix
+        return on
 
     # ---- replicas ---------------------------------------------------------------------------------------------------------
     def flatten_parameters(self):

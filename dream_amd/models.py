@@ -646,10 +646,23 @@ class _SideStream:
         # from a NORMAL-priority stream: a low-priority one captured into the graph slows the replayed step from 344 to 264 frames/s
         # (resnet_h, 16 frames; profiles/r05_ab_train_graph.txt) -- the eager step is the one that gains from the low priority.
         capturing = torch.cuda.is_current_stream_capturing()
+        if capturing and cls.low_priority_allowed:
+            cls.forbid_low_priority()                  # a model that captures was not announced (DreamDataParallel.use_graphs does)
         key = (like.device.index, capturing)
         if key not in cls._streams:
             cls._streams[key] = torch.cuda.Stream(device=like.device) if capturing else cls._new_stream(like.device)
         return cls(cls._streams[key])
+
+    low_priority_allowed = True
+
+    @classmethod
+    def forbid_low_priority(cls):
+        """Processes that replay training steps as hipGraphs get normal-priority weight-gradient streams throughout: with a low-priority
+        stream merely PRESENT in the process (the eager warm-up steps create it) the replayed step runs at 259-263 frames/s instead of 344
+        (resnet_h, 16 frames; profiles/r05_ab_train_graph.txt), whichever stream the side branch was captured from."""
+        if cls.low_priority_allowed:
+            cls.low_priority_allowed = False
+            cls._streams.clear()
 
     @staticmethod
     def _new_stream(device):
@@ -657,6 +670,8 @@ class _SideStream:
         torch.cuda.Stream only offers normal / high), so that the dispatcher prefers the main stream's dependent chain -- the step's
         critical path -- wherever both have workgroups pending; "high": the opposite (A/B); default: a normal-priority stream."""
         want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "low")
+        if want == "low" and not _SideStream.low_priority_allowed:
+            want = "default"
         if want == "high":
             return torch.cuda.Stream(device=device, priority=-1)
         if want != "low":
