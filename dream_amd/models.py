@@ -666,10 +666,13 @@ class _SideStream:
 
     @staticmethod
     def _new_stream(device):
-        """DREAM_SIDE_STREAM_PRIORITY=low: the weight-gradient stream at the LOWEST HIP stream priority (hipStreamCreateWithPriority;
+        """DREAM_SIDE_STREAM_PRIORITY=low (opt-in): the weight-gradient stream at the LOWEST HIP stream priority (hipStreamCreateWithPriority;
         torch.cuda.Stream only offers normal / high), so that the dispatcher prefers the main stream's dependent chain -- the step's
         critical path -- wherever both have workgroups pending; "high": the opposite (A/B); default: a normal-priority stream."""
-        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "low")
+        # "default" is the default: the low priority measured +0.4 % at 16 frames (noise level) and makes the overlap at 128 frames better but
+        # still unreliable, while a low-priority stream in the process slows every replayed training GRAPH by a quarter (below) -- and
+        # nothing is known about its interplay with RCCL's streams on a multi-GPU node.  Opt-in: DREAM_SIDE_STREAM_PRIORITY=low.
+        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "default")
         if want == "low" and not _SideStream.low_priority_allowed:
             want = "default"
         if want == "high":
