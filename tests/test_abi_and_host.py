@@ -176,3 +176,21 @@ def test_python_surface_matches_reference_signatures():
                 assert params(getattr(getattr(mod, cls), name)) == sig, (cls, name)
     for name, sig in surface["dream.image_proc"].items():
         assert params(getattr(image_proc, name)) == sig, name
+
+
+def test_bench_leaves_one_json_error_line_without_a_gpu():
+    """bench.py on a box it cannot run on (here: no GPU) must leave ONE JSON line with an `error` field and a non-zero exit status
+    -- what makes a failed SCALE record diagnosable -- not a bare traceback."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the error path of this test needs none")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], cwd=root, capture_output=True,
+                         text=True, timeout=300)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode != 0 and len(lines) == 1, (out.returncode, out.stdout[-500:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and "needs a GPU" in line["error"] and line["n_gpus"] == 1
