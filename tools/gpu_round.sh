@@ -147,22 +147,6 @@ tg2)
   DREAM_TRAIN_GRAPH=1 DREAM_BN_FUSION_3X3=0 line g_bn3off --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   DREAM_TRAIN_GRAPH=1 DREAM_OVERLAP_WGRAD=0 line g_nooverlap --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   ;;
-conc)
-  # the four phases of a small transposed conv on four streams at once (DREAM_CONVT_CONCURRENT=1, default) vs one after the other (=0)
-  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv_transpose4x4_winograd or resnet or structured or data_parallel or graph" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
-  for r in a b c; do
-    DREAM_CONVT_CONCURRENT=1 line rt16_conc_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
-    DREAM_CONVT_CONCURRENT=0 line rt16_serial_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
-  done
-  for r in a b; do
-    DREAM_CONVT_CONCURRENT=1 line rf32_conc_$r --arch resnet_f --batch 32
-    DREAM_CONVT_CONCURRENT=0 line rf32_serial_$r --arch resnet_f --batch 32
-    DREAM_CONVT_CONCURRENT=1 line rh16_conc_$r --arch resnet_h --batch 16
-    DREAM_CONVT_CONCURRENT=0 line rh16_serial_$r --arch resnet_h --batch 16
-  done
-  DREAM_CONVT_CONCURRENT=1 line rh128_conc --arch resnet_h --batch 128
-  DREAM_CONVT_CONCURRENT=0 line rh128_serial --arch resnet_h --batch 128
-  ;;
 sgrid)
   # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
   echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "conv_transpose4x4_winograd or resnet_h_train_step or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
