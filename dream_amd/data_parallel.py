@@ -27,6 +27,7 @@ device_ids=gpu_ids).cuda()`` does for the reference (/root/reference/dream/netwo
     the gradient exchange is the bucketed RCCL all-reduce inside the model's own autograd node (dream_amd/models.py).
 """
 import copy
+import gc
 import os
 import threading
 import weakref
@@ -161,6 +162,92 @@ class _DataParallelFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _SplitCapture:
+    """A replica's backward captured as a SEQUENCE of hipGraphs (``DREAM_TRAIN_GRAPH_SPLIT=n``: n weight-gradient leaves per
+    segment) instead of one graph with a forked branch -- see models._DeferredSide for why.  ``plan`` = [("main", graph) |
+    ("side", graph) | ("join",)] in capture order.  Main segments share the replica's pool (with the forward graph: they replay in
+    capture order on one stream); the leaf segments have a pool of their own, because they replay CONCURRENTLY with the main
+    segments that follow them -- a block freed inside a leaf segment must not be handed to a later main segment.  What crosses over
+    is kept alive by construction: leaf inputs (main pool) until join(), leaf outputs = the weight gradients (side pool) until
+    the last main segment has packed them."""
+
+    def __init__(self, pool, leaves, device):
+        self.pool, self.side_pool, self.leaves = pool, None, max(1, int(leaves))
+        self.plan, self.cur = [], None
+        from . import models
+        live = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT_STREAM", "live") == "live"
+        self.side = models._SideStream.live_stream(device) if live else torch.cuda.Stream(device=device)   # captures the leaf segments; replays them
+        self.mark = torch.zeros(1, device=device)               # one tiny node per main segment: never an empty graph
+
+    def _begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def _end(self):
+        self.mark.add_(1.0)
+        self.cur.capture_end()
+        self.plan.append(("main", self.cur))
+        self.cur = None
+
+    def cut(self, fns, join=False):
+        """Called by models._DeferredSide from inside the backward: close the running main segment, capture ``fns`` (the collected
+        leaves) on the second stream, open the next main segment; ``join``: the next main segment waits for every leaf segment."""
+        self._end()
+        if fns:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(self.side):
+                if self.side_pool is None:
+                    graph.capture_begin(capture_error_mode="thread_local")
+                else:
+                    graph.capture_begin(pool=self.side_pool, capture_error_mode="thread_local")
+                try:
+                    for fn in fns:
+                        fn()
+                finally:
+                    graph.capture_end()
+            if self.side_pool is None:
+                self.side_pool = graph.pool()
+            self.plan.append(("side", graph))
+        if join:
+            self.plan.append(("join",))
+        self._begin()
+
+    def capture(self, fn):
+        from . import models
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        stream = torch.cuda.Stream(device=self.mark.device)     # captures cannot be taken on the default stream
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            models._split_capture.ctl = self
+            try:
+                self._begin()
+                try:
+                    fn()
+                finally:
+                    self._end()
+            finally:
+                models._split_capture.ctl = None
+        torch.cuda.current_stream().wait_stream(stream)
+
+    def replay(self):
+        main, behind = torch.cuda.current_stream(), False
+        for op in self.plan:
+            if op[0] == "main":
+                op[1].replay()
+            elif op[0] == "side":
+                self.side.wait_stream(main)                     # the leaves read what the segments so far have produced
+                with torch.cuda.stream(self.side):
+                    op[1].replay()
+                behind = True
+            else:
+                main.wait_stream(self.side)
+                behind = False
+        if behind:
+            main.wait_stream(self.side)
+
+
 class DreamDataParallel(nn.Module):
     """Drop-in for ``torch.nn.DataParallel`` on the path of dream/network.py:244-256: ``.module``, ``module.``-prefixed
     ``state_dict()`` keys, ``device_ids`` (None / empty = every visible device), input on ``device_ids[0]``, outputs gathered
@@ -188,6 +275,12 @@ class DreamDataParallel(nn.Module):
         # ResNet-101 step at 16 frames leaves the GPU idle 11 % of the time waiting for the host between its small kernels
         # (profiles/r04_bench_resnet_h_train16_concurrency.txt).  Same kernels in the same order: bit-identical.
         self.single_device_graphs = os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
+        # DREAM_TRAIN_GRAPH_SPLIT=n: a captured backward becomes a sequence of graphs, n weight-gradient leaves per segment, the leaf
+        # segments replayed on a live second stream (_SplitCapture); 0: one graph, the leaves a forked branch inside it.  Unset (None):
+        # 8 for the one-device step, where it was measured (resnet_h, 16 frames: 342 -> 360.5 frames/s, eager 367.8; 2 / 4 / 16 / 32 leaves:
+        # 356 / 358-360 / 358 / 358.5; profiles/r05_ab_train_graph.txt), 0 for the replicas of a multi-device step (no node to measure on).
+        env = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT")
+        self.graph_split_leaves = int(env) if env not in (None, "") else None
         # statistics of the last step (tests, bench): hipGraph replays / eager replica runs / captures
         object.__setattr__(self, "stats", {"replays": 0, "eager": 0, "captures": 0, "param_copies": 0, "replica_steps": 0})
 
@@ -406,9 +499,16 @@ class DreamDataParallel(nn.Module):
                 with DreamDataParallel._capture_lock:
                     entry["gos"] = [None if g is None else g.clone() for g in gos]
                     torch.cuda.current_stream().synchronize()
-                    graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(graph, pool=entry["pool"], capture_error_mode="thread_local"):
-                        self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels)
+                    split = self.graph_split_leaves
+                    if split is None:
+                        split = 8 if len(self.devices()) == 1 else 0
+                    if split > 0:
+                        graph = _SplitCapture(entry["pool"], split, gflat.device)
+                        graph.capture(lambda: self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels))
+                    else:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, pool=entry["pool"], capture_error_mode="thread_local"):
+                            self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels)
                     entry.update(bwd=graph, gflat_ptr=gflat.data_ptr())
                     self.stats["captures"] += 1
             assert entry["gflat_ptr"] == gflat.data_ptr()

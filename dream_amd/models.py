@@ -19,6 +19,7 @@ skip-connection adds, and an NCHW store in the last head conv; ``backward`` walk
 call raises -- there is no CPU path in this package.
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -646,12 +647,24 @@ class _SideStream:
         # from a NORMAL-priority stream: a low-priority one captured into the graph slows the replayed step from 344 to 264 frames/s
         # (resnet_h, 16 frames; profiles/r05_ab_train_graph.txt) -- the eager step is the one that gains from the low priority.
         capturing = torch.cuda.is_current_stream_capturing()
+        ctl = getattr(_split_capture, "ctl", None)
+        if capturing and ctl is not None:
+            return _DeferredSide(ctl)                  # a backward captured in segments (below): the leaves get graphs of their own
         if capturing and cls.low_priority_allowed:
             cls.forbid_low_priority()                  # a model that captures was not announced (DreamDataParallel.use_graphs does)
         key = (like.device.index, capturing)
         if key not in cls._streams:
             cls._streams[key] = torch.cuda.Stream(device=like.device) if capturing else cls._new_stream(like.device)
         return cls(cls._streams[key])
+
+    @classmethod
+    def live_stream(cls, device):
+        """The second stream of eager steps on ``device`` (created on first use): what a backward replayed as a sequence of graphs
+        sends its leaf segments to -- the stream that is known to run beside the main stream, not one more hardware queue."""
+        key = (device.index, False)
+        if key not in cls._streams:
+            cls._streams[key] = cls._new_stream(device)
+        return cls._streams[key]
 
     low_priority_allowed = True
 
@@ -739,6 +752,35 @@ class _SideStream:
         self.main.wait_stream(self.side)
         if self.keep is not None:
             del self.keep[:]
+
+
+_split_capture = threading.local()       # .ctl: the controller of a backward that is being captured in segments (data_parallel._SplitCapture)
+
+
+class _DeferredSide:
+    """The weight-gradient leaves of a backward captured as a SEQUENCE of hipGraphs (DREAM_TRAIN_GRAPH_SPLIT=n, data_parallel
+    ._SplitCapture).  One hipGraph with a forked branch replays no faster than the in-order graph (resnet_h, 16 frames: 343 frames/s
+    with one, two or four executor queues, profiles/r05_ab_train_graph.txt) while the eager step gains 7 % from its second
+    stream.  So the leaves are not forked inside the capture: every ``n`` of them the main capture is cut, the collected leaves
+    are captured into a graph of their own (second stream, second memory pool), and the main capture resumes.  Replayed, the
+    main segments go to the main stream, the leaf segments to a live second stream ordered behind the segment that produced
+    their inputs by an ordinary event: two hardware queues, as in the eager step.  The leaves' inputs stay referenced until
+    join(), so no later main segment can be handed their memory while a leaf segment may still read it."""
+
+    def __init__(self, ctl):
+        self.ctl, self.pending, self.keep = ctl, [], []
+
+    def run(self, fn, *inputs):
+        self.pending.append(fn)
+        self.keep.append(inputs)
+        if len(self.pending) >= self.ctl.leaves:
+            self.ctl.cut(self.pending)
+            del self.pending[:]
+
+    def join(self):
+        self.ctl.cut(self.pending, join=True)
+        del self.pending[:]
+        del self.keep[:]
 
 
 def _on_side(side, fn, *inputs):

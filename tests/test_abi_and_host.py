@@ -194,3 +194,30 @@ def test_bench_leaves_one_json_error_line_without_a_gpu():
     assert out.returncode != 0 and len(lines) == 1, (out.returncode, out.stdout[-500:])
     line = json.loads(lines[0])
     assert line["value"] is None and "needs a GPU" in line["error"] and line["n_gpus"] == 1
+
+
+def test_deferred_side_hands_the_leaves_over_in_segments():
+    """models._DeferredSide (a backward captured as a sequence of graphs, DREAM_TRAIN_GRAPH_SPLIT): leaves are not run where they are
+    queued but handed to the capture controller every `leaves` of them, in order, and the rest at join(); their inputs stay
+    referenced until join()."""
+    from dream_amd import models
+
+    class Ctl:
+        leaves = 3
+
+        def __init__(self):
+            self.cuts = []
+
+        def cut(self, fns, join=False):
+            self.cuts.append(([fn() for fn in fns], join))
+
+    ctl = Ctl()
+    side = models._DeferredSide(ctl)
+    ran = []
+    for i in range(7):
+        side.run(lambda i=i: ran.append(i) or i, "in%d" % i)
+        assert len(ran) == 3 * ((i + 1) // 3) and len(side.keep) == i + 1
+    side.join()
+    assert ctl.cuts == [([0, 1, 2], False), ([3, 4, 5], False), ([6], True)] and side.keep == [] and side.pending == []
+    side.join()                                            # nothing pending: still a cut, so that the main stream waits
+    assert ctl.cuts[-1] == ([], True)

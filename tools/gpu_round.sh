@@ -6,7 +6,7 @@ O=gpurun_out/r05_$1
 mkdir -p $O
 export TMPDIR=/tmp
 PROD=dream_amd/libdream_hip.so
-line() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "
+line() { n=$1; shift; timeout ${LINE_TIMEOUT:-600} python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | python -c "
 import json,sys
 try:
     d=json.loads(sys.stdin.read()); r=d.get('roofline',{})
@@ -146,6 +146,55 @@ tg2)
   DREAM_TRAIN_GRAPH=1 DREAM_SIDE_STREAM_PRIORITY=default DREAM_SIDE_KEEP=0 line g_prio_default_keep0 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   DREAM_TRAIN_GRAPH=1 DREAM_BN_FUSION_3X3=0 line g_bn3off --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   DREAM_TRAIN_GRAPH=1 DREAM_OVERLAP_WGRAD=0 line g_nooverlap --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  ;;
+tg3)
+  # the runtime's side of a captured training step: how many queues the graph executor spreads the two branches over
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  line eager_a $R
+  DREAM_TRAIN_GRAPH=1 line g_a $R
+  for q in 1 2 8; do DREAM_TRAIN_GRAPH=1 DEBUG_HIP_FORCE_GRAPH_QUEUES=$q line g_q$q $R; done
+  for b in 1 100000; do DREAM_TRAIN_GRAPH=1 DEBUG_HIP_GRAPH_BATCH_SIZE=$b line g_b$b $R; done
+  DREAM_TRAIN_GRAPH=1 GPU_MAX_HW_QUEUES=8 line g_hw8 $R
+  DREAM_TRAIN_GRAPH=1 line g_b $R
+  line eager_b $R
+  DREAM_TRAIN_GRAPH=1 AMD_LOG_LEVEL=4 timeout 240 python bench.py --arch resnet_h --mode train --batch 16 --steps 1 --warmup 3 --no-cpu-baseline --no-secondary 2>&1 \
+    | grep -E "max_streams|parallel streams|max streams" | sed 's/^.*\(\[hipGraph\]\|GraphExec\)/\1/' | sort | uniq -c | tee $O/graph_streams.txt
+  ;;
+tg4)
+  # the captured backward as a SEQUENCE of graphs, the weight-gradient leaves replayed on a live second stream (DREAM_TRAIN_GRAPH_SPLIT=leaves per segment)
+  export LINE_TIMEOUT=150
+  echo "== pytest"; timeout 400 python -m pytest tests -m gpu -q -x --timeout 150 -k "one_device_training_step" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  line eager_a $R
+  DREAM_TRAIN_GRAPH=1 line g_a $R
+  for n in 8 2 4 16 32 1000 8; do DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=$n line g_split$n $R; done
+  line eager_b $R
+  ;;
+tg5)
+  # tg4 again: the leaf segments on the eager steps' own second stream (live) or on a fresh one (new); repeats for the spread
+  export LINE_TIMEOUT=150
+  echo "== pytest"; timeout 400 python -m pytest tests -m gpu -q -x --timeout 150 -k "one_device_training_step" > $O/pytest.log 2>&1; echo "rc=$?"; tail -1 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  line eager_a $R
+  for r in a b c; do
+    DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=8 line live8_$r $R
+    DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=8 DREAM_TRAIN_GRAPH_SPLIT_STREAM=new line new8_$r $R
+  done
+  DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=4 line live4 $R
+  line eager_b $R
+  ;;
+tg6)
+  # split graphs as the default of the one-device captured step: every test that captures, and the lines
+  export LINE_TIMEOUT=150
+  echo "== pytest"; timeout 500 python -m pytest tests -m gpu -q -x --timeout 200 -k "graph or data_parallel or replica or dp_" > $O/pytest.log 2>&1; echo "rc=$?"; tail -1 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  V="--mode train --batch 16 --steps 10 --warmup 4"
+  line rt16_eager $R
+  DREAM_TRAIN_GRAPH=1 line rt16_graph $R
+  DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=0 line rt16_graph_one $R
+  line vt16_eager $V
+  DREAM_TRAIN_GRAPH=1 line vt16_graph $V
+  DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=0 line vt16_graph_one $V
   ;;
 sgrid)
   # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
