@@ -225,8 +225,14 @@ class _SplitCapture:
                 self._begin()
                 try:
                     fn()
-                finally:
-                    self._end()
+                except BaseException:
+                    if self.cur is not None:                    # leave no capture open behind the error that is being reported
+                        try:
+                            self.cur.capture_end()
+                        except Exception:
+                            pass
+                    raise
+                self._end()
             finally:
                 models._split_capture.ctl = None
         torch.cuda.current_stream().wait_stream(stream)

@@ -719,8 +719,12 @@ class _SideStream:
         self.keep = [] if os.environ.get("DREAM_SIDE_KEEP", "1") == "1" else None
         self.batch = int(os.environ.get("DREAM_SIDE_BATCH", "1"))
         self.pending = []
+        self.count = 0
+
+    leaves_of_last_backward = 0                  # leaves between create() and join() of the last eager backward (for _DeferredSide)
 
     def run(self, fn, *inputs):
+        self.count += 1
         if self.batch > 1 and self.keep is not None:
             # leaves are launched in groups: ONE event (record on the main stream, wait on the side stream) per `batch` leaves instead
             # of one per leaf -- the side stream has slack, the main stream's queue carries ~330 fewer barrier packets per ResNet step
@@ -750,6 +754,7 @@ class _SideStream:
     def join(self):
         self.flush()
         self.main.wait_stream(self.side)
+        _SideStream.leaves_of_last_backward = self.count
         if self.keep is not None:
             del self.keep[:]
 
@@ -769,11 +774,20 @@ class _DeferredSide:
 
     def __init__(self, ctl):
         self.ctl, self.pending, self.keep = ctl, [], []
+        # The leaves after the last cut run when the main chain has ended: nothing hides them.  With the number of leaves known (the
+        # eager step before the capture counted them) the last segments are tapered -- half of what remains, down to single leaves --
+        # so that the exposed tail is one leaf, as in the eager step.  DREAM_TRAIN_GRAPH_SPLIT_TAPER=0: equal segments throughout.
+        taper = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT_TAPER", "1") == "1"
+        self.total, self.seen = (_SideStream.leaves_of_last_backward if taper else 0), 0
 
     def run(self, fn, *inputs):
         self.pending.append(fn)
         self.keep.append(inputs)
-        if len(self.pending) >= self.ctl.leaves:
+        self.seen += 1
+        want = self.ctl.leaves
+        if self.total > self.seen:
+            want = max(1, min(want, (self.total - self.seen + len(self.pending)) // 2))
+        if len(self.pending) >= want:
             self.ctl.cut(self.pending)
             del self.pending[:]
 

@@ -196,7 +196,7 @@ def test_bench_leaves_one_json_error_line_without_a_gpu():
     assert line["value"] is None and "needs a GPU" in line["error"] and line["n_gpus"] == 1
 
 
-def test_deferred_side_hands_the_leaves_over_in_segments():
+def test_deferred_side_hands_the_leaves_over_in_segments(monkeypatch):
     """models._DeferredSide (a backward captured as a sequence of graphs, DREAM_TRAIN_GRAPH_SPLIT): leaves are not run where they are
     queued but handed to the capture controller every `leaves` of them, in order, and the rest at join(); their inputs stay
     referenced until join()."""
@@ -211,6 +211,7 @@ def test_deferred_side_hands_the_leaves_over_in_segments():
         def cut(self, fns, join=False):
             self.cuts.append(([fn() for fn in fns], join))
 
+    monkeypatch.setattr(models._SideStream, "leaves_of_last_backward", 0)       # number of leaves unknown: equal segments
     ctl = Ctl()
     side = models._DeferredSide(ctl)
     ran = []
@@ -221,3 +222,12 @@ def test_deferred_side_hands_the_leaves_over_in_segments():
     assert ctl.cuts == [([0, 1, 2], False), ([3, 4, 5], False), ([6], True)] and side.keep == [] and side.pending == []
     side.join()                                            # nothing pending: still a cut, so that the main stream waits
     assert ctl.cuts[-1] == ([], True)
+    # number of leaves known from the eager step before: the last segments shrink to single leaves, one leaf is left for join()
+    monkeypatch.setattr(models._SideStream, "leaves_of_last_backward", 20)
+    ctl = Ctl()
+    ctl.leaves = 8
+    side = models._DeferredSide(ctl)
+    for i in range(20):
+        side.run(lambda i=i: i)
+    side.join()
+    assert [len(c[0]) for c in ctl.cuts] == [8, 6, 3, 1, 1, 1] and [c[0] for c in ctl.cuts][-1] == [19] and ctl.cuts[-1][1], ctl.cuts

@@ -1149,7 +1149,7 @@ def test_one_device_training_step_as_graph_replay_equals_eager(arch, res, split)
         plans = [v["bwd"].plan for v in g.model._graphs.values() if v["bwd"] is not None]
         kinds = [op[0] for op in plans[0]]
         assert len(plans) == 1 and kinds[0] == "main" and kinds[-2:] == ["join", "main"], kinds
-        assert kinds.count("join") == 1 and (kinds.count("side") == 1 if split == 1000 else kinds.count("side") >= 3), kinds
+        assert kinds.count("join") == 1 and kinds.count("side") >= (1 if split == 1000 else 3), kinds     # 1000: only the tapered tail
         print(arch, "split", split, "->", kinds.count("main"), "main and", kinds.count("side"), "leaf segments")
     assert lg == le, (lg, le)
     for (k, a), (_, b) in zip(g.model.state_dict().items(), e.model.state_dict().items()):

@@ -196,6 +196,20 @@ tg6)
   DREAM_TRAIN_GRAPH=1 line vt16_graph $V
   DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=0 line vt16_graph_one $V
   ;;
+tg7)
+  # split graphs: the last segments tapered down to single leaves (DREAM_TRAIN_GRAPH_SPLIT_TAPER=1) or equal segments (=0)
+  export LINE_TIMEOUT=150
+  echo "== pytest"; timeout 400 python -m pytest tests -m gpu -q -x --timeout 150 -k "one_device_training_step or graph_replay_equals" > $O/pytest.log 2>&1; echo "rc=$?"; tail -1 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  line eager_a $R
+  for r in a b; do
+    DREAM_TRAIN_GRAPH=1 line taper_$r $R
+    DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT_TAPER=0 line equal_$r $R
+  done
+  DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=12 line taper12 $R
+  DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=5 line taper5 $R
+  line eager_b $R
+  ;;
 sgrid)
   # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
   echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "conv_transpose4x4_winograd or resnet_h_train_step or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
