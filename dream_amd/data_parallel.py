@@ -283,8 +283,9 @@ class DreamDataParallel(nn.Module):
         self.single_device_graphs = os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
         # DREAM_TRAIN_GRAPH_SPLIT=n: a captured backward becomes a sequence of graphs, n weight-gradient leaves per segment, the leaf
         # segments replayed on a live second stream (_SplitCapture); 0: one graph, the leaves a forked branch inside it.  Unset (None):
-        # 8 for the one-device step, where it was measured (resnet_h, 16 frames: 342 -> 360.5 frames/s, eager 367.8; 2 / 4 / 16 / 32 leaves:
-        # 356 / 358-360 / 358 / 358.5; profiles/r05_ab_train_graph.txt), 0 for the replicas of a multi-device step (no node to measure on).
+        # 12 for the one-device step, where it was measured (resnet_h, 16 frames: 342 -> 363-365 frames/s, eager 367; 8 leaves: 360-364, 5: 359.5;
+        # vgg_q at 16 frames 585 -> 590, eager 586.5; profiles/r05_ab_train_graph.txt), 0 for the replicas of a multi-device step (no node to
+        # measure on; four replicas on one GPU with split 8 pass their bit-for-bit test).
         env = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT")
         self.graph_split_leaves = int(env) if env not in (None, "") else None
         # statistics of the last step (tests, bench): hipGraph replays / eager replica runs / captures
@@ -507,7 +508,7 @@ class DreamDataParallel(nn.Module):
                     torch.cuda.current_stream().synchronize()
                     split = self.graph_split_leaves
                     if split is None:
-                        split = 8 if len(self.devices()) == 1 else 0
+                        split = 12 if len(self.devices()) == 1 else 0
                     if split > 0:
                         graph = _SplitCapture(entry["pool"], split, gflat.device)
                         graph.capture(lambda: self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels))

@@ -210,6 +210,19 @@ tg7)
   DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=5 line taper5 $R
   line eager_b $R
   ;;
+suite)
+  # the whole GPU suite + smoke() on the last tree, then leaves per segment of the split graphs (8 / 12) against eager
+  echo "== pytest gpu (all)"; timeout 450 python -m pytest tests -m gpu -q --timeout 200 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
+  echo "== smoke"; timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log | cut -c1-200
+  export LINE_TIMEOUT=60
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  line eager_a $R
+  for r in a b; do
+    DREAM_TRAIN_GRAPH=1 line split8_$r $R
+    DREAM_TRAIN_GRAPH=1 DREAM_TRAIN_GRAPH_SPLIT=12 line split12_$r $R
+  done
+  line eager_b $R
+  ;;
 sgrid)
   # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
   echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "conv_transpose4x4_winograd or resnet_h_train_step or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
