@@ -276,7 +276,7 @@ class DreamDataParallel(nn.Module):
         object.__setattr__(self, "_opt_state", {})        # replica index -> optimizer state buffers on that replica's device
         object.__setattr__(self, "_tick", [0])            # use counter for the LRU of captured graphs
         object.__setattr__(self, "_grad_version", None)   # version of the master's flat gradient buffer right after the all-reduce
-        # Opt-in (DreamNetwork.hip_graph / DREAM_TRAIN_GRAPH=1): a training step on ONE device also runs as two hipGraph replays
+        # Opt-in (DreamNetwork.hip_graph_train / DREAM_TRAIN_GRAPH=1): a training step on ONE device also runs as hipGraph replays
         # (forward, backward) instead of ~2000 launches from Python -- what every replica of a multi-device step already does.  A
         # ResNet-101 step at 16 frames leaves the GPU idle 11 % of the time waiting for the host between its small kernels
         # (profiles/r04_bench_resnet_h_train16_concurrency.txt).  Same kernels in the same order: bit-identical.
