@@ -223,6 +223,12 @@ suite)
   done
   line eager_b $R
   ;;
+tg8)
+  # the captured step where the second stream is NOT used (resnet_h at 128 frames, vgg_q at 128): the plan is one main graph
+  export LINE_TIMEOUT=80
+  DREAM_TRAIN_GRAPH=1 line rt128_graph --arch resnet_h --mode train --batch 128 --steps 4 --warmup 3
+  DREAM_TRAIN_GRAPH=1 line vt_graph --mode train --steps 4 --warmup 3
+  ;;
 sgrid)
   # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
   echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "conv_transpose4x4_winograd or resnet_h_train_step or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
