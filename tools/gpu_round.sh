@@ -229,6 +229,14 @@ tg8)
   DREAM_TRAIN_GRAPH=1 line rt128_graph --arch resnet_h --mode train --batch 128 --steps 4 --warmup 3
   DREAM_TRAIN_GRAPH=1 line vt_graph --mode train --steps 4 --warmup 3
   ;;
+tgprof)
+  # dispatch timeline of the captured step (split graphs): do the leaf segments run beside the main segments?
+  R="$PWD"
+  (cd /tmp && DREAM_TRAIN_GRAPH=1 timeout 110 rocprofv3 --kernel-trace --stats -d "$R/$O/prof" -o g -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 5 --warmup 4 --no-cpu-baseline --no-secondary > "$R/$O/rocprof.log" 2>&1); echo "rc=$?"
+  grep -h '^{"metric' $O/rocprof.log | cut -c1-160
+  db=$(ls $O/prof/*.db $O/prof/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" $O/bench_resnet_h_train16_graph adam_kernel 3 > $O/summ.log 2>&1; echo "summary rc=$?"; rm -rf $O/prof
+  cat $O/bench_resnet_h_train16_graph_concurrency.txt
+  ;;
 sgrid)
   # convT on four-wavefront workgroups where the eight-wavefront grid would leave CUs empty (DREAM_WINO_SMALL_GRID=1, default) vs always eight (=0)
   echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "conv_transpose4x4_winograd or resnet_h_train_step or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
