@@ -73,7 +73,9 @@ def parse():
     ap.add_argument("--concat-ranks", type=int, default=0, help="one process, one GPU: the batch is the concatenation of what ranks 0..N-1 "
                     "of a `--gpus N` run would see (the single-device reference of --dp-check)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` (N = 1) / `scale` (N > 1) blocks")
-    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--secondary-steps", type=int, default=5, help="timed steps of the inference legs of `secondary` / `scale`")
+    ap.add_argument("--secondary-train-steps", type=int, default=10, help="timed steps of the training legs (the ResNet step has a known "
+                    "occasional slow mode: three steps were too few to see it)")
     ap.add_argument("--cpu-seconds", type=float, default=24.0, help="budget of the cpu_baseline block (each CNN leg gets a quarter; a leg whose 3 + 5 iterations do not fit falls back to 1 + 3)")
     return ap.parse_args()
 
@@ -257,6 +259,15 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+# dream_amd.ops entry point -> the kernel family its launches belong to (the names rocprofv3 reports)
+FAMILY = {"conv3x3_winograd4": "conv_wino4_kernel", "conv_transpose4x4s2_winograd4": "conv_wino4_kernel", "conv4x4s2_winograd4": "conv_wino4_kernel",
+          "conv3x3_winograd": "conv_wino_kernel", "conv_transpose4x4s2_winograd": "conv_wino_kernel", "conv4x4s2_winograd": "conv_wino_kernel",
+          "conv3x3": "conv_mfma_kernel", "conv2d": "conv_mfma_kernel", "conv_transpose3x3s2": "conv_mfma_kernel",
+          "conv_transpose4x4s2": "conv_mfma_kernel", "conv2d_amax": "conv_mfma_kernel",
+          "conv1x1": "gemm1x1_kernel", "conv1x1_bn": "gemm1x1_kernel", "conv1x1_bwd_bnmask": "gemm1x1_kernel",
+          "conv2d_f16x3": "conv_f16x3_kernel", "conv_transpose3x3s2_f16x3": "conv_f16x3_kernel", "conv_transpose4x4s2_f16x3": "conv_f16x3_kernel"}
+
+
 class ConvTimer:
     """Per-launch timing of the conv kernels (HIP events on the launch stream): wraps the dream_amd.ops conv entry points once;
     while `recording`, every call is bracketed by two events and its algorithmic / executed FLOPs are noted."""
@@ -268,7 +279,16 @@ class ConvTimer:
         def pooled(flags):                    # a fused 2x2 max-pool stores 1/4 of the conv outputs it computed
             return 4.0 if flags & C else 1.0
 
-        w = self.wrap
+        def w(orig, flops_of, kernel_launches=1, executed=1.0, issued=None):
+            return self.wrap(orig, flops_of, kernel_launches, executed, issued, family=FAMILY.get(getattr(orig, "__name__", ""), "other"))
+
+        def wino4_issued(y, x, u, cout, *a, **k):
+            # multiplications the F(4x4,3x3) kernel really issues: 36 per tile and channel pair, tiles counted in whole 16-tile
+            # blocks of the (image, tile row, tile column) numbering, output channels in whole 128- (wide shape) or 64-blocks (narrow)
+            b, h, wd, cin = (int(v) for v in x.shape)
+            tiles = (b * ((h + 3) // 4) * ((wd + 3) // 4) + 15) // 16 * 16
+            cpad = (cout + 127) // 128 * 128 if cout > 64 else 64
+            return 2.0 * tiles * 36 * cin * cpad
         # algorithmic FLOPs of one launch = 2 * outputs * (input channels * taps); y is NHWC or NCHW [B,...]
         ops.conv3x3 = w(ops.conv3x3, lambda y, x, packed, bias, cout, flags=0, relu_mask=None: 2.0 * y.numel() * pooled(flags) * x.shape[3] * 9)
         ops.conv2d = w(ops.conv2d, lambda y, x, packed, cout, ksize, stride=1, scale=None, shift=None, residual=None, flags=0:
@@ -277,7 +297,7 @@ class ConvTimer:
                                  2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=16.0 / 36.0)
         if hasattr(ops, "conv3x3_winograd4"):
             ops.conv3x3_winograd4 = w(ops.conv3x3_winograd4, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
-                                      2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=36.0 / 144.0)
+                                      2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=36.0 / 144.0, issued=wino4_issued)
         ops.conv1x1 = w(ops.conv1x1, lambda y, x, packed, cout, *a, **k: 2.0 * y.numel() * x.shape[3])
         if hasattr(ops, "conv1x1_bn"):        # the same GEMM with a train-mode BatchNorm folded in on either side (round 4)
             ops.conv1x1_bn = w(ops.conv1x1_bn, lambda y, x, packed, cout, *a, **k: 2.0 * y[0].numel() * x.shape[3])
@@ -305,8 +325,9 @@ class ConvTimer:
                              lambda y, x, amax, p16, cout, ksize, scale=None, shift=None, residual=None, flags=0, want_amax=True:
                              2.0 * y[0].numel() * pooled(flags) * x.shape[3] * ksize * ksize)
 
-    def wrap(self, orig, flops_of, kernel_launches=1, executed=1.0):
-        """executed: executed MACs / direct-algorithm MACs of this operator (Winograd F(2x2): 16 / 36), or a callable of the kwargs."""
+    def wrap(self, orig, flops_of, kernel_launches=1, executed=1.0, issued=None, family="other"):
+        """executed: executed MACs / direct-algorithm MACs of this operator (Winograd F(2x2): 16 / 36), or a callable of the kwargs.
+        issued: FLOPs of the multiplications the kernel really issues (tile and channel padding included), default = executed."""
         def wrapper(*a, **k):
             if not self.recording or k.get("relu_mask") is not None:     # conv3x3(relu_mask=..) forwards to conv2d: timed there
                 return orig(*a, **k)
@@ -316,14 +337,23 @@ class ConvTimer:
             y = orig(*a, **k)
             e_ev.record()
             fl = flops_of(y, *a, **k)
-            self.events.append((s_ev, e_ev, fl, kernel_launches, fl * (executed(k) if callable(executed) else executed)))
+            ex = fl * (executed(k) if callable(executed) else executed)
+            self.events.append((s_ev, e_ev, fl, kernel_launches, ex, family, issued(y, *a, **k) if issued is not None else ex))
             return y
         return wrapper
 
     def summary(self):
-        ms = sum(ev[0].elapsed_time(ev[1]) for ev in self.events)
-        return {"ms": ms, "flops": sum(ev[2] for ev in self.events), "launches": sum(ev[3] for ev in self.events),
-                "executed": sum(ev[4] for ev in self.events)}
+        per = {}
+        for ev in self.events:
+            f = per.setdefault(ev[5], {"ms": 0.0, "flops": 0.0, "launches": 0, "executed": 0.0, "issued": 0.0})
+            f["ms"] += ev[0].elapsed_time(ev[1])
+            f["flops"] += ev[2]
+            f["launches"] += ev[3]
+            f["executed"] += ev[4]
+            f["issued"] += ev[6]
+        return {"ms": sum(f["ms"] for f in per.values()), "flops": sum(f["flops"] for f in per.values()),
+                "launches": sum(f["launches"] for f in per.values()), "executed": sum(f["executed"] for f in per.values()),
+                "families": per}
 
 
 class Context:
@@ -419,11 +449,30 @@ def timed_region(ctx, net, x, tgt, spec):
     barrier()
     dt = time.perf_counter() - t0
     timer.recording = False
+    ctx.rank_seconds = [dt]
     if ctx.world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(ctx.world)]
+        dist.all_gather(every, mine)
+        ctx.rank_seconds = [float(t.item()) for t in every]
+        dt = max(ctx.rank_seconds)                  # the contract: MAX over the ranks
     return dt, timer.summary(), out
+
+
+def dominant_of(conv, steps, peak):
+    """The kernel family with the largest share of the timed conv launches (HIP events on the launch stream): its own time per step
+    and its fraction of the MFMA peak on the multiplications it issues (tile / channel padding included) and on the useful ones."""
+    fams = conv.get("families") or {}
+    if not fams:
+        return None
+    name = max(fams, key=lambda k: fams[k]["ms"])
+    f = fams[name]
+    sec = f["ms"] * 1e-3
+    return {"kernel": name, "ms_per_step": f["ms"] / max(steps, 1), "launches_per_step": f["launches"] / max(steps, 1),
+            "share_of_conv_time": f["ms"] / conv["ms"] if conv["ms"] > 0 else None,
+            "direct_frac": f["flops"] / sec / 1e12 / peak if sec > 0 else None,
+            "issued_frac": f["issued"] / sec / 1e12 / peak if sec > 0 else None,
+            "useful_frac": f["executed"] / sec / 1e12 / peak if sec > 0 else None}
 
 
 def roofline_of(spec, conv, dt, peak):
@@ -444,6 +493,7 @@ def roofline_of(spec, conv, dt, peak):
         "launches": conv["launches"], "avg_launch_ms": ms / max(conv["launches"], 1),
         "algorithmic_gflop_per_launch": fl / max(conv["launches"], 1) / 1e9,
         "share_of_step_time": ms * 1e-3 / dt if dt > 0 else None,
+        "dominant": dominant_of(conv, spec["steps"], peak),
     }
 
 
@@ -467,10 +517,12 @@ def run_side_workload(ctx, spec, label, baseline_index, sharded_total=None):
     block = {"config": label, "workload": workload_text(spec, n_kp, manip, baseline_index),
              "value": total / dt, "unit": "frames/s", "ms_per_step": dt / spec["steps"] * 1e3, "steps": spec["steps"],
              "warmup": spec["warmup"], "batch_per_gpu": spec["batch"], "dtype": "f32",
-             "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "executed_frac", "share_of_step_time")}}
+             "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "executed_frac", "share_of_step_time", "dominant")}}
     if sharded_total is not None:
         n = ctx.n_gpus
-        block.update({"global_batch": sharded_total, "scaling": "strong", "per_gpu_frames_per_s": total / dt / n})
+        block.update({"global_batch": sharded_total, "scaling": "strong", "per_gpu_frames_per_s": total / dt / n,
+                      "rccl_ranks": ctx.rccl_ranks,
+                      "ms_per_step_ranks": {"min": min(ctx.rank_seconds) / spec["steps"] * 1e3, "max": max(ctx.rank_seconds) / spec["steps"] * 1e3}})
     del net, x, tgt
     gc.collect()
     torch.cuda.empty_cache()
@@ -494,8 +546,8 @@ def dp_check(ctx, net):
 
 
 def main():
-    """A failure (RCCL initialisation on a multi-GPU node, a device that is missing ...) leaves ONE JSON line with an `error` field on
-    rank 0 and a non-zero exit status instead of N interleaved tracebacks, so that a SCALE record is diagnosable."""
+    """A failure (RCCL initialisation on a multi-GPU node, a device that is missing ...) leaves ONE JSON line with an `error` field (from
+    the rank that failed) and a non-zero exit status instead of N interleaved tracebacks, so that a SCALE record is diagnosable."""
     args = parse()
     stage = ["start"]
     try:
@@ -504,11 +556,12 @@ def main():
         raise
     except BaseException as e:  # noqa: BLE001
         import traceback
-        if int(os.environ.get("RANK", "0")) == 0:
-            print(json.dumps({"metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
-                              "value": None, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
-                              "error": "%s during %s: %s" % (type(e).__name__, stage[0], str(e)[:600]),
-                              "world_size": int(os.environ.get("WORLD_SIZE", "1"))}), flush=True)
+        # the FAILING rank prints the line, tagged with its rank (rank 0 is usually blocked in a collective when another rank fails; the
+        # launcher then ends the group): one line per failing rank, normally exactly one
+        print(json.dumps({"metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
+                          "value": None, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                          "error": "%s during %s: %s" % (type(e).__name__, stage[0], str(e)[:600]),
+                          "rank": int(os.environ.get("RANK", "0")), "world_size": int(os.environ.get("WORLD_SIZE", "1"))}), flush=True)
         traceback.print_exc(file=sys.stderr)
         raise SystemExit(1)
 
@@ -549,6 +602,7 @@ def _main(args, stage):
         else:
             dist.init_process_group(backend)
     ctx.losses = []
+    ctx.rccl_ranks = dist.get_world_size() if ctx.world > 1 and backend == "nccl" else (1 if not ctx.single else 0)
     if args.global_batch:
         assert args.global_batch % ctx.n_gpus == 0, "--global-batch must divide evenly over the GPUs"
         args.batch = args.global_batch // ctx.n_gpus
@@ -562,6 +616,7 @@ def _main(args, stage):
     net, x, tgt, frames = build_network(ctx, spec)
     stage[0] = "the timed region (first RCCL collective in it for N > 1)"
     dt, conv, out_main = timed_region(ctx, net, x, tgt, spec)
+    main_rank_seconds = list(ctx.rank_seconds)
     check = dp_check(ctx, net) if spec["dp_check"] else None
     stage[0] = "reporting"
     # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
@@ -602,7 +657,7 @@ def _main(args, stage):
         base = {"res": 400, "steps": args.secondary_steps, "warmup": 1, "precision": "fp32", "conv_algorithm": "winograd"}
         # a training step is in its steady state from the third on (the first records which packed weight copies it builds, the
         # second builds the one-launch packing table: models._repack_weights)
-        train = dict(base, warmup=3)
+        train = dict(base, warmup=3, steps=args.secondary_train_steps)
         side = []
         if ctx.n_gpus == 1:
             side.append(run_side_workload(ctx, dict(train, arch="vgg_q", mode="train", batch=128), "configs[2]", 2))
@@ -630,16 +685,18 @@ def _main(args, stage):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
-            "rccl_ranks": (dist.get_world_size() if ctx.world > 1 and backend == "nccl" else (1 if not ctx.single else 0)),
+            "rccl_ranks": ctx.rccl_ranks,
             "per_gpu_frames_per_s": total / dt / ctx.n_gpus,
+            "ms_per_step_ranks": {"min": min(main_rank_seconds) / args.steps * 1e3, "max": max(main_rank_seconds) / args.steps * 1e3},
             "config": {"workload": workload_text(spec, n_kp, manip, (2 if args.mode == "train" else 1)
                                                  if (args.arch, args.batch, args.res) == ("vgg_q", 128, 400) else None),
                        "batch_per_gpu": args.batch, "resolution": [args.res, args.res],
                        "parallelism": "dp%d%s" % (ctx.n_gpus, " (single process, gpu_ids)" if ctx.single
                                                   else (" (one process per GPU, %s)" % ("RCCL" if backend == "nccl" else backend)
                                                         if ctx.world > 1 else "")),
-                       "conv_algorithm": (("winograd F(4x4,3x3) for the stride-1 3x3 convs with >= 128 output channels, F(2x2,3x3) for "
-                                           "those with 64, direct implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else
+                       "conv_algorithm": (("winograd F(4x4,3x3) for the stride-1 3x3 convs with >= 48 output channels where the map and the batch "
+                                           "fill its 4x4 tiles (wide workgroup shape from 128 output channels, narrow shape for 48-64), F(2x2,3x3) "
+                                           "on the remaining stride-1 3x3 convs and the transposed-conv phases, direct implicit GEMM elsewhere" if args.conv_algorithm == "winograd" else
                                            "winograd F(2x2,3x3) for the stride-1 3x3 convs with >= 64 output channels, direct implicit GEMM "
                                            "elsewhere" if args.conv_algorithm == "winograd2" else "direct implicit GEMM")
                                           + ("; stride-1 1x1 convs as LDS-free GEMMs" if args.arch.startswith("resnet") else ""))},

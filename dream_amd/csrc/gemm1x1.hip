@@ -63,11 +63,28 @@ DREAM_DEVICE f32x4 bn_relu4(f32x4 x, f32x4 a, f32x4 b) {
     return r;
 }
 
-template <int KS, bool PRE = false, int EPI = 0>
-#ifndef DREAM_G1_PIPELINED
-#define DREAM_G1_PIPELINED 1
+// Round 6.  What the compiler made of the first version of this kernel (loads written one chunk ahead, `load(1); multiply(0); load(0);
+// multiply(1)`): it sank ALL sixteen loads of a loop iteration behind the first 48 MFMAs and waited for them with vmcnt(14) .. vmcnt(1)
+// right there -- every wavefront stalled for a full memory round trip per two chunks, and on operands that come from HBM (what the
+// training step sees: the warm micro-benchmark had them in the Infinity Cache) the launches ran at 0.24-0.51 of the MFMA peak.  Now the
+// order is PINNED (a scheduling barrier per group of four MFMAs): the ten / eight loads of chunk t + 1 are issued one per group during
+// the first half of chunk t's MFMAs, into the register set the previous chunk freed.  The epilogue's operands (residual, BatchNorm
+// input, stored activation: up to three 16-byte loads per output row) are issued DREAM_G1_EPI_DEPTH rows ahead through buffer
+// descriptors (zeros for a null operand or a row past the end: no branches), the first rows before the LAST chunk's MFMAs.
+#ifndef DREAM_G1_EPI_DEPTH
+#define DREAM_G1_EPI_DEPTH 4
 #endif
-__global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
+#ifndef DREAM_G1_EPI_DEPTH_MASK
+#define DREAM_G1_EPI_DEPTH_MASK 3
+#endif
+#ifndef DREAM_G1_EPI_DEPTH_MASK_KS
+#define DREAM_G1_EPI_DEPTH_MASK_KS 2
+#endif
+// RES: the epilogue adds a residual tensor (EPI 0: a separate instantiation, so that launches without one issue no loads for it; EPI 2
+// always reads per-row operands: a null residual / stored activation there is an empty descriptor that returns zeros).
+template <int KS, bool PRE = false, int EPI = 0, bool RES = false>
+// (with a K split the 64 KB of partial tiles allow two workgroups per CU, i.e. two wavefronts per SIMD and 256 registers)
+__global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const GemmParams p) {
     __shared__ float s_part[KS > 1 ? 4 * 64 * 64 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
     __shared__ double s_stat[(KS > 1 && EPI != 0) ? 4 * 16 * 8 : 1];      // [wave][lane & 15][4 channels][2]: the waves' sums
     const int lane = threadIdx.x & 63;
@@ -104,38 +121,82 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     f32x4 xa[2][4], xb[2][4];
     f32x4 pa[2], pb[2];                              // PRE: scale / shift of this lane's four k's of the chunk
     const BufferRsrc abbuf = make_buffer(PRE ? p.pre_ab : p.x, PRE ? (size_t)2 * p.K * sizeof(float) : 0);
-    auto load = [&](int set, int t) {
-#pragma unroll
-        for (int m = 0; m < 4; ++m) xa[set][m] = buffer_load_x4(xbuf, a_off[m], (unsigned)t * 64u);
-        if (PRE) {
-            pa[set] = buffer_load_x4(abbuf, (unsigned)(4 * lg * 4), (unsigned)t * 64u);
-            pb[set] = buffer_load_x4(abbuf, (unsigned)((p.K + 4 * lg) * 4), (unsigned)t * 64u);
-        }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) xb[set][n] = buffer_load_x4(wbuf, b_off[n], (unsigned)t * b_chunk);
+    constexpr int NLOADS = PRE ? 10 : 8;
+    // the i-th load of chunk t into register set `set`: weights first (L2 residents: they return quickly and the first MFMAs of the
+    // chunk need all four of them), then the PRE scale / shift, then the four row blocks of the activation
+    auto issue = [&](int set, int t, int i) {
+        if (i < 4) xb[set][i] = buffer_load_x4(wbuf, b_off[i], (unsigned)t * b_chunk);
+        else if (PRE && i == 4) pa[set] = buffer_load_x4(abbuf, (unsigned)(4 * lg * 4), (unsigned)t * 64u);
+        else if (PRE && i == 5) pb[set] = buffer_load_x4(abbuf, (unsigned)((p.K + 4 * lg) * 4), (unsigned)t * 64u);
+        else xa[set][i - (NLOADS - 4)] = buffer_load_x4(xbuf, a_off[i - (NLOADS - 4)], (unsigned)t * 64u);
     };
-    auto multiply = [&](int set) {
-        if (PRE) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) xa[set][m] = bn_relu4(xa[set][m], pa[set], pb[set]);
+
+    // ---- epilogue operands: a ring of DREAM_G1_EPI_DEPTH rows -------------------------------------------------------------------
+    // A wavefront owns NR = 16 / KS rows of its lanes: row index i -> block row m = kpart + KS (i >> 2), register r = i & 3.
+    // (EPI 2 loads three operands per row: its ring is shallower, the register budget being 168 at three wavefronts per SIMD)
+    constexpr int DWANT = EPI == 2 ? (KS == 1 ? DREAM_G1_EPI_DEPTH_MASK : DREAM_G1_EPI_DEPTH_MASK_KS) : DREAM_G1_EPI_DEPTH;
+    constexpr int NR = 16 / KS, D = DWANT < NR ? DWANT : NR;
+    constexpr bool HAS_RES = RES || EPI == 2;                 // (the statistics form, EPI 1, has no residual input)
+    constexpr bool EL = HAS_RES;                              // the rows have operands to load
+    const int c0 = cb * 64 + 4 * li;
+    const bool cok = c0 < p.N;                                // N % 4 == 0
+    // descriptors on the tile's first row (tensors may exceed a descriptor's 2 GB: the base moves, the offsets stay small); a null
+    // operand gets an empty descriptor, a row past M or a channel past N reads zeros / stores nothing
+    const long trow = (long)rb * 64;
+    const size_t tbytes = live ? (size_t)(p.M - trow) * p.N * sizeof(float) : 0;
+    const BufferRsrc rbuf = make_buffer(HAS_RES && p.residual ? p.residual + trow * p.N : p.x, HAS_RES && p.residual ? tbytes : 0);
+    const BufferRsrc zbuf = make_buffer(EPI == 2 ? p.st_z + trow * p.N : p.x, EPI == 2 ? tbytes : 0);
+    const BufferRsrc yabuf = make_buffer(EPI == 2 && p.st_yact ? p.st_yact + trow * p.N : p.x, EPI == 2 && p.st_yact ? tbytes : 0);
+    const BufferRsrc ybuf = make_buffer(p.y + trow * p.N, tbytes);
+    // byte offset of row i of this wavefront inside the tile: lane part (OOB for a channel past N: it stays out of range under the
+    // additions below, every descriptor being smaller than 2 GB) + wave-uniform part
+    const unsigned lane_off = cok ? (unsigned)((4 * lg * p.N + c0) * 4) : BUFFER_OOB;
+    const unsigned row_bytes = (unsigned)p.N * 4u;
+    auto row_off = [&](int i) { return lane_off + (unsigned)(16 * (kpart + KS * (i >> 2)) + (i & 3)) * row_bytes; };
+    f32x4 e_res[D], e_z[D], e_ya[D];
+    auto epi_load = [&](int i) {                              // i compile-time after unrolling
+        const unsigned o = row_off(i);
+        if (HAS_RES) e_res[i % D] = buffer_load_x4(rbuf, o, 0u);
+        if (EPI == 2) {
+            e_z[i % D] = buffer_load_x4(zbuf, o, 0u);
+            e_ya[i % D] = buffer_load_x4(yabuf, o, 0u);
         }
+    };
+
+    // multiply the chunk in register set S; meanwhile issue the loads of chunk tn into the other set (LOAD) or the first rows of the
+    // epilogue's operands (EPILOAD: the last chunk)
+    auto step = [&](auto s_tag, int tn, auto load_tag, auto epi_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        constexpr bool LOAD = decltype(load_tag)::value, EPILOAD = decltype(epi_tag)::value;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < 4; ++m) {
+                if (PRE && e == 0) xa[S][m] = bn_relu4(xa[S][m], pa[S], pb[S]);      // eight VALU operations beside the group's MFMAs
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(xa[set][m][e], xb[set][n][e], acc[m][n]);
+                for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(xa[S][m][e], xb[S][n][e], acc[m][n]);
+                const int g = 4 * e + m;                      // group of four MFMAs
+                if (LOAD && g < NLOADS) issue(1 - S, tn, g);
+                if (EPILOAD && EL && g < D) epi_load(g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
     const int nchunks = p.K / 16 / KS;               // even (host side); this wave's chunks start at t0
     const int t0 = kpart * nchunks;
     if (live) {
-        load(0, t0);
-        for (int t = 0; t < nchunks; t += 2) {
-            load(1, t0 + t + 1);
-            multiply(0);
-            load(0, t0 + (t + 2 < nchunks ? t + 2 : t));     // the last pair re-reads a chunk rather than branching
-            multiply(1);
+#pragma unroll
+        for (int i = 0; i < NLOADS; ++i) issue(0, t0, i);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int t = 0; t + 2 < nchunks; t += 2) {
+            step(I0{}, t0 + t + 1, Yes{}, No{});
+            step(I1{}, t0 + t + 2, Yes{}, No{});
         }
+        step(I0{}, t0 + nchunks - 1, Yes{}, No{});
+        step(I1{}, 0, No{}, Yes{});
     }
     // split K: partial tiles through LDS; wave kpart then owns row blocks m = kpart, kpart + KS, .. (fixed summation order)
     if (KS > 1) {
@@ -161,12 +222,11 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
     }
 
     // ---- epilogue: lane holds rows 4 (l >> 4) + r, column j = l & 15 of every block (m, n) = channels 4 j .. 4 j + 3 ----------
-    const int c0 = cb * 64 + 4 * li;
-    const bool cok = c0 < p.N;                       // N % 4 == 0
     f32x4 sc = {1.0f, 1.0f, 1.0f, 1.0f}, sh = {0.0f, 0.0f, 0.0f, 0.0f};
     if (p.scale != nullptr && cok) sc = *(const f32x4 *)(p.scale + c0);
     if (p.shift != nullptr && cok) sh = *(const f32x4 *)(p.shift + c0);
-    const bool relu = (p.flags & DREAM_CONV_RELU) != 0;
+    // ReLU without a branch per row: max(v, 0) or max(v, -inf)
+    const float relu_lo = (p.flags & DREAM_CONV_RELU) != 0 ? 0.0f : -__builtin_inff();
     double st0[4] = {0.0, 0.0, 0.0, 0.0}, st1[4] = {0.0, 0.0, 0.0, 0.0};      // EPI: this lane's sums over its rows
     f32x4 za = {0.0f, 0.0f, 0.0f, 0.0f}, zb = za, zmu = za, zis = za;
     const bool mask_y = EPI == 2 && p.st_yact != nullptr;
@@ -178,115 +238,65 @@ __global__ void __launch_bounds__(256, 3) gemm1x1_kernel(const GemmParams p) {
         zmu = *(const f32x4 *)(p.st_mean + c0);
         zis = *(const f32x4 *)(p.st_invstd + c0);
     }
-    if constexpr (DREAM_G1_PIPELINED) {
-        // A wavefront owns 16 / KS rows of its lanes (block rows m = kpart, kpart + KS, ..): the residual / mask operands of row i + 1 are
-        // loaded BEFORE row i is stored.  (In the loop below every row is its own predicated block -- load, s_waitcnt vmcnt(0), compute,
-        // store: one serialised memory round trip per row.)  Loads are unconditional on a clamped row (a row past M is never stored), so
-        // the body is straight-line code under ONE branch; safe if the output aliases an operand: a thread reads exactly the elements it
-        // writes, one row ahead.  With a K split the block rows depend on the wavefront (kpart): one instantiation per value, chosen by a
-        // wave-uniform branch, so that the accumulator indices stay compile-time constants.
-        auto rows = [&](auto m0_tag) {
-            constexpr int M0 = decltype(m0_tag)::value, NR = 16 / KS;
-            const int row0 = rb * 64 + 4 * lg;
-            const long last = p.M - 1;
-            auto offset_of = [&](int i) {
-                const long row = row0 + 16 * (M0 + KS * (i >> 2)) + (i & 3);
-                return (size_t)(row < last ? row : last) * p.N + c0;
-            };
-            f32x4 nres = {0.0f, 0.0f, 0.0f, 0.0f}, nz = nres, nya = nres;
-            auto load_row = [&](int i) {
-                const size_t o = offset_of(i);
-                if (p.residual != nullptr) nres = *(const f32x4 *)(p.residual + o);
-                if (EPI == 2) {
-                    nz = *(const f32x4 *)(p.st_z + o);
-                    if (mask_y) nya = *(const f32x4 *)(p.st_yact + o);
-                }
-            };
-            load_row(0);
+    // Row i + D's operands are loaded BEFORE row i is stored (safe if the output aliases an operand: a thread reads exactly the elements
+    // it writes, D rows ahead).  With a K split the block rows depend on the wavefront (kpart): one instantiation per value, chosen by a
+    // wave-uniform branch, so that the accumulator indices stay compile-time constants.
+    auto rows = [&](auto m0_tag) {
+        constexpr int M0 = decltype(m0_tag)::value;
+        const int mrows = p.M - (int)trow - 4 * lg;            // rows of this lane's quad column that exist
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                constexpr int dummy = 0;
-                const int m = M0 + KS * (i >> 2), r = i & 3;
-                const f32x4 res = nres, z = nz, ya = nya;
-                if (i + 1 < NR) load_row(i + 1);
-                f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-                v = v * sc + sh;
-                if (p.residual != nullptr) v = v + res;
-                if (relu) {
+        for (int i = 0; i < NR; ++i) {
+            const int m = M0 + KS * (i >> 2), r = i & 3;
+            f32x4 res = {0.0f, 0.0f, 0.0f, 0.0f}, z = res, ya = res;
+            if (EL && HAS_RES) res = e_res[i % D];
+            if (EL && EPI == 2) { z = e_z[i % D]; ya = e_ya[i % D]; }
+            if (EL && i + D < NR) epi_load(i + D);
+            f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+            v = v * sc + sh;
+            if (EL && HAS_RES) v = v + res;                    // (EPI 2 without a residual adds the empty descriptor's zeros: only -0 becomes +0)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-                }
-                const bool rok = row0 + 16 * m + r < p.M;
-                if (EPI == 1 && rok) {
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+            const bool rok = 16 * m + r < mrows;              // (a row past M is not stored and counts as zeros: x + 0 is exact)
+            if (EPI == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { st0[e] += (double)v[e]; st1[e] += (double)v[e] * (double)v[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    const float vm = rok ? v[e] : 0.0f;
+                    st0[e] += (double)vm;
+                    st1[e] += (double)vm * (double)vm;
                 }
-                if (EPI == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool on = mask_y ? ya[e] > 0.0f : __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f;
-                        v[e] = on ? v[e] : 0.0f;
-                        const float xh = (z[e] - zmu[e]) * zis[e];
-                        if (rok) {
-                            st0[e] += (double)v[e];
-                            st1[e] += (double)v[e] * (double)xh;
-                        }
-                    }
-                }
-                if (rok) *(f32x4 *)(p.y + (size_t)(row0 + 16 * m + r) * p.N + c0) = v;
-                (void)dummy;
             }
-        };
-        if (cok && live) {
-            if constexpr (KS == 1) {
-                rows(std::integral_constant<int, 0>{});
-            } else if constexpr (KS == 2) {
-                if (kpart == 0) rows(std::integral_constant<int, 0>{});
-                else rows(std::integral_constant<int, 1>{});
-            } else {
-                switch (kpart) {
-                    case 0: rows(std::integral_constant<int, 0>{}); break;
-                    case 1: rows(std::integral_constant<int, 1>{}); break;
-                    case 2: rows(std::integral_constant<int, 2>{}); break;
-                    default: rows(std::integral_constant<int, 3>{}); break;
+            if (EPI == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool on = mask_y ? ya[e] > 0.0f : __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f;
+                    v[e] = on ? v[e] : 0.0f;
+                    const float xh = (z[e] - zmu[e]) * zis[e];
+                    const float vm = rok ? v[e] : 0.0f;
+                    st0[e] += (double)vm;
+                    st1[e] += (double)vm * (double)xh;
                 }
+            }
+            buffer_store_x4(ybuf, v, row_off(i), 0u);
+            // one row at a time: left alone, the scheduler interleaves all rows' fp64 statistics and the kernel's register count (the
+            // maximum over the program) doubles -- 206 VGPRs + 96 AGPRs for <4, false, 2>, one wavefront per SIMD
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (live) {
+        if constexpr (KS == 1) {
+            rows(std::integral_constant<int, 0>{});
+        } else if constexpr (KS == 2) {
+            if (kpart == 0) rows(std::integral_constant<int, 0>{});
+            else rows(std::integral_constant<int, 1>{});
+        } else {
+            switch (kpart) {
+                case 0: rows(std::integral_constant<int, 0>{}); break;
+                case 1: rows(std::integral_constant<int, 1>{}); break;
+                case 2: rows(std::integral_constant<int, 2>{}); break;
+                default: rows(std::integral_constant<int, 3>{}); break;
             }
         }
-    } else
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = rb * 64 + 16 * m + 4 * lg + r;
-            if ((KS == 1 || m % KS == kpart) && row < p.M && cok) {
-                f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-                v = v * sc + sh;
-                const size_t o = (size_t)row * p.N + c0;
-                if (p.residual != nullptr) v = v + *(const f32x4 *)(p.residual + o);
-                if (relu) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-                }
-                if (EPI == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { st0[e] += (double)v[e]; st1[e] += (double)v[e] * (double)v[e]; }
-                }
-                if (EPI == 2) {
-                    const f32x4 z = *(const f32x4 *)(p.st_z + o);
-                    f32x4 ya = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (mask_y) ya = *(const f32x4 *)(p.st_yact + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const bool on = mask_y ? ya[e] > 0.0f : __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f;
-                        v[e] = on ? v[e] : 0.0f;
-                        const float xh = (z[e] - zmu[e]) * zis[e];
-                        st0[e] += (double)v[e];
-                        st1[e] += (double)v[e] * (double)xh;
-                    }
-                }
-                *(f32x4 *)(p.y + o) = v;
-            }
-        }
+    }
     if (EPI != 0) {
         // the four lanes l, l + 16, l + 32, l + 48 hold the same four channels on different rows: (0 + 1) + (2 + 3) in every lane
 #pragma unroll
@@ -388,36 +398,47 @@ __global__ void __launch_bounds__(256, 2) wgrad1x1_kernel(const Wgrad1x1Params p
         pa = *(const f32x4 *)(p.pre_ab + cib * 64 + 4 * li);
         pb = *(const f32x4 *)(p.pre_ab + p.Cin + cib * 64 + 4 * li);
     }
-    auto load = [&](int set, int c) {
+    // the i-th of the eight loads of chunk c (16 positions) into register set `set`: k-step i >> 1, dy before x
+    auto issue = [&](int set, int c, int i) {
+        // the whole offset in the VECTOR operand: the hardware's bounds check (zeros beyond the last position) does not
+        // see the scalar offset
+        const int s = i >> 1;
+        if ((i & 1) == 0) ya[set][s] = buffer_load_x4(ybuf, y_off + (unsigned)(4 * c + s) * y_step, 0);
+        else xa[set][s] = buffer_load_x4(xbuf, x_off + (unsigned)(4 * c + s) * x_step, 0);
+    };
+    // multiply the chunk in set S and issue the loads of chunk cn into the other set, one per group of four MFMAs during the first
+    // half of the chunk (pinned: left alone, the compiler sinks every load to its use -- round 6, see gemm1x1_kernel)
+    auto step = [&](auto s_tag, int cn, auto load_tag) {
+        constexpr int S = decltype(s_tag)::value;
+        constexpr bool LOAD = decltype(load_tag)::value;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            // the whole offset in the VECTOR operand: the hardware's bounds check (zeros beyond the last position) does not
-            // see the scalar offset
-            ya[set][s] = buffer_load_x4(ybuf, y_off + (unsigned)(4 * c + s) * y_step, 0);
-            xa[set][s] = buffer_load_x4(xbuf, x_off + (unsigned)(4 * c + s) * x_step, 0);
-        }
-    };
-    auto multiply = [&](int set) {
-        if (PRE) {
             // (positions beyond the tensor read zeros on BOTH operands: relu(b) there meets dy = 0)
+            if (PRE) xa[S][s] = bn_relu4(xa[S][s], pa, pb);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) xa[set][s] = bn_relu4(xa[set][s], pa, pb);
+            for (int m = 0; m < 4; ++m) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(ya[S][s][m], xa[S][s][n], acc[m][n]);
+                const int g = 4 * s + m;
+                if (LOAD && g < 8) issue(1 - S, cn, g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(ya[set][s][m], xa[set][s][n], acc[m][n]);
     };
-    const int nchunks = p.chunks_per_wave;
-    load(0, 0);
-    for (int c = 0; c < nchunks; c += 2) {
-        load(1, c + 1);
-        multiply(0);
-        load(0, c + 2 < nchunks ? c + 2 : c);
-        multiply(1);
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    const int nchunks = p.chunks_per_wave;           // even
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue(0, 0, i);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int c = 0; c + 2 < nchunks; c += 2) {
+        step(I0{}, c + 1, Yes{});
+        step(I1{}, c + 2, Yes{});
     }
+    step(I0{}, nchunks - 1, Yes{});
+    step(I1{}, 0, No{});
     // the workgroup's four partial tiles through LDS; wave w then owns row block m = w
     f32x4 *sp = (f32x4 *)s_part;
 #pragma unroll
@@ -488,11 +509,11 @@ Wgrad1x1Plan wgrad1x1_plan(long M, int Cin, int Cout) {
 
 int g_conv1x1_ksplit = 0;     // test hook: 0 = by shape, 1 / 2 / 4 = force
 
-template <bool PRE, int EPI>
+template <bool PRE, int EPI, bool RES = false>
 int gemm1x1_launch_ks(const GemmParams &p, int ks, unsigned grid, void *stream) {
-    if (ks == 1) hipLaunchKernelGGL((gemm1x1_kernel<1, PRE, EPI>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else if (ks == 2) hipLaunchKernelGGL((gemm1x1_kernel<2, PRE, EPI>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm1x1_kernel<4, PRE, EPI>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (ks == 1) hipLaunchKernelGGL((gemm1x1_kernel<1, PRE, EPI, RES>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (ks == 2) hipLaunchKernelGGL((gemm1x1_kernel<2, PRE, EPI, RES>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm1x1_kernel<4, PRE, EPI, RES>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }
@@ -509,7 +530,7 @@ int gemm1x1_launch(GemmParams p, long M, int K, int N, int x_stride, bool pre, i
     DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
     const int per_wg = 4 / ks;
     const unsigned grid = (unsigned)(((tiles + per_wg - 1) / per_wg + 7) / 8 * 8);
-    if (epi == 0) return gemm1x1_launch_ks<false, 0>(p, ks, grid, stream);
+    if (epi == 0) return p.residual != nullptr ? gemm1x1_launch_ks<false, 0, true>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 0, false>(p, ks, grid, stream);
     if (epi == 1) return pre ? gemm1x1_launch_ks<true, 1>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 1>(p, ks, grid, stream);
     return gemm1x1_launch_ks<false, 2>(p, ks, grid, stream);
 }

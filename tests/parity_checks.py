@@ -550,10 +550,11 @@ def check_model_inference(dev, arch, shape, precision="fp32"):
     return float(err)
 
 
-def check_structured(dev, arch, precision="fp32"):
+def check_structured(dev, arch, precision="fp32", repeat=1):
     """North-star bounds on the structured fixture (blob-like maps of magnitude 1, tests/golden/structured_<arch>.npz,
     generated by the reference): belief maps within an ABSOLUTE 1e-4, every detection / rejection decision identical,
-    detected keypoints within 1e-3 px of the reference's."""
+    detected keypoints within 1e-3 px of the reference's.  ``repeat``: the fixture's frames tiled to a batch of repeat x its size
+    (the BASELINE batch sizes: the algorithm selection and the grids of the benchmarked configuration), EVERY copy held to the bounds."""
     case = arch
     arch, manip, k, last, (b, h, w), recipe, zero_bg = cases.STRUCTURED_CASES[case]
     g = np.load(os.path.join(GOLD, "structured_%s.npz" % case))
@@ -567,9 +568,14 @@ def check_structured(dev, arch, precision="fp32"):
         net.model.module.precision = precision
     x, _ = cases.structured_input(case)
     with torch.no_grad():
-        maps, kps = net.inference(to(dev, torch.from_numpy(x)))
+        maps, kps = net.inference(to(dev, torch.from_numpy(x).repeat(repeat, 1, 1, 1)))
     y, got_k, ref_k = maps.cpu().numpy(), kps.numpy(), g["keypoints"]
-    err = float(np.abs(y - g["maps"]).max())
+    ref_maps = g["maps"]
+    if repeat > 1:
+        assert y.shape[0] == repeat * b and got_k.shape[0] == repeat * b
+        ref_maps = np.concatenate([ref_maps] * repeat, axis=0)
+        ref_k = np.concatenate([ref_k] * repeat, axis=0)
+    err = float(np.abs(y - ref_maps).max())
     assert float(g["maps"].max()) <= 1.0 + 1e-6 and float(np.abs(g["maps"]).max()) <= (8.0 if recipe == "smooth" else 1.0 + 1e-6)
     assert err <= 1e-4, (arch, precision, err)
     det = ref_k[..., 0] > -999

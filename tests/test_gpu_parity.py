@@ -294,7 +294,11 @@ def test_full_size_batch_properties():
     ref.eval()
     with torch.no_grad():
         ref_maps = ref(base[:2])[0].numpy()
-    assert np.abs(maps[:2].numpy() - ref_maps).max() <= pc.tol(ref_maps)
+    # ABSOLUTE bound (round 6; was 1e-4 x max|ref| = 1.06e-3 on these recipe-weight maps, which reach 10.6): measured 2e-5 on the
+    # F(4x4,3x3) path this batch selects -- the north-star's 1e-4 holds on maps ten times the magnitude it was stated for
+    err = float(np.abs(maps[:2].numpy() - ref_maps).max())
+    print("b=128 recipe-weight maps (max |ref| %.1f): max |error| %.2e absolute" % (float(np.abs(ref_maps).max()), err))
+    assert err <= 1e-4, err
     assert np.array_equal(kps[:4].numpy(), op.keypoints_from_belief_maps(maps[:4].numpy(), 0.4395))
 
 
@@ -531,6 +535,18 @@ def test_randomised_conv_geometries():
 def test_structured_fixture_absolute_tolerance(arch):
     err, perr = pc.check_structured(DEV, arch)
     print("structured %s fp32: max |map error| %.2e, max keypoint error %.2e px" % (arch, err, perr))
+
+
+@pytest.mark.parametrize("case,repeat", [("vgg_q_400", 64), ("resnet_h", 8), ("resnet_f", 32)])
+def test_structured_fixture_at_headline_batch(case, repeat):
+    """The north-star bounds on the configurations bench.py times (dream/network.py:503-590): the reference's structured fixture tiled
+    to the BASELINE batch -- vgg_q 128 x 400 x 400 (configs[1]), resnet_h 16 frames, resnet_f 32 frames (one GPU's share of configs[3] /
+    [4]) -- with the DEFAULT algorithm selection (ops.winograd_tile by batch: F(4x4,3x3) on the XCD-pinned grids at 128 frames; the
+    2-frame fixtures run F(2x2) unless forced).  Every copy: maps within an ABSOLUTE 1e-4 of the reference's golden maps, identical
+    detection / rejection decisions, keypoints within 1e-3 px."""
+    assert ops._WINOGRAD_TILE_FORCED == 0
+    err, perr = pc.check_structured(DEV, case, repeat=repeat)
+    print("structured %s x %d, default algorithms: max |map error| %.2e, max keypoint error %.2e px" % (case, repeat, err, perr))
 
 
 @pytest.mark.parametrize("arch", ["vgg_q", "vgg_q_400", "vgg_f", "resnet_h"])

@@ -1,8 +1,8 @@
 #!/bin/bash
 # ONE parameterised GPU-box script (replaces the per-round gpu_rNN_* families): tools/gpu_round.sh <stage> [args].
-# Run through gpurun from the repo root; writes under gpurun_out/r05_<stage>/.
+# Run through gpurun from the repo root; writes under gpurun_out/r06_<stage>/ (round 5's stages wrote r05_<stage>).
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-O=gpurun_out/r05_$1
+O=gpurun_out/r06_$1
 mkdir -p $O
 export TMPDIR=/tmp
 PROD=dream_amd/libdream_hip.so
@@ -15,6 +15,41 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+g6a)
+  # Round 6, verdict task 1a: the 1x1 GEMMs of ResNet-101 IN the training step.  (1) parity of the re-scheduled kernels (pinned loads,
+  # deep epilogue prefetch), (2) every form of the GEMM on warm and on cold operands, new library and round 5's (build/libR5.so),
+  # (3) hardware counters of the gemm1x1 / wgrad1x1 launches inside one training step (PMC passes serialise the dispatches: the
+  # kernel's own behaviour on the step's cold operands, without the second stream), (4) training / inference lines, alternating.
+  R="$PWD"
+  echo "== pytest (1x1 GEMM forms, BatchNorm folding, ResNet)"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv1x1 or resnet or bn_fused or stress or headline_batch or full_size_batch" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  echo "== forms, new library"; timeout 400 python tools/microbench_gemm_forms.py --shapes layer3,layer2 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/gemm_forms_new.txt
+  echo "== forms, round-5 library"; withlib R5 timeout 400 python tools/microbench_gemm_forms.py --shapes layer3,layer2 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/gemm_forms_r5.txt
+  P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+  P2="SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE SQ_INSTS_SALU"
+  P3="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"
+  P4="TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_EA0_RDREQ_sum"
+  pmc() { # pmc <tag> <passes...>
+    tag=$1; shift
+    for pass in "$@"; do
+      eval C=\$P$pass
+      (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_${tag}_$pass" -o p -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > "$R/$O/pmc_${tag}_$pass.log" 2>&1); echo "pmc $tag pass $pass rc=$?"
+    done
+    python tools/pmc_kernels.py gemm1x1_kernel,wgrad1x1_kernel $O/pmc_${tag}_* > $O/pmc_gemm1x1_in_step_$tag.txt 2> $O/pmc_$tag.err; head -30 $O/pmc_gemm1x1_in_step_$tag.txt | cut -c1-400
+    rm -rf $O/pmc_${tag}_[1-9]
+  }
+  echo "== PMC in the step, round-5 library"; withlib R5 pmc r5 1 2 3 4
+  echo "== PMC in the step, new library"; pmc new 1 2 3 4
+  for r in a b c; do
+    line rt16_new_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    withlib R5 line rt16_R5_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  line rh128_new --arch resnet_h --batch 128
+  withlib R5 line rh128_R5 --arch resnet_h --batch 128
+  line rf32_new --arch resnet_f --batch 32
+  withlib R5 line rf32_R5 --arch resnet_f --batch 32
+  line rt128_new --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  withlib R5 line rt128_R5 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
 ab1)
   # packed vs scalar fp32 VALU beside the MFMAs (verdict round 4, task 1a), running weight offset, s_setprio
   echo "== pytest on the scalar build"; withlib SC timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "winograd4 or wino4 or structured or pinned or conv_winograd" > $O/pytest_sc.log 2>&1; echo "rc=$?"; tail -2 $O/pytest_sc.log
@@ -69,7 +104,7 @@ mask2)
   ;;
 g1)
   # gemm1x1 epilogue: residual / mask operands one row ahead in every form (product) vs the predicated per-row loop (build/libG0.so)
-  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv1x1 or resnet or bn_fused or stress" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv1x1 or resnet or bn_fused or stress or headline_batch or full_size_batch" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
   for r in a b c; do
     line rt16_pipe_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
     withlib G0 line rt16_G0_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
