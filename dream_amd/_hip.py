@@ -42,6 +42,9 @@ _SIGNATURES = {
     "dream_conv2d_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_convT4x4_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "dream_convT4x4_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dream_convT4x4_wgrad_winograd_applies": (_I, [_I, _I]),
+    "dream_convT4x4_wgrad_winograd_workspace": (_SZ, [_I, _I, _I, _I, _I]),
+    "dream_convT4x4_wgrad_winograd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dream_wgrad_set_variant": (_I, [_I]),
     "dream_convT_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "dream_convT_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -270,6 +270,7 @@ struct WgWinoLdsParams {
     unsigned long long magic_tpi, magic_tx;
     int tiles_per_split;     // multiple of 16 (two stages)
     int ncog;                // groups of 64 output channels
+    int nsplit;              // CONVT: splits per phase (partial = [phase][nsplit][9][Cout][Cin], bias_partial = [phase][nsplit][Cout])
 };
 
 // UPS: x is stored at half resolution and the conv ran on its nearest x2 upsample (compile-time: the run-time form of the few
@@ -279,11 +280,21 @@ struct WgWinoLdsParams {
 // on the way (two packed additions per stage and lane next to 64 MFMAs) -- the stand-alone pass over every gradient tensor
 // (1.8 % of a vgg_q training step, at the HBM roofline) is not launched.  Fixed order: lane, then (wave, row) through LDS, then the
 // splits in the reduction kernel.
-template <bool UPS, bool BIAS>
+// CONVT (round 6): the weight gradient of nn.ConvTranspose2d(k4, s2, p1) (the ResNet decoder, dream/models.py:37-136), one output
+// phase (a, b) = blockIdx.z per workgroup.  Phase (a, b) of the transposed conv is a 2 x 2-tap conv of x, i.e. a pad-1 3x3 conv whose
+// kernel g3 is zero outside rows {a, a + 1} and columns {b, b + 1} (conv_wino.hip, convT4x4_phase_kernels); its output is the phase
+// view Y_ab(i, j) = dY(2 i + a, 2 j + b).  dg3 = G^T dU G is needed on those 2 x 2 taps only, and rows {a, a + 1} of G^T reach positions
+// {a, a + 1, a + 2} of the 4 x 4 domain only (G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]): NINE of the sixteen positions -- the
+// F(2x2,2x2) minimal-filtering count, 9 multiplications per 2 x 2 outputs of a phase where the direct form (wgrad.hip) takes 16.
+// Wave w owns active position q = w (row a + q / 3, column b + q % 3) for the whole 64 x 64 block; the ninth position is shared:
+// wave w takes its blocks (m = w >> 1, n = 2 (w & 1) .. + 1).  36 MFMAs per wave and stage instead of 64; the producers load the same
+// 6 float4 per stage and transform three of V's four columns.
+template <bool UPS, bool BIAS, bool CONVT = false>
 __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsParams p) {
     DREAM_DYNAMIC_LDS(float, smem);
     const int lane = threadIdx.x & 63;
     const int wave = wave_index();
+    const int ph_a = CONVT ? (int)(blockIdx.z >> 1) : 0, ph_b = CONVT ? (int)(blockIdx.z & 1) : 0;     // output phase
     const int cog = (int)blockIdx.x % p.ncog, cig = (int)blockIdx.x / p.ncog;
     const int co0 = cog * 64, ci0 = cig * 64;
     const int split = blockIdx.y;
@@ -295,7 +306,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
     // buffers relative to the first image of this split's tile range (32-bit offsets)
     const int b0 = div_magic40(k_begin, p.magic_tpi);
     const int Hs = UPS ? p.H / 2 : p.H, Ws = UPS ? p.W / 2 : p.W;               // stored extent of x
-    const size_t ximg = (size_t)Hs * Ws * p.Cin, yimg = (size_t)p.H * p.W * p.Cdy;
+    const int Hd = CONVT ? 2 * p.H : p.H, Wd = CONVT ? 2 * p.W : p.W;         // stored extent of dy (CONVT: the full-resolution gradient)
+    const size_t ximg = (size_t)Hs * Ws * p.Cin, yimg = (size_t)Hd * Wd * p.Cdy;
     const BufferRsrc xbuf = make_buffer(p.x + (size_t)b0 * ximg, (size_t)(p.B - b0) * ximg * sizeof(float));
     const BufferRsrc ybuf = make_buffer(p.dy + (size_t)b0 * yimg, (size_t)(p.B - b0) * yimg * sizeof(float));
 
@@ -325,8 +337,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
     // patch row vr - 1 relative to the tile's first output row; with the fused upsample the tile's 4 x 4 patch of the upsampled
     // image is rows / columns {-1, 0, 0, +1} of the stored one around the tile's source pixel ((2 t - 1 + r) >> 1 = t + ((r - 1) >> 1))
     const int lane_dx = UPS ? (int)(((((vr - 1) >> 1) * Ws) * p.Cin + 4 * vq) * 4) : (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);
-    const int lane_dy = (int)(((yr2 * p.W) * p.Cdy + 4 * yq) * 4);
-    const int x_px = p.Cin * 4, y_px = p.Cdy * 4;
+    const int lane_dy = CONVT ? (int)(((yr2 * 2 * Wd) * p.Cdy + 4 * yq) * 4) : (int)(((yr2 * p.W) * p.Cdy + 4 * yq) * 4);
+    const int x_px = p.Cin * 4, y_px = (CONVT ? 2 : 1) * p.Cdy * 4;       // (a phase's neighbouring pixels are two stored pixels apart)
     auto issue_load = [&](int set, int st, int n) {
         const int tau = k_begin + st * LT + wave;                               // wave-uniform from here ...
         const bool tv = tau < k_end;
@@ -340,21 +352,31 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
             const bool ok = col_ok & ((unsigned)(2 * ty - 1 + vr) < (unsigned)p.H);
             xr[set][n] = buffer_load_x4(xbuf, (unsigned)(s_off + lane_dx) | ((unsigned)!ok << 31), 0);     // bit 31: out of range
         } else {
-            const int s_off = (pix * p.Cdy + co0) * 4 + (n - 4) * y_px;
+            const int s_off = CONVT ? ((((b - b0) * Hd + 4 * ty + ph_a) * Wd + 4 * tx + ph_b) * p.Cdy + co0) * 4 + (n - 4) * y_px
+                                    : (pix * p.Cdy + co0) * 4 + (n - 4) * y_px;
             const bool col_ok = tv & ((2 * tx + (n - 4)) < p.W);
             const bool ok = col_ok & ((2 * ty + yr2) < p.H);
             yr[set][n - 4] = buffer_load_x4(ybuf, (unsigned)(s_off + lane_dy) | ((unsigned)!ok << 31), 0);
         }
     };
     // piece k = 0..3 of the V transform (transformed column j = k), 4..5 of the dM transform (column 2 yh + k - 4)
+    // (CONVT: k = 0 stands for the phase's live outer column -- 0 for b = 0, 3 for b = 1 -- chosen by a wave-uniform select)
     auto transform_piece = [&](int set, float *buf, int k) {
         if (k < 4) {
             const f32x4 *d = xr[set];
-            const f32x4 u = k == 0 ? d[0] - d[2] : k == 1 ? d[1] + d[2] : k == 2 ? d[2] - d[1] : d[1] - d[3];
+            f32x4 u;
+            int kcol = k;
+            if (CONVT && k == 0) {
+                const f32x4 lhs = ph_b ? d[1] : d[0], rhs = ph_b ? d[3] : d[2];
+                u = lhs - rhs;
+                kcol = ph_b ? 3 : 0;
+            } else {
+                u = k == 0 ? d[0] - d[2] : k == 1 ? d[1] + d[2] : k == 2 ? d[2] - d[1] : d[1] - d[3];
+            }
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(vsb, quad_perm_2211(u[e]), u[e]);
-            *(f32x4 *)(buf + LOPS + v_store + k * LPS) = v;
+            *(f32x4 *)(buf + LOPS + v_store + kcol * LPS) = v;
         } else {
             // along the dy row: (y0, y1) -> y0, y0 + y1, y0 - y1, y1 (the minus sign of the fourth column is applied at the end)
             const int jj = k - 4;
@@ -373,6 +395,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
 
     // ---- consumer: MFMA operands ---------------------------------------------------------------------------------------------
     const int li = lane & 15, lg = lane >> 4;
+  if constexpr (!CONVT) {
     const int a_lane = lg * 64 + 4 * li;                     // + plane + k-step * 256
     f32x4 acc[2][4][4];                                      // [position of this wave][m: co = 4 i + m][n: ci = 4 j + n]
 #pragma unroll
@@ -441,6 +464,93 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
                 const f32x4 v = {acc[pl][m][0][r], acc[pl][m][1][r], acc[pl][m][2][r], acc[pl][m][3][r]};
                 *(f32x4 *)(out + ((size_t)(2 * wave + pl) * p.Cout + co) * p.Cin + ci0 + 4 * li) = v;
             }
+  } else {
+    // ---- CONVT: nine active positions -------------------------------------------------------------------------------------------
+    const int a_lane = lg * 64 + 4 * li;
+    const int q_own = wave;                                   // active position index 0..7: row ph_a + q / 3, column ph_b + q % 3
+    const int p_own = 4 * (ph_a + q_own / 3) + ph_b + q_own % 3, p_sh = 4 * (ph_a + 2) + ph_b + 2;      // the shared one: q = 8
+    auto plane_y = [](int pp) { return pp * LPS + 8 * ((pp & 3) >> 1) + 16 * (pp >> 3) + 32 * (pp >> 2); };      // = l_plane_y
+    auto plane_v = [](int pp) { return pp * LPS + 8 * (pp >> 2); };                                               // = l_plane_v
+    const int py_own = plane_y(p_own), pv_own = plane_v(p_own), py_sh = plane_y(p_sh), pv_sh = plane_v(p_sh);
+    const int sh_m = wave >> 1, sh_n = wave & 1;              // shared position: blocks (m = sh_m, n = 2 sh_n, 2 sh_n + 1)
+    f32x4 acc[4][4], acc_sh[2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    acc_sh[0] = acc_sh[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 oy[2], ov[2], sy[2], sv[2];
+    auto read_ops = [&](int set, const float *buf, int ks) {
+        oy[set] = *(const f32x4 *)(buf + py_own + ks * 256 + a_lane);
+        ov[set] = *(const f32x4 *)(buf + LOPS + pv_own + ks * 256 + a_lane);
+        sy[set] = *(const f32x4 *)(buf + py_sh + ks * 256 + a_lane);
+        sv[set] = *(const f32x4 *)(buf + LOPS + pv_sh + ks * 256 + a_lane);
+    };
+    // one stage: 2 k-steps x (16 MFMAs of the wave's own position + 2 of the shared one); producer pieces behind single MFMAs as in
+    // the 3x3 form: the six loads of stage st + 2 behind MFMAs 1, 3, .. 11, the five transform pieces of stage st + 1 behind MFMAs 14, 18,
+    // .. 30, the operand reads of the second k-step behind MFMA 4
+    auto stage = [&](auto parity, int st) {
+        constexpr int P = decltype(parity)::value;
+        const float *cur = smem + P * 2 * LOPS;
+        float *nxt = smem + (1 - P) * 2 * LOPS;
+        read_ops(0, cur, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int mn = 0; mn < 18; ++mn) {
+                const int n = ks * 18 + mn;
+                if (mn < 16) {
+                    const int m = mn >> 2, n4 = mn & 3;
+                    acc[m][n4] = mfma_f32_16x16x4(oy[ks][m], ov[ks][n4], acc[m][n4]);
+                } else {
+                    // wave-uniform selects of the shared position's operand components
+                    const f32x4 y = sy[ks], v = sv[ks];
+                    const float am = sh_m == 0 ? y[0] : sh_m == 1 ? y[1] : sh_m == 2 ? y[2] : y[3];
+                    const float bn = mn == 16 ? (sh_n ? v[2] : v[0]) : (sh_n ? v[3] : v[1]);
+                    acc_sh[mn - 16] = mfma_f32_16x16x4(am, bn, acc_sh[mn - 16]);
+                }
+                if (mn == 4 && ks == 0) read_ops(1, cur, 1);
+                if (!(DREAM_WGW_DIAG & 1) && n >= 1 && n < 13 && (n & 1) == 1) issue_load(P, st + 2, (n - 1) >> 1);
+                if (!(DREAM_WGW_DIAG & 2) && n >= 14 && n < 34 && ((n - 14) & 3) == 0) {
+                    const int piece = (n - 14) >> 2;              // 0: V's outer live column, 1, 2: V columns 1, 2; 3, 4: dM
+                    transform_piece(1 - P, nxt, piece < 3 ? piece : piece + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (!(DREAM_WGW_DIAG & 4)) __syncthreads();
+    };
+#pragma unroll
+    for (int n = 0; n < 6; ++n) issue_load(0, 0, n);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (k != 3) transform_piece(0, smem, k);
+#pragma unroll
+    for (int n = 0; n < 6; ++n) issue_load(1, 1, n);
+    __syncthreads();
+    for (int st = 0; st < nstages; st += 2) {
+        stage(std::integral_constant<int, 0>{}, st);
+        stage(std::integral_constant<int, 1>{}, st + 1);
+    }
+    // ---- partial dU of this phase and split: [9][Cout][Cin] ---------------------------------------------------------------------
+    float *out = p.partial + ((size_t)blockIdx.z * p.nsplit + split) * 9 * p.Cout * p.Cin;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = co0 + 4 * (4 * lg + r) + m;
+            const f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
+            *(f32x4 *)(out + ((size_t)q_own * p.Cout + co) * p.Cin + ci0 + 4 * li) = v;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int co = co0 + 4 * (4 * lg + r) + sh_m;
+        float *dst = out + ((size_t)8 * p.Cout + co) * p.Cin + ci0 + 4 * li + 2 * sh_n;
+        dst[0] = acc_sh[0][r];
+        dst[1] = acc_sh[1][r];
+    }
+  }
     if (BIAS && bias_wg) {                                   // the stage loop ended with a barrier: LDS is free
         if (yh == 0) *(f32x4 *)(smem + (2 * wave + yr2) * 64 + 4 * yq) = bsum;
         __syncthreads();
@@ -448,7 +558,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
             float s = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += smem[r * 64 + threadIdx.x];
-            p.bias_partial[(size_t)split * p.Cout + co0 + threadIdx.x] = s;
+            p.bias_partial[((size_t)(CONVT ? blockIdx.z * p.nsplit : 0) + split) * p.Cout + co0 + threadIdx.x] = s;
         }
     }
 }
@@ -505,6 +615,60 @@ __global__ void __launch_bounds__(256) wgrad_wino_lds_reduce_kernel(const float 
         dw[i * 9 + j * 3 + 0] = t0 + hs;
         dw[i * 9 + j * 3 + 1] = hd;
         dw[i * 9 + j * 3 + 2] = hs + t3;
+    }
+}
+
+// ---- CONVT: dwT[ci][co][ky][kx] of nn.ConvTranspose2d(k4, s2, p1) from the four phases' nine-position partials -------------------------
+// partial [phase][nsplit][9][Cout][Cin] (position index q = 3 * row + column over rows a .. a + 2, columns b .. b + 2 of the 4 x 4
+// domain).  Per weight: sum the splits in index order, negate the positions of the fourth column (the deferred signs, as in the 3x3
+// form), apply the two live rows of G^T (G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]: rows {0, 1} over positions {0, 1, 2} for a = 0,
+// rows {1, 2} over {1, 2, 3} for a = 1) and the two live columns of G, and store tap (r, c) of the phase's zero-padded 3x3 kernel where
+// it came from: wT[ci][co][a + 3 - 2 r][b + 3 - 2 c] (conv_wino.hip, convT4x4_phase_kernels).  Waves 0..2 of a workgroup take one
+// column of positions each (lane = weight: 256 contiguous bytes per load), waves 0..1 then one tap row each.
+// db (optional): the bias gradient = sum over phases and splits (fixed order) of the main kernel's column sums of dy.
+__global__ void __launch_bounds__(256) wgrad_wino_convT_reduce_kernel(const float *partial, float *dwT, const float *bias_partial, float *db,
+                                                                      int nsplit, int Cout, int Cin) {
+    __shared__ float t_s[3][2][64];
+    const size_t n = (size_t)Cout * Cin;                     // a multiple of 64 * 64
+    const int lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    const int phase = blockIdx.y, a = phase >> 1, b = phase & 1;
+    const size_t i = (size_t)blockIdx.x * 64 + lane;        // = co * Cin + ci
+    if (db != nullptr && phase == 0) {
+        const int co = (int)blockIdx.x * 256 + (int)threadIdx.x;
+        if (co < Cout) db[co] = sum_splits(bias_partial + co, (size_t)Cout, 4 * nsplit);
+    }
+    if (j < 3) {                                             // column j of the active positions: q = j, 3 + j, 6 + j
+        const float *src = partial + ((size_t)phase * nsplit * 9 + j) * n + i;
+        float u[3] = {0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < nsplit; ++k) {
+            float v[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) v[r] = src[((size_t)k * 9 + 3 * r) * n];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) u[r] += v[r];
+        }
+        if (b + j == 3) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) u[r] = -u[r];
+        }
+        // the two live rows of G^T over the three active row positions
+        float t0, t1;
+        if (a == 0) { t0 = u[0] + 0.5f * (u[1] + u[2]); t1 = 0.5f * (u[1] - u[2]); }       // taps r = 0, 1 from positions 0, 1, 2
+        else        { t0 = 0.5f * (u[0] - u[1]); t1 = 0.5f * (u[0] + u[1]) + u[2]; }       // taps r = 1, 2 from positions 1, 2, 3
+        t_s[j][0][lane] = t0;
+        t_s[j][1][lane] = t1;
+    }
+    __syncthreads();
+    if (j < 2) {                                             // tap row r = a + j; its two live columns
+        const float c0 = t_s[0][j][lane], c1 = t_s[1][j][lane], c2 = t_s[2][j][lane];
+        float g0, g1;
+        if (b == 0) { g0 = c0 + 0.5f * (c1 + c2); g1 = 0.5f * (c1 - c2); }
+        else        { g0 = 0.5f * (c0 - c1); g1 = 0.5f * (c0 + c1) + c2; }
+        const int co = (int)(i / (size_t)Cin), ci = (int)(i - (size_t)co * Cin);
+        const int r = a + j, ky = a + 3 - 2 * r;
+        float *dst = dwT + (((size_t)ci * Cout + co) * 4 + ky) * 4;
+        dst[b + 3 - 2 * b] = g0;                             // tap column c = b
+        dst[b + 3 - 2 * (b + 1)] = g1;                       // tap column c = b + 1
     }
 }
 
@@ -601,6 +765,7 @@ extern "C" int dream_conv3x3_wgrad_winograd_bias_nhwc_f32(const float *x, const 
         p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)pl.TX - 1) / (unsigned long long)pl.TX;
         p.tiles_per_split = pl.tiles_per_split;
         p.ncog = Cout / 64;
+        p.nsplit = pl.nsplit;
         void (*const kernels[4])(WgWinoLdsParams) = {wgrad_wino_lds_kernel<false, false>, wgrad_wino_lds_kernel<true, false>,
                                                      wgrad_wino_lds_kernel<false, true>, wgrad_wino_lds_kernel<true, true>};
         for (int v = 0; v < 4; ++v)
@@ -639,4 +804,67 @@ extern "C" int dream_conv3x3_wgrad_winograd_bias_nhwc_f32(const float *x, const 
 extern "C" int dream_conv3x3_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dw_oihw, void *workspace, int B, int H,
                                                      int W, int Cin, int Cout, int Cdy, int flags, void *stream) {
     return dream_conv3x3_wgrad_winograd_bias_nhwc_f32(x, dy, dw_oihw, nullptr, workspace, B, H, W, Cin, Cout, Cdy, flags, stream);
+}
+
+// ---- nn.ConvTranspose2d(k4, s2, p1) weight gradient by minimal filtering (round 6; dream/models.py:37-136 via network.py:335) -----------
+// x [B,H,W,Cin], dy [B,2H,2W,Cout] NHWC -> dwT [Cin][Cout][4][4] (the module's own layout, overwritten), dbias [Cout] or null
+// (= column sums of dy, summed in the dy loader).  Cin % 64 == 0, Cout % 64 == 0.  ONE launch of the nine-position kernel over
+// (channel blocks) x (splits) x (four phases) + one reduction launch; 9 multiplications per 2 x 2 outputs of a phase where
+// dream_convT4x4_wgrad_nhwc_f32 (the direct kernel) takes 16.
+namespace {
+PlanLds make_plan_convT(int B, int H, int W, int Cin, int Cout) {
+    PlanLds pl;
+    pl.TY = (H + 1) / 2; pl.TX = (W + 1) / 2;
+    pl.ntiles = B * pl.TY * pl.TX;
+    const int blocks = (Cout / 64) * (Cin / 64) * 4;                          // the four phases run side by side
+    int want = (256 + blocks / 2) / blocks;
+    const int max_by_work = (pl.ntiles + 16 * LT - 1) / (16 * LT);          // at least 16 stages per split
+    if (want > max_by_work) want = max_by_work;
+    if (want < 1) want = 1;
+    // 32-bit byte offsets relative to the first image of a split: dy is stored at 2H x 2W
+    const size_t img_bytes = (size_t)4 * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4;
+    const long tiles_per_img = (long)pl.TY * pl.TX;
+    while (((size_t)((pl.ntiles + want - 1) / want / tiles_per_img) + 2) * img_bytes >= ((size_t)1 << 30) && want < pl.ntiles) want *= 2;
+    pl.tiles_per_split = ((pl.ntiles + want - 1) / want + 2 * LT - 1) / (2 * LT) * (2 * LT);
+    pl.nsplit = (pl.ntiles + pl.tiles_per_split - 1) / pl.tiles_per_split;
+    return pl;
+}
+}  // namespace
+
+extern "C" int dream_convT4x4_wgrad_winograd_applies(int Cin, int Cout) { return Cin > 0 && Cout > 0 && Cin % 64 == 0 && Cout % 64 == 0 ? 1 : 0; }
+
+extern "C" size_t dream_convT4x4_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || !dream_convT4x4_wgrad_winograd_applies(Cin, Cout)) return 0;
+    const PlanLds pl = make_plan_convT(B, H, W, Cin, Cout);
+    return (size_t)4 * pl.nsplit * (9 * (size_t)Cout * Cin + Cout) * sizeof(float);
+}
+
+extern "C" int dream_convT4x4_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dwT, float *dbias, void *workspace, int B,
+                                                      int H, int W, int Cin, int Cout, void *stream) {
+    DREAM_REQUIRE(x && dy && dwT && workspace, "winograd convT wgrad: null pointer");
+    DREAM_REQUIRE(B > 0 && H > 0 && W > 0, "winograd convT wgrad: bad shape");
+    DREAM_REQUIRE(dream_convT4x4_wgrad_winograd_applies(Cin, Cout), "winograd convT wgrad: Cin %% 64, Cout %% 64 (got %d, %d)", Cin, Cout);
+    const PlanLds pl = make_plan_convT(B, H, W, Cin, Cout);
+    DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd convT wgrad: too many tiles");
+    DREAM_REQUIRE((size_t)4 * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 29), "winograd convT wgrad: image too large for 32-bit offsets");
+    WgWinoLdsParams p;
+    p.x = x; p.dy = dy; p.partial = (float *)workspace;
+    p.bias_partial = p.partial + (size_t)4 * pl.nsplit * 9 * Cout * Cin;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.Cdy = Cout;
+    p.TY = pl.TY; p.TX = pl.TX; p.ntiles = pl.ntiles;
+    p.magic_tpi = (((unsigned long long)1 << 40) + (unsigned long long)(pl.TY * pl.TX) - 1) / (unsigned long long)(pl.TY * pl.TX);
+    p.magic_tx = (((unsigned long long)1 << 40) + (unsigned long long)pl.TX - 1) / (unsigned long long)pl.TX;
+    p.tiles_per_split = pl.tiles_per_split;
+    p.ncog = Cout / 64;
+    p.nsplit = pl.nsplit;
+    void (*const kernels[2])(WgWinoLdsParams) = {wgrad_wino_lds_kernel<false, false, true>, wgrad_wino_lds_kernel<false, true, true>};
+    for (int v = 0; v < 2; ++v)
+        if (dream_allow_full_lds((const void *)kernels[v])) return 2;
+    const dim3 grid((unsigned)(p.ncog * (Cin / 64)), (unsigned)pl.nsplit, 4);
+    hipLaunchKernelGGL(kernels[dbias ? 1 : 0], grid, dim3(512), L_LDS_BYTES, (hipStream_t)stream, p);
+    DREAM_LAUNCH_OK();
+    hipLaunchKernelGGL(wgrad_wino_convT_reduce_kernel, dim3((unsigned)((size_t)Cout * Cin / 64), 4), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)workspace, dwT, (const float *)p.bias_partial, dbias, pl.nsplit, Cout, Cin);
+    DREAM_LAUNCH_OK();
+    return 0;
 }

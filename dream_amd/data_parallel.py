@@ -171,11 +171,15 @@ class _SplitCapture:
     is kept alive by construction: leaf inputs (main pool) until join(), leaf outputs = the weight gradients (side pool) until
     the last main segment has packed them."""
 
-    def __init__(self, pool, leaves, device):
+    def __init__(self, pool, leaves, device, shared_device=False):
         self.pool, self.side_pool, self.leaves = pool, None, max(1, int(leaves))
         self.plan, self.cur = [], None
         from . import models
-        live = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT_STREAM", "live") == "live"
+        # The leaf segments are captured on, and replayed to, the device's LIVE second stream (the one eager steps use: a stream that
+        # is known to run beside the main stream) -- unless several replicas share the device (gpu_ids=[0, 0, 0, 0], the rehearsal on a
+        # one-GPU box): their threads replay while another thread may hold that stream in a capture (round-5 advice), so each of them
+        # gets a stream of its own.
+        live = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT_STREAM", "live") == "live" and not shared_device
         self.side = models._SideStream.live_stream(device) if live else torch.cuda.Stream(device=device)   # captures the leaf segments; replays them
         self.mark = torch.zeros(1, device=device)               # one tiny node per main segment: never an empty graph
 
@@ -283,9 +287,10 @@ class DreamDataParallel(nn.Module):
         self.single_device_graphs = os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
         # DREAM_TRAIN_GRAPH_SPLIT=n: a captured backward becomes a sequence of graphs, n weight-gradient leaves per segment, the leaf
         # segments replayed on a live second stream (_SplitCapture); 0: one graph, the leaves a forked branch inside it.  Unset (None):
-        # 12 for the one-device step, where it was measured (resnet_h, 16 frames: 342 -> 363-365 frames/s, eager 367; 8 leaves: 360-364, 5: 359.5;
-        # vgg_q at 16 frames 585 -> 590, eager 586.5; profiles/r05_ab_train_graph.txt), 0 for the replicas of a multi-device step (no node to
-        # measure on; four replicas on one GPU with split 8 pass their bit-for-bit test).
+        # 12, measured on the one-device step (resnet_h, 16 frames: 342 -> 363-365 frames/s, eager 367; 8 leaves: 360-364, 5: 359.5;
+        # vgg_q at 16 frames 585 -> 590, eager 586.5; profiles/r05_ab_train_graph.txt).  Round 6: also the default of the replicas of a
+        # multi-device step -- each replica is its device's only user, i.e. exactly the one-device step that was measured (four
+        # replicas on one GPU pass their bit-for-bit test with it; profiles/r06_rehearsal_*).
         env = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT")
         self.graph_split_leaves = int(env) if env not in (None, "") else None
         # statistics of the last step (tests, bench): hipGraph replays / eager replica runs / captures
@@ -508,9 +513,10 @@ class DreamDataParallel(nn.Module):
                     torch.cuda.current_stream().synchronize()
                     split = self.graph_split_leaves
                     if split is None:
-                        split = 12 if len(self.devices()) == 1 else 0
+                        split = 12
                     if split > 0:
-                        graph = _SplitCapture(entry["pool"], split, gflat.device)
+                        devs = self.devices()
+                        graph = _SplitCapture(entry["pool"], split, gflat.device, shared_device=devs.count(devs[i]) > 1)
                         graph.capture(lambda: self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels))
                     else:
                         graph = torch.cuda.CUDAGraph()

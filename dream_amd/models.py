@@ -721,7 +721,13 @@ class _SideStream:
         self.pending = []
         self.count = 0
 
-    leaves_of_last_backward = 0                  # leaves between create() and join() of the last eager backward (for _DeferredSide)
+    # leaves between create() and join() of the last eager backward OF THIS THREAD (for _DeferredSide: the replicas of the
+    # single-process multi-GPU path run their backward passes on one host thread each)
+    _counts = threading.local()
+
+    @classmethod
+    def leaves_of_last_backward(cls):
+        return getattr(cls._counts, "leaves", 0)
 
     def run(self, fn, *inputs):
         self.count += 1
@@ -754,7 +760,7 @@ class _SideStream:
     def join(self):
         self.flush()
         self.main.wait_stream(self.side)
-        _SideStream.leaves_of_last_backward = self.count
+        _SideStream._counts.leaves = self.count
         if self.keep is not None:
             del self.keep[:]
 
@@ -778,7 +784,7 @@ class _DeferredSide:
         # eager step before the capture counted them) the last segments are tapered -- half of what remains, down to single leaves --
         # so that the exposed tail is one leaf, as in the eager step.  DREAM_TRAIN_GRAPH_SPLIT_TAPER=0: equal segments throughout.
         taper = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT_TAPER", "1") == "1"
-        self.total, self.seen = (_SideStream.leaves_of_last_backward if taper else 0), 0
+        self.total, self.seen = (_SideStream.leaves_of_last_backward() if taper else 0), 0
 
     def run(self, fn, *inputs):
         self.pending.append(fn)
@@ -1379,8 +1385,11 @@ class ResnetSimple(nn.Module):
                 dz, _, dgam, dbet = ops.bn_train_bwd(rec["z"], g, rec["y"], bn.weight, rec["mean"], rec["invstd"], True)
                 grads[bn.weight], grads[bn.bias] = dgam, dbet
                 def leaf(m=m, x=rec["x"], dz=dz):
-                    grads[m.weight] = ops.convT4x4_wgrad(x, dz)
-                    grads[m.bias] = ops.channel_sum(dz)
+                    if ops.convT4x4_wgrad_winograd_applies(x, dz):        # nine-position minimal filtering + the bias sums, one launch
+                        grads[m.weight], grads[m.bias] = ops.convT4x4_wgrad_winograd(x, dz)
+                    else:
+                        grads[m.weight] = ops.convT4x4_wgrad(x, dz)
+                        grads[m.bias] = ops.channel_sum(dz)
                 _on_side(side, leaf, rec["x"], dz)
                 cin_t, cout_t = int(m.weight.shape[0]), int(m.weight.shape[1])
                 if (self.convT_algorithm == "winograd" and cout_t % 16 == 0 and cout_t >= 32 and cin_t > 64
@@ -1599,8 +1608,11 @@ class ResnetSimple(nn.Module):
                 dz, _, dgam, dbet = self._bn_bwd_fused(rec, g)
                 grads[bn.weight], grads[bn.bias] = dgam, dbet
                 def leaf(m=m, x=rec["x"], dz=dz):
-                    grads[m.weight] = ops.convT4x4_wgrad(x, dz)
-                    grads[m.bias] = ops.channel_sum(dz)
+                    if ops.convT4x4_wgrad_winograd_applies(x, dz):        # nine-position minimal filtering + the bias sums, one launch
+                        grads[m.weight], grads[m.bias] = ops.convT4x4_wgrad_winograd(x, dz)
+                    else:
+                        grads[m.weight] = ops.convT4x4_wgrad(x, dz)
+                        grads[m.bias] = ops.channel_sum(dz)
                 _on_side(side, leaf, rec["x"], dz)
                 cin_t, cout_t = int(m.weight.shape[0]), int(m.weight.shape[1])
                 if (self.convT_algorithm == "winograd" and cout_t % 16 == 0 and cout_t >= 32 and cin_t > 64

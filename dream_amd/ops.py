@@ -1049,6 +1049,29 @@ def convT4x4_wgrad(x_nhwc, dy_nhwc):
     return dw
 
 
+def convT4x4_wgrad_winograd_applies(x_nhwc, dy_nhwc):
+    """The nine-position F(2x2,2x2) weight gradient of ConvTranspose2d(4,2,1) takes channel counts that are multiples of 64 and a
+    gradient tensor without channel padding at exactly twice the input's extent (DREAM_CONVT_WGRAD=direct: never)."""
+    if _os.environ.get("DREAM_CONVT_WGRAD", "winograd") == "direct":
+        return False
+    b, h, w, cin = (int(v) for v in x_nhwc.shape)
+    return (tuple(dy_nhwc.shape[:3]) == (b, 2 * h, 2 * w)
+            and bool(_hip.lib().dream_convT4x4_wgrad_winograd_applies(cin, int(dy_nhwc.shape[3]))))
+
+
+def convT4x4_wgrad_winograd(x_nhwc, dy_nhwc, want_bias=True):
+    """ConvTranspose2d(4,2,1) weight gradient by minimal filtering (csrc/wgrad_wino.hip, CONVT) -> (dW [Cin,Cout,4,4], dbias [Cout] |
+    None): 9 multiplications per 2x2 outputs of a phase instead of 16, the bias gradient from the same launch."""
+    x, dy = _f32(x_nhwc), _f32(dy_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    cout = int(dy.shape[3])
+    ws = _workspace(_hip.lib().dream_convT4x4_wgrad_winograd_workspace(b, h, w, cin, cout), x.device)
+    dw = torch.empty((cin, cout, 4, 4), dtype=torch.float32, device=x.device)
+    db = torch.empty((cout,), dtype=torch.float32, device=x.device) if want_bias else None
+    call("dream_convT4x4_wgrad_winograd_nhwc_f32", ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), b, h, w, cin, cout, stream())
+    return dw, db
+
+
 def conv4x4s2(x_nhwc, packed16, cout, residual=None):
     """4x4 stride-2 pad-1 conv (data gradient of the 4x4 transposed conv)."""
     x = _f32(x_nhwc)

@@ -386,6 +386,16 @@ int dream_conv2d_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packe
 size_t dream_convT4x4_wgrad_workspace(int B, int H, int W, int CinPad, int Cout);
 int dream_convT4x4_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                   int H, int W, int Cin, int CinPad, int Cout, void *stream);
+/* The same gradient by minimal filtering F(2x2,2x2) (round 6; replaces ATen's conv-transpose backward-weight behind loss.backward(),
+ * /root/reference/dream/network.py:335, for the decoder of /root/reference/dream/models.py:37-136): every output phase of the
+ * transposed conv is a 2 x 2-tap conv whose Winograd-domain weight gradient lives on nine of the sixteen positions of the 4 x 4
+ * domain: 9 multiplications per 2 x 2 outputs of a phase instead of the direct form's 16.  x [B,H,W,Cin], dy [B,2H,2W,Cout] ->
+ * dwT [Cin][Cout][4][4] (the module's layout, no unpack step), dbias [Cout] or NULL (column sums of dy from the same launch).
+ * Cin % 64 == 0 and Cout % 64 == 0 (dream_convT4x4_wgrad_winograd_applies); workspace: dream_convT4x4_wgrad_winograd_workspace() bytes. */
+int dream_convT4x4_wgrad_winograd_applies(int Cin, int Cout);
+size_t dream_convT4x4_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout);
+int dream_convT4x4_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dwT, float *dbias, void *workspace, int B,
+                                           int H, int W, int Cin, int Cout, void *stream);
 size_t dream_convT_wgrad_workspace(int B, int H, int W, int CinPad, int Cout, int ksize);
 int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                int H, int W, int Cin, int CinPad, int Cout, int ksize, void *stream);

@@ -307,6 +307,33 @@ def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0, ups=False):
     return err
 
 
+def check_convT4x4_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0):
+    """nn.ConvTranspose2d(k4, s2, p1) weight gradient on the nine-position F(2x2,2x2) form (csrc/wgrad_wino.hip CONVT) against an
+    fp64 evaluation of torch's conv_transpose2d backward: error relative to sum |terms| at fp32 round-off level, every one of the
+    sixteen taps written (the four phases' 2 x 2 taps tile the 4 x 4 kernel), the bias gradient from the same launch, and agreement
+    with the direct kernel it replaces."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, 2 * H, 2 * W, generator=g)
+    wref = torch.zeros(Cin, Cout, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x.double(), wref, None, stride=2, padding=1).backward(dy.double())
+    aref = torch.zeros(Cin, Cout, 4, 4, dtype=torch.float64, requires_grad=True)
+    F.conv_transpose2d(x.double().abs(), aref, None, stride=2, padding=1).backward(dy.double().abs())
+    xd, dyd = to(dev, _nhwc(x)), to(dev, _nhwc(dy))
+    assert ops.convT4x4_wgrad_winograd_applies(xd, dyd)
+    dw = torch.full((Cin, Cout, 4, 4), float("nan"))
+    dw, db = ops.convT4x4_wgrad_winograd(xd, dyd)
+    assert dw.shape == (Cin, Cout, 4, 4) and bool(torch.isfinite(dw).all())
+    err = float(((dw.cpu().double() - wref.grad).abs() / aref.grad).max())
+    assert err <= 3e-6, (B, H, W, Cin, Cout, err)
+    assert float((db.cpu().double() - dy.double().sum((0, 2, 3))).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())
+    dw2, db2 = ops.convT4x4_wgrad_winograd(xd, dyd, want_bias=False)
+    assert db2 is None and torch.equal(dw, dw2)               # the bias sums ride along without touching the weight gradient
+    direct = ops.convT4x4_wgrad(xd, dyd)
+    assert float((dw - direct).abs().max()) <= 3e-6 * float(aref.grad.max())
+    return err
+
+
 def check_conv_transpose(dev, B, H, W, Cin, Cout, seed=0):
     """ConvTranspose2d(k3,s2,p1,op1) == zero-stuffed conv with mode-1 packed weights."""
     g = torch.Generator().manual_seed(seed)

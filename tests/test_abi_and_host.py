@@ -211,7 +211,7 @@ def test_deferred_side_hands_the_leaves_over_in_segments(monkeypatch):
         def cut(self, fns, join=False):
             self.cuts.append(([fn() for fn in fns], join))
 
-    monkeypatch.setattr(models._SideStream, "leaves_of_last_backward", 0)       # number of leaves unknown: equal segments
+    monkeypatch.setattr(models._SideStream._counts, "leaves", 0, raising=False)       # number of leaves unknown: equal segments
     ctl = Ctl()
     side = models._DeferredSide(ctl)
     ran = []
@@ -223,7 +223,7 @@ def test_deferred_side_hands_the_leaves_over_in_segments(monkeypatch):
     side.join()                                            # nothing pending: still a cut, so that the main stream waits
     assert ctl.cuts[-1] == ([], True)
     # number of leaves known from the eager step before: the last segments shrink to single leaves, one leaf is left for join()
-    monkeypatch.setattr(models._SideStream, "leaves_of_last_backward", 20)
+    monkeypatch.setattr(models._SideStream._counts, "leaves", 20, raising=False)
     ctl = Ctl()
     ctl.leaves = 8
     side = models._DeferredSide(ctl)

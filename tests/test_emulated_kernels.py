@@ -117,6 +117,15 @@ def test_conv1x1_gemm(emu):
     print("conv1x1 wgrad max err / sum|terms|", max(werrs))
 
 
+def test_convT4x4_wgrad_winograd(emu):
+    """The transposed conv's weight gradient on nine of the sixteen Winograd positions (round 6)."""
+    errs = [pc.check_convT4x4_wgrad_winograd("cpu", 1, 8, 8, 64, 64),                # one block, one split
+            pc.check_convT4x4_wgrad_winograd("cpu", 2, 13, 9, 64, 64, seed=1),       # odd phase extents (half tiles), several stages
+            pc.check_convT4x4_wgrad_winograd("cpu", 1, 5, 3, 128, 64, seed=2),       # fewer tiles than a stage, two input-channel blocks
+            pc.check_convT4x4_wgrad_winograd("cpu", 1, 26, 26, 64, 128, seed=3)]     # two output-channel blocks, several splits
+    print("convT4x4 wgrad (F(2x2,2x2), 9 positions) max err / sum|terms|", max(errs))
+
+
 def test_wgrad_winograd(emu):
     errs = [pc.check_wgrad_winograd("cpu", 1, 8, 8, 64, 16),                    # one split, interior + border tiles
             pc.check_wgrad_winograd("cpu", 2, 13, 9, 64, 32, seed=1),            # odd extents (half tiles), several images

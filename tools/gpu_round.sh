@@ -15,6 +15,23 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+g6b)
+  # Round 6, verdict task 1b: ConvTranspose2d(4,2,1) weight gradient on the nine-position F(2x2,2x2) form against the direct kernel
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "convT4x4_wgrad or resnet or train_step or backward_ops or data_parallel" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log; grep "convT4x4 wgrad" $O/pytest.log
+  timeout 300 python tools/microbench_convT_wgrad.py --batch 16 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_convT_wgrad_b16.txt
+  timeout 300 python tools/microbench_convT_wgrad.py --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_convT_wgrad_b128.txt
+  timeout 300 python tools/microbench_convT_wgrad.py --batch 32 --layers 5 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_convT_wgrad_b32.txt
+  for r in a b c; do
+    line rt16_wino_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_CONVT_WGRAD=direct line rt16_direct_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  for r in a b; do
+    line rt128_wino_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+    DREAM_CONVT_WGRAD=direct line rt128_direct_$r --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  done
+  line rft32_wino --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  DREAM_CONVT_WGRAD=direct line rft32_direct --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  ;;
 g6a)
   # Round 6, verdict task 1a: the 1x1 GEMMs of ResNet-101 IN the training step.  (1) parity of the re-scheduled kernels (pinned loads,
   # deep epilogue prefetch), (2) every form of the GEMM on warm and on cold operands, new library and round 5's (build/libR5.so),
