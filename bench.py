@@ -296,7 +296,7 @@ class ConvTimer:
         ops.conv3x3_winograd = w(ops.conv3x3_winograd, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
                                  2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=16.0 / 36.0)
         if hasattr(ops, "conv3x3_winograd4"):
-            ops.conv3x3_winograd4 = w(ops.conv3x3_winograd4, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0:
+            ops.conv3x3_winograd4 = w(ops.conv3x3_winograd4, lambda y, x, u, cout, scale=None, shift=None, residual=None, flags=0, out=None:
                                       2.0 * y.numel() * pooled(flags) * x.shape[3] * 9, executed=36.0 / 144.0, issued=wino4_issued)
         ops.conv1x1 = w(ops.conv1x1, lambda y, x, packed, cout, *a, **k: 2.0 * y.numel() * x.shape[3])
         if hasattr(ops, "conv1x1_bn"):        # the same GEMM with a train-mode BatchNorm folded in on either side (round 4)

@@ -244,6 +244,22 @@ class DreamHourglass(nn.Module):
             return True         # F(4x4,3x3) works on whole 4x4 tiles anyway: the pooled store is free at every map size (saves the 100^2 / 50^2 passes)
         return min(int(x_nhwc.shape[1]), int(x_nhwc.shape[2])) >= 160
 
+    def _first_pair_subbatch(self, layers, li, x_nchw, save):
+        """Frames per sub-batch for the first conv pair of an inference pass (0: run the layers whole).  DREAM_FIRST_SUBBATCH=n; only
+        where the second conv runs on the F(4x4,3x3) kernel with the pool fused, is no skip source, and the batch has several sub-batches."""
+        n = int(os.environ.get("DREAM_FIRST_SUBBATCH", "0"))
+        if n <= 0 or save or self.precision != "fp32" or self.conv_algorithm != "winograd" or li + 2 >= len(layers):
+            return 0
+        (k1, m1, f1), (k2, _, _) = layers[li + 1], layers[li + 2]
+        b, _, h, w = (int(v) for v in x_nchw.shape)
+        if (k1 != "conv" or k2 != "pool" or f1 != CONV_RELU or any(i in self._skip_sources for i in (li, li + 1, li + 2)) or b <= n
+                or h % 2 or w % 2 or int(m1.weight.shape[1]) != int(layers[li][1].weight.shape[0])):
+            return 0
+        cin, cout = int(m1.weight.shape[1]), int(m1.weight.shape[0])
+        if not self._use_winograd(cin, cout, f1) or ops.winograd_tile(h, w, cin, cout, min(n, b)) != 4:
+            return 0
+        return n
+
     def _use_winograd(self, cin, cout, flags):
         """Winograd serves the plain 3x3 convs (bias, ReLU, fused max-pool); measured faster than the direct kernel for every
         DREAM layer with >= 64 output channels (profiles/r02_microbench_wino_b128.txt: 1.5-2.05x), on par at 32."""
@@ -321,7 +337,13 @@ class DreamHourglass(nn.Module):
         layers = self.plan_layers()
         pool_done = add_done = False
         pooled_by_conv = None
+        consumed = 0
         for li, (kind, mod, flags) in enumerate(layers):
+            if consumed > 0:                               # this layer ran inside the sub-batched first pair below
+                consumed -= 1
+                if kind not in ("pool", "add"):
+                    pi += 2
+                continue
             inp = act
             skip = None
             if kind == "pool":
@@ -346,7 +368,21 @@ class DreamHourglass(nn.Module):
                     skip = keep[layers[li + 1][2]]
                 w, bias = params[pi], params[pi + 1]
                 pi += 2
-                if kind == "first":
+                sub = self._first_pair_subbatch(layers, li, inp, save) if kind == "first" else 0
+                if sub:
+                    # inference: conv1_1 -> conv1_2 (+ pool) over sub-batches of `sub` frames, so that the 64-channel full-resolution tensor
+                    # between them (41 MB per frame at 400 x 400: 5.2 GB at 128 frames, written and re-read through HBM) is a
+                    # `sub`-frame buffer that is re-used in place and stays in the 256-MB Infinity Cache (dream/models.py:591-599)
+                    mod2 = layers[li + 1][1]
+                    u2, rows2 = self._packed.get(mod2.weight, "wino4_0")
+                    b_all, h_in, w_in = int(inp.shape[0]), int(inp.shape[2]), int(inp.shape[3])
+                    act = torch.empty((b_all, h_in // 2, w_in // 2, rows2), dtype=torch.float32, device=inp.device)
+                    for s0 in range(0, b_all, sub):
+                        a1 = ops.conv3x3_first(inp[s0:s0 + sub], w, bias, relu=bool(flags & CONV_RELU))
+                        ops.conv3x3_winograd4(a1, u2, rows2, None, params[pi + 1], None, layers[li + 1][2] | CONV_POOL2, out=act[s0:s0 + sub])
+                        del a1
+                    consumed = 2                             # conv1_2 and its pool
+                elif kind == "first":
                     act = ops.conv3x3_first(inp, w, bias, relu=bool(flags & CONV_RELU))
                 else:
                     if kind == "wide" and not x_is_nhwc:

@@ -242,12 +242,18 @@ def pack_weight_winograd4(w_oihw, mode=0):
     return packed, rows
 
 
-def conv3x3_winograd4(x_nhwc, packed_u, cout, scale=None, shift=None, residual=None, flags=0):
-    """3x3 stride-1 pad-1 conv by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): same contract as conv3x3_winograd; Cin % 32 == 0 (Cin % 16 == 0 for Cout <= 64)."""
+def conv3x3_winograd4(x_nhwc, packed_u, cout, scale=None, shift=None, residual=None, flags=0, out=None):
+    """3x3 stride-1 pad-1 conv by Winograd F(4x4,3x3) (csrc/conv_wino4.hip): same contract as conv3x3_winograd; Cin % 32 == 0 (Cin % 16 == 0 for Cout <= 64).
+    ``out``: a contiguous tensor of the result's shape to write into (a batch slice of a larger tensor)."""
     x = _f32(x_nhwc)
     b, h, w, cin = (int(v) for v in x.shape)
     shape = (b, h // 2, w // 2, cout) if flags & CONV_POOL2 else (b, h, w, cout)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device)
+    if out is not None:
+        if tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float32 or out.device != x.device:
+            raise RuntimeError("conv3x3_winograd4: out must be a contiguous float32 tensor of shape %s on %s" % (shape, x.device))
+        y = out
+    else:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device)
     call("dream_conv3x3_winograd4_nhwc_f32", ptr(x), ptr(packed_u), ptr(scale), ptr(shift), ptr(residual), ptr(y), b, h, w, cin,
          cout, flags, stream())
     return y

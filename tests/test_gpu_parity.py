@@ -302,6 +302,25 @@ def test_full_size_batch_properties():
     assert np.array_equal(kps[:4].numpy(), op.keypoints_from_belief_maps(maps[:4].numpy(), 0.4395))
 
 
+def test_first_conv_pair_in_sub_batches_same_bits(monkeypatch):
+    """DREAM_FIRST_SUBBATCH=n (round 6, dream/models.py:591-599): conv1_1 -> conv1_2 (+ pool) of an inference pass over sub-batches of n
+    frames, the full-resolution 64-channel tensor between them an n-frame buffer that stays in the Infinity Cache.  Same kernels on
+    the same frames: bit-identical maps and keypoints; the two layers really run per sub-batch."""
+    net = pc.build_network("vgg_q", DEV)
+    net.enable_evaluation()
+    x = torch.from_numpy(cases.image_batch(8, 400, 400, seed=12)).to(DEV)
+    with torch.no_grad():
+        maps0, kps0 = net.inference(x)
+    calls = []
+    orig = ops.conv3x3_first
+    monkeypatch.setattr(ops, "conv3x3_first", lambda *a, **k: calls.append(int(a[0].shape[0])) or orig(*a, **k))
+    monkeypatch.setenv("DREAM_FIRST_SUBBATCH", "2")
+    with torch.no_grad():
+        maps1, kps1 = net.inference(x)
+    assert calls == [2, 2, 2, 2], calls
+    assert torch.equal(maps0, maps1) and torch.equal(kps0, kps1)
+
+
 def test_full_size_peak_stage():
     """896 maps of 100x100 (batch 128 x 7): gaussian linearity-free check -- compare a strided subset
     with the oracle bit-for-bit and all counts with a NumPy recount on the device-smoothed maps."""
@@ -1055,14 +1074,15 @@ def test_single_process_data_parallel_resnet_batchnorm_semantics():
     assert torch.equal(dp.model.module.bn1.running_mean, halves[0][2].model.module.bn1.running_mean)
 
 
-@pytest.mark.parametrize("split", ["", "8"])
+@pytest.mark.parametrize("split", ["", "0", "8"])
 def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, split):
     """gpu_ids = [0, 0, 0, 0]: from the second sighting of a shape every replica's forward and backward run as hipGraph
     replays (dream_amd/data_parallel.py).  Three ResNet training steps (eager, capture + replay, replay) must equal the same
     steps with DREAM_DP_GRAPHS=0 bit for bit -- same kernels, same order --, the replicas must stay identical to the master
     without a parameter copy, and a replayed step must hold the host (the GIL) for a fraction of an eager step's enqueue time.
-    ``split`` = DREAM_TRAIN_GRAPH_SPLIT: "" = the default of a multi-device step (one backward graph per replica), "8" = every replica's
-    backward as a sequence of graphs with its leaf segments on the second stream (data_parallel._SplitCapture), captured from four threads."""
+    ``split`` = DREAM_TRAIN_GRAPH_SPLIT: "" = the default (round 6: also for multi-device steps every replica's backward is a sequence of
+    graphs, 12 leaves per segment, its leaf segments on a second stream -- data_parallel._SplitCapture, captured from four threads; the
+    replicas share device 0 here, so each has a leaf stream of its own), "8" = eight leaves per segment, "0" = one backward graph per replica."""
     import time
     monkeypatch.setenv("DREAM_TRAIN_GRAPH_SPLIT", split)
     wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
@@ -1091,7 +1111,10 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, spl
     assert dp.stats["replays"] == 4 * 2 * 3 and dp.stats["param_copies"] == 3 and dp.stats["replica_steps"] == 3 * 4
     assert e.model.stats["replays"] == 0
     plans = [getattr(v["bwd"], "plan", None) for v in dp._graphs.values() if v["bwd"] is not None]
-    assert len(plans) == 4 and all((p is not None and sum(op[0] == "side" for op in p) >= 3) if split else p is None for p in plans)
+    assert len(plans) == 4 and all((p is not None and sum(op[0] == "side" for op in p) >= 3) if split != "0" else p is None for p in plans)
+    if split != "0":                                      # replicas that share a device must not share the stream their leaf segments replay on
+        sides = [v["bwd"].side for v in dp._graphs.values() if v["bwd"] is not None]
+        assert len({s.cuda_stream for s in sides}) == 4
     assert lg == le, (lg, le)
     for (k, a), (_, b) in zip(g.model.named_parameters(), e.model.named_parameters()):
         assert torch.equal(a, b), k

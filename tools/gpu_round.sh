@@ -15,6 +15,22 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+rehearse8)
+  # Round 6, verdict task 7: both multi-GPU paths at the REAL rank count (8) on the one GPU of the box -- the numbers mean nothing, the
+  # code path (self-launch under torch.distributed.run, 8 ranks, the `scale` block with configs[3] 8 x 16 frames and configs[4] 8 x 32 frames
+  # at K = 17; 8 replicas in one process, split graphs, one exchange) is what the first 8-GPU node will run.
+  DREAM_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 --secondary-steps 2 --secondary-train-steps 3 > $O/rehearsal_8ranks_gloo.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_8ranks_gloo.log | cut -c1-600
+  DREAM_BENCH_GPU_IDS=0,0,0,0,0,0,0,0 timeout 900 python bench.py --gpus 8 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 128 --no-cpu-baseline > $O/rehearsal_single_process_8replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_8replicas_train.log | cut -c1-600
+  DREAM_BENCH_GPU_IDS=0,0,0,0,0,0,0,0 timeout 900 python bench.py --gpus 8 --single-process --arch resnet_f --steps 3 --warmup 2 --global-batch 256 --no-cpu-baseline > $O/rehearsal_single_process_8replicas_infer.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_8replicas_infer.log | cut -c1-600
+  ;;
+g6c)
+  # Round 6, verdict task 4c: conv1_1 -> conv1_2 (+ pool) over sub-batches (the 64 x 400 x 400 tensor between them stays in the Infinity Cache)
+  echo "== pytest"; timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 -k "sub_batches or headline_batch" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in a b c; do
+    line dflt_whole_$r
+    for n in 4 6 8 16; do DREAM_FIRST_SUBBATCH=$n line dflt_sub${n}_$r; done
+  done
+  ;;
 g6b)
   # Round 6, verdict task 1b: ConvTranspose2d(4,2,1) weight gradient on the nine-position F(2x2,2x2) form against the direct kernel
   echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "convT4x4_wgrad or resnet or train_step or backward_ops or data_parallel" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log; grep "convT4x4 wgrad" $O/pytest.log

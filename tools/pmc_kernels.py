@@ -46,7 +46,8 @@ def main():
     for name in sorted(acc, key=lambda n: -dur.get(n, [0, 0.0])[1]):
         c = {k: v[0] / max(v[1], 1) for k, v in acc[name].items()}
         n = max(v[1] for v in acc[name].values())
-        short = name.split("(")[0].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+        short = name.replace("void ", "").replace("(anonymous namespace)::", "")
+        short = short[:short.index(">(") + 1] if ">(" in short else short.split("(")[0]
         d = dur.get(name, [0, 0.0])
         print("== %s   launches/pass %d   avg duration under PMC %.1f us" % (short, n, d[1] / max(d[0], 1) / 1e3))
         der = []
