@@ -602,7 +602,10 @@ def _main(args, stage):
         else:
             dist.init_process_group(backend)
     ctx.losses = []
-    ctx.rccl_ranks = dist.get_world_size() if ctx.world > 1 and backend == "nccl" else (1 if not ctx.single else 0)
+    # ranks of the RCCL (= nccl) process group; 1: one rank, no collective; 0: no RCCL process group at all (the single-process path's
+    # exchange is csrc/collective.hip's own communicator; a gloo rehearsal of the N-rank path on a one-GPU box)
+    ctx.rccl_ranks = dist.get_world_size() if ctx.world > 1 and backend == "nccl" else (1 if ctx.world == 1 and not ctx.single else 0)
+    ctx.backend = backend if ctx.world > 1 else ("single-process" if ctx.single else "none")
     if args.global_batch:
         assert args.global_batch % ctx.n_gpus == 0, "--global-batch must divide evenly over the GPUs"
         args.batch = args.global_batch // ctx.n_gpus
@@ -685,7 +688,7 @@ def _main(args, stage):
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
-            "rccl_ranks": ctx.rccl_ranks,
+            "rccl_ranks": ctx.rccl_ranks, "collective_backend": ctx.backend,
             "per_gpu_frames_per_s": total / dt / ctx.n_gpus,
             "ms_per_step_ranks": {"min": min(main_rank_seconds) / args.steps * 1e3, "max": max(main_rank_seconds) / args.steps * 1e3},
             "config": {"workload": workload_text(spec, n_kp, manip, (2 if args.mode == "train" else 1)

@@ -15,6 +15,15 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+prof16)
+  # where the ResNet-101 training step at 16 frames goes now: rocprofv3 kernel table + dispatch timeline, the synchronised layer profile
+  R="$PWD"
+  summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" $3 $4 > $O/summ.log 2>&1; echo "summary $2 rc=$?"; rm -rf "$1"; }
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 8 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
+  summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 3
+  timeout 400 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_resnet_h_train16.txt; head -40 $O/layer_profile_resnet_h_train16.txt | cut -c1-200
+  cat $O/bench_resnet_h_train16_concurrency.txt
+  ;;
 rehearse8)
   # Round 6, verdict task 7: both multi-GPU paths at the REAL rank count (8) on the one GPU of the box -- the numbers mean nothing, the
   # code path (self-launch under torch.distributed.run, 8 ranks, the `scale` block with configs[3] 8 x 16 frames and configs[4] 8 x 32 frames
