@@ -46,6 +46,7 @@ _SIGNATURES = {
     "dream_convT4x4_wgrad_winograd_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "dream_convT4x4_wgrad_winograd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dream_wgrad_set_variant": (_I, [_I]),
+    "dream_wgrad_set_width": (_I, [_I]),
     "dream_convT_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I, _I]),
     "dream_convT_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_unpack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

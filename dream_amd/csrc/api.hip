@@ -11,6 +11,16 @@ char *dream_err_buf() {
     return buf;
 }
 
+// Width of the weight-gradient launches of THIS host thread, in per cent of the chip (see dream_hip.h: dream_wgrad_set_width).  Thread-local:
+// the replicas of the single-process data-parallel path plan their launches concurrently, each from its own thread.
+static thread_local int t_wgrad_width = 100;
+int dream_wgrad_width() { return t_wgrad_width; }
+extern "C" int dream_wgrad_set_width(int percent) {
+    DREAM_REQUIRE(percent >= 5 && percent <= 100, "wgrad width %d %% out of range (5 .. 100)", percent);
+    t_wgrad_width = percent;
+    return 0;
+}
+
 extern "C" int dream_hip_abi_version(void) { return DREAM_HIP_ABI_VERSION; }
 extern "C" const char *dream_hip_last_error(void) { return dream_err_buf(); }
 extern "C" int dream_hip_device_count(int *count) {

@@ -30,6 +30,13 @@ char *dream_err_buf();            // thread-local, 512 bytes
 // from whichever host thread launches the kernel on that device first (api.hip).  0 = ok, else the error text is set.
 int dream_allow_full_lds(const void *kernel);
 
+// split-K target of the weight-gradient launches planned by this host thread: `full` workgroups scaled by dream_wgrad_set_width()
+int dream_wgrad_width();
+static inline long wgrad_target_workgroups(long full) {
+    const long t = full * dream_wgrad_width() / 100;
+    return t < 1 ? 1 : t;
+}
+
 #define DREAM_LAUNCH_OK() DREAM_HIP_OK(hipGetLastError())
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -495,7 +495,8 @@ struct Wgrad1x1Plan { int nsplit, chunks_per_wave; };
 Wgrad1x1Plan wgrad1x1_plan(long M, int Cin, int Cout) {
     const int tiles = ((Cout + 63) / 64) * (Cin / 64);
     const long chunks = (M + 15) / 16;
-    long nsplit = (768 + tiles - 1) / tiles;                       // ~3 workgroups per CU in total
+    const long target = wgrad_target_workgroups(768);             // ~3 workgroups per CU in total at full width
+    long nsplit = (target + tiles - 1) / tiles;
     const long max_by_work = (chunks + 31) / 32;                   // at least 8 chunks per wave
     if (nsplit > max_by_work) nsplit = max_by_work;
     if (nsplit < 1) nsplit = 1;

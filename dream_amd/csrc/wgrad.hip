@@ -339,7 +339,7 @@ int pick_splitk_g(int B, const WgradGeom &g, int Cp, int RowsPad, int forced) {
     const long ctiles = (long)ceil_div(RowsPad, var.RW) * ceil_div(Cp, var.CW);
     // 512 workgroups = 256 CUs x 2 resident: every extra split adds a RowsPad x Cp partial to write and re-read, which
     // for the 1x1 layers of the ResNet trunk outweighs the operands themselves (profiles/r01_ab_wgrad.txt)
-    long sk = 512 / ctiles;
+    long sk = wgrad_target_workgroups(512) / ctiles;
     if (sk < 1) sk = 1;
     if (sk > tiles) sk = tiles;
     if (sk > 1024) sk = 1024;

@@ -680,7 +680,7 @@ PlanLds make_plan_lds(int B, int H, int W, int Cin, int Cout) {
     pl.TY = (H + 1) / 2; pl.TX = (W + 1) / 2;
     pl.ntiles = B * pl.TY * pl.TX;
     const int blocks = (Cout / 64) * (Cin / 64);
-    int want = (256 + blocks / 2) / blocks;
+    int want = (int)((wgrad_target_workgroups(256) + blocks / 2) / blocks);
     const int max_by_work = (pl.ntiles + 16 * LT - 1) / (16 * LT);          // at least 16 stages per split
     if (want > max_by_work) want = max_by_work;
     if (want < 1) want = 1;
@@ -701,7 +701,7 @@ Plan make_plan(int B, int H, int W, int Cin, int Cout) {
     pl.TY = (H + 1) / 2; pl.TX = (W + 1) / 2;
     pl.ntiles = B * pl.TY * pl.TX;
     const int blocks = ((Cout + 16 * NCO - 1) / (16 * NCO)) * (Cin / 64);
-    int want = (1024 + blocks - 1) / blocks;                       // ~4 workgroups per CU in total
+    int want = (int)((wgrad_target_workgroups(1024) + blocks - 1) / blocks);     // ~4 workgroups per CU in total at full width
     const int max_by_work = (pl.ntiles + 255) / 256;               // at least 64 k-steps per split
     if (want > max_by_work) want = max_by_work;
     if (want < 1) want = 1;
@@ -817,7 +817,7 @@ PlanLds make_plan_convT(int B, int H, int W, int Cin, int Cout) {
     pl.TY = (H + 1) / 2; pl.TX = (W + 1) / 2;
     pl.ntiles = B * pl.TY * pl.TX;
     const int blocks = (Cout / 64) * (Cin / 64) * 4;                          // the four phases run side by side
-    int want = (256 + blocks / 2) / blocks;
+    int want = (int)((wgrad_target_workgroups(256) + blocks / 2) / blocks);
     const int max_by_work = (pl.ntiles + 16 * LT - 1) / (16 * LT);          // at least 16 stages per split
     if (want > max_by_work) want = max_by_work;
     if (want < 1) want = 1;

@@ -205,8 +205,9 @@ class _SplitCapture:
                 else:
                     graph.capture_begin(pool=self.side_pool, capture_error_mode="thread_local")
                 try:
-                    for fn in fns:
-                        fn()
+                    with ops.wgrad_width(ops.SIDE_WGRAD_WIDTH):       # leaves beside the chain: as the eager step's second stream
+                        for fn in fns:
+                            fn()
                 finally:
                     graph.capture_end()
             if self.side_pool is None:
@@ -503,7 +504,8 @@ class DreamDataParallel(nn.Module):
         rep = self._replica(i)
         with torch.no_grad():
             if ctx[0] == "eager":
-                self._pack_grads(rep.dp_backward(ctx[1], gos), gflat, offsets, numels)
+                from .models import _guarded_backward
+                self._pack_grads(_guarded_backward(rep.dp_backward, ctx[1], gos), gflat, offsets, numels)
                 self.stats["eager"] += 1
                 return
             entry = ctx[1]

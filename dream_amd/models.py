@@ -586,7 +586,7 @@ class _HourglassFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         module = ctx.module
         reducer = _OverlappedAllReduce.create()
-        grads = module.run_backward(ctx.saved_acts, grad_out.contiguous(), reducer=reducer)
+        grads = _guarded_backward(module.run_backward, ctx.saved_acts, grad_out.contiguous(), reducer=reducer)
         ctx.saved_acts = None
         return (None, None) + tuple(_reduced(reducer, grads))
 
@@ -753,6 +753,12 @@ class _SideStream:
         # Measured round 5 (profiles/r05_ab_side_stream_keep.txt, alternating on one box): resnet_h training at 16 frames 359.2 / 359.9 / 360.3
         # (record_stream) -> 364.5 / 364.9 / 363.8 frames/s; at 128 frames equal (451-453).  "0" restores record_stream().
         self.keep = [] if os.environ.get("DREAM_SIDE_KEEP", "1") == "1" else None
+        # ... bounded: past DREAM_SIDE_KEEP_MAX_MB (default: an eighth of the device's memory) of retained inputs the remaining leaves fall
+        # back to record_stream() -- a batch that used to fit must not run out of memory because of this switch (round-5 advice)
+        self.kept_bytes = 0
+        self.keep_limit = int(os.environ.get("DREAM_SIDE_KEEP_MAX_MB", "0")) << 20
+        if self.keep is not None and self.keep_limit <= 0:
+            self.keep_limit = torch.cuda.get_device_properties(stream.device).total_memory // 8
         self.batch = int(os.environ.get("DREAM_SIDE_BATCH", "1"))
         self.pending = []
         self.count = 0
@@ -776,10 +782,12 @@ class _SideStream:
                 self.flush()
             return None
         self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
+        with torch.cuda.stream(self.side), ops.wgrad_width(ops.SIDE_WGRAD_WIDTH):
             out = fn()
-        if self.keep is not None:
+        nbytes = sum(t.numel() * t.element_size() for t in inputs)
+        if self.keep is not None and self.kept_bytes + nbytes <= self.keep_limit:
             self.keep.append(inputs)
+            self.kept_bytes += nbytes
         else:
             for t in inputs:
                 t.record_stream(self.side)
@@ -788,7 +796,7 @@ class _SideStream:
     def flush(self):
         if self.pending:
             self.side.wait_stream(self.main)
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(self.side), ops.wgrad_width(ops.SIDE_WGRAD_WIDTH):
                 for fn in self.pending:
                     fn()
             del self.pending[:]
@@ -799,6 +807,7 @@ class _SideStream:
         _SideStream._counts.leaves = self.count
         if self.keep is not None:
             del self.keep[:]
+            self.kept_bytes = 0
 
 
 _split_capture = threading.local()       # .ctl: the controller of a backward that is being captured in segments (data_parallel._SplitCapture)
@@ -837,6 +846,18 @@ class _DeferredSide:
         self.ctl.cut(self.pending, join=True)
         del self.pending[:]
         del self.keep[:]
+
+
+def _guarded_backward(fn, *args, **kwargs):
+    """Runs a backward plan.  If it raises, the device is synchronised BEFORE the exception leaves this frame: the plan's second stream
+    (_SideStream, DREAM_SIDE_KEEP) may still be reading inputs whose only references are the plan's locals -- the traceback keeps those
+    alive exactly until the handler below has waited for the kernels (round-5 advice)."""
+    try:
+        return fn(*args, **kwargs)
+    except BaseException:
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
+        raise
 
 
 def _on_side(side, fn, *inputs):
@@ -1030,7 +1051,7 @@ class _MultiStageFunction(torch.autograd.Function):
     def backward(ctx, *grad_outs):
         module = ctx.module
         reducer = _OverlappedAllReduce.create()
-        grads = module.run_backward(ctx.saved_acts, list(grad_outs), reducer=reducer)
+        grads = _guarded_backward(module.run_backward, ctx.saved_acts, list(grad_outs), reducer=reducer)
         ctx.saved_acts = None
         return (None, None) + tuple(_reduced(reducer, grads))
 
@@ -1781,7 +1802,7 @@ class _ResnetFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         reducer = _OverlappedAllReduce.create()
-        gdict = ctx.module.run_backward(ctx.tape, grad_out.contiguous(), reducer=reducer)
+        gdict = _guarded_backward(ctx.module.run_backward, ctx.tape, grad_out.contiguous(), reducer=reducer)
         ctx.tape = None
         return (None, None) + tuple(_reduced(reducer, [gdict[p] for p in ctx.params]))
 

@@ -213,7 +213,6 @@ class DreamNetwork:
         # hip_graph_train (or DREAM_TRAIN_GRAPH=1): it keeps a private memory pool per batch shape (several GB for ResNet-101), which
         # a user who sets hip_graph for evaluation and later fine-tunes should not get implicitly (round-4 advice).
         self._hip_graph = False
-        self._hip_graph_train = os.environ.get("DREAM_TRAIN_GRAPH", "0") == "1"
         self._graphs = {}
 
         out_res = list(self.net_output_resolution_from_input_resolution(self.trained_net_input_resolution()))
@@ -233,13 +232,17 @@ class DreamNetwork:
 
     @property
     def hip_graph_train(self):
-        return self._hip_graph_train
+        """The model's own switch (DreamDataParallel.single_device_graphs, which also reads DREAM_TRAIN_GRAPH): ONE copy of the setting."""
+        return bool(getattr(self.model, "single_device_graphs", False))
 
     @hip_graph_train.setter
     def hip_graph_train(self, on):
-        self._hip_graph_train = bool(on)
-        if isinstance(self.model, models.DreamDataParallel):
-            self.model.single_device_graphs = bool(on)
+        if not isinstance(self.model, models.DreamDataParallel):
+            if on:
+                raise RuntimeError("dream_amd: hip_graph_train needs the model behind DreamDataParallel (what DreamNetwork builds); this "
+                                   "network's model is a %s" % type(self.model).__name__)
+            return
+        self.model.single_device_graphs = bool(on)
 
     # ---- small getters (network.py:319-326) ------------------------------------------------------------
     def trained_net_input_resolution(self):

@@ -519,6 +519,29 @@ def upsample2_bwd(dy):
     return dx
 
 
+class wgrad_width:
+    """``with ops.wgrad_width(p):`` the weight-gradient launches planned by this thread inside the block split their contraction only
+    until ``p`` per cent of the full-width workgroup count exist (csrc/api.hip dream_wgrad_set_width: thread-local) -- for leaves that
+    run on a second stream beside the data-gradient chain.  100 restores the full width."""
+
+    def __init__(self, percent):
+        self.percent = int(percent)
+
+    def __enter__(self):
+        if self.percent != 100:
+            call("dream_wgrad_set_width", self.percent)
+        return self
+
+    def __exit__(self, *exc):
+        if self.percent != 100:
+            call("dream_wgrad_set_width", 100)
+        return False
+
+
+# width of the weight-gradient launches that run on the second stream (models._SideStream), per cent of the chip
+SIDE_WGRAD_WIDTH = int(_os.environ.get("DREAM_SIDE_WGRAD_WIDTH", "100"))
+
+
 def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
     """-> (dW OIHW [cout,cin,3,3], dbias [cout]).  dy may carry padded channels (>= cout)."""
     x, dy = _f32(x_nhwc), _f32(dy_nhwc)

@@ -399,6 +399,13 @@ int dream_convT4x4_wgrad_winograd_nhwc_f32(const float *x, const float *dy, floa
 size_t dream_convT_wgrad_workspace(int B, int H, int W, int CinPad, int Cout, int ksize);
 int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                int H, int W, int Cin, int CinPad, int Cout, int ksize, void *stream);
+/* Width of the weight-gradient launches PLANNED BY THE CALLING HOST THREAD from now on, in per cent of the chip (5 .. 100, default 100):
+ * every weight-gradient entry point splits its contraction until ~256 .. 1024 workgroups exist; at `percent` < 100 it stops at that
+ * fraction -- fewer, longer workgroups and proportionally less split-K partial traffic.  For launches that run on a second stream BESIDE
+ * the data-gradient chain (training at small per-GPU batches, dream_amd/models.py _SideStream): a narrow launch leaves the other
+ * compute units to the chain instead of taking the whole chip in bursts.  The matching *_workspace() functions follow the same
+ * thread's setting: query and launch under one setting.  Thread-local, so concurrent replica threads cannot disturb each other. */
+int dream_wgrad_set_width(int percent);
 /* A/B switch between the weight-gradient kernel's register blockings: -1 = heuristic, 0 = always 64-row tiles. */
 int dream_wgrad_set_variant(int variant);
 /* [ntaps][RowsPad][ColsPad] -> [Rows][Cols][ntaps] (OIHW / ConvTranspose [Cin,Cout,kh,kw]) */

@@ -607,8 +607,11 @@ def check_structured(dev, arch, precision="fp32", repeat=1):
     assert err <= 1e-4, (arch, precision, err)
     det = ref_k[..., 0] > -999
     assert np.array_equal(got_k[..., 0] > -999, det), "detection decisions differ from the reference"
-    assert 0 < det.sum() < det.size
-    perr = float(np.abs(got_k - ref_k)[det].max())
+    if cases.STRUCTURED_MIN_DETECTIONS.get(case, 0.25) > 0:
+        assert 0 < det.sum() < det.size
+    else:
+        assert det.sum() < det.size                        # (a case kept for its map values: every keypoint may be rejected)
+    perr = float(np.abs(got_k - ref_k)[det].max()) if det.any() else 0.0
     assert perr <= 1e-3, (arch, precision, perr)
     assert np.array_equal(got_k[~det], ref_k[~det])                 # the -999.999 sentinels, bit for bit
     return err, perr

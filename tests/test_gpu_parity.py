@@ -579,7 +579,7 @@ def test_structured_fixture_at_headline_batch(case, repeat):
     print("structured %s x %d, default algorithms: max |map error| %.2e, max keypoint error %.2e px" % (case, repeat, err, perr))
 
 
-@pytest.mark.parametrize("arch", ["vgg_q", "vgg_q_400", "vgg_f", "resnet_h"])
+@pytest.mark.parametrize("arch", ["vgg_q", "vgg_q_400", "vgg_f", "vgg_f_recipe", "resnet_h"])
 def test_structured_fixture_absolute_tolerance_winograd4(arch):
     """The same north-star bounds with Winograd F(4x4,3x3) on every layer the kernel takes (at batch 128 the default; at the
     fixtures' 1-2 frames the layers would fall back to F(2x2,3x3) for lack of tiles)."""

@@ -79,8 +79,9 @@ def test_structured_fixture_regenerates_from_the_oracle(arch):
     assert np.abs(y - g["maps"]).max() <= 1e-5 and 0.99 <= top <= 1.0 + 1e-6 and np.abs(g["maps"]).max() <= 8.0
     kps = op.keypoints_from_belief_maps(y, op.upsampling_offset(y.shape[3], y.shape[2]))
     det = g["keypoints"][..., 0] > -999
-    assert np.array_equal(kps[..., 0] > -999, det) and 0 < det.sum() < det.size
-    assert np.abs(kps - g["keypoints"])[det].max() < 1e-3
+    want_detections = cases.STRUCTURED_MIN_DETECTIONS.get(case, 0.25) > 0      # (vgg_f_recipe is kept for its map values: all rejected)
+    assert np.array_equal(kps[..., 0] > -999, det) and (0 if want_detections else -1) < det.sum() < det.size
+    assert not det.any() or np.abs(kps - g["keypoints"])[det].max() < 1e-3
 
 
 @pytest.mark.parametrize("opt", ["adam", "sgd"])

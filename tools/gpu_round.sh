@@ -15,6 +15,15 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+g6d)
+  # Round 6: width of the weight-gradient launches on the second stream (DREAM_SIDE_WGRAD_WIDTH, per cent of the full split-K workgroup count):
+  # narrow launches leave compute units to the data-gradient chain instead of taking the whole chip in bursts
+  for r in a b; do for w in 100 60 40 25 15; do
+    DREAM_SIDE_WGRAD_WIDTH=$w line rt16_w${w}_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done; done
+  for w in 100 40 25; do DREAM_SIDE_WGRAD_WIDTH=$w line rft32_w${w} --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2; done
+  for w in 100 40 25; do DREAM_SIDE_WGRAD_WIDTH=$w line rt64_w${w} --arch resnet_h --mode train --batch 64 --steps 4 --warmup 2; done
+  ;;
 prof16)
   # where the ResNet-101 training step at 16 frames goes now: rocprofv3 kernel table + dispatch timeline, the synchronised layer profile
   R="$PWD"
