@@ -45,6 +45,7 @@ _SIGNATURES = {
     "dream_convT4x4_wgrad_winograd_applies": (_I, [_I, _I]),
     "dream_convT4x4_wgrad_winograd_workspace": (_SZ, [_I, _I, _I, _I, _I]),
     "dream_convT4x4_wgrad_winograd_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dream_upsample_conv3x3_wgrad_from_convT4x4": (_I, [_P, _P, _I, _I, _P]),
     "dream_wgrad_set_variant": (_I, [_I]),
     "dream_wgrad_set_width": (_I, [_I]),
     "dream_convT_wgrad_workspace": (_SZ, [_I, _I, _I, _I, _I, _I]),
@@ -96,6 +97,7 @@ _SIGNATURES = {
     "dream_conv3x3_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dream_conv1x1_weight_floats": (_SZ, [_I, _I]),
     "dream_conv1x1_set_ksplit": (_I, [_I]),
+    "dream_conv1x1_set_rows": (_I, [_I]),
     "dream_conv1x1_wgrad_workspace": (_SZ, [_c.c_long, _I, _I]),
     "dream_conv1x1_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P]),
     "dream_pack_conv1x1_weight": (_I, [_P, _P, _I, _I, _I, _P]),

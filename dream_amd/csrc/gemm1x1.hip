@@ -21,6 +21,7 @@
 //     the epilogue loads scale / shift / residual and stores the result as float4 (256 contiguous bytes per 16 lanes);
 //   * buffer descriptors: fixed per-lane offsets, the chunk offset in the scalar operand (no address arithmetic in the loop),
 //     rows beyond the end read zeros and are not stored.
+#include <stdlib.h>
 #include <dream_cdna4.h>
 #include "common.h"
 #include "pack_device.h"
@@ -82,10 +83,15 @@ DREAM_DEVICE f32x4 bn_relu4(f32x4 x, f32x4 a, f32x4 b) {
 #endif
 // RES: the epilogue adds a residual tensor (EPI 0: a separate instantiation, so that launches without one issue no loads for it; EPI 2
 // always reads per-row operands: a null residual / stored activation there is an empty descriptor that returns zeros).
-template <int KS, bool PRE = false, int EPI = 0, bool RES = false>
-// (with a K split the 64 KB of partial tiles allow two workgroups per CU, i.e. two wavefronts per SIMD and 256 registers)
-__global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const GemmParams p) {
-    __shared__ float s_part[KS > 1 ? 4 * 64 * 64 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
+// MB: 16-row blocks of a wavefront tile (4: 64 positions x 64 channels; 2: 32 x 64).  The trunk GEMMs at 16 frames are ~10 000 positions:
+// 2 512 64-row wave tiles on 1 024 SIMDs = 2.45 per SIMD, i.e. some SIMDs carry three and set the pace (98 K MFMA cycles against 80 K for
+// an even spread); 32-row tiles (5 024 half-size ones, four to five per SIMD) come within 2 % of even -- for 1.5x the operand loads
+// per MFMA, which these small problems can afford (the operands are L2 residents).  gemm1x1_launch picks MB by the tile count.
+template <int KS, bool PRE = false, int EPI = 0, bool RES = false, int MB = 4>
+// (with a K split the 16 KB x MB of partial tiles bound the workgroups per CU: two for MB = 4 -- two wavefronts per SIMD, 256 registers --,
+// four for MB = 2 at <= 128 registers)
+__global__ void __launch_bounds__(256, MB == 4 ? (KS == 1 ? 3 : 2) : 4) gemm1x1_kernel(const GemmParams p) {
+    __shared__ float s_part[KS > 1 ? 4 * MB * 4 * 64 * 4 : 1];      // [wave][m][n][lane] float4: the waves' partial tiles
     __shared__ double s_stat[(KS > 1 && EPI != 0) ? 4 * 16 * 8 : 1];      // [wave][lane & 15][4 channels][2]: the waves' sums
     const int lane = threadIdx.x & 63;
     const int wave = wave_index();
@@ -102,47 +108,50 @@ __global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const Gem
 
     const BufferRsrc xbuf = make_buffer(p.x, (size_t)p.M * p.x_stride * sizeof(float));
     const BufferRsrc wbuf = make_buffer(p.w, (size_t)(p.K / 16) * p.NPad * 16 * sizeof(float));
-    unsigned a_off[4], b_off[4];
+    unsigned a_off[MB], b_off[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int row = rb * 64 + 16 * m + li;
+    for (int m = 0; m < MB; ++m) {
+        const int row = rb * (16 * MB) + 16 * m + li;
         a_off[m] = row < p.M ? (unsigned)((row * p.x_stride + 4 * lg) * 4) : BUFFER_OOB;
     }
 #pragma unroll
     for (int n = 0; n < 4; ++n) b_off[n] = (unsigned)(((cb * 64 + 16 * n + li) * 16 + 4 * lg) * 4);
     const unsigned b_chunk = (unsigned)(p.NPad * 16 * 4);        // bytes between k chunks of the packed weights
 
-    f32x4 acc[4][4];
+    f32x4 acc[MB][4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    f32x4 xa[2][4], xb[2][4];
+    f32x4 xa[2][MB], xb[2][4];
     f32x4 pa[2], pb[2];                              // PRE: scale / shift of this lane's four k's of the chunk
     const BufferRsrc abbuf = make_buffer(PRE ? p.pre_ab : p.x, PRE ? (size_t)2 * p.K * sizeof(float) : 0);
-    constexpr int NLOADS = PRE ? 10 : 8;
+    constexpr int NLOADS = (PRE ? 6 : 4) + MB;
     // the i-th load of chunk t into register set `set`: weights first (L2 residents: they return quickly and the first MFMAs of the
     // chunk need all four of them), then the PRE scale / shift, then the four row blocks of the activation
     auto issue = [&](int set, int t, int i) {
         if (i < 4) xb[set][i] = buffer_load_x4(wbuf, b_off[i], (unsigned)t * b_chunk);
         else if (PRE && i == 4) pa[set] = buffer_load_x4(abbuf, (unsigned)(4 * lg * 4), (unsigned)t * 64u);
         else if (PRE && i == 5) pb[set] = buffer_load_x4(abbuf, (unsigned)((p.K + 4 * lg) * 4), (unsigned)t * 64u);
-        else xa[set][i - (NLOADS - 4)] = buffer_load_x4(xbuf, a_off[i - (NLOADS - 4)], (unsigned)t * 64u);
+        else xa[set][i - (NLOADS - MB)] = buffer_load_x4(xbuf, a_off[i - (NLOADS - MB)], (unsigned)t * 64u);
     };
 
     // ---- epilogue operands: a ring of DREAM_G1_EPI_DEPTH rows -------------------------------------------------------------------
-    // A wavefront owns NR = 16 / KS rows of its lanes: row index i -> block row m = kpart + KS (i >> 2), register r = i & 3.
+    // A wavefront owns NR = 4 MB / KS of the 4 MB (block row, register) units of its lanes, in order: unit u = kpart NR + i is block row
+    // m = u >> 2, register r = u & 3 (MB = 2 with a four-way K split: half a block row per wavefront).
     // (EPI 2 loads three operands per row: its ring is shallower, the register budget being 168 at three wavefronts per SIMD)
-    constexpr int DWANT = EPI == 2 ? (KS == 1 ? DREAM_G1_EPI_DEPTH_MASK : DREAM_G1_EPI_DEPTH_MASK_KS) : DREAM_G1_EPI_DEPTH;
-    constexpr int NR = 16 / KS, D = DWANT < NR ? DWANT : NR;
+    // (the 32-row tiles run four wavefronts per SIMD: 128 registers, a ring one row shallower)
+    constexpr int DWANT = EPI == 2 ? (KS == 1 ? DREAM_G1_EPI_DEPTH_MASK : DREAM_G1_EPI_DEPTH_MASK_KS) - (MB == 2 ? 1 : 0) : DREAM_G1_EPI_DEPTH;
+    constexpr int NR = 4 * MB / KS, D = DWANT < NR ? DWANT : NR;
+    static_assert(NR >= 1, "K split too deep for this tile height");
     constexpr bool HAS_RES = RES || EPI == 2;                 // (the statistics form, EPI 1, has no residual input)
     constexpr bool EL = HAS_RES;                              // the rows have operands to load
     const int c0 = cb * 64 + 4 * li;
     const bool cok = c0 < p.N;                                // N % 4 == 0
     // descriptors on the tile's first row (tensors may exceed a descriptor's 2 GB: the base moves, the offsets stay small); a null
     // operand gets an empty descriptor, a row past M or a channel past N reads zeros / stores nothing
-    const long trow = (long)rb * 64;
+    const long trow = (long)rb * (16 * MB);
     const size_t tbytes = live ? (size_t)(p.M - trow) * p.N * sizeof(float) : 0;
     const BufferRsrc rbuf = make_buffer(HAS_RES && p.residual ? p.residual + trow * p.N : p.x, HAS_RES && p.residual ? tbytes : 0);
     const BufferRsrc zbuf = make_buffer(EPI == 2 ? p.st_z + trow * p.N : p.x, EPI == 2 ? tbytes : 0);
@@ -152,7 +161,10 @@ __global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const Gem
     // additions below, every descriptor being smaller than 2 GB) + wave-uniform part
     const unsigned lane_off = cok ? (unsigned)((4 * lg * p.N + c0) * 4) : BUFFER_OOB;
     const unsigned row_bytes = (unsigned)p.N * 4u;
-    auto row_off = [&](int i) { return lane_off + (unsigned)(16 * (kpart + KS * (i >> 2)) + (i & 3)) * row_bytes; };
+    auto row_off = [&](int i) {
+        const int u = kpart * NR + i;
+        return lane_off + (unsigned)(16 * (u >> 2) + (u & 3)) * row_bytes;
+    };
     f32x4 e_res[D], e_z[D], e_ya[D];
     auto epi_load = [&](int i) {                              // i compile-time after unrolling
         const unsigned o = row_off(i);
@@ -171,11 +183,11 @@ __global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const Gem
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MB; ++m) {
                 if (PRE && e == 0) xa[S][m] = bn_relu4(xa[S][m], pa[S], pb[S]);      // eight VALU operations beside the group's MFMAs
 #pragma unroll
                 for (int n = 0; n < 4; ++n) acc[m][n] = mfma_f32_16x16x4(xa[S][m][e], xb[S][n][e], acc[m][n]);
-                const int g = 4 * e + m;                      // group of four MFMAs
+                const int g = MB * e + m;                     // group of four MFMAs
                 if (LOAD && g < NLOADS) issue(1 - S, tn, g);
                 if (EPILOAD && EL && g < D) epi_load(g);
                 __builtin_amdgcn_sched_barrier(0);
@@ -198,23 +210,23 @@ __global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const Gem
         step(I0{}, t0 + nchunks - 1, Yes{}, No{});
         step(I1{}, 0, No{}, Yes{});
     }
-    // split K: partial tiles through LDS; wave kpart then owns row blocks m = kpart, kpart + KS, .. (fixed summation order)
+    // split K: partial tiles through LDS; wave kpart then owns the units [kpart NR, (kpart + 1) NR) = block rows below (fixed summation order)
     if (KS > 1) {
         f32x4 *sp = (f32x4 *)s_part;
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int n = 0; n < 4; ++n) sp[((wave * 4 + m) * 4 + n) * 64 + lane] = acc[m][n];
+            for (int n = 0; n < 4; ++n) sp[((wave * MB + m) * 4 + n) * 64 + lane] = acc[m][n];
         __syncthreads();
         const int w0 = wave - kpart;                 // first wave of this tile
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
-            if (m % KS == kpart) {
+        for (int m = 0; m < MB; ++m)
+            if (m >= ((kpart * NR) >> 2) && m <= (((kpart + 1) * NR - 1) >> 2)) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
-                    f32x4 v = sp[(((w0 + 0) * 4 + m) * 4 + n) * 64 + lane];
+                    f32x4 v = sp[(((w0 + 0) * MB + m) * 4 + n) * 64 + lane];
 #pragma unroll
-                    for (int k = 1; k < KS; ++k) v = v + sp[(((w0 + k) * 4 + m) * 4 + n) * 64 + lane];
+                    for (int k = 1; k < KS; ++k) v = v + sp[(((w0 + k) * MB + m) * 4 + n) * 64 + lane];
                     acc[m][n] = v;
                 }
             }
@@ -241,12 +253,12 @@ __global__ void __launch_bounds__(256, KS == 1 ? 3 : 2) gemm1x1_kernel(const Gem
     // Row i + D's operands are loaded BEFORE row i is stored (safe if the output aliases an operand: a thread reads exactly the elements
     // it writes, D rows ahead).  With a K split the block rows depend on the wavefront (kpart): one instantiation per value, chosen by a
     // wave-uniform branch, so that the accumulator indices stay compile-time constants.
-    auto rows = [&](auto m0_tag) {
-        constexpr int M0 = decltype(m0_tag)::value;
+    auto rows = [&](auto kp_tag) {
+        constexpr int KP = decltype(kp_tag)::value;            // = kpart, as a constant: the accumulator indices below are compile-time
         const int mrows = p.M - (int)trow - 4 * lg;            // rows of this lane's quad column that exist
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const int m = M0 + KS * (i >> 2), r = i & 3;
+            const int m = (KP * NR + i) >> 2, r = (KP * NR + i) & 3;
             f32x4 res = {0.0f, 0.0f, 0.0f, 0.0f}, z = res, ya = res;
             if (EL && HAS_RES) res = e_res[i % D];
             if (EL && EPI == 2) { z = e_z[i % D]; ya = e_ya[i % D]; }
@@ -509,34 +521,61 @@ Wgrad1x1Plan wgrad1x1_plan(long M, int Cin, int Cout) {
 }
 
 int g_conv1x1_ksplit = 0;     // test hook: 0 = by shape, 1 / 2 / 4 = force
+int g_conv1x1_rows = 0;       // test / A-B hook: 0 = by shape, 64 / 32 = force the wavefront tile height
 
-template <bool PRE, int EPI, bool RES = false>
+template <bool PRE, int EPI, bool RES, int MB>
 int gemm1x1_launch_ks(const GemmParams &p, int ks, unsigned grid, void *stream) {
-    if (ks == 1) hipLaunchKernelGGL((gemm1x1_kernel<1, PRE, EPI, RES>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else if (ks == 2) hipLaunchKernelGGL((gemm1x1_kernel<2, PRE, EPI, RES>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((gemm1x1_kernel<4, PRE, EPI, RES>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    if (ks == 1) hipLaunchKernelGGL((gemm1x1_kernel<1, PRE, EPI, RES, MB>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else if (ks == 2) hipLaunchKernelGGL((gemm1x1_kernel<2, PRE, EPI, RES, MB>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((gemm1x1_kernel<4, PRE, EPI, RES, MB>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     DREAM_LAUNCH_OK();
     return 0;
 }
 
+template <int MB>
+int gemm1x1_launch_form(const GemmParams &p, int ks, unsigned grid, bool pre, int epi, void *stream) {
+    if (epi == 0) return p.residual != nullptr ? gemm1x1_launch_ks<false, 0, true, MB>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 0, false, MB>(p, ks, grid, stream);
+    if (epi == 1) return pre ? gemm1x1_launch_ks<true, 1, false, MB>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 1, false, MB>(p, ks, grid, stream);
+    return gemm1x1_launch_ks<false, 2, false, MB>(p, ks, grid, stream);
+}
+
+// wavefront tile height (rows) for a problem of M positions x NPad channels
+int gemm1x1_rows(long M, int NPad) {
+    if (g_conv1x1_rows == 64 || g_conv1x1_rows == 32) return g_conv1x1_rows;
+    static const int env_rows = [] { const char *e = getenv("DREAM_CONV1X1_ROWS"); return e ? atoi(e) : 0; }();      // A/B runs: 64 | 32
+    if (env_rows == 64 || env_rows == 32) return env_rows;
+    // fewer than four 64-row wave tiles per SIMD (K splits included: they are chosen to reach ~2 per SIMD): whole tiles spread
+    // unevenly over the 1 024 SIMDs -- 32-row tiles (measured round 6: profiles/r06_ab_gemm1x1_rows.txt)
+    const long tiles64 = ((M + 63) / 64) * (NPad / 64);
+    return tiles64 < 4096 ? 32 : 64;
+}
+
 int gemm1x1_launch(GemmParams p, long M, int K, int N, int x_stride, bool pre, int epi, void *stream) {
     p.M = (int)M; p.K = K; p.N = N; p.NPad = (N + 63) / 64 * 64; p.x_stride = x_stride;
-    p.nrb = (int)((M + 63) / 64); p.ncb = p.NPad / 64;
+    const int rows = gemm1x1_rows(M, p.NPad);
+    p.nrb = (int)((M + rows - 1) / rows); p.ncb = p.NPad / 64;
     const long tiles = (long)p.nrb * p.ncb;
-    // the chip holds 3072 waves of this kernel (256 CUs x 4 SIMDs x 3): split K until the tiles give ~2 waves per SIMD
+    // 64-row tiles: the chip holds 3072 waves of this kernel (256 CUs x 4 SIMDs x 3): split K until the tiles give ~2 waves per SIMD.
+    // 32-row tiles (half the work each): until they give ~4
     int ks = 1;
+    const long per_level = rows == 64 ? 768 : 1280;
     if (g_conv1x1_ksplit > 0) ks = g_conv1x1_ksplit;
-    else if (tiles < 768 && K % 128 == 0) ks = 4;
-    else if (tiles < 1536 && K % 64 == 0) ks = 2;
+    else if (tiles < per_level && K % 128 == 0) ks = 4;
+    else if (tiles < 2 * per_level && K % 64 == 0) ks = 2;
     DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
     const int per_wg = 4 / ks;
     const unsigned grid = (unsigned)(((tiles + per_wg - 1) / per_wg + 7) / 8 * 8);
-    if (epi == 0) return p.residual != nullptr ? gemm1x1_launch_ks<false, 0, true>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 0, false>(p, ks, grid, stream);
-    if (epi == 1) return pre ? gemm1x1_launch_ks<true, 1>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 1>(p, ks, grid, stream);
-    return gemm1x1_launch_ks<false, 2>(p, ks, grid, stream);
+    return rows == 64 ? gemm1x1_launch_form<4>(p, ks, grid, pre, epi, stream) : gemm1x1_launch_form<2>(p, ks, grid, pre, epi, stream);
 }
 
 }  // namespace
+
+// Test / A-B hook: force the wavefront tile height (0 = by problem size, 64, 32).  Same sums in the same order: same bits.
+extern "C" int dream_conv1x1_set_rows(int rows) {
+    DREAM_REQUIRE(rows == 0 || rows == 64 || rows == 32, "conv1x1: tile height %d", rows);
+    g_conv1x1_rows = rows;
+    return 0;
+}
 
 // Test hook: force the K split (0 = by problem size).  The result depends on it only through the summation order.
 extern "C" int dream_conv1x1_set_ksplit(int ks) {
@@ -580,13 +619,15 @@ extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, con
 }
 
 // ---- the same GEMM with a train-mode BatchNorm folded in on either side (see GemmParams) ---------------------------------------
+// (sized for the 32-row wavefront tiles: one row of partial sums per row block, twice as many as with 64-row tiles)
 extern "C" size_t dream_conv1x1_bn_workspace(long M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return stat_tree_doubles((int)((M + 63) / 64), N) * sizeof(double);
+    return stat_tree_doubles((int)((M + 31) / 32), N) * sizeof(double);
 }
 extern "C" int dream_conv1x1_bn_counters(long M, int N) {
     if (M <= 0 || N <= 0) return 0;
-    return stat_tree_counters((int)((M + 63) / 64), N);
+    const int a = stat_tree_counters((int)((M + 31) / 32), N), b = stat_tree_counters((int)((M + 63) / 64), N);
+    return a > b ? a : b;
 }
 
 // Forward of  [BatchNorm(batch stats) -> ReLU ->] conv1x1 -> (statistics of the result for the BatchNorm that follows):
@@ -608,7 +649,8 @@ extern "C" int dream_conv1x1_bnstats_nhwc_f32(const float *x, const float *w_pac
                   "conv1x1_bnstats: tensor too large for 32-bit offsets");
     GemmParams p = {};
     p.x = x; p.w = w_packed; p.shift = shift; p.y = y; p.pre_ab = pre_ab;
-    p.st = stat_tree_make(workspace, counters, (int)((M + 63) / 64), N);
+    const int trows = gemm1x1_rows(M, (N + 63) / 64 * 64);
+    p.st = stat_tree_make(workspace, counters, (int)((M + trows - 1) / trows), N);
     p.st_fwd.gamma = gamma; p.st_fwd.beta = beta; p.st_fwd.running_mean = running_mean; p.st_fwd.running_var = running_var;
     p.st_fwd.nbt = num_batches_tracked; p.st_fwd.eps = eps; p.st_fwd.momentum = momentum;
     p.st_fwd.ab = out_ab; p.st_fwd.mean = save_mean; p.st_fwd.invstd = save_invstd;
@@ -633,7 +675,8 @@ extern "C" int dream_conv1x1_bwd_bnmask_nhwc_f32(const float *dy, const float *w
                   "conv1x1_bwd_bnmask: tensor too large for 32-bit offsets");
     GemmParams p = {};
     p.x = dy; p.w = w_packed_t; p.y = g_out; p.residual = residual;
-    p.st = stat_tree_make(workspace, counters, (int)((M + 63) / 64), N);
+    const int trows = gemm1x1_rows(M, (N + 63) / 64 * 64);
+    p.st = stat_tree_make(workspace, counters, (int)((M + trows - 1) / trows), N);
     p.st_z = z; p.st_zab = ab; p.st_yact = y_act; p.st_mean = mean; p.st_invstd = invstd;
     p.st_dgamma = dgamma; p.st_dbeta = dbeta;
     return gemm1x1_launch(p, M, K, N, dy_stride, false, 2, stream);

@@ -672,6 +672,29 @@ __global__ void __launch_bounds__(256) wgrad_wino_convT_reduce_kernel(const floa
     }
 }
 
+// nn.Upsample(2, nearest) + Conv2d(3x3, pad 1) IS a ConvTranspose2d(k4, s2, p1) whose phase taps are sums of the 3x3 taps (output row
+// 2 i + a reads source rows {i - 1, i, i} (a = 0) or {i, i, i + 1} (a = 1): dream_upsample_conv3x3_weight_as_convT4x4), so the 3x3
+// kernel's gradient is the matching sum of the transposed conv's: dw3[r][c] = sum over ky in K(r), kx in K(c) of dwT[ky][kx] with
+// K(0) = {2, 3}, K(1) = {1, 2}, K(2) = {0, 1} (ky = a + 3 - 2 r' of phase a's tap row r').  dwT [Cin][Cout][4][4] -> dw OIHW [Cout][Cin][3][3].
+__global__ void __launch_bounds__(256) convT4x4_grad_to_conv3x3_kernel(const float *dwT, float *dw, int Cin, int Cout) {
+    const size_t n = (size_t)Cin * Cout;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int co = (int)(i / (size_t)Cin), ci = (int)(i - (size_t)co * Cin);
+        const float *t = dwT + ((size_t)ci * Cout + co) * 16;
+        float v[4][4];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k >> 2][k & 3] = t[k];
+        float *o = dw + i * 9;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int ky = 2 - r, kx = 2 - c;               // K(r) = {2 - r, 3 - r}
+                o[3 * r + c] = (v[ky][kx] + v[ky][kx + 1]) + (v[ky + 1][kx] + v[ky + 1][kx + 1]);
+            }
+    }
+}
+
 struct PlanLds { int nsplit, tiles_per_split, ntiles, TY, TX; };
 
 // one workgroup per CU (131 KB of LDS): the grid is (channel blocks) x (splits) ~ 256 workgroups of equal work
@@ -865,6 +888,16 @@ extern "C" int dream_convT4x4_wgrad_winograd_nhwc_f32(const float *x, const floa
     DREAM_LAUNCH_OK();
     hipLaunchKernelGGL(wgrad_wino_convT_reduce_kernel, dim3((unsigned)((size_t)Cout * Cin / 64), 4), dim3(256), 0, (hipStream_t)stream,
                        (const float *)workspace, dwT, (const float *)p.bias_partial, dbias, pl.nsplit, Cout, Cin);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// dwT [Cin][Cout][4][4] (gradient of the transposed conv that an upsample + 3x3 conv is) -> dw OIHW [Cout][Cin][3][3]
+extern "C" int dream_upsample_conv3x3_wgrad_from_convT4x4(const float *dwT, float *dw_oihw, int Cin, int Cout, void *stream) {
+    DREAM_REQUIRE(dwT && dw_oihw && Cin > 0 && Cout > 0, "upsample-conv wgrad combine: bad arguments");
+    size_t grid = ((size_t)Cin * Cout + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(convT4x4_grad_to_conv3x3_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, dwT, dw_oihw, Cin, Cout);
     DREAM_LAUNCH_OK();
     return 0;
 }

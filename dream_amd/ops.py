@@ -564,6 +564,12 @@ def conv3x3_wgrad(x_nhwc, dy_nhwc, cout, cin, flags=0):
 WGRAD_BIAS_FUSION = _os.environ.get("DREAM_WGRAD_BIAS_FUSION", "1") != "0"
 
 
+# DREAM_UPS_WGRAD=convT9: the weight gradient of an upsample + conv3x3 on the nine-position transposed-conv form instead of the
+# sixteen-position kernel with the fused upsample.  Measured round 6 (profiles/r06_ab_ups_wgrad_convT9.txt, vgg_q training b=128,
+# alternating): 701.1 vs 700.9 frames/s -- 1.64x fewer MFMAs at 0.54 instead of 0.70 of the peak: no gain, so the default stays.
+UPS_WGRAD_AS_CONVT = _os.environ.get("DREAM_UPS_WGRAD", "winograd16") == "convT9"
+
+
 def wgrad_winograd_pays(pixels, cin, cout):
     """Where the Winograd-domain weight gradient beats the direct kernel (profiles/r02_microbench_wgrad_wino_b128.txt:
     1.2-2.1x on the layers with >= 128 x 64 channel pairs or >= 4 M pixels; it loses on small 64 x 64-channel maps, whose

@@ -105,6 +105,9 @@ int dream_conv3x3_nhwc_f32(const float *x, const float *w_packed, const float *b
  * positions of an NHWC tensor with x_stride (>= K) channels per pixel; K % 32 == 0, N % 4 == 0; flags: DREAM_CONV_RELU. */
 size_t dream_conv1x1_weight_floats(int rows, int K);
 int dream_conv1x1_set_ksplit(int ks);   /* test hook: 0 = K split by problem size (default), 1 / 2 / 4 = forced */
+/* Test / A-B hook: height of a wavefront tile of the 1x1 GEMM: 0 = by problem size (32 rows where 64-row tiles would leave the 1 024 SIMDs
+ * with fewer than four each), 64, 32.  Same sums in the same order: the result does not depend on it. */
+int dream_conv1x1_set_rows(int rows);
 int dream_pack_conv1x1_weight(const float *w_oihw, float *packed, int Cout, int Cin, int mode, void *stream);
 int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift, const float *residual,
                            float *y, long M, int K, int N, int x_stride, int flags, void *stream);
@@ -396,6 +399,9 @@ int dream_convT4x4_wgrad_winograd_applies(int Cin, int Cout);
 size_t dream_convT4x4_wgrad_winograd_workspace(int B, int H, int W, int Cin, int Cout);
 int dream_convT4x4_wgrad_winograd_nhwc_f32(const float *x, const float *dy, float *dwT, float *dbias, void *workspace, int B,
                                            int H, int W, int Cin, int Cout, void *stream);
+/* nn.Upsample(2) + Conv2d(3x3) is such a transposed conv (dream_upsample_conv3x3_weight_as_convT4x4): its 3x3 weight gradient from the
+ * transposed conv's, dw[co][ci][r][c] = sum of dwT[ci][co][ky][kx] over ky in {2 - r, 3 - r}, kx in {2 - c, 3 - c}. */
+int dream_upsample_conv3x3_wgrad_from_convT4x4(const float *dwT, float *dw_oihw, int Cin, int Cout, void *stream);
 size_t dream_convT_wgrad_workspace(int B, int H, int W, int CinPad, int Cout, int ksize);
 int dream_convT_wgrad_nhwc_f32(const float *x, const float *dy, float *dw_packed, void *workspace, int B,
                                int H, int W, int Cin, int CinPad, int Cout, int ksize, void *stream);

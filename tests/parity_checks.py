@@ -245,16 +245,23 @@ def check_conv1x1(dev, B, H, W, Cin, Cout, flags=0, seed=0, mode=0, with_scale=F
     for ks in ksplits:
         if ks and Cin % (32 * ks):
             continue
-        _hip.lib().dream_conv1x1_set_ksplit(ks)
-        try:
-            y = ops.conv1x1(to(dev, _nhwc(x)), packed, Cout, to(dev, scale) if with_scale else None, to(dev, bias),
-                            to(dev, _nhwc(res)) if res is not None else None, flags).cpu().permute(0, 3, 1, 2)
-        finally:
-            _hip.lib().dream_conv1x1_set_ksplit(0)
-        assert y.shape == ref.shape, (tuple(y.shape), tuple(ref.shape))
-        err = float((y.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
-        assert err <= 2e-6, (B, H, W, Cin, Cout, flags, ks, err)
-        worst = max(worst, err)
+        first = None
+        for rows_forced in (0, 64, 32):                  # wavefront tile height: by problem size, 64 rows, 32 rows (round 6)
+            _hip.lib().dream_conv1x1_set_ksplit(ks)
+            _hip.lib().dream_conv1x1_set_rows(rows_forced)
+            try:
+                y = ops.conv1x1(to(dev, _nhwc(x)), packed, Cout, to(dev, scale) if with_scale else None, to(dev, bias),
+                                to(dev, _nhwc(res)) if res is not None else None, flags).cpu().permute(0, 3, 1, 2)
+            finally:
+                _hip.lib().dream_conv1x1_set_ksplit(0)
+                _hip.lib().dream_conv1x1_set_rows(0)
+            assert y.shape == ref.shape, (tuple(y.shape), tuple(ref.shape))
+            err = float((y.double() - ref).abs().max()) / max(1.0, float(ref.abs().max()))
+            assert err <= 2e-6, (B, H, W, Cin, Cout, flags, ks, rows_forced, err)
+            worst = max(worst, err)
+            if ks:                                         # a forced K split: the same sums in the same order whatever the tile height
+                first = y if first is None else first
+                assert torch.equal(y, first), (B, H, W, Cin, Cout, ks, rows_forced)
     return worst
 
 
@@ -302,7 +309,14 @@ def check_wgrad_winograd(dev, B, H, W, Cin, Cout, seed=0, pad_dy=0, ups=False):
             dw2, db2 = ops.conv3x3_wgrad_winograd(to(dev, _nhwc(x)), to(dev, dyn), Cout, Cin, flags=ops.CONV_UPSAMPLE2X if ups else 0)
         finally:
             ops.WGRAD_BIAS_FUSION = True
-        assert torch.equal(dw, dw2) and torch.equal(dw, dwj) and torch.equal(db, dbj)
+        if ups and ops.UPS_WGRAD_AS_CONVT:
+            # round 6: an upsample + conv's gradient with un-padded dy runs on the nine-position transposed-conv form; the padded-dy and
+            # the no-bias launches above took the sixteen-position kernel with the fused upsample: two correct fp32 evaluations
+            scale = float(aref.grad.max())
+            assert float((dw - dwj).abs().max()) <= 3e-6 * scale and float((dw - dw2).abs().max()) <= 3e-6 * scale
+            assert float((db - dbj).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())
+        else:
+            assert torch.equal(dw, dw2) and torch.equal(dw, dwj) and torch.equal(db, dbj)
         assert float((db - db2).abs().max()) <= 1e-5 * float(dy.abs().sum((0, 2, 3)).max())
     return err
 
@@ -1307,17 +1321,19 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
             pre_ab, pre_mean, pre_invstd = ops.bn_stats(zp_d, bn_p2, ctr)
         packed, rows = ops.pack_conv1x1_weight(to(dev, w.detach()), 0)
         packed_t, rows_t = ops.pack_conv1x1_weight(to(dev, w.detach()), 1)
-        for ks in ksplits:
+        for ks, rows_forced in [(k_, r_) for k_ in ksplits for r_ in ((0, 64, 32) if k_ else (0,))]:
             if ks and Cin % (32 * ks):
                 continue
             bn_k, bn_k2 = make_bn(Cout)
             bn_k2.load_state_dict({k_: v.to(bn_k2.weight.device) for k_, v in bn_n.state_dict().items()})
             bn_k2.running_mean.zero_(); bn_k2.running_var.fill_(1.0); bn_k2.num_batches_tracked.zero_()
             _hip.call("dream_conv1x1_set_ksplit", ks)
+            _hip.call("dream_conv1x1_set_rows", rows_forced)
             try:
                 z, ab, mean, invstd = ops.conv1x1_bn(zp_d, packed, rows, bn_k2, ctr, pre_ab=pre_ab, shift=to(dev, bias) if with_bias else None)
             finally:
                 _hip.call("dream_conv1x1_set_ksplit", 0)
+                _hip.call("dream_conv1x1_set_rows", 0)
             assert float((nchw(z.cpu()) - z_ref.detach()).abs().max()) <= tol(z_ref.detach().numpy()), (Cin, Cout, ks)
             y = ops.bn_apply_ab(z, ab, None, True)
             assert float((nchw(y.cpu()) - y_ref.detach()).abs().max()) < 2e-5, (Cin, Cout, ks)
@@ -1333,10 +1349,11 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
         if dw is not None:
             assert float((dw.cpu() - w.grad).abs().max()) <= 3 * tol(w.grad.numpy()), (Cin, Cout)
         if with_pre:
-            for ks in ksplits:
+            for ks, rows_forced in [(k_, r_) for k_ in ksplits for r_ in ((0, 64, 32) if k_ else (0,))]:
                 if ks and Cout % (32 * ks):
                     continue
                 _hip.call("dream_conv1x1_set_ksplit", ks)
+                _hip.call("dream_conv1x1_set_rows", rows_forced)
                 try:
                     gm, dg_p, db_p = ops.conv1x1_bwd_bnmask(dz, packed_t, Cin, zp_d, pre_ab, pre_mean, pre_invstd, ctr)
                     if ks == 0:      # the same with the mask read from the stored activation (+ a second gradient meeting there)
@@ -1345,6 +1362,7 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
                         assert torch.equal(gm2, gm) and torch.equal(dg2, dg_p) and torch.equal(db2, db_p)
                 finally:
                     _hip.call("dream_conv1x1_set_ksplit", 0)
+                    _hip.call("dream_conv1x1_set_rows", 0)
                 assert float((dg_p.cpu() - bn_p.weight.grad).abs().max()) < 3e-4 * max(1.0, float(bn_p.weight.grad.abs().max())), (Cin, ks)
                 assert float((db_p.cpu() - bn_p.bias.grad).abs().max()) < 3e-4 * max(1.0, float(bn_p.bias.grad.abs().max()))
                 dzp, _ = ops.bn_bwd_apply(zp_d, gm, bn_p2.weight, pre_mean, pre_invstd, dg_p, db_p)

@@ -117,6 +117,15 @@ def test_conv1x1_gemm(emu):
     print("conv1x1 wgrad max err / sum|terms|", max(werrs))
 
 
+def test_upsample_conv_wgrad_on_the_transposed_conv_form(emu, monkeypatch):
+    """DREAM_UPS_WGRAD=convT9 (opt-in): nn.Upsample(2) + conv3x3's weight gradient as the transposed conv's nine-position gradient + the
+    4x4 -> 3x3 tap sums, against fp64 and the default sixteen-position kernel with the fused upsample."""
+    monkeypatch.setattr(ops, "UPS_WGRAD_AS_CONVT", True)
+    errs = [pc.check_wgrad_winograd("cpu", 2, 12, 10, 64, 64, seed=9, ups=True),
+            pc.check_wgrad_winograd("cpu", 1, 26, 26, 128, 64, seed=10, ups=True)]
+    print("upsample + conv3x3 wgrad via convT9: max err / sum|terms|", max(errs))
+
+
 def test_convT4x4_wgrad_winograd(emu):
     """The transposed conv's weight gradient on nine of the sixteen Winograd positions (round 6)."""
     errs = [pc.check_convT4x4_wgrad_winograd("cpu", 1, 8, 8, 64, 64),                # one block, one split

@@ -15,6 +15,33 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+g6f)
+  # Round 6: 32-row wavefront tiles of the 1x1 GEMM where 64-row tiles leave the SIMDs with fewer than four each (default) against 64-row tiles
+  # everywhere (DREAM_CONV1X1_ROWS=64)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv1x1 or resnet or bn_fused or stress" > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  timeout 400 python tools/microbench_gemm_forms.py --shapes layer3,layer2,layer4 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/gemm_forms_rows_auto.txt
+  DREAM_CONV1X1_ROWS=64 timeout 400 python tools/microbench_gemm_forms.py --shapes layer3,layer2,layer4 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/gemm_forms_rows64.txt
+  for r in a b c; do
+    line rt16_auto_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+    DREAM_CONV1X1_ROWS=64 line rt16_rows64_$r --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
+  done
+  line rh16_auto --arch resnet_h --batch 16
+  DREAM_CONV1X1_ROWS=64 line rh16_rows64 --arch resnet_h --batch 16
+  line rf32_auto --arch resnet_f --batch 32
+  DREAM_CONV1X1_ROWS=64 line rf32_rows64 --arch resnet_f --batch 32
+  DREAM_CONV1X1_ROWS=32 line rf32_rows32 --arch resnet_f --batch 32
+  line rh128_auto --arch resnet_h --batch 128
+  DREAM_CONV1X1_ROWS=32 line rh128_rows32 --arch resnet_h --batch 128
+  ;;
+g6e)
+  # Round 6: the weight gradient of an upsample + conv3x3 on the nine-position transposed-conv form (default) against the sixteen-position
+  # kernel with the fused upsample (DREAM_UPS_WGRAD=winograd16); vgg_q / vgg_f training; the new structured fixture; advice fixes
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "wgrad_winograd or train_step or train_steps or reference_golden or structured or hip_graph or one_device_training or variant" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in a b c; do
+    line vt_convT9_$r --mode train --steps 5 --warmup 2
+    DREAM_UPS_WGRAD=winograd16 line vt_wino16_$r --mode train --steps 5 --warmup 2
+  done
+  ;;
 g6d)
   # Round 6: width of the weight-gradient launches on the second stream (DREAM_SIDE_WGRAD_WIDTH, per cent of the full split-K workgroup count):
   # narrow launches leave compute units to the data-gradient chain instead of taking the whole chip in bursts
