@@ -83,10 +83,10 @@ DREAM_DEVICE f32x4 bn_relu4(f32x4 x, f32x4 a, f32x4 b) {
 #endif
 // RES: the epilogue adds a residual tensor (EPI 0: a separate instantiation, so that launches without one issue no loads for it; EPI 2
 // always reads per-row operands: a null residual / stored activation there is an empty descriptor that returns zeros).
-// MB: 16-row blocks of a wavefront tile (4: 64 positions x 64 channels; 2: 32 x 64).  The trunk GEMMs at 16 frames are ~10 000 positions:
-// 2 512 64-row wave tiles on 1 024 SIMDs = 2.45 per SIMD, i.e. some SIMDs carry three and set the pace (98 K MFMA cycles against 80 K for
-// an even spread); 32-row tiles (5 024 half-size ones, four to five per SIMD) come within 2 % of even -- for 1.5x the operand loads
-// per MFMA, which these small problems can afford (the operands are L2 residents).  gemm1x1_launch picks MB by the tile count.
+// MB: 16-row blocks of a wavefront tile (4: 64 positions x 64 channels, the product; 2: 32 x 64, an experiment kept behind
+// dream_conv1x1_set_rows / DREAM_CONV1X1_ROWS=32).  The trunk GEMMs at 16 frames are ~10 000 positions: 2 512 64-row wave tiles on 1 024
+// SIMDs = 2.45 per SIMD, i.e. some SIMDs carry three and set the pace (98 K MFMA cycles against 80 K for an even spread); 32-row tiles
+// (5 024 half-size ones, four to five per SIMD) come within 2 % of even -- on paper.  Measured: slower (gemm1x1_rows below).
 template <int KS, bool PRE = false, int EPI = 0, bool RES = false, int MB = 4>
 // (with a K split the 16 KB x MB of partial tiles bound the workgroups per CU: two for MB = 4 -- two wavefronts per SIMD, 256 registers --,
 // four for MB = 2 at <= 128 registers)
@@ -544,10 +544,13 @@ int gemm1x1_rows(long M, int NPad) {
     if (g_conv1x1_rows == 64 || g_conv1x1_rows == 32) return g_conv1x1_rows;
     static const int env_rows = [] { const char *e = getenv("DREAM_CONV1X1_ROWS"); return e ? atoi(e) : 0; }();      // A/B runs: 64 | 32
     if (env_rows == 64 || env_rows == 32) return env_rows;
-    // fewer than four 64-row wave tiles per SIMD (K splits included: they are chosen to reach ~2 per SIMD): whole tiles spread
-    // unevenly over the 1 024 SIMDs -- 32-row tiles (measured round 6: profiles/r06_ab_gemm1x1_rows.txt)
-    const long tiles64 = ((M + 63) / 64) * (NPad / 64);
-    return tiles64 < 4096 ? 32 : 64;
+    // 64 rows.  The 32-row tiles were built for the trunk GEMMs at 16 frames (~10 000 positions: 2.45 64-row wave tiles per SIMD, i.e. the
+    // SIMDs that carry three set the pace; 4.9 half-size ones spread evenly) and MEASURED (round 6, profiles/r06_ab_gemm1x1_rows.txt,
+    // alternating on one box): 8-12 % SLOWER per launch on the 25 x 25 and 50 x 50 layers (the fixed cost per wavefront -- first-load
+    // latency, LDS exchange, epilogue -- doubles), faster only on the six 13 x 13 launches of a step; resnet_h training at 16 frames
+    // 377-381 against 383 frames/s.  They stay behind the hook / DREAM_CONV1X1_ROWS=32.
+    (void)M; (void)NPad;
+    return 64;
 }
 
 int gemm1x1_launch(GemmParams p, long M, int K, int N, int x_stride, bool pre, int epi, void *stream) {
