@@ -90,7 +90,24 @@ def pmc_traffic(spec):
     of this same command, FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md and calibrated on the max-pool
     kernel).  Counters cannot be read from inside the process, so the committed summary of the newest round is reported -- but
     only when it was taken with THIS bench.py (the summary records the file's hash) on this workload; null otherwise."""
-    if (spec["arch"], spec["mode"], spec["batch"], spec["res"], spec["conv_algorithm"]) != ("vgg_q", "inference", 128, 400, "winograd"):
+    key = (spec["arch"], spec["mode"], spec["batch"], spec["res"], spec["conv_algorithm"])
+    if key == ("resnet_h", "train", 16, 400, "winograd"):
+        # one GPU's share of configs[3]: the same two passes over `bench.py --arch resnet_h --mode train --batch 16` (tools/pmc_traffic.py,
+        # generic mode: totals per kernel family); the conv families are the ones this leg's roofline times
+        names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic_resnet_train.json") and n[0] == "r"),
+                       reverse=True)
+        for name in names:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                d = json.load(f)
+            if d.get("bench_py_sha") != bench_sha():
+                continue
+            fams = [v for k, v in d.get("families", {}).items() if k in ("gemm1x1_kernel", "conv_mfma_kernel", "conv_wino_kernel",
+                                                                          "conv_wino_stat_kernel", "conv_wino4_kernel")]
+            n = sum(v["dispatches"] for v in fams)
+            if n:
+                return sum(v["fetch_gb_corrected"] + v["write_gb"] for v in fams) * 1e9 / n
+        return None
+    if key != ("vgg_q", "inference", 128, 400, "winograd"):
         return None
     names = sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("_pmc_traffic.json") and n[0] == "r"),
                    reverse=True)
@@ -514,10 +531,12 @@ def run_side_workload(ctx, spec, label, baseline_index, sharded_total=None):
     n_kp, manip = ARCH_K[spec["arch"]]
     total = frames * spec["steps"] * ctx.world
     roof = roofline_of(spec, conv, dt, PEAK_F32_MFMA_TFLOPS)
+    roof["traffic"] = pmc_traffic(spec)                   # bytes per conv launch from the PMC passes of this bench.py, or null
     block = {"config": label, "workload": workload_text(spec, n_kp, manip, baseline_index),
              "value": total / dt, "unit": "frames/s", "ms_per_step": dt / spec["steps"] * 1e3, "steps": spec["steps"],
              "warmup": spec["warmup"], "batch_per_gpu": spec["batch"], "dtype": "f32",
-             "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "executed_frac", "share_of_step_time", "dominant")}}
+             "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "executed_frac", "share_of_step_time", "dominant", "traffic",
+                                              "algorithmic_gflop_per_launch", "launches")}}
     if sharded_total is not None:
         n = ctx.n_gpus
         block.update({"global_batch": sharded_total, "scaling": "strong", "per_gpu_frames_per_s": total / dt / n,

@@ -376,20 +376,22 @@ dflt)
   T0=$SECONDS; timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-2500; echo "$((SECONDS - T0)) s wall"
   ;;
 final)
-  # The round's measurement set (one GPU call): full GPU suite, smoke(), rehearsals of both multi-GPU paths on this one GPU, rocprofv3
-  # kernel tables, the calibrated HBM-traffic and SQ PMC passes, ResNet training traffic, the secondary lines, layer profiles,
-  # micro-benchmarks, and the default line LAST (it picks up this bench.py's PMC traffic).  `collect` (dev container) copies the
-  # summaries into profiles/r05_*.
+  # The round's measurement set (one GPU call): full GPU suite, smoke(), rehearsals of both multi-GPU paths on this one GPU (2 and 8 ranks /
+  # replicas), rocprofv3 kernel tables, the calibrated HBM-traffic and SQ PMC passes, ResNet training traffic + per-kernel counters of the 1x1
+  # GEMMs inside the step, the secondary lines, ten consecutive runs of the ResNet step (the round-5 "slow mode"), layer profiles,
+  # micro-benchmarks, and the default line LAST (it picks up this bench.py's PMC traffic).  `collect` (dev container) copies the summaries
+  # into profiles/r06_*.
   R="$PWD"
   summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" $3 $4 > $O/summ.log 2>&1; echo "summary $2 rc=$?"; rm -rf "$1"; }
   lraw() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | cut -c1-160; }
   if [ "$2" != "notests" ]; then
-    echo "== pytest gpu (all)"; timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
+    echo "== pytest gpu (all)"; timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
     echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-200
   fi
-  echo "== two ranks on this one GPU over gloo / four replicas in one process (rehearsals: the numbers mean nothing)"
-  DREAM_BENCH_BACKEND=gloo timeout 900 python bench.py --gpus 2 --steps 2 --warmup 1 --no-secondary > $O/rehearsal_2ranks_selflaunch.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_2ranks_selflaunch.log | cut -c1-200
-  DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 32 --no-cpu-baseline > $O/rehearsal_single_process_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_train.log | cut -c1-200
+  echo "== rehearsals on this one GPU (the numbers mean nothing)"
+  DREAM_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 --secondary-steps 2 --secondary-train-steps 3 > $O/rehearsal_8ranks_gloo.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_8ranks_gloo.log | cut -c1-200
+  DREAM_BENCH_GPU_IDS=0,0,0,0,0,0,0,0 timeout 900 python bench.py --gpus 8 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 128 --no-cpu-baseline > $O/rehearsal_single_process_8replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_8replicas_train.log | cut -c1-200
+  DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 6 --warmup 3 --global-batch 64 --no-cpu-baseline > $O/rehearsal_single_process_4replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_4replicas_train.log | cut -c1-200
   echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline --no-secondary > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; grep -h '^{"metric' $O/rocprof_default.log | cut -c1-200
   summ $O/prof_default $O/bench_default peaks_kernel 2
   for C in FETCH_SIZE WRITE_SIZE; do
@@ -412,46 +414,79 @@ for k,v in d.items(): print(k, {a: round(b,3) for a,b in v.items() if a in ('mfm
   done
   python tools/pmc_traffic.py $(ls $O/pmc_rt_FETCH_SIZE/*/*.db $O/pmc_rt_FETCH_SIZE/*.db 2>/dev/null | head -1) $(ls $O/pmc_rt_WRITE_SIZE/*/*.db $O/pmc_rt_WRITE_SIZE/*.db 2>/dev/null | head -1) $O/pmc_traffic_resnet_train.json "bn_,gemm1x1_kernel,wgrad1x1,conv_mfma_kernel,conv_wino_kernel,conv_wino_stat_kernel,conv_wino4_kernel,wgrad_kernel<,wgrad_wino,adam,pack" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 | head -40
   rm -rf $O/pmc_rt_FETCH_SIZE $O/pmc_rt_WRITE_SIZE
-  lraw train --mode train --steps 4 --warmup 1
-  lraw resnet_h_train16 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3
-  lraw resnet_h_train128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 1
+  # per-kernel counters of the 1x1 GEMM family inside the training step (four passes; the PMC passes serialise the dispatches)
+  P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+  P2="SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE SQ_INSTS_SALU"
+  P3="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"
+  P4="TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCC_EA0_RDREQ_sum"
+  for pass in 1 2 3 4; do
+    eval C=\$P$pass
+    (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_g_$pass" -o p -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > "$R/$O/pmc_g_$pass.log" 2>&1); echo "pmc gemm pass $pass rc=$?"
+  done
+  python tools/pmc_kernels.py gemm1x1_kernel,wgrad1x1_kernel,wgrad_wino_lds_kernel $O/pmc_g_* > $O/pmc_gemm1x1_in_step.txt 2> $O/pmc_g.err; head -12 $O/pmc_gemm1x1_in_step.txt | cut -c1-260
+  rm -rf $O/pmc_g_[1-9]
+  lraw train --mode train --steps 5 --warmup 2
+  echo "== ten consecutive 10-step runs of the ResNet-101 training step at 16 frames"
+  for i in 0 1 2 3 4 5 6 7 8 9; do lraw resnet_h_train16_run$i --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3; done
+  cp $O/bench_resnet_h_train16_run9.log $O/bench_resnet_h_train16.log
+  lraw resnet_h_train128 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   lraw resnet_f_b32 --arch resnet_f --batch 32
   lraw resnet_h_b128 --arch resnet_h --batch 128
   lraw vgg_f_b32 --arch vgg_f --batch 32
+  lraw resnet_f_train32 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   echo "== rocprof train"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_train" -o train -- python "$R/bench.py" --mode train --steps 3 --warmup 2 --no-cpu-baseline > "$R/$O/rocprof_train.log" 2>&1); echo "rc=$?"
   summ $O/prof_train $O/bench_train adam_kernel 1
-  echo "== rocprof resnet_h train16"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 5 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
-  summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 2
+  echo "== rocprof resnet_h train16"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 8 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
+  summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 3
   echo "== layer profiles"
   for cfg in "resnet_h train 16" "vgg_q infer 128" "vgg_q train 128"; do set -- $cfg
     timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-200
   done
   echo "== microbenches"; timeout 300 python tools/microbench_wino4.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino4_b128.txt; tail -1 $O/microbench_wino4_b128.txt
-  timeout 400 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/wino4_diag.txt; tail -2 $O/wino4_diag.txt | cut -c1-300
-  cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json
-  echo "== default bench (with the PMC traffic of this bench.py)"; T0=$SECONDS; timeout 900 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-1800; echo "$((SECONDS - T0)) s wall"
+  timeout 300 python tools/microbench_gemm_forms.py --shapes layer3 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/microbench_gemm_forms.txt; tail -3 $O/microbench_gemm_forms.txt
+  timeout 300 python tools/microbench_conv1x1.py --batch 16 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/microbench_conv1x1_b16.txt; tail -1 $O/microbench_conv1x1_b16.txt
+  timeout 400 python tools/wgw_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/wgw_diag.txt; tail -4 $O/wgw_diag.txt | cut -c1-300
+  cp $O/pmc_traffic.json profiles/r06_pmc_traffic.json
+  cp $O/pmc_traffic_resnet_train.json profiles/r06_pmc_traffic_resnet_train.json
+  echo "== default bench (with the PMC traffic of this bench.py)"; T0=$SECONDS; timeout 1200 python bench.py > $O/bench_default.log 2> $O/bench_default.err; tail -1 $O/bench_default.log | cut -c1-2400; echo "$((SECONDS - T0)) s wall"
   du -sh $O
   ;;
 collect)
-  # dev container: gpurun_out/r05_final -> profiles/r05_*
-  O=gpurun_out/r05_final
+  # dev container: gpurun_out/r06_final -> profiles/r06_*
+  O=gpurun_out/r06_final
   for n in default train resnet_h_train16; do
-    cp $O/bench_${n}_kernel_stats.csv profiles/r05_bench_${n}_kernel_stats.csv
-    cp $O/bench_${n}_conv_dispatches.csv profiles/r05_bench_${n}_conv_dispatches.csv
-    [ -f $O/bench_${n}_concurrency.txt ] && cp $O/bench_${n}_concurrency.txt profiles/r05_bench_${n}_concurrency.txt
+    cp $O/bench_${n}_kernel_stats.csv profiles/r06_bench_${n}_kernel_stats.csv
+    cp $O/bench_${n}_conv_dispatches.csv profiles/r06_bench_${n}_conv_dispatches.csv
+    [ -f $O/bench_${n}_concurrency.txt ] && cp $O/bench_${n}_concurrency.txt profiles/r06_bench_${n}_concurrency.txt
   done
-  cp $O/pmc_traffic.json profiles/r05_pmc_traffic.json
-  cp $O/pmc_traffic_resnet_train.json profiles/r05_pmc_traffic_resnet_train.json
-  cp $O/pmc_mfma.json profiles/r05_pmc_mfma.json
-  for n in default train resnet_h_train16 resnet_h_train128 resnet_f_b32 resnet_h_b128 vgg_f_b32; do tail -1 $O/bench_$n.log > profiles/r05_bench_${n}_line.json; done
-  grep -h '^{"metric' $O/rocprof_default.log > profiles/r05_bench_default_under_rocprof_line.json
-  grep -E "passed|failed" $O/pytest_gpu.log | tail -1 > profiles/r05_pytest_gpu_tail.txt
-  for f in $O/layer_profile_*.txt; do cp $f profiles/r05_$(basename $f); done
-  cp $O/microbench_wino4_b128.txt profiles/r05_microbench_wino4_b128.txt
-  cp $O/wino4_diag.txt profiles/r05_wino4_diag.txt
-  tail -1 $O/rehearsal_2ranks_selflaunch.log > profiles/r05_rehearsal_2ranks_gloo_selflaunch_line.json
-  tail -1 $O/rehearsal_single_process_train.log > profiles/r05_rehearsal_single_process_4replicas_train_line.json
-  tail -3 $O/smoke.log > profiles/r05_smoke_tail.txt
-  ls profiles/r05_*
+  cp $O/pmc_traffic.json profiles/r06_pmc_traffic.json
+  cp $O/pmc_traffic_resnet_train.json profiles/r06_pmc_traffic_resnet_train.json
+  cp $O/pmc_mfma.json profiles/r06_pmc_mfma.json
+  cp $O/pmc_gemm1x1_in_step.txt profiles/r06_pmc_gemm1x1_in_step.txt
+  for n in default train resnet_h_train16 resnet_h_train128 resnet_f_b32 resnet_h_b128 vgg_f_b32 resnet_f_train32; do tail -1 $O/bench_$n.log > profiles/r06_bench_${n}_line.json; done
+  python - <<'PY' > profiles/r06_resnet_h_train16_ten_runs.txt
+import json
+v = []
+for i in range(10):
+    d = json.loads(open("gpurun_out/r06_final/bench_resnet_h_train16_run%d.log" % i).read().strip().split("\n")[-1])
+    v.append(d["value"])
+m = sorted(v)[len(v) // 2]
+print("# ten consecutive `bench.py --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3` runs on one box (tools/gpu_round.sh final): frames/s")
+print(" ".join("%.1f" % x for x in v))
+print("median %.1f  min %.1f (%.1f %%)  max %.1f (+%.1f %%)" % (m, min(v), 100 * (min(v) / m - 1), max(v), 100 * (max(v) / m - 1)))
+PY
+  cat profiles/r06_resnet_h_train16_ten_runs.txt
+  grep -h '^{"metric' $O/rocprof_default.log > profiles/r06_bench_default_under_rocprof_line.json
+  grep -E "passed|failed" $O/pytest_gpu.log | tail -1 > profiles/r06_pytest_gpu_tail.txt
+  for f in $O/layer_profile_*.txt; do cp $f profiles/r06_$(basename $f); done
+  cp $O/microbench_wino4_b128.txt profiles/r06_microbench_wino4_b128.txt
+  cp $O/microbench_gemm_forms.txt profiles/r06_microbench_gemm_forms_final.txt
+  cp $O/microbench_conv1x1_b16.txt profiles/r06_microbench_conv1x1_b16.txt
+  cp $O/wgw_diag.txt profiles/r06_wgw_diag.txt
+  tail -1 $O/rehearsal_8ranks_gloo.log > profiles/r06_rehearsal_8ranks_gloo_line.json
+  tail -1 $O/rehearsal_single_process_8replicas_train.log > profiles/r06_rehearsal_single_process_8replicas_train_line.json
+  tail -1 $O/rehearsal_single_process_4replicas_train.log > profiles/r06_rehearsal_single_process_4replicas_train_line.json
+  tail -3 $O/smoke.log > profiles/r06_smoke_tail.txt
+  ls profiles/r06_*
   ;;
 esac

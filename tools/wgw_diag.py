@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KS = [1, 2, 4]
+KS = [1, 2, 3, 4]
 OUT = os.path.join(ROOT, "build", "diag")
 
 
