@@ -460,12 +460,27 @@ def timed_region(ctx, net, x, tgt, spec):
     sync()
     t0 = time.perf_counter()
     out = None
-    for _ in range(spec["steps"]):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(spec["steps"] + 1)] if not ctx.single else []
+    host = [t0]
+    if marks:
+        marks[0].record()
+    for i in range(spec["steps"]):
         out = step()
+        if marks:
+            marks[i + 1].record()                   # (no synchronisation: the events ride on the stream the step ends on)
+        host.append(time.perf_counter())
     sync()
     barrier()
     dt = time.perf_counter() - t0
     timer.recording = False
+    # per-step GPU time between consecutive end-of-step events and host enqueue time per step: an occasional slow run (round 5: about one
+    # 10-step run in eight of the ResNet step is 4-8 % slow) shows here as ONE long step or as a uniformly slower run
+    ctx.step_ms = None
+    if marks:
+        gpu = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(spec["steps"]))
+        hst = sorted((host[i + 1] - host[i]) * 1e3 for i in range(spec["steps"]))
+        ctx.step_ms = {"gpu_min": gpu[0], "gpu_median": gpu[len(gpu) // 2], "gpu_max": gpu[-1],
+                       "host_median": hst[len(hst) // 2], "host_max": hst[-1]}
     ctx.rank_seconds = [dt]
     if ctx.world > 1:
         mine = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -533,7 +548,7 @@ def run_side_workload(ctx, spec, label, baseline_index, sharded_total=None):
     roof = roofline_of(spec, conv, dt, PEAK_F32_MFMA_TFLOPS)
     roof["traffic"] = pmc_traffic(spec)                   # bytes per conv launch from the PMC passes of this bench.py, or null
     block = {"config": label, "workload": workload_text(spec, n_kp, manip, baseline_index),
-             "value": total / dt, "unit": "frames/s", "ms_per_step": dt / spec["steps"] * 1e3, "steps": spec["steps"],
+             "value": total / dt, "unit": "frames/s", "ms_per_step": dt / spec["steps"] * 1e3, "step_ms": ctx.step_ms, "steps": spec["steps"],
              "warmup": spec["warmup"], "batch_per_gpu": spec["batch"], "dtype": "f32",
              "roofline": {k: roof[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "executed_frac", "share_of_step_time", "dominant", "traffic",
                                               "algorithmic_gflop_per_launch", "launches")}}
@@ -639,6 +654,7 @@ def _main(args, stage):
     stage[0] = "the timed region (first RCCL collective in it for N > 1)"
     dt, conv, out_main = timed_region(ctx, net, x, tgt, spec)
     main_rank_seconds = list(ctx.rank_seconds)
+    main_step_ms = ctx.step_ms
     check = dp_check(ctx, net) if spec["dp_check"] else None
     stage[0] = "reporting"
     # roofline peak: the fp32 MFMA rate for the exact kernel; for the split kernel every algorithmic MAC costs three
@@ -704,7 +720,8 @@ def _main(args, stage):
         line = {
             "metric": "frames/s DREAM-%s %dx%d b=%d %s" % (args.arch.replace("_", "-"), args.res, args.res, args.batch, args.mode),
             "value": total / dt, "unit": "frames/s", "n_gpus": ctx.n_gpus, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.global_batch else "weak",
+            "ms_per_step": dt / args.steps * 1e3, "step_ms": main_step_ms, "higher_is_better": True,
+            "scaling": "strong" if args.global_batch else "weak",
             "vs_baseline": None, "dtype": "f32" if args.precision == "fp32" else "f32 (f16x3 split MFMA, f32 accumulate)",
             "data": "synthetic",
             "rccl_ranks": ctx.rccl_ranks, "collective_backend": ctx.backend,

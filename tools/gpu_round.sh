@@ -15,6 +15,17 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+slow)
+  # the occasional slow run of the ResNet-101 training step at 16 frames: N consecutive runs, per-step GPU / host times from bench.py's
+  # end-of-step events (one long step, or a uniformly slower run?); $2 = extra environment (e.g. PYTHONGC=off handled by bench.py)
+  for i in $(seq 1 ${3:-16}); do
+    env $2 timeout 300 python bench.py --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/run_$i.log 2>&1
+    tail -1 $O/run_$i.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d['step_ms']
+print('run $i %.1f frames/s  gpu step ms min %.2f median %.2f max %.2f  host median %.2f max %.2f' % (d['value'], s['gpu_min'], s['gpu_median'], s['gpu_max'], s['host_median'], s['host_max']))"
+  done
+  ;;
 g6f)
   # Round 6: 32-row wavefront tiles of the 1x1 GEMM where 64-row tiles leave the SIMDs with fewer than four each (default) against 64-row tiles
   # everywhere (DREAM_CONV1X1_ROWS=64)
@@ -439,7 +450,7 @@ for k,v in d.items(): print(k, {a: round(b,3) for a,b in v.items() if a in ('mfm
   echo "== rocprof resnet_h train16"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 8 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
   summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 3
   echo "== layer profiles"
-  for cfg in "resnet_h train 16" "vgg_q infer 128" "vgg_q train 128"; do set -- $cfg
+  for cfg in "resnet_h train 16" "vgg_q infer 128" "vgg_q train 128" "resnet_f infer 32"; do set -- $cfg
     timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-200
   done
   echo "== microbenches"; timeout 300 python tools/microbench_wino4.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino4_b128.txt; tail -1 $O/microbench_wino4_b128.txt
