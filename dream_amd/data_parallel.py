@@ -162,6 +162,35 @@ class _DataParallelFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+class _EarlyBucket:
+    """One replica's early bucket of the single-process gradient exchange (round 6; dream/network.py:244-256,335: nn.DataParallel
+    reduces the replicas' gradients after the backward pass).  ``dp_parameters()[k:]`` -- for ResNet-101 everything from layer3 up,
+    97 % of the 216 MB -- is final well before the backward pass ends; the replica's backward plan packs it into its flat gradient
+    buffer by a leaf on the second stream and records ``event`` behind that leaf (models._early_bucket_hook); the exchange of
+    ``gflat[lo:]`` then waits for the event only and runs on the device's exchange stream beside the rest of the backward pass.
+    The object is handed to ``dp_backward`` in the reducer slot (``add`` is what the gradient containers call per assignment)."""
+
+    def __init__(self, k, marker, views, lo):
+        self.early_k, self.early_marker, self.views, self.lo = k, marker, views, lo      # views: gflat views of dp_parameters()[k:]
+        self.event = None
+        self.packed = False            # the plan contains the pack (set when the plan runs or is captured)
+        self.marked = False            # the event was recorded in the step that is running
+
+    def add(self, g):
+        pass
+
+    def pack_early(self, grads):
+        torch._foreach_copy_(self.views, [g.contiguous() for g in grads])
+        self.packed = True
+
+    def mark_early(self, stream):
+        if stream is not None:
+            if self.event is None:
+                self.event = torch.cuda.Event()
+            self.event.record(stream)
+        self.marked = True
+
+
 class _SplitCapture:
     """A replica's backward captured as a SEQUENCE of hipGraphs (``DREAM_TRAIN_GRAPH_SPLIT=n``: n weight-gradient leaves per
     segment) instead of one graph with a forked branch -- see models._DeferredSide for why.  ``plan`` = [("main", graph) |
@@ -193,9 +222,10 @@ class _SplitCapture:
         self.plan.append(("main", self.cur))
         self.cur = None
 
-    def cut(self, fns, join=False):
+    def cut(self, fns, join=False, after=None):
         """Called by models._DeferredSide from inside the backward: close the running main segment, capture ``fns`` (the collected
-        leaves) on the second stream, open the next main segment; ``join``: the next main segment waits for every leaf segment."""
+        leaves) on the second stream, open the next main segment; ``join``: the next main segment waits for every leaf segment;
+        ``after``: called with the leaf stream at every replay once the leaf segment has been launched (and once now)."""
         self._end()
         if fns:
             graph = torch.cuda.CUDAGraph()
@@ -213,6 +243,9 @@ class _SplitCapture:
             if self.side_pool is None:
                 self.side_pool = graph.pool()
             self.plan.append(("side", graph))
+        if after is not None:
+            self.plan.append(("call", after))
+            after(None)                                         # (capture time: nothing runs, nothing to record -- the plan's state only)
         if join:
             self.plan.append(("join",))
         self._begin()
@@ -252,6 +285,8 @@ class _SplitCapture:
                 with torch.cuda.stream(self.side):
                     op[1].replay()
                 behind = True
+            elif op[0] == "call":
+                op[1](self.side)
             else:
                 main.wait_stream(self.side)
                 behind = False
@@ -279,6 +314,7 @@ class DreamDataParallel(nn.Module):
         object.__setattr__(self, "_graphs", {})           # (replica index, key) -> captured launch sequence
         object.__setattr__(self, "_reduced", 0)           # replicas whose flat gradient buffer holds this step's all-reduced sum
         object.__setattr__(self, "_opt_state", {})        # replica index -> optimizer state buffers on that replica's device
+        object.__setattr__(self, "_xstreams", {})         # device index -> the stream the early bucket of the gradient exchange runs on
         object.__setattr__(self, "_tick", [0])            # use counter for the LRU of captured graphs
         object.__setattr__(self, "_grad_version", None)   # version of the master's flat gradient buffer right after the all-reduce
         # Opt-in (DreamNetwork.hip_graph_train / DREAM_TRAIN_GRAPH=1): a training step on ONE device also runs as hipGraph replays
@@ -499,15 +535,44 @@ class DreamDataParallel(nn.Module):
             entry.update(fwd=graph, outs=outs, saved=c, bumps=list(bumps), pool=graph.pool())
             self.stats["captures"] += 1
 
-    def _replica_backward(self, i, ctx, gos, gflat, offsets, numels):
-        """One replica's backward; its parameter gradients land in ``gflat`` (the replica's flat gradient buffer)."""
+    def _early_bucket(self, i, gflat, offsets, numels, n):
+        """The early bucket of replica i for this step's exchange, or None (one device and no forced exchange, DREAM_DP_BUCKETS=0, a
+        model without ``dp_early_bucket``, a parameter order that does not match the flat layout)."""
+        if (n <= 1 and not _force_exchange()) or os.environ.get("DREAM_DP_BUCKETS", "1") == "0":
+            return None
         rep = self._replica(i)
+        spec = rep.dp_early_bucket() if hasattr(rep, "dp_early_bucket") else None
+        if spec is None:
+            return None
+        k, marker = spec
+        if not (0 < k < len(offsets)) or any(offsets[j] < offsets[k] for j in range(k, len(offsets))) \
+                or any(offsets[j] >= offsets[k] for j in range(k)):
+            return None                                     # the bucket must be one contiguous tail of the flat buffer
+        views = [gflat[o:o + m] for o, m in zip(offsets[k:], numels[k:])]
+        return _EarlyBucket(k, marker, views, offsets[k])
+
+    def _replica_backward(self, i, ctx, gos, gflat, offsets, numels, n=1):
+        """One replica's backward; its parameter gradients land in ``gflat`` (the replica's flat gradient buffer).  -> the replica's
+        early bucket when this step packed and marked one (its slice of ``gflat`` may be exchanged as soon as its event has passed)."""
+        rep = self._replica(i)
+
+        def run_and_pack(saved, grad_outs, early):
+            grads = rep.dp_backward(saved, grad_outs, reducer=early) if early is not None else rep.dp_backward(saved, grad_outs)
+            if early is not None and early.packed:          # the early bucket is in place already (and may be in flight): the rest only
+                k = early.early_k
+                self._pack_grads(grads[:k], gflat, offsets[:k], numels[:k])
+            else:
+                self._pack_grads(grads, gflat, offsets, numels)
+
         with torch.no_grad():
             if ctx[0] == "eager":
                 from .models import _guarded_backward
-                self._pack_grads(_guarded_backward(rep.dp_backward, ctx[1], gos), gflat, offsets, numels)
+                early = self._early_bucket(i, gflat, offsets, numels, n)
+                if early is not None:
+                    early.views = [v.view_as(p) for v, p in zip(early.views, rep.dp_parameters()[early.early_k:])]
+                _guarded_backward(run_and_pack, ctx[1], gos, early)
                 self.stats["eager"] += 1
-                return
+                return early if early is not None and early.packed and early.marked else None
             entry = ctx[1]
             if entry["bwd"] is None:
                 with DreamDataParallel._capture_lock:
@@ -516,22 +581,31 @@ class DreamDataParallel(nn.Module):
                     split = self.graph_split_leaves
                     if split is None:
                         split = 12
+                    early = None
                     if split > 0:
                         devs = self.devices()
+                        early = self._early_bucket(i, gflat, offsets, numels, n)      # (one backward graph: no early bucket -- an event
+                        if early is not None:                                          #  recorded inside a capture cannot be waited for outside)
+                            early.views = [v.view_as(p) for v, p in zip(early.views, rep.dp_parameters()[early.early_k:])]
                         graph = _SplitCapture(entry["pool"], split, gflat.device, shared_device=devs.count(devs[i]) > 1)
-                        graph.capture(lambda: self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels))
+                        graph.capture(lambda: run_and_pack(entry["saved"], entry["gos"], early))
                     else:
                         graph = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(graph, pool=entry["pool"], capture_error_mode="thread_local"):
                             self._pack_grads(rep.dp_backward(entry["saved"], entry["gos"]), gflat, offsets, numels)
-                    entry.update(bwd=graph, gflat_ptr=gflat.data_ptr())
+                    entry.update(bwd=graph, gflat_ptr=gflat.data_ptr(), early=early if early is not None and early.packed else None, n=n)
                     self.stats["captures"] += 1
             assert entry["gflat_ptr"] == gflat.data_ptr()
             for s, g in zip(entry["gos"], gos):
                 if s is not None:
                     s.copy_(g, non_blocking=True)
+            early = entry.get("early")
+            if early is not None:
+                early.marked = False
             entry["bwd"].replay()
             self.stats["replays"] += 1
+            # (a graph captured for another number of devices keeps its plan: the bucket is then simply not exchanged early)
+            return early if early is not None and early.marked and entry.get("n") == n else None
 
     @staticmethod
     def _pack_grads(grads, gflat, offsets, numels):
@@ -578,20 +652,46 @@ class DreamDataParallel(nn.Module):
             def run():
                 gos = [None if s[i] is None else (s[i].contiguous() if s[i].device == devs[i] else s[i].to(devs[i], non_blocking=True))
                        for s in splits]
-                self._replica_backward(i, ctxs[i], gos, flats[i], offsets, numels)
+                return self._replica_backward(i, ctxs[i], gos, flats[i], offsets, numels, n)
             return run
         with self._lock:
-            self._run([job(i) for i in range(n)])
-            # ONE all-reduce(sum) over the replicas' flat gradient buffers, in place, ordered behind each replica's backward
-            # on that replica's stream (RCCL over xGMI for distinct GPUs; csrc/collective.hip)
-            if n > 1:
-                ops.allreduce_sum_(flats)
+            earlies = self._run([job(i) for i in range(n)])
+            # The exchange: all-reduce(sum) over the replicas' flat gradient buffers, in place (RCCL over xGMI for distinct GPUs;
+            # csrc/collective.hip).  Round 6: in TWO pieces where every replica marked its early bucket -- the tail gflat[lo:] on the
+            # devices' exchange streams behind each replica's event (it overlaps what is left of the backward passes), then the head
+            # behind the backward passes themselves; otherwise ONE call behind each replica's backward on that replica's stream.
+            if n > 1 or _force_exchange():
+                self._exchange(flats, earlies, devs[:n])
             object.__setattr__(self, "_reduced", n)
         total_flat = flats[0]
         # what step_replicas checks: any in-place edit of the gradients autograd is about to receive (clip_grad_norm_, manual
         # scaling: the views share the buffer's version counter) happens on the master only and must not be replayed blindly
         object.__setattr__(self, "_grad_version", total_flat._version)
         return [total_flat[o:o + m].view(prm.shape) for o, m, prm in zip(offsets, numels, params)]
+
+    def _exchange(self, flats, earlies, devs):
+        los = {e.lo for e in earlies if e is not None}
+        if any(e is None for e in earlies) or len(los) != 1 or devs[0].type != "cuda":
+            ops.allreduce_sum_(flats)
+            self.stats["exchanges"] = self.stats.get("exchanges", 0) + 1
+            return
+        lo = los.pop()
+        xs = []
+        for d in devs:                                      # one exchange stream per device (replicas that share a device share it)
+            if d.index not in self._xstreams:
+                self._xstreams[d.index] = torch.cuda.Stream(device=d)
+            xs.append(self._xstreams[d.index])
+        mains = [torch.cuda.current_stream(d) for d in devs]
+        for x, e in zip(xs, earlies):
+            x.wait_event(e.event)
+        ops.allreduce_sum_([f[lo:] for f in flats], streams=xs)          # the early bucket: beside the rest of the backward passes
+        for x, m in zip(xs, mains):
+            x.wait_stream(m)
+        if lo > 0:
+            ops.allreduce_sum_([f[:lo] for f in flats], streams=xs)      # the late bucket: behind them
+        for x, m in zip(xs, mains):
+            m.wait_stream(x)
+        self.stats["exchanges"] = self.stats.get("exchanges", 0) + (2 if lo > 0 else 1)
 
     @staticmethod
     def _release_grad_buffer(params, flat, offsets, numels):
@@ -686,6 +786,12 @@ class _Null:
 
     def __exit__(self, *exc):
         return False
+
+
+def _force_exchange():
+    """DREAM_FORCE_RCCL=1: the exchange runs for a one-device list too (through RCCL itself: csrc/collective.hip) -- the one-GPU test box's
+    way to execute the calls an 8-GPU node makes."""
+    return os.environ.get("DREAM_FORCE_RCCL", "0") == "1"
 
 
 def _distributed_world():

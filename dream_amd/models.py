@@ -450,9 +450,14 @@ class DreamHourglass(nn.Module):
             return (idx >= 0 and layers[idx][0] in ("first", "wide", "conv", "deconv") and bool(layers[idx][2] & CONV_RELU)
                     and idx not in self._skip_sources)
 
+        early = getattr(reducer, "early_marker", None)    # single-process exchange: the plan entry from which the early bucket is final
         for li in range(len(layers) - 1, -1, -1):
             kind, mod, flags = layers[li]
             inp, out = saved[li]
+            if early is not None and li < early:           # every entry >= early is done: pack the early bucket (a leaf), mark it
+                k_early = reducer.early_k
+                _early_bucket_hook(reducer, early, side, lambda: list(grads[k_early:]))
+                early = None
             if li in pending:                              # two consumers of this activation: gradients add
                 g = ops.add_(g, pending.pop(li))
             if kind == "pool":
@@ -541,6 +546,22 @@ class DreamHourglass(nn.Module):
     def dp_parameters(self):
         """Parameters in the order dp_backward returns their gradients."""
         return self.plan_parameters()
+
+    def dp_early_bucket(self):
+        """-> (index k into dp_parameters(), plan entry li): the gradients of dp_parameters()[k:] are final once the backward plan has
+        finished the entries >= li.  The late bucket is the longest prefix of the plan that holds at most 4 % of the parameters -- for
+        vgg_q conv1_1 .. conv3_1, whose data / weight gradients at 400 x 400 and 200 x 200 are a quarter of the backward pass."""
+        layers = self.plan_layers()
+        total = sum(m.weight.numel() + m.bias.numel() for _, m, _ in layers if m is not None)
+        seen, k = 0, 0
+        for li, (_, m, _) in enumerate(layers):
+            if m is None:
+                continue
+            n = m.weight.numel() + m.bias.numel()
+            if seen + n > 0.04 * total:
+                return (k, li) if k > 0 else None
+            seen, k = seen + n, k + 2
+        return None
 
     def dp_trainable(self):
         return True
@@ -702,6 +723,19 @@ class _SideStream:
             cls._streams[key] = cls._new_stream(device)
         return cls._streams[key]
 
+    _memory = {}
+
+    @classmethod
+    def _device_memory(cls, device):
+        """Total memory of ``device`` (cached; a replica's pool thread may not be able to query the device properties: 32 GB then)."""
+        idx = device.index if device.index is not None else -1
+        if idx not in cls._memory:
+            try:
+                cls._memory[idx] = int(torch.cuda.get_device_properties(device).total_memory)
+            except (AssertionError, RuntimeError):
+                return 32 << 30
+        return cls._memory[idx]
+
     low_priority_allowed = True
 
     @classmethod
@@ -758,7 +792,7 @@ class _SideStream:
         self.kept_bytes = 0
         self.keep_limit = int(os.environ.get("DREAM_SIDE_KEEP_MAX_MB", "0")) << 20
         if self.keep is not None and self.keep_limit <= 0:
-            self.keep_limit = torch.cuda.get_device_properties(stream.device).total_memory // 8
+            self.keep_limit = _SideStream._device_memory(stream.device) // 8
         self.batch = int(os.environ.get("DREAM_SIDE_BATCH", "1"))
         self.pending = []
         self.count = 0
@@ -792,6 +826,12 @@ class _SideStream:
             for t in inputs:
                 t.record_stream(self.side)
         return out
+
+    def checkpoint(self, cb):
+        """Everything queued so far is launched, then ``cb(stream)`` runs with the second stream (an event recorded there is behind every
+        leaf queued before this call)."""
+        self.flush()
+        cb(self.side)
 
     def flush(self):
         if self.pending:
@@ -842,6 +882,12 @@ class _DeferredSide:
             self.ctl.cut(self.pending)
             del self.pending[:]
 
+    def checkpoint(self, cb):
+        """The leaves collected so far become a segment of their own; when it has been replayed, ``cb(stream of the leaf segments)`` runs
+        (every replay: a plan entry, data_parallel._SplitCapture)."""
+        self.ctl.cut(self.pending, after=cb)
+        del self.pending[:]
+
     def join(self):
         self.ctl.cut(self.pending, join=True)
         del self.pending[:]
@@ -858,6 +904,21 @@ def _guarded_backward(fn, *args, **kwargs):
         if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
             torch.cuda.synchronize()
         raise
+
+
+def _early_bucket_hook(reducer, marker, side, early_grads):
+    """Single-process data parallelism (data_parallel._EarlyBucket): when a backward plan passes ``marker`` -- from here on no gradient
+    of the early bucket (the parameters registered from the marker's layer on: for ResNet-101 everything from layer3 up, 97 % of the
+    bytes) changes any more -- the bucket is packed into the replica's flat gradient buffer by a leaf on the second stream (behind
+    the weight-gradient leaves that produce it) and an event is recorded behind that leaf; the exchange of the bucket waits for the
+    event only and overlaps the rest of the backward pass (dream/network.py:244-256,335: nn.DataParallel's gradient reduction)."""
+    if reducer is None or getattr(reducer, "early_marker", None) != marker:
+        return
+    _on_side(side, lambda: reducer.pack_early(early_grads()))
+    if side is not None:
+        side.checkpoint(reducer.mark_early)
+    else:
+        reducer.mark_early(torch.cuda.current_stream() if torch.cuda.is_available() else None)
 
 
 def _on_side(side, fn, *inputs):
@@ -1491,6 +1552,7 @@ class ResnetSimple(nn.Module):
                 other = block["g_ds"] if rec["ds"] else block["g_idt"]
                 g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
                 block = None
+                _early_bucket_hook(reducer, rec["name"], side, lambda: [grads[p] for p in self._early_bucket_params()])
             elif kind == "pool":
                 g = ops.maxpool3s2_bwd(g, rec["x"])
             elif kind == "stem":
@@ -1747,6 +1809,7 @@ class ResnetSimple(nn.Module):
                 else:
                     g = self._bwd_data(name1, conv1, dz, cin, k, stride, in_hw, residual=other)
                 block = None
+                _early_bucket_hook(reducer, rec["name"], side, lambda: [grads[p] for p in self._early_bucket_params()])
             elif kind == "pool":
                 g = ops.maxpool3s2_idx_bwd(g, rec["idx"], rec["x"].shape)
             elif kind == "stem":
@@ -1771,6 +1834,22 @@ class ResnetSimple(nn.Module):
             out, tape = self.run_forward_train(x)
             return [out], (tape if save else None)
         return [self.run_forward(x)], None
+
+    EARLY_BUCKET_FROM = "layer3"                 # the early bucket of the single-process exchange: parameters from this layer on
+
+    def dp_early_bucket(self):
+        """-> (index k into dp_parameters() of the first parameter of the early bucket, marker of the backward plan) or None: the
+        gradients of dp_parameters()[k:] are final once the backward plan has passed the block ``marker`` (the first Bottleneck of
+        EARLY_BUCKET_FROM; its own BatchNorm gradients were produced by the blocks behind it)."""
+        names = [n for n, _ in self.named_parameters()]
+        ks = [i for i, n in enumerate(names) if n.startswith(self.EARLY_BUCKET_FROM + ".")]
+        if not ks or ks[0] == 0:
+            return None
+        return ks[0], self.EARLY_BUCKET_FROM + ".0"
+
+    def _early_bucket_params(self):
+        k = self.dp_early_bucket()[0]
+        return list(self.parameters())[k:]
 
     def dp_backward(self, tape, grad_outs, reducer=None):
         gdict = self.run_backward(tape, grad_outs[0].contiguous(), reducer=reducer)

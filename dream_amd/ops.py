@@ -1175,10 +1175,10 @@ def add_(dst, src):
     return dst
 
 
-def allreduce_sum_(flats):
+def allreduce_sum_(flats, streams=None):
     """In place: every tensor of ``flats`` -- one flat fp32 buffer per data-parallel replica, each on its replica's GPU, same
     length -- becomes the element-wise sum of all of them (one RCCL all-reduce over xGMI for distinct GPUs, csrc/collective.hip).
-    Ordered on the stream the calling thread currently uses on each device."""
+    Ordered on ``streams[i]`` (a torch stream per buffer), default: the stream the calling thread currently uses on each device."""
     n = len(flats)
     count = int(flats[0].numel())
     for t in flats:
@@ -1186,8 +1186,11 @@ def allreduce_sum_(flats):
             raise RuntimeError("allreduce_sum_: buffers must be float32 of equal length")
     devs = (ctypes.c_int * n)(*[(t.device.index or 0) if t.is_cuda else 0 for t in flats])
     bufs = (ctypes.c_void_p * n)(*[ptr(t) for t in flats])
-    streams = (ctypes.c_void_p * n)(*[stream_on(t.device) if t.is_cuda else None for t in flats])
-    call("dream_allreduce_sum_f32", n, devs, bufs, count, streams)
+    if streams is None:
+        handles = [stream_on(t.device) if t.is_cuda else None for t in flats]
+    else:
+        handles = [None if st is None else st.cuda_stream for st in streams]
+    call("dream_allreduce_sum_f32", n, devs, bufs, count, (ctypes.c_void_p * n)(*handles))
     return flats
 
 

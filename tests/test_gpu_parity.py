@@ -1115,6 +1115,10 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, spl
     if split != "0":                                      # replicas that share a device must not share the stream their leaf segments replay on
         sides = [v["bwd"].side for v in dp._graphs.values() if v["bwd"] is not None]
         assert len({s.cuda_stream for s in sides}) == 4
+    # the exchange (round 6): two pieces per step -- the early bucket (layer3 and up) behind each replica's event, then the rest -- wherever
+    # the backward is a sequence of graphs or eager; ONE piece per step behind a single backward graph
+    assert dp.stats.get("exchanges") == (8 if split != "0" else 2 + 3), dp.stats
+    assert e.model.stats.get("exchanges") == 8, e.model.stats
     assert lg == le, (lg, le)
     for (k, a), (_, b) in zip(g.model.named_parameters(), e.model.named_parameters()):
         assert torch.equal(a, b), k
@@ -1131,6 +1135,42 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, spl
         ref = e.inference(x)
     for m, k in outs:
         assert torch.equal(m, ref[0]) and torch.equal(k, ref[1])
+
+
+def test_bucketed_exchange_through_rccl_on_one_device(monkeypatch):
+    """DREAM_FORCE_RCCL=1 (round 6): a one-device step runs the gradient exchange of the single-process multi-GPU path THROUGH RCCL (a
+    one-rank communicator: dlopen, ncclCommInitAll, group calls) -- in two pieces per step: the early bucket on the exchange stream behind
+    the replica's event, the rest behind the backward pass (dream/network.py:244-256,335).  At least two RCCL calls per step, the early
+    one over everything from layer3 up; the training run equals the one without the forced exchange bit for bit (a sum over one rank)."""
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(4, 64, 64, seed=43)).to(DEV)
+
+    def run(force):
+        monkeypatch.setenv("DREAM_FORCE_RCCL", "1" if force else "0")
+        net = _dp_network("resnet_h", [0], optimizer="adam", lr=1e-5, in_res=(64, 64), weights=wts)
+        net.hip_graph_train = True
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=(64, 64), seed=43)).to(DEV)
+        calls = []
+        orig = ops.allreduce_sum_
+        monkeypatch.setattr(ops, "allreduce_sum_", lambda flats, streams=None: calls.append((int(flats[0].numel()), streams is not None,
+                                                                                              ops.allreduce_uses_rccl([0]))) or orig(flats, streams))
+        losses = [net.train([x], t).item() for _ in range(4)]
+        torch.cuda.synchronize()
+        monkeypatch.setattr(ops, "allreduce_sum_", orig)
+        return net, losses, calls
+
+    f, lf, cf = run(True)
+    p, lp, cp = run(False)
+    assert cp == [] and len(cf) == 8, (len(cp), cf)                       # two pieces per step, none without the switch
+    total = int(f.model.module._dream_flat["params"].numel())
+    for early, late in zip(cf[0::2], cf[1::2]):
+        assert early[1] and late[1] and early[2] and late[2]              # on the exchange stream, through RCCL
+        assert early[0] + late[0] == total and early[0] > 0.9 * total     # layer3 and up: 97 % of ResNet-101's parameters
+    assert lf == lp, (lf, lp)
+    for (k, a), (_, b) in zip(f.model.named_parameters(), p.model.named_parameters()):
+        assert torch.equal(a, b), k
 
 
 def test_conv3x3_bn_fused_ops():

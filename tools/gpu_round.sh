@@ -15,6 +15,17 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+g6g)
+  # Round 6, verdict task 2b: the single-process exchange in two pieces (early bucket behind each replica's event on an exchange stream)
+  echo "== pytest"; timeout 1800 python -m pytest tests -m gpu -q -x --timeout 900 -k "data_parallel or allreduce or bucketed or one_device_training or graph" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
+  for r in a b; do
+    DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 6 --warmup 3 --global-batch 64 --no-cpu-baseline > $O/dp4_buckets_$r.log 2>&1; tail -1 $O/dp4_buckets_$r.log | cut -c1-160
+    DREAM_DP_BUCKETS=0 DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 6 --warmup 3 --global-batch 64 --no-cpu-baseline > $O/dp4_one_piece_$r.log 2>&1; tail -1 $O/dp4_one_piece_$r.log | cut -c1-160
+  done
+  DREAM_FORCE_RCCL=1 DREAM_TRAIN_GRAPH=1 line rt16_graph_rccl_buckets --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  DREAM_TRAIN_GRAPH=1 line rt16_graph --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  line rt16_eager --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  ;;
 slow)
   # the occasional slow run of the ResNet-101 training step at 16 frames: N consecutive runs, per-step GPU / host times from bench.py's
   # end-of-step events (one long step, or a uniformly slower run?); $2 = extra environment (e.g. PYTHONGC=off handled by bench.py)
