@@ -30,6 +30,7 @@ _SIGNATURES = {
     "dream_hip_last_error": (_c.c_char_p, []),
     "dream_hip_device_count": (_I, [_c.POINTER(_I)]),
     "dream_hip_device_name": (_I, [_I, _c.c_char_p, _SZ]),
+    "dream_hip_stream_create": (_I, [_I, _I, _c.POINTER(_P)]),
     "dream_pack_conv3x3_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "dream_unpack_conv3x3_weight": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_pack_conv_weight": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -250,6 +251,33 @@ def stream_on(device):
     """HIP stream the calling thread currently uses on ``device`` (a torch.device of type cuda)."""
     import torch
     return torch.cuda.current_stream(device).cuda_stream
+
+
+_own_streams = {}
+_own_lock = None
+
+
+def own_stream(device, role, priority=0):
+    """The process's own HIP stream for ``role`` on ``device`` (a torch.device of type cuda), as a torch stream: created once by
+    dream_hip_stream_create and kept for the life of the process.  torch.cuda.Stream() draws from a pool of 32 streams per device
+    and priority, round-robin: in a long-running process the 33rd request returns the first stream again, and a hipGraph capture
+    begun on such an alias swallows whatever another thread launches on "its" stream.  Roles: "leaves" (the weight-gradient stream
+    of training steps), "exchange" (gradient exchange), "capture" / "capture-leaves" (hipGraph captures; taken one at a time,
+    process-wide), "warmup"."""
+    import threading
+    import torch
+    global _own_lock
+    if _own_lock is None:
+        _own_lock = threading.Lock()
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, role, priority)
+    with _own_lock:
+        st = _own_streams.get(key)
+        if st is None:
+            handle = _c.c_void_p()
+            call("dream_hip_stream_create", int(index), int(priority), _c.byref(handle))
+            st = _own_streams[key] = torch.cuda.ExternalStream(handle.value, device=torch.device("cuda", index))
+    return st
 
 
 def cout_pad(cout):

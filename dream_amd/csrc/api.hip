@@ -36,6 +36,26 @@ extern "C" int dream_hip_device_name(int dev, char *buf, size_t buflen) {
     return 0;
 }
 
+extern "C" int dream_hip_stream_create(int dev, int priority, void **stream) {
+    DREAM_REQUIRE(stream != nullptr, "null pointer");
+    int saved = 0;
+    DREAM_HIP_OK(hipGetDevice(&saved));
+    DREAM_HIP_OK(hipSetDevice(dev));
+    hipStream_t s = nullptr;
+    hipError_t e;
+    if (priority == 0) {
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    } else {
+        int least = 0, greatest = 0;
+        e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority > 0 ? least : greatest);
+    }
+    (void)hipSetDevice(saved);
+    DREAM_HIP_OK(e);
+    *stream = (void *)s;
+    return 0;
+}
+
 int dream_allow_full_lds(const void *kernel) {
     static std::mutex mu;
     static std::set<std::pair<int, const void *>> done;

@@ -39,5 +39,13 @@ static inline long wgrad_target_workgroups(long full) {
 
 #define DREAM_LAUNCH_OK() DREAM_HIP_OK(hipGetLastError())
 
+// Zero / copy device memory (whole 32-bit words) with a KERNEL launch instead of hipMemsetAsync / hipMemcpyAsync.  Every entry point of
+// this library may be captured into a hipGraph (the training steps of the data-parallel replicas are), and a memset / memcpy NODE of a
+// replayed graph is not reliably ordered with the kernel nodes around it on this runtime (ROCm 7.2, graph packet capture on): after a
+// hipDeviceSynchronize() between two replays the stride-2 1x1 data gradient below read its "zeroed" output as it had been left by the
+// previous owner of the memory (tools/dp_exchange_probe.py; profiles/r06_dp_exchange_probe.txt).  0 = ok, else the error text is set.
+int dream_zero_words(void *dst, size_t nbytes, hipStream_t stream);
+int dream_copy_words(void *dst, const void *src, size_t nbytes, hipStream_t stream);
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline size_t ceil_div_sz(size_t a, size_t b) { return (a + b - 1) / b; }

@@ -390,7 +390,7 @@ extern "C" int dream_pack_conv_weight_f16x3(const float *w_oihw, void *hi, void 
     DREAM_REQUIRE(w_oihw && hi && lo && exp_out && scratch && Cout > 0 && Cin > 0 && ntaps > 0 && (mode == 0 || mode == 1),
                   "pack_conv_weight_f16x3: bad arguments");
     DREAM_REQUIRE(RowsPad >= (mode == 0 ? Cout : Cin) && ColsPad >= (mode == 0 ? Cin : Cout), "pack_conv_weight_f16x3: padding too small");
-    DREAM_HIP_OK(hipMemsetAsync(scratch, 0, sizeof(unsigned), (hipStream_t)stream));
+    if (dream_zero_words(scratch, sizeof(unsigned), (hipStream_t)stream)) return 2;
     const size_t n = (size_t)Cout * Cin * ntaps;
     size_t g = (n + 255) / 256;
     if (g > 1024) g = 1024;
@@ -490,7 +490,7 @@ extern "C" int dream_pack_convT4x4_weight_f16x3(const float *wT, void *hi, void 
                                                 int Cout, int RowsPad, int ColsPad, void *stream) {
     DREAM_REQUIRE(wT && hi && lo && exp_out && scratch && Cin > 0 && Cout > 0 && RowsPad >= Cout && ColsPad >= Cin,
                   "pack_convT4x4_weight_f16x3: bad arguments");
-    DREAM_HIP_OK(hipMemsetAsync(scratch, 0, sizeof(unsigned), (hipStream_t)stream));
+    if (dream_zero_words(scratch, sizeof(unsigned), (hipStream_t)stream)) return 2;
     const size_t n = (size_t)Cin * Cout * 16;
     size_t g = (n + 255) / 256;
     if (g > 1024) g = 1024;

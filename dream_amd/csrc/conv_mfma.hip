@@ -595,7 +595,7 @@ extern "C" int dream_conv2d_s2_bwd_data_nhwc_f32(const float *dy, const float *w
     DREAM_REQUIRE(dy && w_packed_mode1 && dx && (ksize == 1 || ksize == 3), "conv2d_s2_bwd_data: bad arguments");
     if (ksize == 3) return conv_transpose3x3s2_impl(dy, w_packed_mode1, nullptr, dx, B, Hy, Wy, Hx, Wx, C, Cx, RowsPad, 0, stream);
     DREAM_REQUIRE((Hx == 2 * Hy || Hx == 2 * Hy - 1) && (Wx == 2 * Wy || Wx == 2 * Wy - 1), "conv2d_s2_bwd_data: output %dx%d for input %dx%d", Hx, Wx, Hy, Wy);
-    DREAM_HIP_OK(hipMemsetAsync(dx, 0, (size_t)B * Hx * Wx * Cx * sizeof(float), (hipStream_t)stream));
+    if (dream_zero_words(dx, (size_t)B * Hx * Wx * Cx * sizeof(float), (hipStream_t)stream)) return 2;     // (a kernel: common.h)
     ConvGeom g;
     g.H = Hy; g.W = Wy; g.Hin = Hy; g.Win = Wy; g.Hs = Hy; g.Ws = Wy; g.Ho = Hx; g.Wo = Wx;
     g.in_scale = 1; g.in_step = 1; g.lane_stride = 1; g.pad = 0;

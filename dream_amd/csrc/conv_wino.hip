@@ -244,8 +244,8 @@ extern "C" int dream_pack_conv3x3_winograd_weight(const float *w_oihw, float *u,
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode);
     DREAM_LAUNCH_OK();
-    DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / WKC) * 16 * rows_pad * WKC, 0, (size_t)B_AHEAD * rows_pad * WKC * sizeof(float),
-                                (hipStream_t)stream));
+    if (dream_zero_words(u + (size_t)(cols / WKC) * 16 * rows_pad * WKC, (size_t)B_AHEAD * rows_pad * WKC * sizeof(float), (hipStream_t)stream))
+        return 2;
     return 0;
 }
 

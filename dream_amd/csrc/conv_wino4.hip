@@ -807,8 +807,8 @@ extern "C" int dream_pack_conv3x3_winograd4_weight(const float *w_oihw, float *u
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(wino4_pack_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, w_oihw, u, Cout, Cin, mode);
     DREAM_LAUNCH_OK();
-    DREAM_HIP_OK(hipMemsetAsync(u + (size_t)(cols / ps.k) * W4P * ps.rows_pad * ps.k, 0, (size_t)ps.ahead * ps.rows_pad * ps.k * sizeof(float),
-                                (hipStream_t)stream));
+    if (dream_zero_words(u + (size_t)(cols / ps.k) * W4P * ps.rows_pad * ps.k, (size_t)ps.ahead * ps.rows_pad * ps.k * sizeof(float), (hipStream_t)stream))
+        return 2;
     return 0;
 }
 

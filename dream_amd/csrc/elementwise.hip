@@ -781,6 +781,36 @@ extern "C" int dream_maxpool3s2_idx_bwd_nhwc_f32(const float *dy, const unsigned
     DREAM_LAUNCH_OK();
     return 0;
 }
+// common.h: zero / copy whole words with a kernel (graph-safe replacements of hipMemsetAsync / hipMemcpyAsync)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) zero_words_kernel(unsigned *dst, size_t n) {
+    const bool wide = (((size_t)dst) & 15) == 0;
+    const size_t n4 = wide ? n / 4 : 0;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) ((u32x4 *)dst)[i] = z;
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = 0u;
+}
+__global__ void __launch_bounds__(256) copy_words_kernel(unsigned *dst, const unsigned *src, size_t n) {
+    const bool wide = ((((size_t)dst) | ((size_t)src)) & 15) == 0;
+    const size_t n4 = wide ? n / 4 : 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) ((u32x4 *)dst)[i] = ((const u32x4 *)src)[i];
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+int dream_zero_words(void *dst, size_t nbytes, hipStream_t stream) {
+    DREAM_REQUIRE(dst && nbytes % 4 == 0 && (((size_t)dst) & 3) == 0, "zero_words: whole aligned 32-bit words expected");
+    if (nbytes == 0) return 0;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(nbytes / 16 + 1)), dim3(256), 0, stream, (unsigned *)dst, nbytes / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+int dream_copy_words(void *dst, const void *src, size_t nbytes, hipStream_t stream) {
+    DREAM_REQUIRE(dst && src && nbytes % 4 == 0 && ((((size_t)dst) | ((size_t)src)) & 3) == 0, "copy_words: whole aligned 32-bit words expected");
+    if (nbytes == 0) return 0;
+    hipLaunchKernelGGL(copy_words_kernel, dim3(grid_for(nbytes / 16 + 1)), dim3(256), 0, stream, (unsigned *)dst, (const unsigned *)src, nbytes / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+
 extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream) {
     DREAM_REQUIRE(dst && src, "add_inplace: null pointer");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dst, src, n);
@@ -789,7 +819,7 @@ extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, voi
 }
 extern "C" int dream_add_f32(const float *a, const float *b, float *out, size_t n, unsigned *amax_out, void *stream) {
     DREAM_REQUIRE(a && b && out, "add: null pointer");
-    if (amax_out) DREAM_HIP_OK(hipMemsetAsync(amax_out, 0, sizeof(unsigned), (hipStream_t)stream));
+    if (amax_out && dream_zero_words(amax_out, sizeof(unsigned), (hipStream_t)stream)) return 2;
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, amax_out);
     DREAM_LAUNCH_OK();
     return 0;
@@ -798,7 +828,7 @@ extern "C" int dream_stage_input_nhwc_f32(const float *img_nchw, const float *ma
                                           int Ci, int K, int up, int Cpad, unsigned *amax_out, void *stream) {
     DREAM_REQUIRE(img_nchw && maps_nchw && out_nhwc && B > 0 && H > 0 && W > 0 && Ci > 0 && K > 0, "stage_input: bad arguments");
     DREAM_REQUIRE(up >= 1 && H % up == 0 && W % up == 0 && Cpad % 4 == 0 && Cpad >= Ci + K, "stage_input: bad up / Cpad");
-    if (amax_out) DREAM_HIP_OK(hipMemsetAsync(amax_out, 0, sizeof(unsigned), (hipStream_t)stream));
+    if (amax_out && dream_zero_words(amax_out, sizeof(unsigned), (hipStream_t)stream)) return 2;
     hipLaunchKernelGGL(stage_input_kernel, dim3(grid_for((size_t)B * H * W * (Cpad / 4))), dim3(256), 0, (hipStream_t)stream,
                        img_nchw, maps_nchw, out_nhwc, B, H, W, Ci, K, up, Cpad, amax_out);
     DREAM_LAUNCH_OK();

@@ -409,8 +409,7 @@ int launch_wgrad(const float *tile_t, const float *patch_t, float *dw_packed, fl
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
                            (const float *)bias_part, bias_part + (size_t)p.splitk * RowsPad, (size_t)RowsPad, p.splitk);
         DREAM_LAUNCH_OK();
-        DREAM_HIP_OK(hipMemcpyAsync(dbias, bias_part + (size_t)p.splitk * RowsPad, (size_t)nbias * sizeof(float),
-                                    hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        if (dream_copy_words(dbias, bias_part + (size_t)p.splitk * RowsPad, (size_t)nbias * sizeof(float), (hipStream_t)stream)) return 2;
     }
     return 0;
 }

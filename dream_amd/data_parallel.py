@@ -162,6 +162,14 @@ class _DataParallelFunction(torch.autograd.Function):
         return (None, None) + tuple(grads)
 
 
+def _probe_sync(where):
+    """DREAM_DP_PROBE_SYNC=<where> (tools/dp_exchange_probe.py): a device-wide synchronisation at one point of the data-parallel step --
+    backward_begin | backward_end | exchange_begin | exchange_mid | exchange_end.  A step's results must not depend on it; they did, until
+    round 6 replaced the memset nodes of the captured graphs by kernels (csrc/common.h: dream_zero_words)."""
+    if os.environ.get("DREAM_DP_PROBE_SYNC", "") == where and torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
 class _EarlyBucket:
     """One replica's early bucket of the single-process gradient exchange (round 6; dream/network.py:244-256,335: nn.DataParallel
     reduces the replicas' gradients after the backward pass).  ``dp_parameters()[k:]`` -- for ResNet-101 everything from layer3 up,
@@ -200,16 +208,20 @@ class _SplitCapture:
     is kept alive by construction: leaf inputs (main pool) until join(), leaf outputs = the weight gradients (side pool) until
     the last main segment has packed them."""
 
-    def __init__(self, pool, leaves, device, shared_device=False):
+    def __init__(self, pool, leaves, device):
         self.pool, self.side_pool, self.leaves = pool, None, max(1, int(leaves))
         self.plan, self.cur = [], None
         from . import models
-        # The leaf segments are captured on, and replayed to, the device's LIVE second stream (the one eager steps use: a stream that
-        # is known to run beside the main stream) -- unless several replicas share the device (gpu_ids=[0, 0, 0, 0], the rehearsal on a
-        # one-GPU box): their threads replay while another thread may hold that stream in a capture (round-5 advice), so each of them
-        # gets a stream of its own.
-        live = os.environ.get("DREAM_TRAIN_GRAPH_SPLIT_STREAM", "live") == "live" and not shared_device
-        self.side = models._SideStream.live_stream(device) if live else torch.cuda.Stream(device=device)   # captures the leaf segments; replays them
+        # The leaf segments are replayed to the device's LIVE second stream (the one eager steps use: a stream that is known to run
+        # beside the main stream) and captured on the process's capture stream for leaves (captures are taken one at a time,
+        # process-wide: _capture_lock) -- never on the live stream itself: with replicas that share a device (gpu_ids=[0, 0, 0, 0], the
+        # rehearsal on a one-GPU box) another replica's thread may be replaying to it at that moment (round-5 advice).  Both are
+        # streams of the process's own (_hip.own_stream), not drawn from torch's pool of 32, where a long-running process is handed
+        # the same stream twice: a capture begun on such an alias of the live stream failed another replica's replay with
+        # "Cannot prepare for replay during capturing stage" (tools/dp_exchange_probe.py, sixth run in one process).
+        from . import _hip
+        self.side = models._SideStream.live_stream(device)               # replays the leaf segments
+        self.capture_side = _hip.own_stream(device, "capture-leaves")    # captures them
         self.mark = torch.zeros(1, device=device)               # one tiny node per main segment: never an empty graph
 
     def _begin(self):
@@ -229,7 +241,7 @@ class _SplitCapture:
         self._end()
         if fns:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.stream(self.side):
+            with torch.cuda.stream(self.capture_side):
                 if self.side_pool is None:
                     graph.capture_begin(capture_error_mode="thread_local")
                 else:
@@ -255,7 +267,8 @@ class _SplitCapture:
         torch.cuda.synchronize()
         gc.collect()
         torch.cuda.empty_cache()
-        stream = torch.cuda.Stream(device=self.mark.device)     # captures cannot be taken on the default stream
+        from . import _hip
+        stream = _hip.own_stream(self.mark.device, "capture")   # captures cannot be taken on the default stream
         stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             models._split_capture.ctl = self
@@ -587,7 +600,7 @@ class DreamDataParallel(nn.Module):
                         early = self._early_bucket(i, gflat, offsets, numels, n)      # (one backward graph: no early bucket -- an event
                         if early is not None:                                          #  recorded inside a capture cannot be waited for outside)
                             early.views = [v.view_as(p) for v, p in zip(early.views, rep.dp_parameters()[early.early_k:])]
-                        graph = _SplitCapture(entry["pool"], split, gflat.device, shared_device=devs.count(devs[i]) > 1)
+                        graph = _SplitCapture(entry["pool"], split, gflat.device)
                         graph.capture(lambda: run_and_pack(entry["saved"], entry["gos"], early))
                     else:
                         graph = torch.cuda.CUDAGraph()
@@ -655,7 +668,9 @@ class DreamDataParallel(nn.Module):
                 return self._replica_backward(i, ctxs[i], gos, flats[i], offsets, numels, n)
             return run
         with self._lock:
+            _probe_sync("backward_begin")
             earlies = self._run([job(i) for i in range(n)])
+            _probe_sync("backward_end")
             # The exchange: all-reduce(sum) over the replicas' flat gradient buffers, in place (RCCL over xGMI for distinct GPUs;
             # csrc/collective.hip).  Round 6: in TWO pieces where every replica marked its early bucket -- the tail gflat[lo:] on the
             # devices' exchange streams behind each replica's event (it overlaps what is left of the backward passes), then the head
@@ -679,18 +694,22 @@ class DreamDataParallel(nn.Module):
         xs = []
         for d in devs:                                      # one exchange stream per device (replicas that share a device share it)
             if d.index not in self._xstreams:
-                self._xstreams[d.index] = torch.cuda.Stream(device=d)
+                from . import _hip
+                self._xstreams[d.index] = _hip.own_stream(d, "exchange")
             xs.append(self._xstreams[d.index])
         mains = [torch.cuda.current_stream(d) for d in devs]
+        _probe_sync("exchange_begin")
         for x, e in zip(xs, earlies):
             x.wait_event(e.event)
         ops.allreduce_sum_([f[lo:] for f in flats], streams=xs)          # the early bucket: beside the rest of the backward passes
+        _probe_sync("exchange_mid")
         for x, m in zip(xs, mains):
             x.wait_stream(m)
         if lo > 0:
             ops.allreduce_sum_([f[:lo] for f in flats], streams=xs)      # the late bucket: behind them
         for x, m in zip(xs, mains):
             m.wait_stream(x)
+        _probe_sync("exchange_end")
         self.stats["exchanges"] = self.stats.get("exchanges", 0) + (2 if lo > 0 else 1)
 
     @staticmethod

@@ -711,7 +711,8 @@ class _SideStream:
             cls.forbid_low_priority()                  # a model that captures was not announced (DreamDataParallel.use_graphs does)
         key = (like.device.index, capturing)
         if key not in cls._streams:
-            cls._streams[key] = torch.cuda.Stream(device=like.device) if capturing else cls._new_stream(like.device)
+            from . import _hip
+            cls._streams[key] = _hip.own_stream(like.device, "capture-leaves") if capturing else cls._new_stream(like.device)
         return cls(cls._streams[key])
 
     @classmethod
@@ -749,35 +750,21 @@ class _SideStream:
 
     @staticmethod
     def _new_stream(device):
-        """DREAM_SIDE_STREAM_PRIORITY=low (opt-in): the weight-gradient stream at the LOWEST HIP stream priority (hipStreamCreateWithPriority;
-        torch.cuda.Stream only offers normal / high), so that the dispatcher prefers the main stream's dependent chain -- the step's
-        critical path -- wherever both have workgroups pending; "high": the opposite (A/B); default: a normal-priority stream."""
+        """The device's weight-gradient stream: one of the process's own HIP streams (_hip.own_stream -- not one of torch's 32 pooled
+        streams, which long-running processes see handed out twice).  DREAM_SIDE_STREAM_PRIORITY=low (opt-in): at the LOWEST HIP stream
+        priority, so that the dispatcher prefers the main stream's dependent chain -- the step's critical path -- wherever both have
+        workgroups pending; "high": the opposite (A/B); default: normal priority."""
         # "default" is the default: the low priority measured +0.4 % at 16 frames (noise level) and makes the overlap at 128 frames better but
         # still unreliable, while a low-priority stream in the process slows every replayed training GRAPH by a quarter (below) -- and
         # nothing is known about its interplay with RCCL's streams on a multi-GPU node.  Opt-in: DREAM_SIDE_STREAM_PRIORITY=low.
-        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "default")
-        if want == "low" and not _SideStream.low_priority_allowed:
-            want = "default"
-        if want == "high":
-            return torch.cuda.Stream(device=device, priority=-1)
-        if want != "low":
-            return torch.cuda.Stream(device=device)
         # Measured round 5 (profiles/r05_ab_side_stream_priority.txt, resnet_h training, one box, alternating): 16 frames 356.7 (normal) /
         # 358.0 (low) / 353.7 (high) frames/s; at 128 frames with the overlap forced the low-priority stream reaches 446-450 against the
         # in-order 434-436 -- but two early runs dropped to 300 as in round 4 and the final measurement run to 414: the threshold stays 96.
-        try:
-            import ctypes
-            hip = ctypes.CDLL("libamdhip64.so")
-            least, greatest = ctypes.c_int(0), ctypes.c_int(0)
-            with torch.cuda.device(device):
-                if hip.hipDeviceGetStreamPriorityRange(ctypes.byref(least), ctypes.byref(greatest)) != 0:
-                    raise OSError("hipDeviceGetStreamPriorityRange failed")
-                handle = ctypes.c_void_p()
-                if hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(least.value)) != 0:   # 1 = hipStreamNonBlocking
-                    raise OSError("hipStreamCreateWithPriority failed")
-            return torch.cuda.ExternalStream(handle.value, device=device)
-        except OSError:                                  # no HIP runtime library to call directly: a normal-priority torch stream
-            return torch.cuda.Stream(device=device)
+        want = os.environ.get("DREAM_SIDE_STREAM_PRIORITY", "default")
+        if want == "low" and not _SideStream.low_priority_allowed:
+            want = "default"
+        from . import _hip
+        return _hip.own_stream(device, "leaves", {"high": -1, "low": 1}.get(want, 0))
 
     def __init__(self, stream):
         self.side, self.main = stream, torch.cuda.current_stream()

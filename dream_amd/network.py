@@ -365,7 +365,8 @@ class DreamNetwork:
         entry = self._graphs.get(key)
         if entry is None or entry["state"] != state:
             static_x = x.clone()
-            side = torch.cuda.Stream()
+            from . import _hip
+            side = _hip.own_stream(x.device, "warmup")
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                   # warm-up off the capture: first-use attribute calls, weight packing
                 for _ in range(2):

@@ -54,6 +54,11 @@ const char *dream_hip_last_error(void);
 /* number of visible devices / name of device `dev` (into buf); used by smoke tests */
 int         dream_hip_device_count(int *count);
 int         dream_hip_device_name(int dev, char *buf, size_t buflen);
+/* A HIP stream of its own on device `dev` (hipStreamNonBlocking; priority: 0 normal, -1 high, 1 lowest), never destroyed.  The host
+ * side keeps a handful per device for the whole process -- the weight-gradient stream, the gradient-exchange stream, the two streams
+ * hipGraph captures are taken on -- instead of drawing from torch's pool of 32 round-robin streams per device, where the 33rd
+ * torch.cuda.Stream() of a long-running process IS the first one again (a capture begun on it would swallow another thread's replays). */
+int         dream_hip_stream_create(int dev, int priority, void **stream);
 
 /* ---- weight packing ------------------------------------------------------------------------
  * OIHW [Cout,Cin,3,3] (torch.nn.Conv2d.weight, dream/models.py:594-615,695-747) ->

@@ -1081,8 +1081,7 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, spl
     steps with DREAM_DP_GRAPHS=0 bit for bit -- same kernels, same order --, the replicas must stay identical to the master
     without a parameter copy, and a replayed step must hold the host (the GIL) for a fraction of an eager step's enqueue time.
     ``split`` = DREAM_TRAIN_GRAPH_SPLIT: "" = the default (round 6: also for multi-device steps every replica's backward is a sequence of
-    graphs, 12 leaves per segment, its leaf segments on a second stream -- data_parallel._SplitCapture, captured from four threads; the
-    replicas share device 0 here, so each has a leaf stream of its own), "8" = eight leaves per segment, "0" = one backward graph per replica."""
+    graphs, 12 leaves per segment, its leaf segments on the device's second stream -- data_parallel._SplitCapture, captured from four threads), "8" = eight leaves per segment, "0" = one backward graph per replica."""
     import time
     monkeypatch.setenv("DREAM_TRAIN_GRAPH_SPLIT", split)
     wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
@@ -1112,9 +1111,13 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, spl
     assert e.model.stats["replays"] == 0
     plans = [getattr(v["bwd"], "plan", None) for v in dp._graphs.values() if v["bwd"] is not None]
     assert len(plans) == 4 and all((p is not None and sum(op[0] == "side" for op in p) >= 3) if split != "0" else p is None for p in plans)
-    if split != "0":                                      # replicas that share a device must not share the stream their leaf segments replay on
+    if split != "0":
+        # every replica replays its leaf segments to the device's one live second stream (more busy streams than hardware queues lose
+        # the order between replayed segments on this runtime: tools/dp_exchange_probe.py) and none of them CAPTURES on it (another
+        # replica's thread may be replaying to it at that moment)
         sides = [v["bwd"].side for v in dp._graphs.values() if v["bwd"] is not None]
-        assert len({s.cuda_stream for s in sides}) == 4
+        assert len({s.cuda_stream for s in sides}) == 1
+        assert all(v["bwd"].capture_side.cuda_stream != sides[0].cuda_stream for v in dp._graphs.values() if v["bwd"] is not None)
     # the exchange (round 6): two pieces per step -- the early bucket (layer3 and up) behind each replica's event, then the rest -- wherever
     # the backward is a sequence of graphs or eager; ONE piece per step behind a single backward graph
     assert dp.stats.get("exchanges") == (8 if split != "0" else 2 + 3), dp.stats
@@ -1135,6 +1138,60 @@ def test_single_process_data_parallel_graph_replay_equals_eager(monkeypatch, spl
         ref = e.inference(x)
     for m, k in outs:
         assert torch.equal(m, ref[0]) and torch.equal(k, ref[1])
+
+
+@pytest.mark.parametrize("where", ["backward_end", "exchange_begin"])
+def test_replayed_steps_do_not_depend_on_a_device_synchronisation(monkeypatch, where):
+    """tools/dp_exchange_probe.py as a test: a device-wide synchronisation inside the replayed steps (DREAM_DP_PROBE_SYNC) changes the
+    timing and nothing else -- five ResNet training steps with gpu_ids=[0, 0, 0, 0] must reproduce the eager steps' losses bit for bit.
+    Until round 6 they did not: the memset NODES that hipMemsetAsync left in the captured graphs were not reliably ordered with the
+    kernel nodes around them on this runtime (the stride-2 1x1 data gradient then read uninitialised memory: gradients of 1e20 from
+    layer4.0 down); the library zeroes with kernels now (csrc/common.h)."""
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(8, 64, 64, seed=41)).to(DEV)
+
+    def run(graphs, sync):
+        monkeypatch.setenv("DREAM_DP_GRAPHS", "1" if graphs else "0")
+        monkeypatch.setenv("DREAM_DP_PROBE_SYNC", sync)
+        net = _dp_network("resnet_h", [0, 0, 0, 0], optimizer="adam", lr=1e-5, in_res=(64, 64), weights=wts)
+        net.enable_training()
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(8, 7, (ow, oh), in_wh=(64, 64), seed=41)).to(DEV)
+        losses = [net.train([x], t).item() for _ in range(5)]
+        torch.cuda.synchronize()
+        return losses, net
+
+    ref, _ = run(False, "")
+    got, net = run(True, where)
+    assert net.model.stats["replays"] == 4 * 2 * 4, net.model.stats
+    assert got == ref, (got, ref)
+
+
+def test_strided_data_gradient_zeroes_its_output_inside_a_graph():
+    """The stride-2 1x1 data gradient (the downsample convs of ResNet-101) writes the even positions of dx and zeroes the rest -- with a
+    KERNEL (round 6: a hipGraph memset node was not reliably ordered on this runtime).  Captured, then replayed over poisoned memory
+    with a device synchronisation in between: the odd positions are zero every time."""
+    torch.manual_seed(5)
+    cin, cout = 64, 128
+    w = torch.randn(cout, cin, 1, 1, device=DEV)
+    dy = torch.randn(2, 3, 3, cout, device=DEV)
+    packed_t, rows, _ = ops.pack_conv_weight(w, 1)
+    ref = ops.conv2d_bwd_data(dy, packed_t, cin, 1, 2, (6, 6)).clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        dx = ops.conv2d_bwd_data(dy, packed_t, cin, 1, 2, (6, 6))
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(4):
+        dx.fill_(1e20)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dx, ref)
+    assert float(ref[:, 1::2].abs().max()) == 0.0 and float(ref[:, :, 1::2].abs().max()) == 0.0 and float(ref.abs().max()) > 0.0
 
 
 def test_bucketed_exchange_through_rccl_on_one_device(monkeypatch):

@@ -15,6 +15,42 @@ except Exception as e: print('$n', 'FAILED', e)
 "; }
 withlib() { cp $PROD /tmp/lib_keep.so; cp build/lib$1.so $PROD; shift; "$@"; cp /tmp/lib_keep.so $PROD; }
 case "$1" in
+tests)
+  # the whole GPU suite + smoke() + the timing probe of the data-parallel steps
+  echo "== pytest gpu (all)"; timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
+  echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-60,100-190
+  timeout 1200 python tools/dp_exchange_probe.py 3 > $O/dp_exchange_probe.txt 2> $O/dp_exchange_probe.err; echo "probe rc=$?"; tail -1 $O/dp_exchange_probe.txt
+  ;;
+nodes)
+  # do the captured steps still hold memset / memcpy nodes?  (the runtime executes them as __amd_rocclr_* blit kernels: count those in the
+  # kernel traces of 4 and of 10 replayed steps -- the difference / 6 is what ONE replayed step holds; such nodes are not reliably ordered
+  # with the kernel nodes around them on this runtime -- tools/dp_exchange_probe.py)
+  cd /tmp
+  for w in ${2:+"resnet_h train 16" "vgg_q train 32"} "vgg_q inference 32 --graph" "resnet_h inference 16 --graph"; do
+    set -- $w
+    for k in 4 10; do
+      rm -rf /tmp/prof_nodes
+      DREAM_TRAIN_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_nodes -o t -- python $GRAFT_REPO_ROOT/bench.py --arch $1 --mode $2 --batch $3 $4 --steps $k --warmup 3 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/$O/run_$1_$2_$k.log 2>&1
+      db=$(ls /tmp/prof_nodes/*.db /tmp/prof_nodes/*/*.db 2>/dev/null | head -1)
+      python - "$db" "$w" $k <<'PY' | tee -a $GRAFT_REPO_ROOT/$O/graph_nodes.txt
+import sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+rows = list(cur.execute("select name, count(*) from kernels group by name"))
+tot = sum(n for _, n in rows)
+blit = sorted((k.split("(")[0], n) for k, n in rows if "rocclr" in k)
+print("%-28s %2s timed steps: kernels traced %6d; runtime blit kernels: %s" % (sys.argv[2], sys.argv[3], tot, blit or "none"))
+PY
+    done
+  done
+  ;;
+probe)
+  # Round 6: do the replayed data-parallel training steps depend on when the GPU runs them?  (tools/dp_exchange_probe.py; $2 = runs a setting,
+  # $3 = environment settings of the HIP runtime to try, e.g. "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0")
+  for v in ${3:-""}; do
+    echo "== env: $v"
+    env $v timeout 1200 python tools/dp_exchange_probe.py ${2:-3} > $O/dp_exchange_probe_$v.txt 2> $O/dp_exchange_probe.err; echo "rc=$?"; cut -c1-75,215- $O/dp_exchange_probe_$v.txt
+  done
+  ;;
 g6g)
   # Round 6, verdict task 2b: the single-process exchange in two pieces (early bucket behind each replica's event on an exchange stream)
   echo "== pytest"; timeout 1800 python -m pytest tests -m gpu -q -x --timeout 900 -k "data_parallel or allreduce or bucketed or one_device_training or graph" -s > $O/pytest.log 2>&1; echo "rc=$?"; tail -3 $O/pytest.log
@@ -79,7 +115,7 @@ prof16)
   summ() { db=$(ls $1/*.db $1/*/*.db 2>/dev/null | head -1); python tools/prof_summary.py "$db" "$2" $3 $4 > $O/summ.log 2>&1; echo "summary $2 rc=$?"; rm -rf "$1"; }
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_rtrain" -o rtrain -- python "$R/bench.py" --arch resnet_h --mode train --batch 16 --steps 8 --warmup 3 --no-cpu-baseline > "$R/$O/rocprof_rtrain.log" 2>&1); echo "rc=$?"
   summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 3
-  timeout 400 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_resnet_h_train16.txt; head -40 $O/layer_profile_resnet_h_train16.txt | cut -c1-200
+  timeout 400 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_resnet_h_train16.txt; head -40 $O/layer_profile_resnet_h_train16.txt | cut -c1-60,100-190
   cat $O/bench_resnet_h_train16_concurrency.txt
   ;;
 rehearse8)
@@ -261,7 +297,7 @@ diag)
   ;;
 lp)
   for cfg in "vgg_q train 128" "resnet_h train 16" "resnet_h infer 128"; do set -- $cfg
-    timeout 400 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -12 $O/layer_profile_$1_$2$3.txt | cut -c1-200
+    timeout 400 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -12 $O/layer_profile_$1_$2$3.txt | cut -c1-60,100-190
   done
   ;;
 tg)
@@ -348,7 +384,7 @@ tg7)
 suite)
   # the whole GPU suite + smoke() on the last tree, then leaves per segment of the split graphs (8 / 12) against eager
   echo "== pytest gpu (all)"; timeout 450 python -m pytest tests -m gpu -q --timeout 200 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
-  echo "== smoke"; timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log | cut -c1-200
+  echo "== smoke"; timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/smoke.log | cut -c1-60,100-190
   export LINE_TIMEOUT=60
   R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
   line eager_a $R
@@ -408,13 +444,13 @@ final)
   lraw() { n=$1; shift; timeout 600 python bench.py "$@" --no-cpu-baseline --no-secondary > $O/bench_$n.log 2>&1; tail -1 $O/bench_$n.log | cut -c1-160; }
   if [ "$2" != "notests" ]; then
     echo "== pytest gpu (all)"; timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log; grep -E "^FAILED|^ERROR" $O/pytest_gpu.log | head
-    echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-200
+    echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-60,100-190
   fi
   echo "== rehearsals on this one GPU (the numbers mean nothing)"
-  DREAM_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 --secondary-steps 2 --secondary-train-steps 3 > $O/rehearsal_8ranks_gloo.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_8ranks_gloo.log | cut -c1-200
-  DREAM_BENCH_GPU_IDS=0,0,0,0,0,0,0,0 timeout 900 python bench.py --gpus 8 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 128 --no-cpu-baseline > $O/rehearsal_single_process_8replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_8replicas_train.log | cut -c1-200
-  DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 6 --warmup 3 --global-batch 64 --no-cpu-baseline > $O/rehearsal_single_process_4replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_4replicas_train.log | cut -c1-200
-  echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline --no-secondary > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; grep -h '^{"metric' $O/rocprof_default.log | cut -c1-200
+  DREAM_BENCH_BACKEND=gloo timeout 1500 python bench.py --gpus 8 --steps 2 --warmup 1 --secondary-steps 2 --secondary-train-steps 3 > $O/rehearsal_8ranks_gloo.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_8ranks_gloo.log | cut -c1-60,100-190
+  DREAM_BENCH_GPU_IDS=0,0,0,0,0,0,0,0 timeout 900 python bench.py --gpus 8 --single-process --arch resnet_h --mode train --steps 4 --warmup 3 --global-batch 128 --no-cpu-baseline > $O/rehearsal_single_process_8replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_8replicas_train.log | cut -c1-60,100-190
+  DREAM_BENCH_GPU_IDS=0,0,0,0 timeout 600 python bench.py --gpus 4 --single-process --arch resnet_h --mode train --steps 6 --warmup 3 --global-batch 64 --no-cpu-baseline > $O/rehearsal_single_process_4replicas_train.log 2>&1; echo "rc=$?"; tail -1 $O/rehearsal_single_process_4replicas_train.log | cut -c1-60,100-190
+  echo "== rocprof default bench (kernel trace)"; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d "$R/$O/prof_default" -o dflt -- python "$R/bench.py" --no-cpu-baseline --no-secondary > "$R/$O/rocprof_default.log" 2>&1); echo "rc=$?"; grep -h '^{"metric' $O/rocprof_default.log | cut -c1-60,100-190
   summ $O/prof_default $O/bench_default peaks_kernel 2
   for C in FETCH_SIZE WRITE_SIZE; do
     echo "== pmc $C"; (cd /tmp && DREAM_BENCH_PMC_CALIBRATE=1 timeout 600 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_$C" -o pmc -- python "$R/bench.py" --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > "$R/$O/pmc_$C.log" 2>&1); echo "rc=$?"
@@ -462,7 +498,7 @@ for k,v in d.items(): print(k, {a: round(b,3) for a,b in v.items() if a in ('mfm
   summ $O/prof_rtrain $O/bench_resnet_h_train16 adam_kernel 3
   echo "== layer profiles"
   for cfg in "resnet_h train 16" "vgg_q infer 128" "vgg_q train 128" "resnet_f infer 32"; do set -- $cfg
-    timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-200
+    timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-60,100-190
   done
   echo "== microbenches"; timeout 300 python tools/microbench_wino4.py --batch 128 2>&1 | grep -v amdgpu.ids > $O/microbench_wino4_b128.txt; tail -1 $O/microbench_wino4_b128.txt
   timeout 300 python tools/microbench_gemm_forms.py --shapes layer3 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/microbench_gemm_forms.txt; tail -3 $O/microbench_gemm_forms.txt
