@@ -40,6 +40,7 @@ struct GemmParams {
     int M, K, N, NPad, x_stride;
     int nrb, ncb;            // 64-row / 64-column blocks
     int flags;               // DREAM_CONV_RELU
+    int prio_round;          // > 0: workgroups per dispatch round (one per CU); round r of a launch runs at wave priority 3 - r (below)
     // ---- train-mode BatchNorm folded into this GEMM (dream/models.py:22-32: conv -> BatchNorm2d -> ReLU chains of the Bottlenecks)
     // PRE: the A operand is relu(a[k] * x + b[k]) -- the PREVIOUS BatchNorm + ReLU applied in the loader, its output never stored
     const float *pre_ab;     // [2][K]: a then b
@@ -103,6 +104,17 @@ __global__ void __launch_bounds__(256, MB == 4 ? (KS == 1 ? 3 : 2) : 4) gemm1x1_
     const int kpart = wave % KS;
     const bool live = tile < p.nrb * p.ncb;
     if (KS == 1 && !live) return;
+    // De-phasing (round 6).  The two or three wavefronts a SIMD holds come from workgroups that were dispatched within microseconds of
+    // each other: they run their K loops side by side, sharing the matrix pipe, and then reach their epilogues -- 64 rows x up to three
+    // 16-byte operand loads + a store per lane, no MFMA -- TOGETHER, with the pipe idle.  Wave priorities by dispatch round (the first
+    // 256 workgroups of a launch land one per CU, the next 256 beside them, ...) let the first round's wave win the pipe, so that it
+    // finishes its K loop early and its epilogue runs under the second round's MFMAs, and so on.
+    if (p.prio_round > 0) {
+        const int round = (int)blockIdx.x / p.prio_round;
+        if (round == 0) __builtin_amdgcn_s_setprio(3);
+        else if (round == 1) __builtin_amdgcn_s_setprio(2);
+        else if (round == 2) __builtin_amdgcn_s_setprio(1);
+    }
     const int cb = tile % p.ncb, rb = tile / p.ncb;
     const int li = lane & 15, lg = lane >> 4;
 
@@ -568,6 +580,8 @@ int gemm1x1_launch(GemmParams p, long M, int K, int N, int x_stride, bool pre, i
     DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
     const int per_wg = 4 / ks;
     const unsigned grid = (unsigned)(((tiles + per_wg - 1) / per_wg + 7) / 8 * 8);
+    static const int env_prio = [] { const char *e = getenv("DREAM_G1_PRIO"); return e ? atoi(e) : 0; }();       // A/B: workgroups per priority round
+    p.prio_round = env_prio;
     return rows == 64 ? gemm1x1_launch_form<4>(p, ks, grid, pre, epi, stream) : gemm1x1_launch_form<2>(p, ks, grid, pre, epi, stream);
 }
 

@@ -21,6 +21,18 @@ tests)
   echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-60,100-190
   timeout 1200 python tools/dp_exchange_probe.py 3 > $O/dp_exchange_probe.txt 2> $O/dp_exchange_probe.err; echo "probe rc=$?"; tail -1 $O/dp_exchange_probe.txt
   ;;
+g6h)
+  # Round 6: wave priorities by dispatch round in the 1x1 GEMMs (de-phasing K loops and epilogues of the wavefronts a SIMD holds)
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_G1_PRIO=0 line prio0_$r $R
+    DREAM_G1_PRIO=256 line prio256_$r $R
+    DREAM_G1_PRIO=128 line prio128_$r $R
+    DREAM_G1_PRIO=512 line prio512_$r $R
+  done
+  DREAM_G1_PRIO=0 timeout 300 python tools/microbench_gemm_forms.py --shapes layer3 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/forms_prio0.txt; tail -14 $O/forms_prio0.txt
+  DREAM_G1_PRIO=256 timeout 300 python tools/microbench_gemm_forms.py --shapes layer3 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/forms_prio256.txt; tail -14 $O/forms_prio256.txt
+  ;;
 nodes)
   # do the captured steps still hold memset / memcpy nodes?  (the runtime executes them as __amd_rocclr_* blit kernels: count those in the
   # kernel traces of 4 and of 10 replayed steps -- the difference / 6 is what ONE replayed step holds; such nodes are not reliably ordered
