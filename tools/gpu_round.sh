@@ -21,17 +21,14 @@ tests)
   echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-60,100-190
   timeout 1200 python tools/dp_exchange_probe.py 3 > $O/dp_exchange_probe.txt 2> $O/dp_exchange_probe.err; echo "probe rc=$?"; tail -1 $O/dp_exchange_probe.txt
   ;;
-g6h)
-  # Round 6: wave priorities by dispatch round in the 1x1 GEMMs (de-phasing K loops and epilogues of the wavefronts a SIMD holds)
-  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
-  for r in a b c; do
-    DREAM_G1_PRIO=0 line prio0_$r $R
-    DREAM_G1_PRIO=256 line prio256_$r $R
-    DREAM_G1_PRIO=128 line prio128_$r $R
-    DREAM_G1_PRIO=512 line prio512_$r $R
+lp)
+  # layer profiles with queued event pairs (no launch latency inside the measurements) against the per-call synchronisation of rounds 2-6
+  for t in queued sync; do
+    timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 45 --timing $t 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_resnet_h_train16_$t.txt; head -16 $O/layer_profile_resnet_h_train16_$t.txt | cut -c1-120
   done
-  DREAM_G1_PRIO=0 timeout 300 python tools/microbench_gemm_forms.py --shapes layer3 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/forms_prio0.txt; tail -14 $O/forms_prio0.txt
-  DREAM_G1_PRIO=256 timeout 300 python tools/microbench_gemm_forms.py --shapes layer3 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/forms_prio256.txt; tail -14 $O/forms_prio256.txt
+  for cfg in "vgg_q infer 128" "vgg_q train 128" "resnet_f infer 32"; do set -- $cfg
+    timeout 300 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 45 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -3 $O/layer_profile_$1_$2$3.txt | cut -c1-120
+  done
   ;;
 nodes)
   # do the captured steps still hold memset / memcpy nodes?  (the runtime executes them as __amd_rocclr_* blit kernels: count those in the
@@ -306,11 +303,6 @@ keep)
   ;;
 diag)
   DREAM_W4_DIAG_KS=${2:-128,256,15,2,16,8} timeout 600 python tools/wino4_diag.py run --batch 128 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/wino4_diag.txt
-  ;;
-lp)
-  for cfg in "vgg_q train 128" "resnet_h train 16" "resnet_h infer 128"; do set -- $cfg
-    timeout 400 python tools/layer_profile.py --arch $1 --mode $2 --batch $3 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_$1_$2$3.txt; head -12 $O/layer_profile_$1_$2$3.txt | cut -c1-60,100-190
-  done
   ;;
 tg)
   # the one-device training step as two hipGraph replays (DREAM_TRAIN_GRAPH=1) against the eager step, on the round's last tree

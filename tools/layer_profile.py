@@ -68,7 +68,14 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--res", type=int, default=400)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--timing", choices=("queued", "sync"), default="queued",
+                    help="queued (default): the step runs IN ORDER on one stream (DREAM_OVERLAP_WGRAD=0) with an event pair around every operator "
+                         "call and ONE synchronisation per step -- the host stays ahead, so a pair brackets the call's kernels (plus the gap to the "
+                         "previous kernel) and nothing of the launch path; sync: a synchronisation after every call (rounds 2-6: every call then "
+                         "carries its own launch latency, 10-25 us -- a third of a 60-us GEMM)")
     a = ap.parse_args()
+    if a.timing == "queued":
+        os.environ["DREAM_OVERLAP_WGRAD"] = "0"
 
     sys.argv = sys.argv[:1]
     import bench
@@ -89,16 +96,27 @@ def main():
             finally:
                 state["depth"] = 0
             e1.record()
-            e1.synchronize()
             shapes = tuple(tuple(x.shape) for x in args if torch.is_tensor(x))[:2]
             ints = tuple(x for x in args if isinstance(x, int) and not isinstance(x, bool))[:4]
             key = (name, shapes, ints)
             rec = table.setdefault(key, [0, 0.0, 0.0])
             rec[0] += 1
-            rec[1] += e0.elapsed_time(e1)
             rec[2] += flops_of(name, args, out)
+            if a.timing == "sync":
+                e1.synchronize()
+                rec[1] += e0.elapsed_time(e1)
+            else:
+                queued.append((rec, e0, e1))
             return out
         return timed
+
+    queued = []
+
+    def resolve():
+        torch.cuda.synchronize()
+        for rec, e0, e1 in queued:
+            rec[1] += e0.elapsed_time(e1)
+        del queued[:]
 
     skip = {"round_up", "bump_version", "wgrad_winograd_pays", "new_amax", "conv1x1_applies", "conv1x1_wgrad_applies", "bn_counter_buffer"}
     for name in dir(ops):
@@ -147,7 +165,7 @@ def main():
     state["on"] = True
     for _ in range(a.steps):
         step()
-    torch.cuda.synchronize()
+        resolve()
     state["on"] = False
 
     rows = sorted(table.items(), key=lambda kv: -kv[1][1])
@@ -157,7 +175,8 @@ def main():
         by_op[name][0] += v[0]
         by_op[name][1] += v[1]
         by_op[name][2] += v[2]
-    print("%s %s b=%d: %.2f ms/step inside dream_amd.ops (synchronised calls)" % (a.arch, a.mode, a.batch, total))
+    print("%s %s b=%d: %.2f ms/step inside dream_amd.ops (%s)" % (a.arch, a.mode, a.batch, total,
+          "in order on one stream, event pairs, one synchronisation per step" if a.timing == "queued" else "a synchronisation after every call"))
     print("-- by operator")
     for name, v in sorted(by_op.items(), key=lambda kv: -kv[1][1]):
         tf = v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 and v[2] > 0 else 0.0
