@@ -76,6 +76,7 @@ _SIGNATURES = {
     "dream_maxpool3s2_idx_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_maxpool3s2_idx_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_add_inplace_f32": (_I, [_P, _P, _SZ, _P]),
+    "dream_copy_f32": (_I, [_P, _P, _SZ, _P]),
     "dream_copy_chunk_bytes": (_SZ, []),
     "dream_multi_copy_f32": (_I, [_P, _P, _I, _P]),
     "dream_allreduce_sum_f32": (_I, [_I, _c.POINTER(_I), _c.POINTER(_P), _SZ, _c.POINTER(_P)]),
@@ -117,6 +118,8 @@ _SIGNATURES = {
     "dream_conv3x3_winograd4_pool_both_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dream_pack_job_bytes": (_SZ, []),
     "dream_pack_weights_batched": (_I, [_P, _I, _I, _P]),
+    "dream_pack_span_bytes": (_SZ, []),
+    "dream_pack_weights_spans": (_I, [_P, _P, _I, _P]),
     "dream_convT4x4_winograd_weight_floats": (_SZ, [_I, _I]),
     "dream_pack_convT4x4_winograd_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "dream_conv4x4s2_winograd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -811,6 +811,10 @@ int dream_copy_words(void *dst, const void *src, size_t nbytes, hipStream_t stre
     return 0;
 }
 
+extern "C" int dream_copy_f32(float *dst, const float *src, size_t n, void *stream) {
+    DREAM_REQUIRE(dst && src, "copy: null pointer");
+    return dream_copy_words(dst, src, n * sizeof(float), (hipStream_t)stream) ? 2 : 0;
+}
 extern "C" int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream) {
     DREAM_REQUIRE(dst && src, "add_inplace: null pointer");
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dst, src, n);

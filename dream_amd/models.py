@@ -465,7 +465,7 @@ class DreamHourglass(nn.Module):
                 g = ops.maxpool2_bwd(g, inp, relu=masked)
                 continue
             if kind == "add":
-                pending[flags] = g.clone()                 # later in-place ReLU masks must not touch this copy
+                pending[flags] = ops.clone(g)              # later in-place ReLU masks must not touch this copy
                 masked = False
                 continue
             pi -= 2
@@ -1046,7 +1046,7 @@ class DreamHourglassMultiStage(nn.Module):
             if g is None:
                 g = carry
             elif carry is not None:
-                g = ops.add_(g.contiguous().clone(), carry)
+                g = ops.add(g.contiguous(), carry)[0]
             if s > 0:
                 per_stage[s], g_in = stages[s].run_backward(saved[s], g.contiguous(), need_input_grad=True, reducer=reducer)
                 b, h, w, c = (int(v) for v in g_in.shape)
@@ -1238,9 +1238,15 @@ class ResnetSimple(nn.Module):
             st["keys"] = list(st["records"].items())
             descs = [d for _, (_, _, ds) in st["keys"] for d in ds]
             st["table"], st["njobs"] = ops.pack_job_table(descs, first.device), len(descs)
+            # the launch's workgroups by job size (round 6): the decoder's 2048 -> 256 transposed conv is 19 M packed floats, a 64 x 64 1x1 conv
+            # 4 K -- with 16 workgroups each the large jobs set the launch's length (0.50 ms; DREAM_PACK_SPANS=0 restores that)
+            st["spans"] = ops.pack_span_table(descs, first.device) if os.environ.get("DREAM_PACK_SPANS", "1") != "0" else None
         tags = {key: tuple((t._version, t.data_ptr()) for t in tensors) for key, (tensors, _, _) in st["keys"]}
         if any(self._cache.get(key, (None,))[0] != tag or self._cache[key][1] is not st["records"][key][1] for key, tag in tags.items()):
-            ops.pack_weights_batched(st["table"], st["njobs"])
+            if st.get("spans") is not None:
+                ops.pack_weights_spans(st["table"], st["spans"][0], st["spans"][1])
+            else:
+                ops.pack_weights_batched(st["table"], st["njobs"])
             for key, tag in tags.items():
                 self._cache[key] = (tag, st["records"][key][1])
 

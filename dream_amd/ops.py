@@ -63,6 +63,25 @@ def pack_weights_batched(table, njobs, workgroups_per_job=16):
     call("dream_pack_weights_batched", ptr(table), int(njobs), int(workgroups_per_job), stream())
 
 
+def pack_span_table(descs, device, floats_per_workgroup=1 << 15, max_parts=512):
+    """Device-resident dream_pack_span table for pack_weights_spans: the workgroups of the one launch dealt out by the size of each job's
+    packed copy (one per ``floats_per_workgroup`` floats, at least one) -> (table, number of workgroups)."""
+    import numpy as np
+    dt = np.dtype([("job", np.int32), ("part", np.int32), ("nparts", np.int32), ("reserved", np.int32)])
+    if int(_hip.lib().dream_pack_span_bytes()) != dt.itemsize:
+        raise RuntimeError("dream_pack_span layout mismatch")
+    rows = []
+    for job, d in enumerate(descs):
+        nparts = max(1, min(int(max_parts), -(-int(d[2].numel()) // int(floats_per_workgroup))))
+        rows.extend((job, part, nparts, 0) for part in range(nparts))
+    arr = np.array(rows, dtype=dt)
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(rows)
+
+
+def pack_weights_spans(table, spans, nspans):
+    call("dream_pack_weights_spans", ptr(table), ptr(spans), int(nspans), stream())
+
+
 class MultiCopyPlan:
     """Gathers a fixed list of fp32 tensors into fixed views of one flat buffer with ONE launch per call (csrc/elementwise.hip,
     dream_multi_copy_f32) -- what ``torch._foreach_copy_(views, tensors)`` does with one hipMemcpyAsync per tensor.  The
@@ -1168,6 +1187,15 @@ def maxpool3s2_bwd(dy, x):
     dx = torch.empty_like(x)
     call("dream_maxpool3s2_bwd_nhwc_f32", ptr(_f32(dy)), ptr(x), ptr(dx), b, h, w, c, stream())
     return dx
+
+
+def clone(t):
+    """``t.clone()`` by a kernel launch: a copy that stays a KERNEL node when the caller is being captured into a hipGraph (ATen's copy of
+    a contiguous tensor is a hipMemcpyAsync -> a memcpy node; see dream_copy_f32 in include/dream_hip.h)."""
+    src = _f32(t)
+    out = torch.empty_like(src)
+    call("dream_copy_f32", ptr(out), ptr(src), src.numel(), stream())
+    return out
 
 
 def add_(dst, src):

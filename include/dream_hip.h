@@ -164,6 +164,14 @@ typedef struct dream_pack_job {
 } dream_pack_job;
 size_t dream_pack_job_bytes(void);
 int dream_pack_weights_batched(const dream_pack_job *jobs_device, int njobs, int workgroups_per_job, void *stream);
+/* the same with the workgroups dealt out by SIZE (round 6): spans: DEVICE array, one entry per workgroup -- workgroup i runs part `part` of
+ * `nparts` of job `job`.  With a fixed number of workgroups per job the decoder's 2048 -> 256 transposed conv (19 M packed floats) ran on
+ * as many workgroups as a 64 x 64 1x1 conv and set the launch's length (0.50 ms for ResNet-101 + decoder; by size: see DESIGN.md 4.9). */
+typedef struct dream_pack_span {
+    int job, part, nparts, reserved;
+} dream_pack_span;
+size_t dream_pack_span_bytes(void);
+int dream_pack_weights_spans(const dream_pack_job *jobs_device, const dream_pack_span *spans_device, int nspans, void *stream);
 /* nn.ConvTranspose2d(k4,s2,p1) (+ folded BatchNorm / bias, ReLU) of the ResNet decoder (dream/models.py:37-136) by minimal
  * filtering on the Winograd kernel: each output phase is a 2x2-tap conv = a 3x3 conv whose transformed weights vanish on 7 of
  * the 16 positions: 9 multiplications per 2x2 outputs of a phase instead of 16, same fp32 arithmetic.  x [B,H,W,Cin] ->
@@ -520,6 +528,10 @@ size_t dream_copy_chunk_bytes(void);
 int dream_multi_copy_f32(const void *srcs, const void *chunks, int nchunks, void *stream);
 /* dst += src (gradient accumulation where two branches meet) */
 int dream_add_inplace_f32(float *dst, const float *src, size_t n, void *stream);
+/* dst[i] = src[i] with a kernel launch -- `tensor.clone()` for code that may be captured into a hipGraph (ATen copies contiguous tensors
+ * with hipMemcpyAsync, which becomes a memcpy NODE there; round 6 found a replayed memset node out of order on this runtime and the
+ * captured steps hold kernel nodes only since): the gradient copies at the skip connections / between the stages of dream/models.py:774-827 */
+int dream_copy_f32(float *dst, const float *src, size_t n, void *stream);
 
 /* ---- gradient exchange of the single-process data-parallel path (SURVEY.md 8b "allreduce_grads", 8e; what
  * torch.nn.DataParallel's ReduceAddCoalesced + the next forward's parameter broadcast do for dream/network.py:244-256,335) ----

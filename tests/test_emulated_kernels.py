@@ -408,6 +408,13 @@ def test_batched_weight_packing(emu):
             jobs.append((kind, wT, out[ph * per:(ph + 1) * per], d[3], d[4], d[5]))
             singles.append(ref[ph * per:(ph + 1) * per])
     table = ops.pack_job_table(jobs, "cpu")
+    spans, nspans = ops.pack_span_table(jobs, "cpu", floats_per_workgroup=1 << 12)          # workgroups by job size (round 6): same bits
+    assert nspans > len(jobs)
+    poisoned = [j[2].clone() for j in jobs]
+    ops.pack_weights_spans(table, spans, nspans)
+    for (kind, w, out, cout, cin, mode), ref, before in zip(jobs, singles, poisoned):
+        assert torch.equal(out, ref), (kind, cout, cin, mode)
+        out.copy_(before)
     ops.pack_weights_batched(table, len(jobs), workgroups_per_job=3)
     for (kind, w, out, cout, cin, mode), ref in zip(jobs, singles):
         assert torch.equal(out, ref), (kind, cout, cin, mode)

@@ -1194,6 +1194,33 @@ def test_strided_data_gradient_zeroes_its_output_inside_a_graph():
     assert float(ref[:, 1::2].abs().max()) == 0.0 and float(ref[:, :, 1::2].abs().max()) == 0.0 and float(ref.abs().max()) > 0.0
 
 
+def test_clone_by_kernel_any_length_and_alignment():
+    """ops.clone (dream_copy_f32: the kernel that stands where ATen would leave a memcpy node in a captured graph): every length, and
+    sources / destinations that are not 16-byte aligned (views that start one element into their storage)."""
+    torch.manual_seed(9)
+    for n in (1, 3, 4, 5, 255, 1024, 4097, (1 << 20) + 3):
+        base = torch.randn(n + 1, device=DEV)
+        for src in (base[:n], base[1:]):
+            out = ops.clone(src)
+            assert out.data_ptr() != src.data_ptr() and torch.equal(out, src)
+    graph = torch.cuda.CUDAGraph()
+    src = torch.randn(3, 5, 7, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph.capture_begin()
+        out = ops.clone(src)
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        src.normal_()
+        out.fill_(7.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, src)
+
+
 def test_bucketed_exchange_through_rccl_on_one_device(monkeypatch):
     """DREAM_FORCE_RCCL=1 (round 6): a one-device step runs the gradient exchange of the single-process multi-GPU path THROUGH RCCL (a
     one-rank communicator: dlopen, ncclCommInitAll, group calls) -- in two pieces per step: the early bucket on the exchange stream behind

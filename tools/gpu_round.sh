@@ -21,6 +21,24 @@ tests)
   echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log | cut -c1-60,100-190
   timeout 1200 python tools/dp_exchange_probe.py 3 > $O/dp_exchange_probe.txt 2> $O/dp_exchange_probe.err; echo "probe rc=$?"; tail -1 $O/dp_exchange_probe.txt
   ;;
+g6i)
+  # Round 6: the one-launch weight re-pack with its workgroups dealt out by job size (DREAM_PACK_SPANS=0: 16 per job as before)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "clone or pack or variant or ms2 or skip or golden or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_PACK_SPANS=0 line spans0_$r $R
+    line spans1_$r $R
+  done
+  DREAM_PACK_SPANS=0 line rf32_spans0 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  line rf32_spans1 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_pack -o t -- python $GRAFT_REPO_ROOT/bench.py $R --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/$O/rocprof.log 2>&1)
+  python - $(ls /tmp/prof_pack/*.db /tmp/prof_pack/*/*.db 2>/dev/null | head -1) <<'PY' | tee $O/pack_kernels.txt
+import sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+for name, n, tot, mn in cur.execute("select name, count(*), sum(duration), min(duration) from kernels where name like '%pack%' group by name"):
+    print("%-90s launches %4d  avg %8.1f us  min %8.1f us" % (name.split("(")[0][-90:], n, tot / n / 1e3, mn / 1e3))
+PY
+  ;;
 lp)
   # layer profiles with queued event pairs (no launch latency inside the measurements) against the per-call synchronisation of rounds 2-6
   for t in queued sync; do
