@@ -1135,6 +1135,8 @@ class ResnetSimple(nn.Module):
         # WINO_STAT) -- 66 launches fewer per ResNet-101 step; measured round 5 (profiles/r05_ab_bn_fusion_3x3.txt, alternating on one
         # box): 350.4 -> 358.5 frames/s at 16 frames (+2.3 %), so on by default; "0" = the stand-alone bn_stats / bn_bwd_stats passes
         self.bn_fusion_3x3 = os.environ.get("DREAM_BN_FUSION_3X3", "1") == "1"
+        # ... and (round 6) the last decoder BatchNorm's in the head conv's data gradient (run_backward_fused, "final")
+        self.bn_fusion_head = os.environ.get("DREAM_BN_FUSION_HEAD", "1") == "1"
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
@@ -1713,8 +1715,26 @@ class ResnetSimple(nn.Module):
                 def leaf(m=m, x=rec["x"], gy=gy, cout=cout, cin=cin):
                     grads[m.weight], grads[m.bias] = ops.conv2d_wgrad(x, gy, cout, cin, 1, 1, 0, want_bias=True)
                 _on_side(side, leaf, rec["x"], gy)
-                packed_t, rows, _ = self._packed_w(rec["name"], m, 1)
-                g = ops.conv2d(gy, packed_t, rows, 1, 1)
+                prev = tape[idx - 1] if idx >= 1 else None
+                if (self.bn_fusion_head and prev is not None and prev["kind"] == "convT" and prev["y"] is rec["x"] and prev.get("ab") is not None
+                        and self.conv1x1_algorithm == "gemm" and int(m.kernel_size[0]) == 1 and cin % 64 == 0
+                        and tuple(prev["z"].shape) == tuple(gy.shape[:3]) + (cin,) and prev["z"].numel() < (1 << 29)):
+                    # Round 6: the head's data gradient on the 1x1 GEMM with the LAST decoder BatchNorm's ReLU mask and its two backward sums
+                    # in the epilogue (the trunk's form, conv1x1_bwd_bnmask): one launch instead of the direct conv + the stand-alone
+                    # reduction pass over two 16 x 208 x 208 x 256 tensors.  The contraction is the K = 7 (17) keypoint channels, zero-padded
+                    # to the GEMM's 32.
+                    kp = ops.round_up(cout, 32)
+                    gy32 = gy if int(gy.shape[3]) == kp else ops.nchw_to_nhwc(grad_out_nchw, cpad=kp)
+                    def build(m=m, kp=kp, cout=cout, cin=cin):
+                        w2 = m.weight.detach().reshape(cout, cin)
+                        return ops.pack_conv1x1_weight(torch.cat([w2, w2.new_zeros((kp - cout, cin))]).reshape(kp, cin, 1, 1), 1)
+                    packed_t, _ = self._cached(("g1h", rec["name"]), [m.weight], build)
+                    gmask, dgh, dbh = ops.conv1x1_bwd_bnmask(gy32, packed_t, cin, prev["z"], prev["ab"], prev["mean"], prev["invstd"],
+                                                             self._ctr(gy32.device), y_act=prev["y"])
+                    g = ("masked", gmask, dgh, dbh)
+                else:
+                    packed_t, rows, _ = self._packed_w(rec["name"], m, 1)
+                    g = ops.conv2d(gy, packed_t, rows, 1, 1)
             elif kind == "convT":
                 m, bn = rec["conv"], rec["bn"]
                 dz, _, dgam, dbet = self._bn_bwd_fused(rec, g)

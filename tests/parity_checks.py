@@ -1302,6 +1302,8 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
     # ---- the 1x1 conv with the BatchNorm on either side folded in --------------------------------------------------------------------
     for (B, H, W, Cin, Cout, with_pre, with_bias) in [(2, 9, 11, 64, 96, True, False), (1, 13, 13, 128, 256, True, True),
                                                       (3, 5, 5, 256, 64, False, False), (2, 7, 6, 32, 160, True, False),
+                                                      (2, 9, 11, 64, 32, True, True),           # 32 output channels: the data gradient contracts over K = 32
+                                                                                                 # (the head conv's zero-padded keypoint channels, round 6)
                                                       (3, 33, 41, 64, 64, True, False),         # 64 row blocks: both levels of the ticket tree
                                                       (4, 65, 66, 32, 64, True, False)]:        # 269 row blocks: groups of 17 rows (> one round trip)
         bn_p, bn_p2 = make_bn(Cin)

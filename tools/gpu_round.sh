@@ -39,6 +39,19 @@ for name, n, tot, mn in cur.execute("select name, count(*), sum(duration), min(d
     print("%-90s launches %4d  avg %8.1f us  min %8.1f us" % (name.split("(")[0][-90:], n, tot / n / 1e3, mn / 1e3))
 PY
   ;;
+g6j)
+  # Round 6: the last decoder BatchNorm's masked backward sums in the head conv's data gradient (DREAM_BN_FUSION_HEAD=0: stand-alone pass)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "resnet or conv1x1 or bn" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_BN_FUSION_HEAD=0 line head0_$r $R
+    line head1_$r $R
+  done
+  DREAM_BN_FUSION_HEAD=0 line rt128_head0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  line rt128_head1 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  DREAM_BN_FUSION_HEAD=0 line rf32_head0 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  line rf32_head1 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  ;;
 lp)
   # layer profiles with queued event pairs (no launch latency inside the measurements) against the per-call synchronisation of rounds 2-6
   for t in queued sync; do
