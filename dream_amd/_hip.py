@@ -104,6 +104,7 @@ _SIGNATURES = {
     "dream_conv1x1_wgrad_nhwc_f32": (_I, [_P, _P, _P, _P, _c.c_long, _I, _I, _I, _P]),
     "dream_pack_conv1x1_weight": (_I, [_P, _P, _I, _I, _I, _P]),
     "dream_conv1x1_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _P, _c.c_long, _I, _I, _I, _I, _P]),
+    "dream_conv1x1_pre_nhwc_f32": (_I, [_P, _P, _P, _P, _P, _c.c_long, _I, _I, _I, _P]),
     "dream_conv3x3_winograd_weight_floats": (_SZ, [_I, _I]),
     "dream_conv3x3_winograd_set_variant": (_I, [_I]),
     "dream_conv3x3_winograd_set_max_workgroups": (_I, [_I]),

@@ -546,6 +546,7 @@ int gemm1x1_launch_ks(const GemmParams &p, int ks, unsigned grid, void *stream) 
 
 template <int MB>
 int gemm1x1_launch_form(const GemmParams &p, int ks, unsigned grid, bool pre, int epi, void *stream) {
+    if (epi == 0 && pre) return gemm1x1_launch_ks<true, 0, false, MB>(p, ks, grid, stream);          // (the head conv behind the last decoder BatchNorm)
     if (epi == 0) return p.residual != nullptr ? gemm1x1_launch_ks<false, 0, true, MB>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 0, false, MB>(p, ks, grid, stream);
     if (epi == 1) return pre ? gemm1x1_launch_ks<true, 1, false, MB>(p, ks, grid, stream) : gemm1x1_launch_ks<false, 1, false, MB>(p, ks, grid, stream);
     return gemm1x1_launch_ks<false, 2, false, MB>(p, ks, grid, stream);
@@ -633,6 +634,20 @@ extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, con
     p.x = x; p.w = w_packed; p.scale = scale; p.shift = shift; p.residual = residual; p.y = y;
     p.flags = flags;
     return gemm1x1_launch(p, M, K, N, x_stride, false, 0, stream);
+}
+
+// y = relu(pre_ab[0][k] * x + pre_ab[1][k]) . w^T + shift: the conv behind a train-mode BatchNorm + ReLU whose output is never stored
+// (round 6: the head conv of the ResNet decoder, dream/models.py:37-136 -- 256 channels -> the keypoint maps; N = their count rounded up to 4)
+extern "C" int dream_conv1x1_pre_nhwc_f32(const float *x, const float *w_packed, const float *pre_ab, const float *shift, float *y, long M,
+                                          int K, int N, int x_stride, void *stream) {
+    DREAM_REQUIRE(x && w_packed && pre_ab && y, "conv1x1_pre: null pointer");
+    DREAM_REQUIRE(M > 0 && K > 0 && N > 0 && x_stride >= K, "conv1x1_pre: bad shape M=%ld K=%d N=%d stride=%d", M, K, N, x_stride);
+    DREAM_REQUIRE(K % 32 == 0 && N % 4 == 0 && x_stride % 4 == 0, "conv1x1_pre: K %% 32, N %% 4, stride %% 4 (got %d, %d, %d)", K, N, x_stride);
+    DREAM_REQUIRE((size_t)M * (size_t)x_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
+                  "conv1x1_pre: tensor too large for 32-bit offsets");
+    GemmParams p = {};
+    p.x = x; p.w = w_packed; p.shift = shift; p.y = y; p.pre_ab = pre_ab;
+    return gemm1x1_launch(p, M, K, N, x_stride, true, 0, stream);
 }
 
 // ---- the same GEMM with a train-mode BatchNorm folded in on either side (see GemmParams) ---------------------------------------

@@ -1668,10 +1668,28 @@ class ResnetSimple(nn.Module):
                         packed, cout = self._cached(("w", name), [m.weight], lambda m=m: ops.pack_convT4x4_weight(m.weight.detach()))
                         z = ops.conv_transpose4x4s2(y, packed, cout, None, m.bias.detach(), 0)
                     ab, mean, invstd = ops.bn_stats(z, bn, self._ctr(z.device))
-                    y2 = ops.bn_apply_ab(z, ab, None, True)
+                    # Round 6: the LAST decoder layer's normalised activation is consumed by the head conv only -- which applies the
+                    # BatchNorm + ReLU in its loader (and so do its weight gradient and the mask of its data gradient): never stored
+                    head = mods[i + 3] if i + 3 < len(mods) else None
+                    y2 = None if self._head_on_gemm(head, z) else ops.bn_apply_ab(z, ab, None, True)
                     tape.append(dict(kind="convT", name=name, conv=m, bn=bn, relu=True, x=y, z=z, y=y2, ab=ab, mean=mean, invstd=invstd))
                     y = y2
                     i += 3
+                elif y is None:                                   # the head conv on the 1x1 GEMM, behind the BatchNorm loader
+                    prev = tape[-1]
+                    cout, cin = int(m.weight.shape[0]), int(m.weight.shape[1])
+                    n4 = ops.round_up(cout, 4)
+                    def build(m=m, n4=n4, cout=cout, cin=cin):
+                        w2 = m.weight.detach().reshape(cout, cin)
+                        return ops.pack_conv1x1_weight(torch.cat([w2, w2.new_zeros((n4 - cout, cin))]).reshape(n4, cin, 1, 1), 0)
+                    packed, _ = self._cached(("g0h", name), [m.weight], build)
+                    bias4 = self._cached(("g0hb", name), [m.bias], lambda m=m, n4=n4, cout=cout: torch.cat([m.bias.detach(), m.bias.new_zeros((n4 - cout,))]))
+                    out = ops.nhwc_to_nchw(ops.conv1x1_pre(prev["z"], packed, n4, prev["ab"], bias4))
+                    if n4 != cout:
+                        out = out[:, :cout].contiguous()
+                    tape.append(dict(kind="final", name=name, conv=m, x=None))
+                    y = out
+                    i += 1
                 else:
                     packed, rows, _ = self._packed_w(name, m, 0)
                     out = ops.conv2d(y, packed, rows, 1, 1, None, m.bias.detach(), None, CONV_OUT_NCHW)
@@ -1679,6 +1697,13 @@ class ResnetSimple(nn.Module):
                     y = out
                     i += 1
         return y, tape
+
+    def _head_on_gemm(self, head, z):
+        """Does the decoder's head conv (the module behind the last ConvTranspose2d + BatchNorm + ReLU) run on the 1x1 GEMM with that
+        BatchNorm in its loader?  (a 1x1 conv from a multiple of 64 channels, tensors within the GEMM's 2-GB operand limit)"""
+        return (self.bn_fusion_head and isinstance(head, nn.Conv2d) and self.conv1x1_algorithm == "gemm" and int(head.kernel_size[0]) == 1
+                and int(head.stride[0]) == 1 and head.bias is not None and int(head.weight.shape[1]) == int(z.shape[3]) and int(z.shape[3]) % 64 == 0
+                and (z.numel() // int(z.shape[3]) + 64) * int(z.shape[3]) * 4 < (1 << 31))
 
     def _bn_bwd_fused(self, rec, dy, want_g=False):
         """BatchNorm backward of a unit in two launches: (dgamma, dbeta) finished inside the reduction launch, then dz (and the masked
@@ -1712,13 +1737,21 @@ class ResnetSimple(nn.Module):
                 m = rec["conv"]
                 cout, cin = int(m.weight.shape[0]), int(m.weight.shape[1])
                 gy = ops.nchw_to_nhwc(grad_out_nchw, cpad=ops.round_up(cout, 16))
-                def leaf(m=m, x=rec["x"], gy=gy, cout=cout, cin=cin):
-                    grads[m.weight], grads[m.bias] = ops.conv2d_wgrad(x, gy, cout, cin, 1, 1, 0, want_bias=True)
-                _on_side(side, leaf, rec["x"], gy)
                 prev = tape[idx - 1] if idx >= 1 else None
+                if rec["x"] is None:                              # the head ran behind the BatchNorm loader: so does its weight gradient
+                    def leaf(m=m, prev=prev, gy=gy, cout=cout, cin=cin):
+                        n4 = ops.round_up(cout, 4)
+                        grads[m.weight] = ops.conv1x1_wgrad(prev["z"], gy, n4, cin, pre_ab=prev["ab"])[:cout]
+                        grads[m.bias] = ops.channel_sum(gy)[:cout]
+                    _on_side(side, leaf, prev["z"], gy, prev["ab"])
+                else:
+                    def leaf(m=m, x=rec["x"], gy=gy, cout=cout, cin=cin):
+                        grads[m.weight], grads[m.bias] = ops.conv2d_wgrad(x, gy, cout, cin, 1, 1, 0, want_bias=True)
+                    _on_side(side, leaf, rec["x"], gy)
                 if (self.bn_fusion_head and prev is not None and prev["kind"] == "convT" and prev["y"] is rec["x"] and prev.get("ab") is not None
                         and self.conv1x1_algorithm == "gemm" and int(m.kernel_size[0]) == 1 and cin % 64 == 0
-                        and tuple(prev["z"].shape) == tuple(gy.shape[:3]) + (cin,) and prev["z"].numel() < (1 << 29)):
+                        and tuple(prev["z"].shape) == tuple(gy.shape[:3]) + (cin,) and prev["z"].numel() < (1 << 31)
+                        and (prev["z"].numel() // cin) * ops.round_up(cout, 32) * 4 < (1 << 31)):
                     # Round 6: the head's data gradient on the 1x1 GEMM with the LAST decoder BatchNorm's ReLU mask and its two backward sums
                     # in the epilogue (the trunk's form, conv1x1_bwd_bnmask): one launch instead of the direct conv + the stand-alone
                     # reduction pass over two 16 x 208 x 208 x 256 tensors.  The contraction is the K = 7 (17) keypoint channels, zero-padded
@@ -1730,7 +1763,7 @@ class ResnetSimple(nn.Module):
                         return ops.pack_conv1x1_weight(torch.cat([w2, w2.new_zeros((kp - cout, cin))]).reshape(kp, cin, 1, 1), 1)
                     packed_t, _ = self._cached(("g1h", rec["name"]), [m.weight], build)
                     gmask, dgh, dbh = ops.conv1x1_bwd_bnmask(gy32, packed_t, cin, prev["z"], prev["ab"], prev["mean"], prev["invstd"],
-                                                             self._ctr(gy32.device), y_act=prev["y"])
+                                                             self._ctr(gy32.device), y_act=prev["y"])      # (y None: the mask from (z, ab))
                     g = ("masked", gmask, dgh, dbh)
                 else:
                     packed_t, rows, _ = self._packed_w(rec["name"], m, 1)

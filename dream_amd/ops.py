@@ -735,6 +735,15 @@ def conv1x1(x_nhwc, packed, cout, scale=None, shift=None, residual=None, flags=0
     return y
 
 
+def conv1x1_pre(x_nhwc, packed, cout, pre_ab, shift=None):
+    """1x1 conv of relu(pre_ab[0] x + pre_ab[1]) (a train-mode BatchNorm + ReLU applied in the loader: its output is never stored), + shift."""
+    x = _f32(x_nhwc)
+    b, h, w, cin = (int(v) for v in x.shape)
+    y = torch.empty((b, h, w, cout), dtype=torch.float32, device=x.device)
+    call("dream_conv1x1_pre_nhwc_f32", ptr(x), ptr(packed), ptr(pre_ab), ptr(shift), ptr(y), b * h * w, cin, cout, cin, stream())
+    return y
+
+
 def conv1x1_wgrad_applies(x_nhwc, dy_nhwc, cout):
     cin, cdy = int(x_nhwc.shape[3]), int(dy_nhwc.shape[3])
     # (measured: 1.2-1.8x the direct weight-gradient kernel from 64 x 256 channel pairs on, 0.74x at 64 x 64)

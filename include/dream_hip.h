@@ -116,6 +116,11 @@ int dream_conv1x1_set_rows(int rows);
 int dream_pack_conv1x1_weight(const float *w_oihw, float *packed, int Cout, int Cin, int mode, void *stream);
 int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, const float *scale, const float *shift, const float *residual,
                            float *y, long M, int K, int N, int x_stride, int flags, void *stream);
+/* y = relu(pre_ab[0][k] x + pre_ab[1][k]) . w^T + shift: the conv behind a train-mode BatchNorm + ReLU applied in its loader (pre_ab [2][K]:
+ * the BatchNorm's scale / shift from the batch statistics), so that the normalised activation is never stored (round 6: the decoder's head
+ * conv in training, dream/models.py:37-136; the trunk uses dream_conv1x1_bnstats_nhwc_f32, which also sums the next BatchNorm's statistics) */
+int dream_conv1x1_pre_nhwc_f32(const float *x, const float *w_packed, const float *pre_ab, const float *shift, float *y, long M, int K, int N,
+                               int x_stride, void *stream);
 /* Weight gradient of the same conv (gemm1x1.hip): x [M][Cin], dy [M][Cdy >= Cout] -> dw [Cout][Cin], overwritten; Cin % 64 == 0,
  * Cout % 4 == 0, Cdy % 4 == 0; deterministic split over positions (fixed-order sums). */
 size_t dream_conv1x1_wgrad_workspace(long M, int Cin, int Cout);

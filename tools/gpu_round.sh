@@ -41,7 +41,7 @@ PY
   ;;
 g6j)
   # Round 6: the last decoder BatchNorm's masked backward sums in the head conv's data gradient (DREAM_BN_FUSION_HEAD=0: stand-alone pass)
-  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "resnet or conv1x1 or bn" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "resnet or conv1x1 or bn or data_parallel or probe or synchronisation" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
   R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
   for r in a b c; do
     DREAM_BN_FUSION_HEAD=0 line head0_$r $R
@@ -49,8 +49,10 @@ g6j)
   done
   DREAM_BN_FUSION_HEAD=0 line rt128_head0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
   line rt128_head1 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
-  DREAM_BN_FUSION_HEAD=0 line rf32_head0 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
-  line rf32_head1 --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  for r in a b; do
+    DREAM_BN_FUSION_HEAD=0 line rf32_head0_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+    line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  done
   ;;
 lp)
   # layer profiles with queued event pairs (no launch latency inside the measurements) against the per-call synchronisation of rounds 2-6
