@@ -144,6 +144,7 @@ _SIGNATURES = {
     "dream_nhwc_to_nchw_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_keypoints_from_belief_maps_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _D, _P]),
     "dream_keypoints_from_belief_maps_rule_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _D, _I, _D, _P]),
+    "dream_peaks_set_fused": (_I, [_I]),
     "dream_peaks_from_belief_maps_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _D, _P]),
     "dream_gaussian_sigma3_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "dream_softargmax_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),

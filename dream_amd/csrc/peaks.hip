@@ -14,6 +14,7 @@
 //     8-lane pairwise scheme, divided, offset added, then rounded once to fp32.
 //   * no FMA contraction anywhere on these paths (dmul/dadd/ddiv = __dmul_rn/__dadd_rn/__ddiv_rn).
 // The Gaussian passes stage their inputs in LDS (25 taps per output from there); fp64 rate is irrelevant at 25 taps / pixel.
+#include <stdlib.h>
 #include <dream_cdna4.h>
 #include "common.h"
 #include "../../include/dream_hip.h"
@@ -242,6 +243,131 @@ __global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const flo
     }
 }
 
+// ---- round 6: the second Gaussian pass and the peak scan in one kernel (the keypoint rule only needs counts and the two best peaks) -------
+// A workgroup owns FT output rows x 64 columns of one map: it stages FT + 2 rows of the column pass' result (one halo row above and
+// below; 64 + 2 + 24 columns, reflected), runs the row pass for those (FT + 2) x 66 pixels into LDS -- the same tap_sum, the same fp32
+// rounding: the values ARE the smoothed map's -- and tests its FT x 64 pixels against their four neighbours there.  The smoothed map is
+// never written (a third of the three-kernel form's traffic) and a 416 x 416 map is scanned by 210 workgroups instead of one.  A
+// workgroup leaves (best score, second best, index of the best, count); finish_kernel merges a map's records (the merge is
+// associative and commutative: ties go to the smaller index) and applies network.py:546-577.
+constexpr int FT = 14;
+int g_peaks_fused = -1;          // dream_peaks_set_fused: -1 = by DREAM_PEAKS_FUSED (default on), 0 / 1 = forced
+struct PeakPart {
+    float s1, s2;
+    int i1, count;
+};
+
+__global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps, const float *colpass, PeakPart *parts, int H, int W) {
+    __shared__ float stage[(FT + 2) * (66 + 2 * R)];
+    __shared__ float sm[(FT + 2) * 66];
+    __shared__ PeakPart s_part[4];
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, lane = tx;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * FT, n = blockIdx.z;
+    const float *ori = maps + (size_t)n * H * W;
+    const float *base = colpass + (size_t)n * H * W;
+    constexpr int SW = 66 + 2 * R;                                   // staged columns: map columns x0 - 1 - R .. x0 + 64 + R
+    for (int i = tid; i < (FT + 2) * SW; i += 256) {
+        const int r = i / SW, c = i - r * SW;
+        const int y = y0 - 1 + r, xx = x0 - 1 - R + c;
+        const int q = (xx >= 0 && xx < W) ? xx : reflect_index(xx, W);
+        stage[i] = (y >= 0 && y < H) ? base[(size_t)y * W + q] : 0.0f;   // (rows outside the map are never looked at)
+    }
+    __syncthreads();
+    auto tap_sum = [&](auto at) {                     // (as gauss_pass_kernel: acc = x[l] w[c]; for i = -12..-1: acc += (x[l+i] + x[l-i]) w[c+i])
+        double acc = dmul((double)at(0), kTaps[R]);
+#pragma unroll
+        for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd((double)at(i), (double)at(-i)), kTaps[R + i]));
+        return (float)acc;
+    };
+    for (int i = tid; i < (FT + 2) * 66; i += 256) {                 // smoothed pixel (row y0 - 1 + r, column x0 - 1 + c)
+        const int r = i / 66, c = i - r * 66;
+        sm[i] = tap_sum([&](int k) { return stage[r * SW + c + R + k]; });
+    }
+    __syncthreads();
+    const float thresh = 0.01f;                       // image_proc.py:925 (compared in fp32)
+    const float NEG_INF = -__builtin_huge_valf();
+    Top2 best = {NEG_INF, NEG_INF, -1};
+    int cnt = 0;
+    const int x = x0 + tx;
+    for (int r = 1 + ty; r <= FT; r += 4) {
+        const int y = y0 - 1 + r;
+        if (x < W && y < H) {
+            const int c = tx + 1;
+            const float v = sm[r * 66 + c];
+            const float up = y > 0 ? sm[(r - 1) * 66 + c] : 0.0f, down = y + 1 < H ? sm[(r + 1) * 66 + c] : 0.0f;
+            const float left = x > 0 ? sm[r * 66 + c - 1] : 0.0f, right = x + 1 < W ? sm[r * 66 + c + 1] : 0.0f;
+            if ((v >= up) && (v >= down) && (v >= left) && (v >= right) && (v > thresh)) {
+                const int idx = y * W + x;
+                const Top2 mine = {ori[idx], NEG_INF, idx};
+                best = top2_merge(best, mine);
+                ++cnt;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Top2 other;
+        other.s1 = lane_xor(best.s1, m);
+        other.s2 = lane_xor(best.s2, m);
+        other.i1 = lane_xor(best.i1, m);
+        best = top2_merge(best, other);
+        cnt += lane_xor(cnt, m);
+    }
+    if (lane == 0) s_part[ty] = PeakPart{best.s1, best.s2, best.i1, cnt};
+    __syncthreads();
+    if (tid == 0) {
+        Top2 b = {s_part[0].s1, s_part[0].s2, s_part[0].i1};
+        int total = s_part[0].count;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const Top2 o = {s_part[w].s1, s_part[w].s2, s_part[w].i1};
+            b = top2_merge(b, o);
+            total += s_part[w].count;
+        }
+        const int nper = (int)(gridDim.x * gridDim.y);
+        parts[(size_t)n * nper + blockIdx.y * gridDim.x + blockIdx.x] = PeakPart{b.s1, b.s2, b.i1, total};
+    }
+}
+
+// one wavefront per map: merge its workgroups' records, then network.py:546-577 (as the tail of peaks_kernel)
+__global__ void __launch_bounds__(256) peaks_finish_kernel(const float *maps, const PeakPart *parts, int nper, float *keypoints, int32_t *counts,
+                                                           int N, int H, int W, double offset, int use_scores, double next_best) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const float NEG_INF = -__builtin_huge_valf();
+    Top2 best = {NEG_INF, NEG_INF, -1};
+    int running = 0;
+    for (int i = lane; i < nper; i += 64) {
+        const PeakPart p = parts[(size_t)n * nper + i];
+        const Top2 o = {p.s1, p.s2, p.i1};
+        best = top2_merge(best, o);
+        running += p.count;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Top2 other;
+        other.s1 = lane_xor(best.s1, m);
+        other.s2 = lane_xor(best.s2, m);
+        other.i1 = lane_xor(best.i1, m);
+        best = top2_merge(best, other);
+        running += lane_xor(running, m);
+    }
+    if (lane != 0) return;
+    const float *ori = maps + (size_t)n * H * W;
+    if (counts) counts[n] = running;
+    float kx = -999.999f, ky = -999.999f;
+    const bool accept = (running == 1) || (running > 1 && use_scores != 0 && (double)(best.s1 - best.s2) >= next_best);
+    if (accept) {
+        const int y = best.i1 / W, x = best.i1 - y * W;
+        double cx, cy;
+        centroid_5x5(ori, H, W, x, y, offset, &cx, &cy);
+        kx = (float)cx;
+        ky = (float)cy;
+    }
+    keypoints[(size_t)n * 2 + 0] = kx;
+    keypoints[(size_t)n * 2 + 1] = ky;
+}
+
 int smooth_maps(const float *maps, float *tmp, float *out, int N, int H, int W, hipStream_t s) {
     DREAM_REQUIRE((H + 3) / 4 <= 65535, "gaussian: more than 262140 rows");
     for (int n0 = 0; n0 < N; n0 += 65535) {                  // grid.z limit
@@ -270,11 +396,37 @@ extern "C" int dream_keypoints_from_belief_maps_rule_f32(const float *maps, floa
                                                          double belief_peak_next_best_score, void *stream) {
     DREAM_REQUIRE(maps && scratch && keypoints && N > 0 && H > 0 && W > 0, "keypoints_from_belief_maps: bad arguments");
     const size_t total = (size_t)N * H * W;
+    // round 6: column pass, then the row pass fused with the scan (gauss_row_peaks_kernel), then one wavefront per map -- when a map's
+    // workgroup records fit where its smoothed copy would have gone (they do from 3 x 3 maps on) and the grid fits
+    const int gx = (W + 63) / 64, gy = (H + FT - 1) / FT, nper = gx * gy;
+    static const bool env_fused = [] { const char *e = getenv("DREAM_PEAKS_FUSED"); return !(e && e[0] == '0'); }();
+    const bool fused = g_peaks_fused < 0 ? env_fused : g_peaks_fused != 0;
+    if (fused && (size_t)nper * 4 + 4 <= (size_t)H * W && N <= 65535 && gy <= 65535 && (H + GT - 1) / GT <= 65535) {
+        hipLaunchKernelGGL(gauss_pass_kernel<0>, dim3((unsigned)gx, (unsigned)((H + GT - 1) / GT), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                           maps, scratch, N, H, W);
+        DREAM_LAUNCH_OK();
+        PeakPart *parts = (PeakPart *)(scratch + ((total + 3) & ~(size_t)3));      // (16-byte records)
+        hipLaunchKernelGGL(gauss_row_peaks_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)N), dim3(256), 0, (hipStream_t)stream, maps,
+                           (const float *)scratch, parts, H, W);
+        DREAM_LAUNCH_OK();
+        hipLaunchKernelGGL(peaks_finish_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, maps, (const PeakPart *)parts, nper,
+                           keypoints, peak_counts, N, H, W, offset_due_to_upsampling, use_belief_peak_scores, belief_peak_next_best_score);
+        DREAM_LAUNCH_OK();
+        return 0;
+    }
     if (int rc = smooth_maps(maps, scratch, scratch + total, N, H, W, (hipStream_t)stream)) return rc;
     hipLaunchKernelGGL(peaks_kernel<false>, dim3(N), dim3(256), 0, (hipStream_t)stream, maps,
                        (const float *)(scratch + total), keypoints, peak_counts, (double *)nullptr, (float *)nullptr,
                        H, W, 0, offset_due_to_upsampling, use_belief_peak_scores, belief_peak_next_best_score);
     DREAM_LAUNCH_OK();
+    return 0;
+}
+
+// Test / A-B hook: the keypoint rule through the fused row pass + scan (1), the three-kernel form of rounds 1-5 (0), or by
+// DREAM_PEAKS_FUSED (-1, default: fused).  Same bits either way.
+extern "C" int dream_peaks_set_fused(int on) {
+    DREAM_REQUIRE(on >= -1 && on <= 1, "peaks: fused = %d", on);
+    g_peaks_fused = on;
     return 0;
 }
 

@@ -312,6 +312,9 @@ int dream_keypoints_from_belief_maps_f32(const float *maps, float *scratch, floa
 /* same with the two DreamNetwork attributes callers may change (dream/network.py:189-191, read at :553-560):
  * use_belief_peak_scores (0: several peaks -> no detection) and belief_peak_next_best_score (the fp32 score difference is
  * compared against this double); the entry point above uses the reference's defaults (1, 0.25). */
+/* Test / A-B hook (round 6): 1 = the second Gaussian pass fused with the peak scan (default: the smoothed map is never written, a map is
+ * scanned by many workgroups), 0 = three kernels (rounds 1-5), -1 = by DREAM_PEAKS_FUSED.  Bit-identical results. */
+int dream_peaks_set_fused(int on);
 int dream_keypoints_from_belief_maps_rule_f32(const float *maps, float *scratch, float *keypoints,
                                               int32_t *peak_counts, int N, int H, int W,
                                               double offset_due_to_upsampling, int use_belief_peak_scores,

@@ -1370,3 +1370,36 @@ def check_bn_fused_ops(dev, ksplits=(0, 1, 2, 4)):
                 dzp, _ = ops.bn_bwd_apply(zp_d, gm, bn_p2.weight, pre_mean, pre_invstd, dg_p, db_p)
                 assert float((nchw(dzp.cpu()) - zp.grad).abs().max()) <= 3 * tol(zp.grad.numpy()), (Cin, Cout, ks)
                 assert int(ctr.cpu().abs().sum()) == 0
+
+
+def check_peaks_fused_equals_three_kernels(dev, sizes=((1, 7, 5, 9), (2, 3, 37, 45), (1, 2, 64, 64), (2, 7, 100, 100), (1, 2, 130, 71))):
+    """The keypoint rule through the fused row pass + scan (round 6, csrc/peaks.hip: gauss_row_peaks_kernel + peaks_finish_kernel) against the
+    three-kernel form: keypoints and peak counts bit for bit, on smooth random maps with several peaks (ties and the next-best rule included)."""
+    rs = np.random.RandomState(11)
+    most = 0
+    for b, k, h, w in sizes:
+        yy, xx = np.mgrid[0:h, 0:w]
+        maps = np.zeros((b, k, h, w), np.float32)
+        for i in range(b):
+            for j in range(k):
+                for _ in range(int(rs.randint(0, 4))):
+                    cy, cx, s, a = rs.uniform(0, h), rs.uniform(0, w), rs.uniform(1.0, 4.0), rs.uniform(0.2, 1.0)
+                    maps[i, j] += (a * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))).astype(np.float32)
+        maps[0, 0] = maps[0, 0].T.copy().T if h == w else maps[0, 0]
+        maps += (rs.rand(b, k, h, w) < 0.002).astype(np.float32) * 0.5            # isolated spikes: more peaks, equal scores
+        m = to(dev, torch.from_numpy(maps))
+        outs = []
+        for fused in (1, 0):
+            _hip.call("dream_peaks_set_fused", fused)
+            try:
+                for use_scores, nb in ((True, 0.25), (True, 0.0), (False, 0.25)):
+                    kp, cnt = ops.keypoints_from_belief_maps(m, 0.0 if h % 2 else 0.5, use_scores, nb)
+                    outs.append((fused, kp.cpu().clone(), cnt.cpu().clone()))
+            finally:
+                _hip.call("dream_peaks_set_fused", -1)
+        half = len(outs) // 2
+        for (f1, kp1, c1), (f0, kp0, c0) in zip(outs[:half], outs[half:]):
+            assert torch.equal(c1, c0), (b, k, h, w, c1.tolist(), c0.tolist())
+            assert kp1.numpy().tobytes() == kp0.numpy().tobytes(), (b, k, h, w)
+        most = max(most, int(outs[0][2].max()))
+    assert most >= 2                                                               # the case families really have maps with several peaks

@@ -201,6 +201,10 @@ def test_peak_rule_settings(emu):
     pc.check_peak_rule_settings("cpu")
 
 
+def test_peaks_fused_row_pass_and_scan_same_bits(emu):
+    pc.check_peaks_fused_equals_three_kernels("cpu", sizes=((1, 7, 5, 9), (2, 3, 37, 45), (1, 2, 64, 64), (1, 2, 30, 71)))
+
+
 def test_peaks_api_reference_kat(emu):
     pc.check_peaks_api("cpu")
 

@@ -1194,6 +1194,12 @@ def test_strided_data_gradient_zeroes_its_output_inside_a_graph():
     assert float(ref[:, 1::2].abs().max()) == 0.0 and float(ref[:, :, 1::2].abs().max()) == 0.0 and float(ref.abs().max()) > 0.0
 
 
+def test_peaks_fused_row_pass_and_scan_same_bits():
+    """csrc/peaks.hip, round 6: the second Gaussian pass fused with the peak scan against the three-kernel form -- keypoints and counts bit
+    for bit, up to the 416 x 416 maps of DREAM-resnet-F."""
+    pc.check_peaks_fused_equals_three_kernels(DEV, sizes=((1, 7, 5, 9), (2, 3, 37, 45), (1, 2, 64, 64), (2, 7, 100, 100), (1, 2, 130, 71), (2, 17, 416, 416)))
+
+
 def test_clone_by_kernel_any_length_and_alignment():
     """ops.clone (dream_copy_f32: the kernel that stands where ATen would leave a memcpy node in a captured graph): every length, and
     sources / destinations that are not 16-byte aligned (views that start one element into their storage)."""

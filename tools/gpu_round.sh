@@ -54,6 +54,25 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6k)
+  # Round 6: belief-map peak extraction with the second Gaussian pass fused with the scan (DREAM_PEAKS_FUSED=0: three kernels)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "peaks or abi or smoke or structured or inference or golden" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for r in a b c; do
+    DREAM_PEAKS_FUSED=0 line rf32_three_$r --arch resnet_f --batch 32
+    line rf32_fused_$r --arch resnet_f --batch 32
+  done
+  for r in a b; do
+    DREAM_PEAKS_FUSED=0 line vq128_three_$r
+    line vq128_fused_$r
+  done
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_pk -o t -- python $GRAFT_REPO_ROOT/bench.py --arch resnet_f --batch 32 --no-cpu-baseline --no-secondary > $GRAFT_REPO_ROOT/$O/rocprof.log 2>&1)
+  python - $(ls /tmp/prof_pk/*.db /tmp/prof_pk/*/*.db 2>/dev/null | head -1) <<'PY' | tee $O/peaks_kernels.txt
+import sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+for name, n, tot, mn in cur.execute("select name, count(*), sum(duration), min(duration) from kernels where name like '%gauss%' or name like '%peaks%' group by name"):
+    print("%-60s launches %4d  avg %8.1f us  min %8.1f us" % (name.split("(")[0][-60:], n, tot / n / 1e3, mn / 1e3))
+PY
+  ;;
 lp)
   # layer profiles with queued event pairs (no launch latency inside the measurements) against the per-call synchronisation of rounds 2-6
   for t in queued sync; do
