@@ -65,10 +65,19 @@ __global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float 
             tile[r * 64 + tx] = x < W ? base[(size_t)q * W + x] : 0.0f;
         }
         __syncthreads();
+        // round 6: a thread owns FOUR CONSECUTIVE rows of its column: their 4 x 25 taps are 28 staged values, read and converted to
+        // fp64 once (was: rows ty, ty + 4, .. -- 100 LDS reads and conversions for the same four outputs).  Same sums, same order.
+        static_assert(GT == 16, "four rows per thread x four waves");
+        double d[4 + 2 * R];
 #pragma unroll
-        for (int k = 0; k < GT / 4; ++k) {
-            const int ly = ty + 4 * k, y = y0 + ly;
-            if (x < W && y < H) obase[(size_t)y * W + x] = tap_sum([&](int i) { return tile[(ly + R + i) * 64 + tx]; });
+        for (int j = 0; j < 4 + 2 * R; ++j) d[j] = (double)tile[(4 * ty + j) * 64 + tx];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = y0 + 4 * ty + k;
+            double acc = dmul(d[k + R], kTaps[R]);
+#pragma unroll
+            for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd(d[k + R + i], d[k + R - i]), kTaps[R + i]));
+            if (x < W && y < H) obase[(size_t)y * W + x] = (float)acc;
         }
     } else {
         const int y = y0 + ty;
@@ -250,7 +259,7 @@ __global__ void __launch_bounds__(256) peaks_kernel(const float *maps, const flo
 // never written (a third of the three-kernel form's traffic) and a 416 x 416 map is scanned by 210 workgroups instead of one.  A
 // workgroup leaves (best score, second best, index of the best, count); finish_kernel merges a map's records (the merge is
 // associative and commutative: ties go to the smaller index) and applies network.py:546-577.
-constexpr int FT = 14;
+constexpr int FT = 13;            // (FT + 2) rows x 17 groups of four columns = 255 work items of the row pass: one per thread
 int g_peaks_fused = -1;          // dream_peaks_set_fused: -1 = by DREAM_PEAKS_FUSED (default on), 0 / 1 = forced
 struct PeakPart {
     float s1, s2;
@@ -258,14 +267,15 @@ struct PeakPart {
 };
 
 __global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps, const float *colpass, PeakPart *parts, int H, int W) {
-    __shared__ float stage[(FT + 2) * (66 + 2 * R)];
-    __shared__ float sm[(FT + 2) * 66];
+    constexpr int SW = 68 + 2 * R;                                   // staged columns: map columns x0 - 1 - R .. x0 + 66 + R (the last two: padding
+                                                                     // of the 17th group of four; 92 floats: rows stay 16-byte aligned)
+    __shared__ __attribute__((aligned(16))) float stage[(FT + 2) * SW];
+    __shared__ float sm[(FT + 2) * 68];
     __shared__ PeakPart s_part[4];
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, lane = tx;
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * FT, n = blockIdx.z;
     const float *ori = maps + (size_t)n * H * W;
     const float *base = colpass + (size_t)n * H * W;
-    constexpr int SW = 66 + 2 * R;                                   // staged columns: map columns x0 - 1 - R .. x0 + 64 + R
     for (int i = tid; i < (FT + 2) * SW; i += 256) {
         const int r = i / SW, c = i - r * SW;
         const int y = y0 - 1 + r, xx = x0 - 1 - R + c;
@@ -273,15 +283,25 @@ __global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps,
         stage[i] = (y >= 0 && y < H) ? base[(size_t)y * W + q] : 0.0f;   // (rows outside the map are never looked at)
     }
     __syncthreads();
-    auto tap_sum = [&](auto at) {                     // (as gauss_pass_kernel: acc = x[l] w[c]; for i = -12..-1: acc += (x[l+i] + x[l-i]) w[c+i])
-        double acc = dmul((double)at(0), kTaps[R]);
+    // the row pass for (FT + 2) rows x 68 columns (66 needed), a thread = four consecutive columns of one row: 28 staged values (seven
+    // 16-byte LDS reads), converted to fp64 once, feed its 4 x 25 taps.  Same sums, same order as gauss_pass_kernel<1>.
+    if (tid < (FT + 2) * 17) {
+        const int r = tid / 17, c0 = 4 * (tid - r * 17);             // smoothed pixels (row y0 - 1 + r, columns x0 - 1 + c0 .. + 3)
+        double d[4 + 2 * R];
+        const f32x4 *src = (const f32x4 *)&stage[r * SW + c0];
 #pragma unroll
-        for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd((double)at(i), (double)at(-i)), kTaps[R + i]));
-        return (float)acc;
-    };
-    for (int i = tid; i < (FT + 2) * 66; i += 256) {                 // smoothed pixel (row y0 - 1 + r, column x0 - 1 + c)
-        const int r = i / 66, c = i - r * 66;
-        sm[i] = tap_sum([&](int k) { return stage[r * SW + c + R + k]; });
+        for (int j = 0; j < (4 + 2 * R) / 4; ++j) {
+            const f32x4 v = src[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[4 * j + e] = (double)v[e];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double acc = dmul(d[k + R], kTaps[R]);
+#pragma unroll
+            for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd(d[k + R + i], d[k + R - i]), kTaps[R + i]));
+            sm[r * 68 + c0 + k] = (float)acc;
+        }
     }
     __syncthreads();
     const float thresh = 0.01f;                       // image_proc.py:925 (compared in fp32)
@@ -293,9 +313,9 @@ __global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps,
         const int y = y0 - 1 + r;
         if (x < W && y < H) {
             const int c = tx + 1;
-            const float v = sm[r * 66 + c];
-            const float up = y > 0 ? sm[(r - 1) * 66 + c] : 0.0f, down = y + 1 < H ? sm[(r + 1) * 66 + c] : 0.0f;
-            const float left = x > 0 ? sm[r * 66 + c - 1] : 0.0f, right = x + 1 < W ? sm[r * 66 + c + 1] : 0.0f;
+            const float v = sm[r * 68 + c];
+            const float up = y > 0 ? sm[(r - 1) * 68 + c] : 0.0f, down = y + 1 < H ? sm[(r + 1) * 68 + c] : 0.0f;
+            const float left = x > 0 ? sm[r * 68 + c - 1] : 0.0f, right = x + 1 < W ? sm[r * 68 + c + 1] : 0.0f;
             if ((v >= up) && (v >= down) && (v >= left) && (v >= right) && (v > thresh)) {
                 const int idx = y * W + x;
                 const Top2 mine = {ori[idx], NEG_INF, idx};
