@@ -1137,6 +1137,7 @@ class ResnetSimple(nn.Module):
         self.bn_fusion_3x3 = os.environ.get("DREAM_BN_FUSION_3X3", "1") == "1"
         # ... and (round 6) the last decoder BatchNorm's in the head conv's data gradient (run_backward_fused, "final")
         self.bn_fusion_head = os.environ.get("DREAM_BN_FUSION_HEAD", "1") == "1"
+        self.stem_on_gemm = os.environ.get("DREAM_STEM_GEMM", "1") == "1"     # training: the 7x7 stem + its statistics + its weight gradient on the 1x1 GEMM
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
@@ -1620,11 +1621,23 @@ class ResnetSimple(nn.Module):
         self._repack_weights()
         self._ctr_pos = 0
         tape = [dict(kind="begin", fused=True)]
-        col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
-        w1 = self._cached(("w", "conv1"), [self.conv1.weight],
-                          lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
-        z = ops.conv2d(col, w1[0], 64, 1, 1)
-        ab, mean, invstd = ops.bn_stats(z, self.bn1, self._ctr(z.device))
+        ho, wo = (int(x.shape[2]) + 6 - 7) // 2 + 1, (int(x.shape[3]) + 6 - 7) // 2 + 1
+        if self.stem_on_gemm and self.conv1x1_algorithm == "gemm" and (int(x.shape[0]) * ho * wo + 64) * 192 * 4 < (1 << 31):
+            # Round 6: the 7x7 stem as a GEMM over im2col rows of 192 columns (147 taps, zero-padded to the 1x1 GEMM's granularity -- 160
+            # for the direct kernel): the BatchNorm statistics ride in its epilogue (one pass over the 16 x 200 x 200 x 64 output less) and
+            # its weight gradient runs on the GEMM-shaped kernel (0.56 -> ~0.2 ms on the MAIN stream: it is the last launch of a step)
+            col = ops.im2col_nchw(x, 7, 7, 2, 3, 192)
+            def build():
+                w2 = self.conv1.weight.detach().reshape(64, 147)
+                return ops.pack_conv1x1_weight(torch.cat([w2, w2.new_zeros((64, 45))], dim=1).reshape(64, 192, 1, 1), 0)
+            packed, _ = self._cached(("g0", "conv1"), [self.conv1.weight], build)
+            z, ab, mean, invstd = ops.conv1x1_bn(col, packed, 64, self.bn1, self._ctr(col.device))
+        else:
+            col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
+            w1 = self._cached(("w", "conv1"), [self.conv1.weight],
+                              lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
+            z = ops.conv2d(col, w1[0], 64, 1, 1)
+            ab, mean, invstd = ops.bn_stats(z, self.bn1, self._ctr(z.device))
         y = ops.bn_apply_ab(z, ab, None, True)
         tape.append(dict(kind="stem", conv=self.conv1, bn=self.bn1, relu=True, x=col, z=z, y=y, ab=ab, mean=mean, invstd=invstd))
         yp, pidx = ops.maxpool3s2_idx(y)               # the backward pass compares one stored byte per window
@@ -1862,8 +1875,12 @@ class ResnetSimple(nn.Module):
                 bn = rec["bn"]
                 dz, _, dgam, dbet = self._bn_bwd_fused(rec, g)
                 grads[bn.weight], grads[bn.bias] = dgam, dbet
-                dw, _ = ops.conv2d_wgrad(rec["x"], dz, 64, 160, 1, 1)
-                grads[rec["conv"].weight] = dw.reshape(64, 160)[:, :147].reshape(64, 3, 7, 7).contiguous()
+                kcol = int(rec["x"].shape[3])                   # 192: the stem ran on the 1x1 GEMM (run_forward_train_fused), 160: direct
+                if kcol == 192:
+                    dw = ops.conv1x1_wgrad(rec["x"], dz, 64, 192)
+                else:
+                    dw, _ = ops.conv2d_wgrad(rec["x"], dz, 64, 160, 1, 1)
+                grads[rec["conv"].weight] = dw.reshape(64, kcol)[:, :147].reshape(64, 3, 7, 7).contiguous()
                 g = None
         if side is not None:
             side.join()

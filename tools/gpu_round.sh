@@ -54,6 +54,22 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6l)
+  # Round 6: the 7x7 stem on the 1x1 GEMM (im2col rows of 192 columns, BatchNorm statistics in its epilogue, GEMM-shaped weight gradient)
+  # against the direct kernels on 160 columns (DREAM_STEM_GEMM=0)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "resnet or conv1x1 or bn or data_parallel or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_STEM_GEMM=0 line stem0_$r $R
+    line stem1_$r $R
+  done
+  DREAM_STEM_GEMM=0 line rt128_stem0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  line rt128_stem1 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  for r in a b; do
+    DREAM_STEM_GEMM=0 line rf32_stem0_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+    line rf32_stem1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  done
+  ;;
 g6k)
   # Round 6: belief-map peak extraction with the second Gaussian pass fused with the scan (DREAM_PEAKS_FUSED=0: three kernels)
   echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "peaks or abi or smoke or structured or inference or golden" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
