@@ -114,7 +114,9 @@ def reset_weight_caches(module):
         for name in ("_cache", "_aux"):
             if name in m.__dict__:
                 setattr(m, name, {})
-        for name in ("_pack_state", "_pack_records"):       # ResnetSimple._repack_weights: its graph writes into the old copies
+        if m.__dict__.get("_pack_pending") is not None:
+            m._pack_join()                                  # a re-pack on the second stream still writes into the old copies
+        for name in ("_pack_state", "_pack_records", "_pack_pending"):       # ResnetSimple._repack_weights: its graph writes into the old copies
             m.__dict__.pop(name, None)
 
 
@@ -401,7 +403,7 @@ class DreamDataParallel(nn.Module):
             # the master's packed weight copies and its flat record stay with the master: a replica builds its own on its device
             memo = {id(v): None for m in self.module.modules()
                     for v in (m.__dict__.get("_packed"), m.__dict__.get("_cache"), m.__dict__.get("_aux"), m.__dict__.get("_dream_flat"),
-                              m.__dict__.get("_pack_state"), m.__dict__.get("_pack_records"))
+                              m.__dict__.get("_pack_state"), m.__dict__.get("_pack_records"), m.__dict__.get("_pack_pending"))
                     if v is not None}
             rep = copy.deepcopy(self.module, memo)
             rep.__dict__.pop("_dream_flat", None)

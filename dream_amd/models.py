@@ -1191,6 +1191,9 @@ class ResnetSimple(nn.Module):
         rec = self.__dict__.get("_pack_records")
         if rec is not None and key[0] != "bn":
             return self._cached_recording(key, tensors, build, rec)
+        pend = self.__dict__.get("_pack_pending")
+        if pend is not None and key not in pend[1]:
+            self._pack_join()                        # the late part of the step's re-pack runs on the second stream (_repack_weights)
         tag = tuple((t._version, t.data_ptr()) for t in tensors)
         hit = self._cache.get(key)
         if hit is None or hit[0] != tag:
@@ -1198,6 +1201,13 @@ class ResnetSimple(nn.Module):
                 hit = (tag, build())
             self._cache[key] = hit
         return hit[1]
+
+    def _pack_join(self):
+        """The main stream waits for the late part of this step's re-pack (second stream); a no-op when none is pending."""
+        pend = self.__dict__.get("_pack_pending")
+        if pend is not None:
+            object.__setattr__(self, "_pack_pending", None)
+            torch.cuda.current_stream().wait_event(pend[0])
 
     # ---- training: all packed weight copies of a step refreshed by ONE launch ------------------------------------------------------
     def _cached_recording(self, key, tensors, build, rec):
@@ -1213,7 +1223,7 @@ class ResnetSimple(nn.Module):
                 rec[key] = (tensors, out, list(descs))
         return hit[1]
 
-    def _repack_weights(self):
+    def _repack_weights(self, split=False):
         """A training step re-packs every conv weight (the optimizer changed them all): 216 launches of 2-10 us, 6.8 % of a
         step at 16 frames (profiles/r02_layer_profile_resnet_h_train16.txt).  The first training step records which packed copies
         it builds from which parameter; from the second step on ONE launch (dream_pack_weights_batched: a device-resident job
@@ -1222,6 +1232,7 @@ class ResnetSimple(nn.Module):
         transposed convs' phase kernels) stay lazy.  Skipped while a hipGraph capture is under way (the data-parallel replicas
         capture their whole step, packing included)."""
         first = next(self.parameters())
+        self._pack_join()
         if not first.is_cuda and not os.environ.get("DREAM_PACK_BATCHED_ON_CPU"):
             return
         if (first.is_cuda and torch.cuda.is_current_stream_capturing()) or os.environ.get("DREAM_PACK_BATCHED", "1") == "0":
@@ -1244,9 +1255,32 @@ class ResnetSimple(nn.Module):
             # the launch's workgroups by job size (round 6): the decoder's 2048 -> 256 transposed conv is 19 M packed floats, a 64 x 64 1x1 conv
             # 4 K -- with 16 workgroups each the large jobs set the launch's length (0.50 ms; DREAM_PACK_SPANS=0 restores that)
             st["spans"] = ops.pack_span_table(descs, first.device) if os.environ.get("DREAM_PACK_SPANS", "1") != "0" else None
+            # Round 6, measured and NOT adopted (DREAM_PACK_SPLIT=1 opts in): the re-pack in two launches.  The copies the stem, layer1 and
+            # layer2 read (3 % of the floats) are rewritten on the main stream; the rest -- layer3 on, the decoder, every data-gradient
+            # operator -- on the SECOND stream, which is idle during a forward pass, while the main stream runs the first seven Bottlenecks
+            # (~6 ms at 16 frames); the main stream waits for it at the first use of a late copy (_cached -> _pack_join).  One box,
+            # alternating (profiles/r06_ab_pack_split.txt): 395.4 / 395.4 / 393.9 frames/s with one launch, 392.6 / 393.4 / 396.1 with two --
+            # the 0.4-ms copy takes from the forward kernels what it saves (it moves 1.5 GB while they run).
+            st["split"] = None
+            if split and first.is_cuda and st["spans"] is not None and os.environ.get("DREAM_PACK_SPLIT", "0") == "1":
+                early = [str(key[1]).startswith(("conv1", "layer1.", "layer2.")) for key, _ in st["keys"]]
+                parts = []
+                for want in (True, False):
+                    ds = [d for (_, (_, _, dd)), e in zip(st["keys"], early) if e == want for d in dd]
+                    parts.append((ops.pack_job_table(ds, first.device), ops.pack_span_table(ds, first.device)) if ds else None)
+                if parts[0] is not None and parts[1] is not None:
+                    st["split"] = (parts[0], parts[1], frozenset(key for (key, _), e in zip(st["keys"], early) if e))
         tags = {key: tuple((t._version, t.data_ptr()) for t in tensors) for key, (tensors, _, _) in st["keys"]}
         if any(self._cache.get(key, (None,))[0] != tag or self._cache[key][1] is not st["records"][key][1] for key, tag in tags.items()):
-            if st.get("spans") is not None:
+            if split and st.get("split") is not None:
+                (t0, s0), (t1, s1), early_keys = st["split"]
+                ops.pack_weights_spans(t0, s0[0], s0[1])
+                main, side = torch.cuda.current_stream(), _SideStream.live_stream(first.device)
+                side.wait_stream(main)                   # behind the optimizer step and the previous backward's reads of the old copies
+                with torch.cuda.stream(side):
+                    ops.pack_weights_spans(t1, s1[0], s1[1])
+                    object.__setattr__(self, "_pack_pending", (side.record_event(), early_keys))
+            elif st.get("spans") is not None:
                 ops.pack_weights_spans(st["table"], st["spans"][0], st["spans"][1])
             else:
                 ops.pack_weights_batched(st["table"], st["njobs"])
@@ -1618,7 +1652,7 @@ class ResnetSimple(nn.Module):
         return rec["y"]
 
     def run_forward_train_fused(self, x):
-        self._repack_weights()
+        self._repack_weights(split=True)
         self._ctr_pos = 0
         tape = [dict(kind="begin", fused=True)]
         ho, wo = (int(x.shape[2]) + 6 - 7) // 2 + 1, (int(x.shape[3]) + 6 - 7) // 2 + 1

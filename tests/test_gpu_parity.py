@@ -1350,6 +1350,7 @@ def test_resnet_batched_packing_equals_lazy_packing(monkeypatch):
 
     def run(flag):
         monkeypatch.setenv("DREAM_PACK_BATCHED", flag)
+        monkeypatch.setenv("DREAM_PACK_SPLIT", "1")          # the opt-in two-launch form (late copies on the second stream) is the one under test
         net = _dp_network("resnet_h", [0], optimizer="adam", lr=1e-5, in_res=(96, 64), weights=wts)
         net.enable_training()
         ow, oh = net.trained_net_output_resolution()
@@ -1366,6 +1367,8 @@ def test_resnet_batched_packing_equals_lazy_packing(monkeypatch):
     b, lb, mb = run("0")
     st = a.model.module._pack_state
     assert st["table"] is not None and st["njobs"] >= 190 and "_pack_state" not in b.model.module.__dict__, st.get("njobs")
+    # round 6 (opt-in): the re-pack as two launches -- the copies layer3 and everything behind it read are rewritten on the second stream
+    assert st["split"] is not None and 0 < len(st["split"][2]) < len(st["keys"]) and a.model.module.__dict__.get("_pack_pending") is None
     assert la == lb and torch.equal(ma, mb), (la, lb)
     for (k, pa), (_, pb) in zip(a.model.named_parameters(), b.model.named_parameters()):
         assert torch.equal(pa, pb), k

@@ -54,6 +54,22 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6m)
+  # Round 6: the step's weight re-pack in two launches, the late one (layer3 on, decoder, data-gradient operators) on the second stream beside the
+  # forward pass of the stem, layer1 and layer2 (DREAM_PACK_SPLIT=1; measured: no gain, opt-in) against one launch on the main stream
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "packing or resnet or data_parallel or train or graph" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    line split0_$r $R
+    DREAM_PACK_SPLIT=1 line split1_$r $R
+  done
+  for r in a b; do
+    line rf32_split0_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+    DREAM_PACK_SPLIT=1 line rf32_split1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  done
+  line rt128_split0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  DREAM_PACK_SPLIT=1 line rt128_split1 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
 g6l)
   # Round 6: the 7x7 stem on the 1x1 GEMM (im2col rows of 192 columns, BatchNorm statistics in its epilogue, GEMM-shaped weight gradient)
   # against the direct kernels on 160 columns (DREAM_STEM_GEMM=0)
