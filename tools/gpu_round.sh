@@ -54,6 +54,19 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+pk)
+  # Round 6: hardware counters of the peak-extraction kernels inside the resnet_f inference step (544 maps of 416 x 416)
+  R="$PWD"
+  P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"
+  P2="SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAVES GRBM_GUI_ACTIVE"
+  P3="TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum"
+  for pass in 1 2 3; do
+    eval C=\$P$pass
+    (cd /tmp && timeout 300 rocprofv3 --pmc $C --kernel-trace -d "$R/$O/pmc_$pass" -o p -- python "$R/bench.py" --arch resnet_f --batch 32 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > "$R/$O/pmc_$pass.log" 2>&1); echo "pmc pass $pass rc=$?"
+  done
+  python tools/pmc_kernels.py gauss,peaks $O/pmc_* > $O/pmc_peaks.txt 2> $O/pmc.err; cat $O/pmc_peaks.txt | cut -c1-400
+  rm -rf $O/pmc_[1-9]
+  ;;
 g6m)
   # Round 6: the step's weight re-pack in two launches, the late one (layer3 on, decoder, data-gradient operators) on the second stream beside the
   # forward pass of the stem, layer1 and layer2 (DREAM_PACK_SPLIT=1; measured: no gain, opt-in) against one launch on the main stream
