@@ -37,6 +37,22 @@ DREAM_DEVICE int reflect_index(int i, int n) {
     return i < n ? i : period - 1 - i;
 }
 
+// ... on maps of at least 2R x 2R pixels (SMALL = false) ONE reflection covers every index a stored output depends on (|distance outside|
+// <= R <= n); the positions staged beyond that feed outputs outside the map only and are clamped to a valid address.  Smaller maps take the
+// general form (two integer divisions per index).
+template <bool SMALL>
+DREAM_DEVICE int reflect_at(int i, int n) {
+    if (SMALL) return reflect_index(i, n);
+    const int q = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+    return q < 0 ? 0 : (q >= n ? n - 1 : q);
+}
+
+// Element `idx` of a map whose base pointer is wavefront-uniform: a 32-bit byte offset beside the scalar base (global_load ... saddr) instead of
+// a 64-bit multiply-add per access -- the launchers require H x W < 2^30.  (PMC, resnet_f at 32 frames: the Gaussian kernels are VALU-bound,
+// 62 % / 96 % busy, and two fifths of their vector instructions were index arithmetic; profiles/r06_pmc_peaks.txt.)
+DREAM_DEVICE float ld_map(const float *base, int idx) { return *(const float *)((const char *)base + (unsigned)(idx << 2)); }
+DREAM_DEVICE void st_map(float *base, int idx, float v) { *(float *)((char *)base + (unsigned)(idx << 2)) = v; }
+
 // One 1-D pass.  Workgroup = 256 threads on a 64-column strip of one map (3-D grid: no 64-bit index division per pixel); lanes
 // run along x.  The inputs of the strip are staged ONCE in LDS, reflected where the strip leaves the map, and every output takes
 // its 25 taps from there: the row pass (AXIS 1) stages 4 rows x (64 + 24) columns for 4 x 64 outputs, the column pass (AXIS 0)
@@ -44,7 +60,7 @@ DREAM_DEVICE int reflect_index(int i, int n) {
 // version issued 25 (it ran at 0.26 TB/s on the 400 x 400 maps of DREAM-resnet-F: bound by its load instructions, not by memory).
 // Same values, same order of additions as before: bit-identical.
 constexpr int GT = 16;            // output rows per workgroup of the column pass
-template <int AXIS>
+template <int AXIS, bool SMALL>
 __global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float *out, int N, int H, int W) {
     __shared__ float tile[AXIS == 0 ? (GT + 2 * R) * 64 : 4 * (64 + 2 * R)];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -59,10 +75,20 @@ __global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float 
     };
     if (AXIS == 0) {
         const int x = x0 + tx;
-        for (int r = ty; r < GT + 2 * R; r += 4) {    // staged row r = map row y0 - R + r, reflected
-            const int yy = y0 - R + r;
-            const int q = (yy >= 0 && yy < H) ? yy : reflect_index(yy, H);
-            tile[r * 64 + tx] = x < W ? base[(size_t)q * W + x] : 0.0f;
+        const bool xin = x < W;
+        {   // staged row r = map row y0 - R + r, reflected.  A wavefront stages rows wv, wv + 4, ..: the row arithmetic is scalar, and ALL
+            // ten loads are in flight before the first LDS store (the rolled loop waited for each load before it issued the next: ten
+            // memory latencies in sequence per workgroup -- 71 % of the wave-cycles parked, profiles/r06_pmc_peaks.txt)
+            const int wv = wave_index();
+            static_assert((GT + 2 * R) % 4 == 0, "rows per wavefront");
+            float v[(GT + 2 * R) / 4];
+#pragma unroll
+            for (int k = 0; k < (GT + 2 * R) / 4; ++k) {
+                const int q = reflect_at<SMALL>(y0 - R + wv + 4 * k, H);
+                v[k] = xin ? ld_map(base, q * W + x) : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < (GT + 2 * R) / 4; ++k) tile[(wv + 4 * k) * 64 + tx] = v[k];
         }
         __syncthreads();
         // round 6: a thread owns FOUR CONSECUTIVE rows of its column: their 4 x 25 taps are 28 staged values, read and converted to
@@ -77,18 +103,20 @@ __global__ void __launch_bounds__(256) gauss_pass_kernel(const float *in, float 
             double acc = dmul(d[k + R], kTaps[R]);
 #pragma unroll
             for (int i = -R; i < 0; ++i) acc = dadd(acc, dmul(dadd(d[k + R + i], d[k + R - i]), kTaps[R + i]));
-            if (x < W && y < H) obase[(size_t)y * W + x] = (float)acc;
+            if (xin && y < H) st_map(obase, y * W + x, (float)acc);
         }
     } else {
         const int y = y0 + ty;
-        for (int c = tx; c < 64 + 2 * R; c += 64) {   // staged column c = map column x0 - R + c, reflected
-            const int xx = x0 - R + c;
-            const int q = (xx >= 0 && xx < W) ? xx : reflect_index(xx, W);
-            tile[ty * (64 + 2 * R) + c] = y < H ? base[(size_t)y * W + q] : 0.0f;
+        {   // staged column c = map column x0 - R + c, reflected: lanes 0-63 the first 64, lanes 0-23 the rest; both loads before the stores
+            const bool yin = y < H, more = tx < 2 * R;
+            const float v0 = yin ? ld_map(base, y * W + reflect_at<SMALL>(x0 - R + tx, W)) : 0.0f;
+            const float v1 = (yin && more) ? ld_map(base, y * W + reflect_at<SMALL>(x0 - R + 64 + tx, W)) : 0.0f;
+            tile[ty * (64 + 2 * R) + tx] = v0;
+            if (more) tile[ty * (64 + 2 * R) + 64 + tx] = v1;
         }
         __syncthreads();
         const int x = x0 + tx;
-        if (x < W && y < H) obase[(size_t)y * W + x] = tap_sum([&](int i) { return tile[ty * (64 + 2 * R) + tx + R + i]; });
+        if (x < W && y < H) st_map(obase, y * W + x, tap_sum([&](int i) { return tile[ty * (64 + 2 * R) + tx + R + i]; }));
     }
 }
 
@@ -266,6 +294,7 @@ struct PeakPart {
     int i1, count;
 };
 
+template <bool SMALL>
 __global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps, const float *colpass, PeakPart *parts, int H, int W) {
     constexpr int SW = 68 + 2 * R;                                   // staged columns: map columns x0 - 1 - R .. x0 + 66 + R (the last two: padding
                                                                      // of the 17th group of four; 92 floats: rows stay 16-byte aligned)
@@ -276,11 +305,28 @@ __global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps,
     const int x0 = blockIdx.x * 64, y0 = blockIdx.y * FT, n = blockIdx.z;
     const float *ori = maps + (size_t)n * H * W;
     const float *base = colpass + (size_t)n * H * W;
-    for (int i = tid; i < (FT + 2) * SW; i += 256) {
-        const int r = i / SW, c = i - r * SW;
-        const int y = y0 - 1 + r, xx = x0 - 1 - R + c;
-        const int q = (xx >= 0 && xx < W) ? xx : reflect_index(xx, W);
-        stage[i] = (y >= 0 && y < H) ? base[(size_t)y * W + q] : 0.0f;   // (rows outside the map are never looked at)
+    {   // a wavefront stages whole rows (row and row test wavefront-uniform, no division): lanes 0-63 the first 64 columns, lanes 0-27 the rest
+        // ... and all of a wavefront's (up to eight) loads are in flight before its first LDS store
+        const int q0 = reflect_at<SMALL>(x0 - 1 - R + tx, W), q1 = reflect_at<SMALL>(x0 - 1 - R + 64 + tx, W);
+        const int wv = wave_index();
+        const bool more = tx < SW - 64;
+        constexpr int NR = (FT + 2 + 3) / 4;
+        float v0[NR], v1[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = wv + 4 * k, y = y0 - 1 + r;
+            const bool yin = r < FT + 2 && y >= 0 && y < H;            // (rows outside the map are never looked at)
+            v0[k] = yin ? ld_map(base, y * W + q0) : 0.0f;
+            v1[k] = (yin && more) ? ld_map(base, y * W + q1) : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int r = wv + 4 * k;
+            if (r < FT + 2) {
+                stage[r * SW + tx] = v0[k];
+                if (more) stage[r * SW + 64 + tx] = v1[k];
+            }
+        }
     }
     __syncthreads();
     // the row pass for (FT + 2) rows x 68 columns (66 needed), a thread = four consecutive columns of one row: 28 staged values (seven
@@ -318,20 +364,22 @@ __global__ void __launch_bounds__(256) gauss_row_peaks_kernel(const float *maps,
             const float left = x > 0 ? sm[r * 68 + c - 1] : 0.0f, right = x + 1 < W ? sm[r * 68 + c + 1] : 0.0f;
             if ((v >= up) && (v >= down) && (v >= left) && (v >= right) && (v > thresh)) {
                 const int idx = y * W + x;
-                const Top2 mine = {ori[idx], NEG_INF, idx};
+                const Top2 mine = {ld_map(ori, idx), NEG_INF, idx};
                 best = top2_merge(best, mine);
                 ++cnt;
             }
         }
     }
+    if (__ballot(cnt != 0) != 0ull) {                 // most wavefronts hold no peak at all: their record is the empty one as it stands
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        Top2 other;
-        other.s1 = lane_xor(best.s1, m);
-        other.s2 = lane_xor(best.s2, m);
-        other.i1 = lane_xor(best.i1, m);
-        best = top2_merge(best, other);
-        cnt += lane_xor(cnt, m);
+        for (int m = 32; m >= 1; m >>= 1) {
+            Top2 other;
+            other.s1 = lane_xor(best.s1, m);
+            other.s2 = lane_xor(best.s2, m);
+            other.i1 = lane_xor(best.i1, m);
+            best = top2_merge(best, other);
+            cnt += lane_xor(cnt, m);
+        }
     }
     if (lane == 0) s_part[ty] = PeakPart{best.s1, best.s2, best.i1, cnt};
     __syncthreads();
@@ -388,16 +436,25 @@ __global__ void __launch_bounds__(256) peaks_finish_kernel(const float *maps, co
     keypoints[(size_t)n * 2 + 1] = ky;
 }
 
+bool small_map(int H, int W) { return H < 2 * R || W < 2 * R; }      // -> the kernels' SMALL instances (reflect_at)
+
 int smooth_maps(const float *maps, float *tmp, float *out, int N, int H, int W, hipStream_t s) {
     DREAM_REQUIRE((H + 3) / 4 <= 65535, "gaussian: more than 262140 rows");
+    DREAM_REQUIRE((size_t)H * W < ((size_t)1 << 30), "gaussian: maps of 2^30 pixels and more are not supported (32-bit byte offsets inside a map)");
     for (int n0 = 0; n0 < N; n0 += 65535) {                  // grid.z limit
         const int nn = N - n0 < 65535 ? N - n0 : 65535;
         const size_t off = (size_t)n0 * H * W;
         const dim3 grid0((unsigned)((W + 63) / 64), (unsigned)((H + GT - 1) / GT), (unsigned)nn);
         const dim3 grid1((unsigned)((W + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)nn);
-        hipLaunchKernelGGL(gauss_pass_kernel<0>, grid0, dim3(256), 0, s, maps + off, tmp + off, nn, H, W);
-        DREAM_LAUNCH_OK();
-        hipLaunchKernelGGL(gauss_pass_kernel<1>, grid1, dim3(256), 0, s, (const float *)(tmp + off), out + off, nn, H, W);
+        if (small_map(H, W)) {
+            hipLaunchKernelGGL((gauss_pass_kernel<0, true>), grid0, dim3(256), 0, s, maps + off, tmp + off, nn, H, W);
+            DREAM_LAUNCH_OK();
+            hipLaunchKernelGGL((gauss_pass_kernel<1, true>), grid1, dim3(256), 0, s, (const float *)(tmp + off), out + off, nn, H, W);
+        } else {
+            hipLaunchKernelGGL((gauss_pass_kernel<0, false>), grid0, dim3(256), 0, s, maps + off, tmp + off, nn, H, W);
+            DREAM_LAUNCH_OK();
+            hipLaunchKernelGGL((gauss_pass_kernel<1, false>), grid1, dim3(256), 0, s, (const float *)(tmp + off), out + off, nn, H, W);
+        }
         DREAM_LAUNCH_OK();
     }
     return 0;
@@ -415,6 +472,7 @@ extern "C" int dream_keypoints_from_belief_maps_rule_f32(const float *maps, floa
                                                          double offset_due_to_upsampling, int use_belief_peak_scores,
                                                          double belief_peak_next_best_score, void *stream) {
     DREAM_REQUIRE(maps && scratch && keypoints && N > 0 && H > 0 && W > 0, "keypoints_from_belief_maps: bad arguments");
+    DREAM_REQUIRE((size_t)H * W < ((size_t)1 << 30), "keypoints_from_belief_maps: maps of 2^30 pixels and more are not supported");
     const size_t total = (size_t)N * H * W;
     // round 6: column pass, then the row pass fused with the scan (gauss_row_peaks_kernel), then one wavefront per map -- when a map's
     // workgroup records fit where its smoothed copy would have gone (they do from 3 x 3 maps on) and the grid fits
@@ -422,12 +480,17 @@ extern "C" int dream_keypoints_from_belief_maps_rule_f32(const float *maps, floa
     static const bool env_fused = [] { const char *e = getenv("DREAM_PEAKS_FUSED"); return !(e && e[0] == '0'); }();
     const bool fused = g_peaks_fused < 0 ? env_fused : g_peaks_fused != 0;
     if (fused && (size_t)nper * 4 + 4 <= (size_t)H * W && N <= 65535 && gy <= 65535 && (H + GT - 1) / GT <= 65535) {
-        hipLaunchKernelGGL(gauss_pass_kernel<0>, dim3((unsigned)gx, (unsigned)((H + GT - 1) / GT), (unsigned)N), dim3(256), 0, (hipStream_t)stream,
-                           maps, scratch, N, H, W);
-        DREAM_LAUNCH_OK();
+        const dim3 grid0((unsigned)gx, (unsigned)((H + GT - 1) / GT), (unsigned)N), grid1((unsigned)gx, (unsigned)gy, (unsigned)N);
         PeakPart *parts = (PeakPart *)(scratch + ((total + 3) & ~(size_t)3));      // (16-byte records)
-        hipLaunchKernelGGL(gauss_row_peaks_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)N), dim3(256), 0, (hipStream_t)stream, maps,
-                           (const float *)scratch, parts, H, W);
+        if (small_map(H, W)) {
+            hipLaunchKernelGGL((gauss_pass_kernel<0, true>), grid0, dim3(256), 0, (hipStream_t)stream, maps, scratch, N, H, W);
+            DREAM_LAUNCH_OK();
+            hipLaunchKernelGGL(gauss_row_peaks_kernel<true>, grid1, dim3(256), 0, (hipStream_t)stream, maps, (const float *)scratch, parts, H, W);
+        } else {
+            hipLaunchKernelGGL((gauss_pass_kernel<0, false>), grid0, dim3(256), 0, (hipStream_t)stream, maps, scratch, N, H, W);
+            DREAM_LAUNCH_OK();
+            hipLaunchKernelGGL(gauss_row_peaks_kernel<false>, grid1, dim3(256), 0, (hipStream_t)stream, maps, (const float *)scratch, parts, H, W);
+        }
         DREAM_LAUNCH_OK();
         hipLaunchKernelGGL(peaks_finish_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, maps, (const PeakPart *)parts, nper,
                            keypoints, peak_counts, N, H, W, offset_due_to_upsampling, use_belief_peak_scores, belief_peak_next_best_score);

@@ -54,6 +54,19 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+pk2)
+  # Round 6: peak-extraction kernels with the loads of a strip in flight together and 32-bit offsets (build/libpeaks_old.so = before)
+  echo "== pytest"; timeout 1200 python -m pytest tests -m gpu -q -x --timeout 900 -k "peaks or abi or gauss or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for r in a b; do
+    for v in old new; do
+      echo "-- $v $r"; withlib peaks_$v timeout 200 python tools/microbench_peaks.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_peaks_$v.txt
+    done
+  done
+  for r in a b; do
+    withlib peaks_old line rf32_old_$r --arch resnet_f --batch 32
+    withlib peaks_new line rf32_new_$r --arch resnet_f --batch 32
+  done
+  ;;
 pk)
   # Round 6: hardware counters of the peak-extraction kernels inside the resnet_f inference step (544 maps of 416 x 416)
   R="$PWD"
