@@ -289,12 +289,18 @@ struct WgWinoLdsParams {
 // Wave w owns active position q = w (row a + q / 3, column b + q % 3) for the whole 64 x 64 block; the ninth position is shared:
 // wave w takes its blocks (m = w >> 1, n = 2 (w & 1) .. + 1).  36 MFMAs per wave and stage instead of 64; the producers load the same
 // 6 float4 per stage and transform three of V's four columns.
-template <bool UPS, bool BIAS, bool CONVT = false>
-__global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsParams p) {
-    DREAM_DYNAMIC_LDS(float, smem);
+// PHB (CONVT): the phase's column b is a compile-time constant of the body -- the kernel branches once on blockIdx.z & 1 --, so that the
+// patch column the phase never reads (3 for b = 0, 0 for b = 1: V's live columns b .. b + 2 are combinations of patch columns b .. b + 2
+// only) is not loaded: FIVE float4 loads per stage instead of six next to 36 MFMAs, and the eight wave-uniform selects per stage that
+// picked the operands of the outer live column are gone.  Likewise the patch ROW the phase never reads (3 for a = 0, 0 for a = 1; a is
+// wave-uniform at run time): its lanes' loads are masked out of range (no memory traffic; their V row is never read).  Same values,
+// same order of additions as the six-load form: bit-identical (profiles/r06_ab_convT_wgrad_five_loads.txt).
+template <bool UPS, bool BIAS, bool CONVT, int PHB>
+DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
     const int lane = threadIdx.x & 63;
     const int wave = wave_index();
-    const int ph_a = CONVT ? (int)(blockIdx.z >> 1) : 0, ph_b = CONVT ? (int)(blockIdx.z & 1) : 0;     // output phase
+    const int ph_a = CONVT ? (int)(blockIdx.z >> 1) : 0;                                                   // output phase
+    constexpr int ph_b = CONVT ? PHB : 0;
     const int cog = (int)blockIdx.x % p.ncog, cig = (int)blockIdx.x / p.ncog;
     const int co0 = cog * 64, ci0 = cig * 64;
     const int split = blockIdx.y;
@@ -338,6 +344,8 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
     // image is rows / columns {-1, 0, 0, +1} of the stored one around the tile's source pixel ((2 t - 1 + r) >> 1 = t + ((r - 1) >> 1))
     const int lane_dx = UPS ? (int)(((((vr - 1) >> 1) * Ws) * p.Cin + 4 * vq) * 4) : (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);
     const int lane_dy = CONVT ? (int)(((yr2 * 2 * Wd) * p.Cdy + 4 * yq) * 4) : (int)(((yr2 * p.W) * p.Cdy + 4 * yq) * 4);
+    // the patch row in the row test: the lanes of the phase's dead patch row (CONVT) fail it for every tile
+    const int vr_chk = (CONVT && vr == (ph_a ? 0 : 3)) ? (1 << 29) : vr;
     const int x_px = p.Cin * 4, y_px = (CONVT ? 2 : 1) * p.Cdy * 4;       // (a phase's neighbouring pixels are two stored pixels apart)
     auto issue_load = [&](int set, int st, int n) {
         const int tau = k_begin + st * LT + wave;                               // wave-uniform from here ...
@@ -346,10 +354,12 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
         const int ty = div_magic40(rem, p.magic_tx), tx = rem - ty * p.TX;
         const int pix = ((b - b0) * p.H + 2 * ty) * p.W + 2 * tx;               // the tile's first output pixel
         if (n < 4) {
-            const int s_off = UPS ? ((((b - b0) * Hs + ty) * Ws + tx) * p.Cin + ci0) * 4 + ((n - 1) >> 1) * x_px
-                                    : (pix * p.Cin + ci0) * 4 + (n - 1) * x_px;  // ... to here
-            const bool col_ok = tv & ((unsigned)(2 * tx - 1 + n) < (unsigned)p.W);
-            const bool ok = col_ok & ((unsigned)(2 * ty - 1 + vr) < (unsigned)p.H);
+            if (CONVT && n == 3) return;                                         // three live patch columns: ph_b + n
+            const int c = n + ph_b;
+            const int s_off = UPS ? ((((b - b0) * Hs + ty) * Ws + tx) * p.Cin + ci0) * 4 + ((c - 1) >> 1) * x_px
+                                    : (pix * p.Cin + ci0) * 4 + (c - 1) * x_px;  // ... to here
+            const bool col_ok = tv & ((unsigned)(2 * tx - 1 + c) < (unsigned)p.W);
+            const bool ok = col_ok & ((unsigned)(2 * ty - 1 + vr_chk) < (unsigned)p.H);
             xr[set][n] = buffer_load_x4(xbuf, (unsigned)(s_off + lane_dx) | ((unsigned)!ok << 31), 0);     // bit 31: out of range
         } else {
             const int s_off = CONVT ? ((((b - b0) * Hd + 4 * ty + ph_a) * Wd + 4 * tx + ph_b) * p.Cdy + co0) * 4 + (n - 4) * y_px
@@ -360,16 +370,16 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
         }
     };
     // piece k = 0..3 of the V transform (transformed column j = k), 4..5 of the dM transform (column 2 yh + k - 4)
-    // (CONVT: k = 0 stands for the phase's live outer column -- 0 for b = 0, 3 for b = 1 -- chosen by a wave-uniform select)
+    // (CONVT: k = 0 stands for the phase's live outer column -- 0 for b = 0, 3 for b = 1)
     auto transform_piece = [&](int set, float *buf, int k) {
         if (k < 4) {
             const f32x4 *d = xr[set];
             f32x4 u;
             int kcol = k;
-            if (CONVT && k == 0) {
-                const f32x4 lhs = ph_b ? d[1] : d[0], rhs = ph_b ? d[3] : d[2];
-                u = lhs - rhs;
-                kcol = ph_b ? 3 : 0;
+            if (CONVT) {                           // d[0..2] = patch columns ph_b .. ph_b + 2
+                if (ph_b == 0) u = k == 0 ? d[0] - d[2] : k == 1 ? d[1] + d[2] : d[2] - d[1];
+                else u = k == 0 ? d[0] - d[2] : k == 1 ? d[0] + d[1] : d[1] - d[0];
+                kcol = k == 0 ? (ph_b ? 3 : 0) : k;
             } else {
                 u = k == 0 ? d[0] - d[2] : k == 1 ? d[1] + d[2] : k == 2 ? d[2] - d[1] : d[1] - d[3];
             }
@@ -479,12 +489,16 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
 #pragma unroll
         for (int n = 0; n < 4; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     acc_sh[0] = acc_sh[1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    f32x4 oy[2], ov[2], sy[2], sv[2];
+    // the shared position's operands: the wave needs component sh_m of dM's quad and components 2 sh_n, 2 sh_n + 1 of V's -- read exactly
+    // those (a b32 and a b64 read at wave-constant offsets) instead of two b128 reads + ten wave-uniform selects per stage
+    f32x4 oy[2], ov[2];
+    float sy[2];
+    f32x2 sv[2];
     auto read_ops = [&](int set, const float *buf, int ks) {
         oy[set] = *(const f32x4 *)(buf + py_own + ks * 256 + a_lane);
         ov[set] = *(const f32x4 *)(buf + LOPS + pv_own + ks * 256 + a_lane);
-        sy[set] = *(const f32x4 *)(buf + py_sh + ks * 256 + a_lane);
-        sv[set] = *(const f32x4 *)(buf + LOPS + pv_sh + ks * 256 + a_lane);
+        sy[set] = buf[py_sh + ks * 256 + a_lane + sh_m];
+        sv[set] = *(const f32x2 *)(buf + LOPS + pv_sh + ks * 256 + a_lane + 2 * sh_n);
     };
     // one stage: 2 k-steps x (16 MFMAs of the wave's own position + 2 of the shared one); producer pieces behind single MFMAs as in
     // the 3x3 form: the six loads of stage st + 2 behind MFMAs 1, 3, .. 11, the five transform pieces of stage st + 1 behind MFMAs 14, 18,
@@ -504,11 +518,7 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
                     const int m = mn >> 2, n4 = mn & 3;
                     acc[m][n4] = mfma_f32_16x16x4(oy[ks][m], ov[ks][n4], acc[m][n4]);
                 } else {
-                    // wave-uniform selects of the shared position's operand components
-                    const f32x4 y = sy[ks], v = sv[ks];
-                    const float am = sh_m == 0 ? y[0] : sh_m == 1 ? y[1] : sh_m == 2 ? y[2] : y[3];
-                    const float bn = mn == 16 ? (sh_n ? v[2] : v[0]) : (sh_n ? v[3] : v[1]);
-                    acc_sh[mn - 16] = mfma_f32_16x16x4(am, bn, acc_sh[mn - 16]);
+                    acc_sh[mn - 16] = mfma_f32_16x16x4(sy[ks], sv[ks][mn - 16], acc_sh[mn - 16]);
                 }
                 if (mn == 4 && ks == 0) read_ops(1, cur, 1);
                 if (!(DREAM_WGW_DIAG & 1) && n >= 1 && n < 13 && (n & 1) == 1) issue_load(P, st + 2, (n - 1) >> 1);
@@ -561,6 +571,13 @@ __global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsP
             p.bias_partial[((size_t)(CONVT ? blockIdx.z * p.nsplit : 0) + split) * p.Cout + co0 + threadIdx.x] = s;
         }
     }
+}
+
+template <bool UPS, bool BIAS, bool CONVT = false>
+__global__ void __launch_bounds__(512, 1) wgrad_wino_lds_kernel(const WgWinoLdsParams p) {
+    DREAM_DYNAMIC_LDS(float, smem);
+    if (CONVT && (blockIdx.z & 1)) wgrad_wino_lds_body<UPS, BIAS, CONVT, 1>(p, smem);      // workgroup-uniform
+    else wgrad_wino_lds_body<UPS, BIAS, CONVT, 0>(p, smem);
 }
 
 // dw_oihw[co][ci][3][3] = G^T (sum over splits, fixed order, of dU) G with the deferred signs (fourth column of the positions).

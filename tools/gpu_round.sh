@@ -54,6 +54,39 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6o)
+  # Round 6: CONVT weight gradient, step 2: the shared position's operands read as the components the wave uses (no selects) -- build/libwgw_new2.so
+  # against step 1 (build/libwgw_new.so) and the tree before (build/libwgw_old.so)
+  for v in old new2; do withlib wgw_$v timeout 300 python tools/microbench_convT_wgrad.py --digest --layers 5 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/digest_$v.txt; done
+  cmp $O/digest_old.txt $O/digest_new2.txt && echo "digests identical"
+  for r in a b; do for v in new new2; do
+    echo "-- $v $r"; withlib wgw_$v timeout 300 python tools/microbench_convT_wgrad.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_$v.txt | cut -c88-200
+  done; done
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    withlib wgw_old line rt16_old_$r $R
+    withlib wgw_new2 line rt16_new2_$r $R
+  done
+  ;;
+g6n)
+  # Round 6: ConvTranspose2d weight gradient (nine positions) with the phase column compile-time: five loads per stage instead of six, no operand
+  # selects, the dead patch row's lanes masked (build/libwgw_old.so = before).  Digests: bit-identity of the two builds.
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "convT or wgrad or resnet or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for v in old new; do withlib wgw_$v timeout 300 python tools/microbench_convT_wgrad.py --digest --layers 5 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/digest_$v.txt; done
+  cmp $O/digest_old.txt $O/digest_new.txt && echo "digests identical"; cat $O/digest_new.txt
+  for r in a b; do for v in old new; do
+    echo "-- $v $r"; withlib wgw_$v timeout 300 python tools/microbench_convT_wgrad.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_$v.txt | cut -c1-200
+  done; done
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    withlib wgw_old line rt16_old_$r $R
+    withlib wgw_new line rt16_new_$r $R
+  done
+  withlib wgw_old line rt128_old --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  withlib wgw_new line rt128_new --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  withlib wgw_old line rf32_old --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  withlib wgw_new line rf32_new --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  ;;
 pk2)
   # Round 6: peak-extraction kernels with the loads of a strip in flight together and 32-bit offsets (build/libpeaks_old.so = before)
   echo "== pytest"; timeout 1200 python -m pytest tests -m gpu -q -x --timeout 900 -k "peaks or abi or gauss or structured" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log

@@ -33,7 +33,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--digest", action="store_true", help="seeded inputs; print a sha256 of the F(2x2,2x2) form's outputs per layer "
+                    "(bit-identity of two library builds: tools/gpu_round.sh g6n)")
     a = ap.parse_args()
+    if a.digest:
+        import hashlib
+        for (res, cin, cout) in LAYERS[:a.layers]:
+            g = torch.Generator(device="cuda").manual_seed(res)
+            x = torch.randn(a.batch, res, res, cin, device="cuda", generator=g)
+            dy = torch.randn(a.batch, 2 * res, 2 * res, cout, device="cuda", generator=g)
+            w, b = ops.convT4x4_wgrad_winograd(x, dy)
+            print("%4d^2 %5d->%4d  sha256(dw) %s  sha256(db) %s" % (res, cin, cout, hashlib.sha256(w.cpu().numpy().tobytes()).hexdigest()[:16],
+                                                                hashlib.sha256(b.cpu().numpy().tobytes()).hexdigest()[:16]))
+        return
     td = tw = 0.0
     for (res, cin, cout) in LAYERS[:a.layers]:
         x = torch.randn(a.batch, res, res, cin, device="cuda")
