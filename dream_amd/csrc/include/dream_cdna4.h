@@ -147,6 +147,21 @@ DREAM_DEVICE float quad_perm_2211(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x5A, 0xF, 0xF, true));
 }
 
+// u[e] + s * quad_perm_2211(u[e]) for the four components, fused (one rounding, = fmaf(s, quad_perm_2211(u[e]), u[e]) bit for bit), as
+// four v_fmac_f32 with the DPP modifier on the multiplicand.  The compiler does not fold v_mov_b32_dpp into v_fmac / v_pk_fma (it emitted
+// 4 + 2 instructions per call), hence the assembly; the s_nop covers the two wait states a DPP read needs after a VALU write of its
+// source, which the compiler's hazard recogniser does not see inside an asm block.
+DREAM_DEVICE f32x4 fma_quad_perm_2211(f32x4 u, float s) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[2,2,1,1] row_mask:0xf bank_mask:0xf"
+        : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3])
+        : "v"(s));
+    return u;
+}
+
 // DPP quad_perm [1,0,3,2]: the two lanes of every pair swap
 DREAM_DEVICE float quad_perm_1032(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));

@@ -324,6 +324,7 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
     const int yr2 = lane & 1, yh = (lane >> 1) & 1, yq = lane >> 2;
     const float vsb = (vr == 1) ? 1.0f : -1.0f;             // column transform of V: u_r + vsb * u_partner (conv_wino.hip)
     const float ysg = (yr2 == 0) ? 1.0f : -1.0f;            // mixed dM row: partner + ysg * own
+    const float c_sub = yh ? -1.0f : 0.0f, c_add = yh ? 0.0f : 1.0f;      // row transform of dM (transform_piece)
     const int v_store = l_plane_v(4 * vr) + wave * 64 + 4 * vq;              // V[4 vr + j]: + j * LPS
     // dM rows of this lane: row A = its own values (row 0 for the upper dy row, row 3 for the lower one), row B = the mixed
     // one (row 1 = upper + lower, row 2 = upper - lower); columns 2 yh + jj
@@ -339,7 +340,14 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
     // VALU instructions share the SIMD's issue slots with the MFMAs (measured: every VALU instruction in this loop shows up
     // in the run time), so the address is split: everything that depends on the tile is wave-uniform and computed on the
     // scalar unit (offset of the tile's first output pixel + column), the lane adds its constant (patch row, channel quad)
-    // with one v_add and sets bit 31 where the pixel is outside the image (beyond any buffer: the hardware returns zeros).
+    // with ONE v_add.  Pixels outside the image are loaded as zeros by the hardware's range check (offsets with bit 31 set are
+    // beyond any buffer), and the two reasons for it keep their own out-of-range words so that the add is all a load costs: a dead
+    // COLUMN (or a tile past the split's end) is wave-uniform -- the scalar part becomes OOB_WAVE by a scalar select --, a dead ROW
+    // is per lane and the same for all loads of the stage -- the lane part becomes OOB_LANE by one select per operand and stage
+    // (was: add + select + or per load).  With valid scalar parts in [0, 2^30) (the plans keep a split's span below that) and lane
+    // constants below 2^24 in magnitude, every sum that involves an out-of-range word lands in [2^31, 2^32):
+    //   valid + OOB_LANE in [0xC0000000, 2^32),  OOB_WAVE + lane constant = 0xE0000000 +- 2^24,  OOB_WAVE + OOB_LANE = 0xA0000000 (mod 2^32).
+    constexpr unsigned OOB_LANE = 0xC0000000u, OOB_WAVE = 0xE0000000u;
     // patch row vr - 1 relative to the tile's first output row; with the fused upsample the tile's 4 x 4 patch of the upsampled
     // image is rows / columns {-1, 0, 0, +1} of the stored one around the tile's source pixel ((2 t - 1 + r) >> 1 = t + ((r - 1) >> 1))
     const int lane_dx = UPS ? (int)(((((vr - 1) >> 1) * Ws) * p.Cin + 4 * vq) * 4) : (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);
@@ -358,15 +366,15 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
             const int c = n + ph_b;
             const int s_off = UPS ? ((((b - b0) * Hs + ty) * Ws + tx) * p.Cin + ci0) * 4 + ((c - 1) >> 1) * x_px
                                     : (pix * p.Cin + ci0) * 4 + (c - 1) * x_px;  // ... to here
-            const bool col_ok = tv & ((unsigned)(2 * tx - 1 + c) < (unsigned)p.W);
-            const bool ok = col_ok & ((unsigned)(2 * ty - 1 + vr_chk) < (unsigned)p.H);
-            xr[set][n] = buffer_load_x4(xbuf, (unsigned)(s_off + lane_dx) | ((unsigned)!ok << 31), 0);     // bit 31: out of range
+            const bool col_ok = tv & ((unsigned)(2 * tx - 1 + c) < (unsigned)p.W);                  // wave-uniform
+            const bool row_ok = (unsigned)(2 * ty - 1 + vr_chk) < (unsigned)p.H;                    // per lane, the same for the stage's loads
+            xr[set][n] = buffer_load_x4(xbuf, (col_ok ? (unsigned)s_off : OOB_WAVE) + (row_ok ? (unsigned)lane_dx : OOB_LANE), 0);
         } else {
             const int s_off = CONVT ? ((((b - b0) * Hd + 4 * ty + ph_a) * Wd + 4 * tx + ph_b) * p.Cdy + co0) * 4 + (n - 4) * y_px
                                     : (pix * p.Cdy + co0) * 4 + (n - 4) * y_px;
             const bool col_ok = tv & ((2 * tx + (n - 4)) < p.W);
-            const bool ok = col_ok & ((2 * ty + yr2) < p.H);
-            yr[set][n - 4] = buffer_load_x4(ybuf, (unsigned)(s_off + lane_dy) | ((unsigned)!ok << 31), 0);
+            const bool row_ok = (2 * ty + yr2) < p.H;
+            yr[set][n - 4] = buffer_load_x4(ybuf, (col_ok ? (unsigned)s_off : OOB_WAVE) + (row_ok ? (unsigned)lane_dy : OOB_LANE), 0);
         }
     };
     // piece k = 0..3 of the V transform (transformed column j = k), 4..5 of the dM transform (column 2 yh + k - 4)
@@ -383,19 +391,23 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
             } else {
                 u = k == 0 ? d[0] - d[2] : k == 1 ? d[1] + d[2] : k == 2 ? d[2] - d[1] : d[1] - d[3];
             }
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(vsb, quad_perm_2211(u[e]), u[e]);
+            // u + vsb * (u of the partner row), fused: four v_fmac_f32 with a DPP source (was: four v_mov_b32_dpp + two v_pk_fma_f32)
+            const f32x4 v = fma_quad_perm_2211(u, vsb);
             *(f32x4 *)(buf + LOPS + v_store + kcol * LPS) = v;
         } else {
             // along the dy row: (y0, y1) -> y0, y0 + y1, y0 - y1, y1 (the minus sign of the fourth column is applied at the end)
             const int jj = k - 4;
             const f32x4 y0 = yr[set][0], y1 = yr[set][1];
             if (BIAS && jj == 0 && bias_wg) bsum = bsum + (y0 + y1);           // out-of-range pixels and tiles were loaded as zeros
+            // the lane's column (2 yh + jj) of the row transform as ONE fused multiply-add with a lane constant instead of an
+            // addition / subtraction + a per-lane select: jj = 0: y0 (yh = 0) or y0 - y1 (yh = 1) = fma(c_sub, y1, y0) with c_sub = 0 / -1;
+            // jj = 1: y0 + y1 or y1 = fma(c_add, y0, y1) with c_add = 1 / 0.  Products by +-1 are exact and a product by 0 is a zero, so
+            // the values are the same; only the SIGN of a zero can differ (-0 + +0 = +0), which no accumulated value can see (the
+            // accumulators start at +0 and x + (+-0) = x; +0 + (-0) = +0).  (A non-finite dy makes the results NaN either way.)
             f32x4 m, mixed;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                m[e] = jj == 0 ? (yh ? y0[e] - y1[e] : y0[e]) : (yh ? y1[e] : y0[e] + y1[e]);
+                m[e] = jj == 0 ? __builtin_fmaf(c_sub, y1[e], y0[e]) : __builtin_fmaf(c_add, y0[e], y1[e]);
                 mixed[e] = __builtin_fmaf(ysg, m[e], quad_perm_1032(m[e]));     // upper lane: own + partner; lower: partner - own
             }
             *(f32x4 *)(buf + y_store_a + jj * LPS) = m;
@@ -796,6 +808,9 @@ extern "C" int dream_conv3x3_wgrad_winograd_bias_nhwc_f32(const float *x, const 
     if (use_lds_version(Cin, Cout, Cdy)) {
         const PlanLds pl = make_plan_lds(B, H, W, Cin, Cout);
         DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd wgrad: too many tiles");
+        // the kernel's out-of-range words (OOB_LANE / OOB_WAVE) need the byte offsets inside a split's span of images below 2^30
+        DREAM_REQUIRE(((size_t)(pl.tiles_per_split / ((long)pl.TY * pl.TX)) + 2) * (size_t)H * W * (size_t)(Cin > Cdy ? Cin : Cdy) * 4 < ((size_t)1 << 30),
+                      "winograd wgrad: a split's span of images is too large for 32-bit offsets");
         WgWinoLdsParams p;
         p.x = x; p.dy = dy; p.partial = (float *)workspace;
         p.bias_partial = p.partial + (size_t)pl.nsplit * 16 * Cout * Cin;
@@ -887,6 +902,8 @@ extern "C" int dream_convT4x4_wgrad_winograd_nhwc_f32(const float *x, const floa
     const PlanLds pl = make_plan_convT(B, H, W, Cin, Cout);
     DREAM_REQUIRE((long)B * pl.TY * pl.TX < ((long)1 << 24), "winograd convT wgrad: too many tiles");
     DREAM_REQUIRE((size_t)4 * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 29), "winograd convT wgrad: image too large for 32-bit offsets");
+    DREAM_REQUIRE(((size_t)(pl.tiles_per_split / ((long)pl.TY * pl.TX)) + 2) * (size_t)4 * H * W * (size_t)(Cin > Cout ? Cin : Cout) * 4 < ((size_t)1 << 30),
+                  "winograd convT wgrad: a split's span of images is too large for 32-bit offsets");
     WgWinoLdsParams p;
     p.x = x; p.dy = dy; p.partial = (float *)workspace;
     p.bias_partial = p.partial + (size_t)4 * pl.nsplit * 9 * Cout * Cin;

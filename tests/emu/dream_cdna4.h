@@ -116,6 +116,11 @@ inline float quad_perm_2211(float v) {
     const int l = emu::lane(), src = (l & ~3) | ((l & 3) < 2 ? 2 : 1);
     return emu_exchange(v, src);
 }
+inline f32x4 fma_quad_perm_2211(f32x4 u, float s) {
+    f32x4 r;
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(s, quad_perm_2211(u[e]), u[e]);
+    return r;
+}
 inline float quad_perm_1032(float v) { return emu_exchange(v, emu::lane() ^ 1); }
 inline int wave_index() { return emu::wave(); }
 inline int lane_id() { return emu::lane(); }

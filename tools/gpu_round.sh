@@ -54,6 +54,33 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6p)
+  # Round 6: weight-gradient kernels in the Winograd domain (3x3 and CONVT forms), step 3: one v_add per load (separate out-of-range words for the
+  # dead row / dead column), the V row transform as v_fmac_f32 with a DPP source, the dM row transform as one fma with a lane constant --
+  # build/libwgw_new3.so against step 2 (build/libwgw_new2.so) and the tree before (build/libwgw_old.so)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "convT or wgrad or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for v in old new3; do
+    withlib wgw_$v timeout 300 python tools/microbench_convT_wgrad.py --digest --layers 5 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/digest_convT_$v.txt
+    withlib wgw_$v timeout 300 python tools/microbench_wgrad_wino.py --digest --batch 16 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/digest_3x3_$v.txt
+  done
+  cmp $O/digest_convT_old.txt $O/digest_convT_new3.txt && echo "convT digests identical"
+  cmp $O/digest_3x3_old.txt $O/digest_3x3_new3.txt && echo "3x3 digests identical"
+  for r in a b; do for v in new2 new3; do
+    echo "-- $v $r"; withlib wgw_$v timeout 300 python tools/microbench_convT_wgrad.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_convT_$v.txt | cut -c88-160
+  done; done
+  for r in a b; do for v in old new3; do
+    echo "-- 3x3 $v $r"; withlib wgw_$v timeout 400 python tools/microbench_wgrad_wino.py --only-winograd 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_3x3_$v.txt
+  done; done
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    withlib wgw_old line rt16_old_$r $R
+    withlib wgw_new3 line rt16_new3_$r $R
+  done
+  for r in a b; do
+    withlib wgw_old line vq_train_old_$r --mode train --steps 5 --warmup 2
+    withlib wgw_new3 line vq_train_new3_$r --mode train --steps 5 --warmup 2
+  done
+  ;;
 g6o)
   # Round 6: CONVT weight gradient, step 2: the shared position's operands read as the components the wave uses (no selects) -- build/libwgw_new2.so
   # against step 1 (build/libwgw_new.so) and the tree before (build/libwgw_old.so)

@@ -32,7 +32,34 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--digest", action="store_true", help="seeded inputs; sha256 of the Winograd form's dw / db per layer (bit-identity of two "
+                    "library builds), no timing")
+    ap.add_argument("--only-winograd", action="store_true", help="time the Winograd form only")
     args = ap.parse_args()
+    if args.digest:
+        import hashlib
+        for (res, cin, cout, count) in LAYERS:
+            g = torch.Generator(device="cuda").manual_seed(res + cin)
+            x = torch.randn(args.batch, res, res, cin, device="cuda", generator=g)
+            dy = torch.randn(args.batch, res, res, cout, device="cuda", generator=g)
+            w, db = ops.conv3x3_wgrad_winograd(x, dy, cout, cin)
+            print("%4d %4d->%4d  sha256(dw) %s  sha256(db) %s" % (res, cin, cout, hashlib.sha256(w.cpu().numpy().tobytes()).hexdigest()[:16],
+                  "-" if db is None else hashlib.sha256(db.cpu().numpy().tobytes()).hexdigest()[:16]))
+            del x, dy, w
+        return
+    if args.only_winograd:
+        tw = 0.0
+        for (res, cin, cout, count) in LAYERS:
+            x = torch.randn(args.batch, res, res, cin, device="cuda")
+            dy = torch.randn(args.batch, res, res, cout, device="cuda")
+            ms_w = timeit(lambda: ops.conv3x3_wgrad_winograd(x, dy, cout, cin), args.reps)
+            flops = 2.0 * args.batch * res * res * cin * cout * 9
+            tw += count * ms_w
+            print("%4d %4d->%4d x%d  winograd %8.3f ms %6.1f TF-equiv (%.3f of peak on its own MACs)" % (
+                res, cin, cout, count, ms_w, flops / ms_w / 1e9, flops / 2.25 / ms_w / 1e9 / 157.3), flush=True)
+            del x, dy
+        print("sum over the vgg_q layers (b=%d): winograd %.2f ms" % (args.batch, tw))
+        return
     td = tw = 0.0
     for (res, cin, cout, count) in LAYERS:
         b = args.batch
