@@ -54,6 +54,28 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6q)
+  # Round 6: F(2x2,3x3) forward / data-gradient kernels (conv_wino_body.inc): the column transform's quad exchange folded into v_fmac_f32 with a DPP
+  # source (16 of the loop's 50 VALU instructions per 72 MFMAs) -- build/libcw_new.so against build/libwgw_new3.so (= the commit before)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "winograd or resnet or structured or vgg_f" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for v in wgw_new3 cw_new; do
+    for cfg in "resnet_h infer 16" "resnet_h train 16" "vgg_f infer 8"; do set -- $cfg
+      withlib $v timeout 300 python tools/digest_step.py --arch $1 --mode $2 --batch $3 2>&1 | grep sha256 >> $O/digest_$v.txt
+    done
+  done
+  cmp $O/digest_wgw_new3.txt $O/digest_cw_new.txt && echo "digests identical"; cat $O/digest_cw_new.txt
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    withlib wgw_new3 line rt16_old_$r $R
+    withlib cw_new line rt16_new_$r $R
+  done
+  for r in a b; do
+    withlib wgw_new3 line ri16_old_$r --arch resnet_h --batch 16
+    withlib cw_new line ri16_new_$r --arch resnet_h --batch 16
+    withlib wgw_new3 line vf32_old_$r --arch vgg_f --batch 32
+    withlib cw_new line vf32_new_$r --arch vgg_f --batch 32
+  done
+  ;;
 g6p)
   # Round 6: weight-gradient kernels in the Winograd domain (3x3 and CONVT forms), step 3: one v_add per load (separate out-of-range words for the
   # dead row / dead column), the V row transform as v_fmac_f32 with a DPP source, the dM row transform as one fma with a lane constant --
