@@ -276,10 +276,15 @@ __global__ void __launch_bounds__(256, MB == 4 ? (KS == 1 ? 3 : 2) : 4) gemm1x1_
             if (EL && EPI == 2) { z = e_z[i % D]; ya = e_ya[i % D]; }
             if (EL && i + D < NR) epi_load(i + D);
             f32x4 v = {acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r]};
-            v = v * sc + sh;
+            // the entry points of the statistics forms pass no scale and no ReLU flag (EPI 1: an optional shift; EPI 2: nothing): their
+            // epilogues do not spend a multiplication, an addition and a maximum per element on 1, 0 and -inf
+            if (EPI == 0) v = v * sc + sh;
+            if (EPI == 1) v = v + sh;
             if (EL && HAS_RES) v = v + res;                    // (EPI 2 without a residual adds the empty descriptor's zeros: only -0 becomes +0)
+            if (EPI == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_lo);
+            }
             const bool rok = 16 * m + r < mrows;              // (a row past M is not stored and counts as zeros: x + 0 is exact)
             if (EPI == 1) {
 #pragma unroll
@@ -295,9 +300,10 @@ __global__ void __launch_bounds__(256, MB == 4 ? (KS == 1 ? 3 : 2) : 4) gemm1x1_
                     const bool on = mask_y ? ya[e] > 0.0f : __builtin_fmaf(za[e], z[e], zb[e]) > 0.0f;
                     v[e] = on ? v[e] : 0.0f;
                     const float xh = (z[e] - zmu[e]) * zis[e];
-                    const float vm = rok ? v[e] : 0.0f;
-                    st0[e] += (double)vm;
-                    st1[e] += (double)vm * (double)xh;
+                    // a row past M needs no mask here: its operand rows (dy, residual, z) lie beyond their buffers and were loaded as
+                    // zeros, so v = 0 and xh is finite
+                    st0[e] += (double)v[e];
+                    st1[e] += (double)v[e] * (double)xh;
                 }
             }
             buffer_store_x4(ybuf, v, row_off(i), 0u);

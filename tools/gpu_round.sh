@@ -54,6 +54,22 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6r)
+  # Round 6: 1x1 GEMM epilogues of the statistics forms: no scale / ReLU arithmetic where the entry points pass none, no row mask in the masked
+  # data gradient (rows past M are loaded as zeros), its two sums in fp32 over the lane's rows (fp64 over lanes, waves and tiles) --
+  # build/libg1_new.so against build/libcw_new.so (= the commit before)
+  echo "== pytest"; timeout 1800 python -m pytest tests -m gpu -q -x --timeout 900 -k "conv1x1 or resnet or bn or train or data_parallel or probe" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for v in cw_new g1_new; do
+    echo "-- $v"; withlib $v timeout 300 python tools/microbench_conv1x1.py --batch 16 2>&1 | grep -v "Warning\|amdgpu.ids" | tee $O/microbench_conv1x1_$v.txt | tail -12 | cut -c1-200
+  done
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    withlib cw_new line rt16_old_$r $R
+    withlib g1_new line rt16_new_$r $R
+  done
+  withlib cw_new line rt128_old --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  withlib g1_new line rt128_new --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  ;;
 g6q)
   # Round 6: F(2x2,3x3) forward / data-gradient kernels (conv_wino_body.inc): the column transform's quad exchange folded into v_fmac_f32 with a DPP
   # source (16 of the loop's 50 VALU instructions per 72 MFMAs) -- build/libcw_new.so against build/libwgw_new3.so (= the commit before)
