@@ -162,6 +162,23 @@ DREAM_DEVICE f32x4 fma_quad_perm_2211(f32x4 u, float s) {
     return u;
 }
 
+// the same with quad_perm [1,0,3,2] (the lane pair's partner)
+DREAM_DEVICE f32x4 fma_quad_perm_1032(f32x4 u, float s) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %0, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %1, %1, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %2, %2, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f32_dpp %3, %3, %4 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+        : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3])
+        : "v"(s));
+    return u;
+}
+
+// DPP quad_perm [2,3,0,1]: lanes 0 <-> 2 and 1 <-> 3 of every quad swap
+DREAM_DEVICE float quad_perm_2301(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+}
+
 // DPP quad_perm [1,0,3,2]: the two lanes of every pair swap
 DREAM_DEVICE float quad_perm_1032(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));

@@ -318,23 +318,29 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
     const BufferRsrc ybuf = make_buffer(p.dy + (size_t)b0 * yimg, (size_t)(p.B - b0) * yimg * sizeof(float));
 
     // ---- producer roles: the wave's tile of a stage is (stage tile + wave); its decomposition is scalar work ----------------
-    // V: patch row vr = lane & 3, channel quad vq = lane >> 2.  dM: dy row yr2 = lane & 1, column half yh = (lane >> 1) & 1
-    // (the lane stores transformed columns 2 yh and 2 yh + 1), channel quad yq = lane >> 2.
+    // V: patch row vr = lane & 3, channel quad vq = lane >> 2.  dM: the lane owns ONE pixel of the tile's 2 x 2 dy pixels -- row yr2 = lane & 1,
+    // column yh = (lane >> 1) & 1 -- for channel quad yq = lane >> 2: one float4 load per stage (was: both pixels of the row in each of the
+    // two lanes of a column pair, i.e. every dy element loaded twice); the other column / row come from the quad neighbours by DPP.  The
+    // lane stores transformed columns {0, 1} (yh = 0) or {3, 2} (yh = 1) of rows {0, 1} (yr2 = 0) or {3, 2} (yr2 = 1).
     const int vr = lane & 3, vq = lane >> 2;
     const int yr2 = lane & 1, yh = (lane >> 1) & 1, yq = lane >> 2;
     const float vsb = (vr == 1) ? 1.0f : -1.0f;             // column transform of V: u_r + vsb * u_partner (conv_wino.hip)
     const float ysg = (yr2 == 0) ? 1.0f : -1.0f;            // mixed dM row: partner + ysg * own
-    const float c_sub = yh ? -1.0f : 0.0f, c_add = yh ? 0.0f : 1.0f;      // row transform of dM (transform_piece)
+    const float csg = yh ? -1.0f : 1.0f;                    // mixed dM column: partner + csg * own  (y0 + y1 / y0 - y1)
     const int v_store = l_plane_v(4 * vr) + wave * 64 + 4 * vq;              // V[4 vr + j]: + j * LPS
-    // dM rows of this lane: row A = its own values (row 0 for the upper dy row, row 3 for the lower one), row B = the mixed
-    // one (row 1 = upper + lower, row 2 = upper - lower); columns 2 yh + jj
-    const int y_store_a = l_plane_y((yr2 == 0 ? 0 : 12) + 2 * yh) + wave * 64 + 4 * yq;
-    const int y_store_b = l_plane_y((yr2 == 0 ? 4 : 8) + 2 * yh) + wave * 64 + 4 * yq;
+    // dM rows of this lane: row A = its own values (row 0 for the upper dy row, row 3 for the lower one), row B = the mixed one (row 1 =
+    // upper + lower; row 2 is stored NEGATED, lower - upper: own + ysg * partner is one v_fmac_f32 with a DPP source, in place -- the
+    // reduction kernels flip the sign of the row-2 positions, exactly).  Columns: A = the pixel's own (0 / 3), B = the mixed one (1 / 2).
+    const int y_store_aa = l_plane_y((yr2 == 0 ? 0 : 12) + (yh ? 3 : 0)) + wave * 64 + 4 * yq;
+    const int y_store_ab = l_plane_y((yr2 == 0 ? 0 : 12) + (yh ? 2 : 1)) + wave * 64 + 4 * yq;
+    const int y_store_ba = l_plane_y((yr2 == 0 ? 4 : 8) + (yh ? 3 : 0)) + wave * 64 + 4 * yq;
+    const int y_store_bb = l_plane_y((yr2 == 0 ? 4 : 8) + (yh ? 2 : 1)) + wave * 64 + 4 * yq;
 
     f32x4 xr[2][4];                                          // [register set][column]
-    f32x4 yr[2][2];                                          // [register set][column]
+    f32x4 yr[2];                                             // [register set]: the lane's dy pixel
+    f32x4 ycb[2];                                            // the mixed column of the stage being transformed (piece 4 -> piece 5)
     const bool bias_wg = BIAS && cig == 0;                   // workgroup-uniform
-    f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};                   // dy of (wave's tiles, row yr2, quad yq); lanes yh = 0 / 1 hold the same
+    f32x4 bsum = {0.0f, 0.0f, 0.0f, 0.0f};                   // dy of (wave's tiles, pixel (yr2, yh), quad yq)
 
     // one load of stage st into register set `set`: n = 0..3 the patch row's columns, 4..5 the dy row's columns.
     // VALU instructions share the SIMD's issue slots with the MFMAs (measured: every VALU instruction in this loop shows up
@@ -351,10 +357,10 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
     // patch row vr - 1 relative to the tile's first output row; with the fused upsample the tile's 4 x 4 patch of the upsampled
     // image is rows / columns {-1, 0, 0, +1} of the stored one around the tile's source pixel ((2 t - 1 + r) >> 1 = t + ((r - 1) >> 1))
     const int lane_dx = UPS ? (int)(((((vr - 1) >> 1) * Ws) * p.Cin + 4 * vq) * 4) : (int)((((vr - 1) * p.W) * p.Cin + 4 * vq) * 4);
-    const int lane_dy = CONVT ? (int)(((yr2 * 2 * Wd) * p.Cdy + 4 * yq) * 4) : (int)(((yr2 * p.W) * p.Cdy + 4 * yq) * 4);
+    const int lane_dy = CONVT ? (int)(((yr2 * 2 * Wd + 2 * yh) * p.Cdy + 4 * yq) * 4) : (int)(((yr2 * p.W + yh) * p.Cdy + 4 * yq) * 4);
     // the patch row in the row test: the lanes of the phase's dead patch row (CONVT) fail it for every tile
     const int vr_chk = (CONVT && vr == (ph_a ? 0 : 3)) ? (1 << 29) : vr;
-    const int x_px = p.Cin * 4, y_px = (CONVT ? 2 : 1) * p.Cdy * 4;       // (a phase's neighbouring pixels are two stored pixels apart)
+    const int x_px = p.Cin * 4;
     auto issue_load = [&](int set, int st, int n) {
         const int tau = k_begin + st * LT + wave;                               // wave-uniform from here ...
         const bool tv = tau < k_end;
@@ -370,11 +376,11 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
             const bool row_ok = (unsigned)(2 * ty - 1 + vr_chk) < (unsigned)p.H;                    // per lane, the same for the stage's loads
             xr[set][n] = buffer_load_x4(xbuf, (col_ok ? (unsigned)s_off : OOB_WAVE) + (row_ok ? (unsigned)lane_dx : OOB_LANE), 0);
         } else {
-            const int s_off = CONVT ? ((((b - b0) * Hd + 4 * ty + ph_a) * Wd + 4 * tx + ph_b) * p.Cdy + co0) * 4 + (n - 4) * y_px
-                                    : (pix * p.Cdy + co0) * 4 + (n - 4) * y_px;
-            const bool col_ok = tv & ((2 * tx + (n - 4)) < p.W);
-            const bool row_ok = (2 * ty + yr2) < p.H;
-            yr[set][n - 4] = buffer_load_x4(ybuf, (col_ok ? (unsigned)s_off : OOB_WAVE) + (row_ok ? (unsigned)lane_dy : OOB_LANE), 0);
+            if (n == 5) return;                                                  // one dy load per stage
+            const int s_off = CONVT ? ((((b - b0) * Hd + 4 * ty + ph_a) * Wd + 4 * tx + ph_b) * p.Cdy + co0) * 4
+                                    : (pix * p.Cdy + co0) * 4;
+            const bool pix_ok = ((2 * ty + yr2) < p.H) & ((2 * tx + yh) < p.W);                      // per lane
+            yr[set] = buffer_load_x4(ybuf, (tv ? (unsigned)s_off : OOB_WAVE) + (pix_ok ? (unsigned)lane_dy : OOB_LANE), 0);
         }
     };
     // piece k = 0..3 of the V transform (transformed column j = k), 4..5 of the dM transform (column 2 yh + k - 4)
@@ -395,23 +401,24 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
             const f32x4 v = fma_quad_perm_2211(u, vsb);
             *(f32x4 *)(buf + LOPS + v_store + kcol * LPS) = v;
         } else {
-            // along the dy row: (y0, y1) -> y0, y0 + y1, y0 - y1, y1 (the minus sign of the fourth column is applied at the end)
-            const int jj = k - 4;
-            const f32x4 y0 = yr[set][0], y1 = yr[set][1];
-            if (BIAS && jj == 0 && bias_wg) bsum = bsum + (y0 + y1);           // out-of-range pixels and tiles were loaded as zeros
-            // the lane's column (2 yh + jj) of the row transform as ONE fused multiply-add with a lane constant instead of an
-            // addition / subtraction + a per-lane select: jj = 0: y0 (yh = 0) or y0 - y1 (yh = 1) = fma(c_sub, y1, y0) with c_sub = 0 / -1;
-            // jj = 1: y0 + y1 or y1 = fma(c_add, y0, y1) with c_add = 1 / 0.  Products by +-1 are exact and a product by 0 is a zero, so
-            // the values are the same; only the SIGN of a zero can differ (-0 + +0 = +0), which no accumulated value can see (the
-            // accumulators start at +0 and x + (+-0) = x; +0 + (-0) = +0).  (A non-finite dy makes the results NaN either way.)
-            f32x4 m, mixed;
+            // A dY A^T of the tile's 2 x 2 pixels, a lane = one pixel.  Piece 4: along the row -- (y0, y1) -> y0, y0 + y1, y0 - y1, y1 (the
+            // minus sign of the fourth column is applied at the end): the lane's own value IS column 0 / 3, the mixed column is
+            // partner + csg * own (y1 + y0 / y0 - y1); both go to row A.  Piece 5: along the column, in place: own + ysg * partner for the two
+            // columns = row 1 (upper lanes) / minus row 2 (lower lanes).
+            if (k == 4) {
+                const f32x4 own = yr[set];
+                if (BIAS && bias_wg) bsum = bsum + own;                           // out-of-range pixels and tiles were loaded as zeros
+                f32x4 cb;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                m[e] = jj == 0 ? __builtin_fmaf(c_sub, y1[e], y0[e]) : __builtin_fmaf(c_add, y0[e], y1[e]);
-                mixed[e] = __builtin_fmaf(ysg, m[e], quad_perm_1032(m[e]));     // upper lane: own + partner; lower: partner - own
+                for (int e = 0; e < 4; ++e) cb[e] = __builtin_fmaf(csg, own[e], quad_perm_2301(own[e]));
+                ycb[set] = cb;
+                *(f32x4 *)(buf + y_store_aa) = own;
+                *(f32x4 *)(buf + y_store_ab) = cb;
+            } else {
+                const f32x4 ma = fma_quad_perm_1032(yr[set], ysg), mb = fma_quad_perm_1032(ycb[set], ysg);
+                *(f32x4 *)(buf + y_store_ba) = ma;
+                *(f32x4 *)(buf + y_store_bb) = mb;
             }
-            *(f32x4 *)(buf + y_store_a + jj * LPS) = m;
-            *(f32x4 *)(buf + y_store_b + jj * LPS) = mixed;
         }
     };
 
@@ -574,12 +581,12 @@ DREAM_DEVICE void wgrad_wino_lds_body(const WgWinoLdsParams &p, float *smem) {
     }
   }
     if (BIAS && bias_wg) {                                   // the stage loop ended with a barrier: LDS is free
-        if (yh == 0) *(f32x4 *)(smem + (2 * wave + yr2) * 64 + 4 * yq) = bsum;
+        *(f32x4 *)(smem + (4 * wave + 2 * yr2 + yh) * 64 + 4 * yq) = bsum;
         __syncthreads();
         if (threadIdx.x < 64) {
             float s = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += smem[r * 64 + threadIdx.x];
+            for (int r = 0; r < 32; ++r) s += smem[r * 64 + threadIdx.x];
             p.bias_partial[((size_t)(CONVT ? blockIdx.z * p.nsplit : 0) + split) * p.Cout + co0 + threadIdx.x] = s;
         }
     }
@@ -631,6 +638,7 @@ __global__ void __launch_bounds__(256) wgrad_wino_lds_reduce_kernel(const float 
 #pragma unroll
         for (int r = 0; r < 4; ++r) u[r] = -u[r];
     }
+    u[2] = -u[2];                                   // the main kernel stores row 2 of A dY A^T negated (its dM transform, piece 5)
     {                                               // G^T dU, G^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,1]]
         const float hs = 0.5f * (u[1] + u[2]), hd = 0.5f * (u[1] - u[2]);
         t_s[j][0][lane] = u[0] + hs;
@@ -680,6 +688,7 @@ __global__ void __launch_bounds__(256) wgrad_wino_convT_reduce_kernel(const floa
 #pragma unroll
             for (int r = 0; r < 3; ++r) u[r] = -u[r];
         }
+        u[2 - a] = -u[2 - a];                               // domain row 2 (active row 2 - a): stored negated by the main kernel
         // the two live rows of G^T over the three active row positions
         float t0, t1;
         if (a == 0) { t0 = u[0] + 0.5f * (u[1] + u[2]); t1 = 0.5f * (u[1] - u[2]); }       // taps r = 0, 1 from positions 0, 1, 2

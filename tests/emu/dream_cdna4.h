@@ -122,6 +122,12 @@ inline f32x4 fma_quad_perm_2211(f32x4 u, float s) {
     return r;
 }
 inline float quad_perm_1032(float v) { return emu_exchange(v, emu::lane() ^ 1); }
+inline float quad_perm_2301(float v) { return emu_exchange(v, emu::lane() ^ 2); }
+inline f32x4 fma_quad_perm_1032(f32x4 u, float s) {
+    f32x4 r;
+    for (int e = 0; e < 4; ++e) r[e] = __builtin_fmaf(s, quad_perm_1032(u[e]), u[e]);
+    return r;
+}
 inline int wave_index() { return emu::wave(); }
 inline int lane_id() { return emu::lane(); }
 inline float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }

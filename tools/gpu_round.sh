@@ -54,6 +54,31 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6s)
+  # Round 6: Winograd-domain weight gradients, step 4: ONE dy load per stage (a lane owns one pixel of the tile's 2 x 2; the other column / row by DPP;
+  # row 2 of A dY A^T stored negated, flipped by the reduction kernels) -- build/libwgw_new4.so against build/libhead.so (= the commit before)
+  echo "== pytest"; timeout 1500 python -m pytest tests -m gpu -q -x --timeout 900 -k "convT or wgrad or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for v in head wgw_new4; do
+    withlib $v timeout 300 python tools/microbench_convT_wgrad.py --digest --layers 5 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/digest_convT_$v.txt
+    withlib $v timeout 300 python tools/microbench_wgrad_wino.py --digest --batch 16 2>&1 | grep -v "Warning\|amdgpu.ids" > $O/digest_3x3_$v.txt
+  done
+  echo "digest lines that differ (dw must not; db may: its order of additions changed):"; diff $O/digest_convT_head.txt $O/digest_convT_wgw_new4.txt | head -12; diff $O/digest_3x3_head.txt $O/digest_3x3_wgw_new4.txt | head -26
+  for r in a b; do for v in head wgw_new4; do
+    echo "-- $v $r"; withlib $v timeout 300 python tools/microbench_convT_wgrad.py 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_convT_$v.txt | cut -c88-160
+  done; done
+  for r in a b; do for v in head wgw_new4; do
+    echo "-- 3x3 $v $r"; withlib $v timeout 400 python tools/microbench_wgrad_wino.py --only-winograd 2>&1 | grep -v "Warning\|amdgpu.ids" | tee -a $O/microbench_3x3_$v.txt | tail -1
+  done; done
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    withlib head line rt16_old_$r $R
+    withlib wgw_new4 line rt16_new_$r $R
+  done
+  for r in a b; do
+    withlib head line vq_train_old_$r --mode train --steps 5 --warmup 2
+    withlib wgw_new4 line vq_train_new_$r --mode train --steps 5 --warmup 2
+  done
+  ;;
 g6r)
   # Round 6: 1x1 GEMM epilogues of the statistics forms: no scale / ReLU arithmetic where the entry points pass none, no row mask in the masked
   # data gradient (rows past M are loaded as zeros), its two sums in fp32 over the lane's rows (fp64 over lanes, waves and tiles) --
