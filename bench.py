@@ -447,6 +447,16 @@ def timed_region(ctx, net, x, tgt, spec):
     del timer.events[:]
     for _ in range(spec["warmup"]):
         step()
+    # experiment switch (tools/gpu_round.sh gcx): the cyclic garbage collector during the timed steps -- "off": disabled, "freeze": every
+    # object alive after the warm-up moved to the permanent generation (a full collection then has little to traverse)
+    _gc_mode = os.environ.get("DREAM_BENCH_GC", "")
+    if _gc_mode in ("off", "freeze"):
+        import gc
+        gc.collect()
+        if _gc_mode == "off":
+            gc.disable()
+        else:
+            gc.freeze()
     if os.environ.get("DREAM_BENCH_PMC_CALIBRATE") == "1":
         # the HBM-traffic PMC passes (tools/pmc_traffic.py): two stand-alone max-pool launches on tensors of known size, OUTSIDE the
         # timed region -- pure streaming reads whose algorithmic byte count is exact, against which the FETCH_SIZE counter's unit

@@ -304,6 +304,18 @@ g6g)
   DREAM_TRAIN_GRAPH=1 line rt16_graph --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   line rt16_eager --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
   ;;
+gcx)
+  # the occasional long step of the ResNet-101 training run (one step of ten at +16-19 ms in 2 of the final set's 10 runs): is it the cyclic GC?
+  # interleaved runs: default / DREAM_BENCH_GC=off / DREAM_BENCH_GC=freeze
+  for i in $(seq 1 ${2:-14}); do for m in default off freeze; do
+    if [ $m = default ]; then E=""; else E="DREAM_BENCH_GC=$m"; fi
+    env $E timeout 300 python bench.py --arch resnet_h --mode train --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-secondary > $O/run_${m}_$i.log 2>&1
+    tail -1 $O/run_${m}_$i.log | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d['step_ms']
+print('$m run $i %.1f frames/s  gpu step ms min %.2f median %.2f max %.2f  host median %.2f max %.2f' % (d['value'], s['gpu_min'], s['gpu_median'], s['gpu_max'], s['host_median'], s['host_max']))" | tee -a $O/runs.txt
+  done; done
+  ;;
 slow)
   # the occasional slow run of the ResNet-101 training step at 16 frames: N consecutive runs, per-step GPU / host times from bench.py's
   # end-of-step events (one long step, or a uniformly slower run?); $2 = extra environment (e.g. PYTHONGC=off handled by bench.py)
