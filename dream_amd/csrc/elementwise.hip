@@ -86,6 +86,38 @@ __global__ void __launch_bounds__(256) maxpool2_bwd_kernel(const f32x4 *dy, cons
     }
 }
 
+// Every second pixel of every second row (the positions a stride-2 1x1 conv reads): y[b,i,j,:] = x[b,2i,2j,:], Ho = (H + 1) / 2.  The
+// ResNet trunk's three stride-2 downsample convs (dream/models.py:22-32 -> torchvision Bottleneck.downsample) then run as plain GEMMs
+// over the gathered rows (round 6) -- and the transpose: x[b,y,x,:] = ys[b,y/2,x/2,:] at even (y, x), zeros elsewhere (their data
+// gradient back on the block input's grid).
+__global__ void __launch_bounds__(256) subsample2_kernel(const f32x4 *x, f32x4 *y, int B, int H, int W, int C4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        y[i] = x[(((size_t)b * H + 2 * oy) * W + 2 * ox) * C4 + c];
+    }
+}
+__global__ void __launch_bounds__(256) scatter2_kernel(const f32x4 *ys, f32x4 *x, int B, int H, int W, int C4) {
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const size_t total = (size_t)B * H * W * C4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int px = (int)(r % W);
+        r /= W;
+        const int py = (int)(r % H);
+        const int b = (int)(r / H);
+        x[i] = ((px | py) & 1) ? zero : ys[(((size_t)b * Ho + (py >> 1)) * Wo + (px >> 1)) * C4 + c];
+    }
+}
+
 // nearest x2 upsample backward: dx[b,y,x,:] = sum of the 2x2 block of dy
 __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const f32x4 *dy, f32x4 *dx, int B, int H, int W, int C4) {
     const int Hs = H / 2, Ws = W / 2;
@@ -601,6 +633,20 @@ extern "C" int dream_maxpool2_relu_bwd_nhwc_f32(const float *dy, const float *x,
     const size_t total = (size_t)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const f32x4 *)dy, (const f32x4 *)x, (f32x4 *)dx, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_subsample2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "subsample2: bad arguments (C=%d must be a multiple of 4)", C);
+    const size_t total = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (f32x4 *)y, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_scatter2_nhwc_f32(const float *ys, float *x, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(ys && x && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "scatter2: bad arguments (C=%d must be a multiple of 4)", C);
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(scatter2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)ys, (f32x4 *)x, B, H, W, C / 4);
     DREAM_LAUNCH_OK();
     return 0;
 }

@@ -1138,6 +1138,7 @@ class ResnetSimple(nn.Module):
         # ... and (round 6) the last decoder BatchNorm's in the head conv's data gradient (run_backward_fused, "final")
         self.bn_fusion_head = os.environ.get("DREAM_BN_FUSION_HEAD", "1") == "1"
         self.stem_on_gemm = os.environ.get("DREAM_STEM_GEMM", "1") == "1"     # training: the 7x7 stem + its statistics + its weight gradient on the 1x1 GEMM
+        self.ds_on_gemm = os.environ.get("DREAM_DS_GEMM", "1") == "1"         # training: the stride-2 downsample convs on the 1x1 GEMM over gathered pixels
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
@@ -1622,9 +1623,19 @@ class ResnetSimple(nn.Module):
         k, stride = int(conv.kernel_size[0]), int(conv.stride[0])
         bias = conv.bias.detach() if conv.bias is not None else None
         cout = int(conv.weight.shape[0])
+        sub2 = None
+        if (self.ds_on_gemm and k == 1 and stride == 2 and pre is None and self.conv1x1_algorithm == "gemm"
+                and int(conv.weight.shape[1]) == int(x.shape[3]) and int(x.shape[3]) % 64 == 0):
+            # Round 6: a stride-2 1x1 conv (the trunk's three downsample branches) reads every second pixel of every second row: gathered
+            # once (ops.subsample2), it IS a stride-1 1x1 conv -- the GEMM kernel with the BatchNorm statistics in its epilogue instead of the
+            # direct kernel + a statistics pass; its weight gradient and its data gradient (scattered back onto the block input's grid in
+            # run_backward_fused) are GEMMs as well
+            xs = ops.subsample2(x)
+            if ops.conv1x1_applies(xs, cout):
+                sub2, x, stride = (int(x.shape[1]), int(x.shape[2])), xs, 1
         rec = dict(kind="conv", name=name, conv=conv, bn=bn, relu=relu, x=x, pre=pre, k=k, stride=stride, has_res=residual is not None,
-                   y=None)
-        if self._gemm1x1(conv, x):
+                   y=None, sub2=sub2)
+        if self._gemm1x1(conv, x) or sub2 is not None:
             packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
             rec["z"], rec["ab"], rec["mean"], rec["invstd"] = ops.conv1x1_bn(
                 x, packed, rows, bn, self._ctr(x.device), pre_ab=None if pre is None else pre["ab"], shift=bias)
@@ -1864,6 +1875,8 @@ class ResnetSimple(nn.Module):
                 in_hw = (int(rec["x"].shape[1]), int(rec["x"].shape[2]))
                 if is_ds:
                     block["g_ds"] = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
+                    if rec.get("sub2") is not None:       # the conv ran on the gathered pixels: its data gradient back on the input's grid
+                        block["g_ds"] = ops.scatter2(block["g_ds"], *rec["sub2"])
                 elif name.endswith(".1"):
                     block["dz1"] = (name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
                 elif pre is not None:

@@ -538,6 +538,26 @@ def upsample2_bwd(dy):
     return dx
 
 
+def subsample2(x):
+    """x[:, ::2, ::2, :] of an NHWC tensor as a contiguous tensor: the pixels a stride-2 1x1 conv reads."""
+    x = _f32(x)
+    b, h, w, c = (int(v) for v in x.shape)
+    y = torch.empty((b, (h + 1) // 2, (w + 1) // 2, c), dtype=torch.float32, device=x.device)
+    call("dream_subsample2_nhwc_f32", ptr(x), ptr(y), b, h, w, c, stream())
+    return y
+
+
+def scatter2(ys, h, w):
+    """The transpose of subsample2: an NHWC tensor of height h and width w with ys at its even pixels and zeros elsewhere."""
+    ys = _f32(ys)
+    b, hs, ws, c = (int(v) for v in ys.shape)
+    if (hs, ws) != ((h + 1) // 2, (w + 1) // 2):
+        raise RuntimeError("scatter2: %dx%d is not the subsampled grid of %dx%d" % (hs, ws, h, w))
+    x = torch.empty((b, h, w, c), dtype=torch.float32, device=ys.device)
+    call("dream_scatter2_nhwc_f32", ptr(ys), ptr(x), b, h, w, c, stream())
+    return x
+
+
 class wgrad_width:
     """``with ops.wgrad_width(p):`` the weight-gradient launches planned by this thread inside the block split their contraction only
     until ``p`` per cent of the full-width workgroup count exist (csrc/api.hip dream_wgrad_set_width: thread-local) -- for leaves that

@@ -377,6 +377,12 @@ int dream_maxpool2_bwd_nhwc_f32(const float *dy, const float *x, float *dx,
  * dx = maxpool_bwd(dy) * (x > 0) in one pass. */
 int dream_maxpool2_relu_bwd_nhwc_f32(const float *dy, const float *x, float *dx, int B, int H, int W, int C, void *stream);
 /* nearest x2 upsample backward: dy [B,H,W,C] -> dx [B,H/2,W/2,C] = sum of the 2x2 block */
+/* Round 6: the pixels a stride-2 1x1 convolution reads, gathered -- y[b,i,j,:] = x[b,2i,2j,:], y is [B,(H+1)/2,(W+1)/2,C] -- and the
+ * transpose (x[b,y,x,:] = ys[b,y/2,x/2,:] at even (y, x), zeros elsewhere; x is [B,H,W,C], overwritten).  With them the three stride-2
+ * downsample convs of the ResNet-101 trunk (/root/reference/dream/models.py:22-32 -> torchvision Bottleneck.downsample, reached from
+ * network.py:310-335) run on the 1x1 GEMM entry points above in the forward, weight-gradient and data-gradient direction.  C % 4 == 0. */
+int dream_subsample2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream);
+int dream_scatter2_nhwc_f32(const float *ys, float *x, int B, int H, int W, int C, void *stream);
 int dream_upsample2_bwd_nhwc_f32(const float *dy, float *dx, int B, int H, int W, int C, void *stream);
 /* conv3x3 weight+bias gradient: x [B,H,W,Cin] (or half-res with UPSAMPLE2X), dy [B,H,W,Cout] NHWC
  * -> dw_packed [9][CoutPad][Cin] (mode-0 layout, overwritten), dbias [Cout] (overwritten).

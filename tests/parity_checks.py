@@ -436,6 +436,14 @@ def check_pool_and_layouts(dev):
     p = ops.nchw_to_nhwc(to(dev, x), 16).cpu()
     assert torch.equal(p[..., :7], x.permute(0, 2, 3, 1)) and float(p[..., 7:].abs().max()) == 0.0
     assert torch.equal(ops.nhwc_to_nchw(to(dev, x.permute(0, 2, 3, 1).contiguous())).cpu(), x)
+    # the pixels a stride-2 1x1 conv reads, gathered, and the transpose (round 6: the trunk's downsample convs on the 1x1 GEMM)
+    for shape in ((2, 9, 14, 8), (1, 25, 25, 64), (3, 1, 6, 4), (2, 8, 1, 12)):
+        x = torch.randn(*shape)
+        ys = ops.subsample2(to(dev, x))
+        assert torch.equal(ys.cpu(), x[:, ::2, ::2, :])
+        full = torch.zeros_like(x)
+        full[:, ::2, ::2, :] = x[:, ::2, ::2, :]
+        assert torch.equal(ops.scatter2(ys, shape[1], shape[2]).cpu(), full)
     w = torch.randn(40, 24, 3, 3)
     packed, rows, rp, cp = ops.pack_weight(to(dev, w), 0)
     assert rows == 40 and rp % 128 == 0 and cp == 32

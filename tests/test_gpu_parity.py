@@ -253,6 +253,45 @@ def test_resnet_h_train_step_three_launch_batchnorm(monkeypatch):
     pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
 
 
+def test_resnet_h_train_step_downsample_on_direct_kernels(monkeypatch):
+    """DREAM_DS_GEMM=0: the stride-2 downsample convs on the direct kernels (rounds 1-6) stay selectable and correct; the default
+    (gathered pixels + 1x1 GEMM in all three directions) is what every other ResNet training test runs."""
+    monkeypatch.setenv("DREAM_DS_GEMM", "0")
+    pc.check_resnet_train_step(DEV, "resnet_h", (4, 128, 128))
+
+
+def test_resnet_downsample_on_gemm_is_used_and_close_to_direct(monkeypatch):
+    """The default training forward gathers the input of the three stride-2 downsample convs (tape records carry `sub2`), and one
+    step's loss and gradients agree with the direct-kernel path (two fp32 algorithms: relative 1e-4 on the loss, direction and norm
+    of every gradient)."""
+    wts = om.recipe_weights(om.build_model("resnet_h", 7).state_dict(), ("upsample.12.weight", "upsample.12.bias"), 0.1)
+    x = torch.from_numpy(cases.image_batch(4, 128, 128, seed=7)).to(DEV)
+    runs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("DREAM_DS_GEMM", flag)
+        net = _dp_network("resnet_h", [0], optimizer="sgd", lr=0.0, in_res=(128, 128), weights=wts)
+        net.enable_training()
+        mod = net.model.module
+        assert mod.ds_on_gemm == (flag == "1")
+        ow, oh = net.trained_net_output_resolution()
+        t = torch.from_numpy(cases.target_batch(4, 7, (ow, oh), in_wh=(128, 128), seed=7)).to(DEV)
+        if flag == "1":
+            with torch.no_grad():
+                _, tape = mod.run_forward_train(x)
+            assert sum(1 for r in tape if r.get("kind") == "conv" and r.get("sub2") is not None) == 3
+        loss = net.train([x], t).item()
+        runs.append((loss, [p.grad.clone() for p in net.model.parameters()]))
+    assert abs(runs[0][0] - runs[1][0]) <= 1e-4 * abs(runs[1][0])
+    top = max(float(b.norm()) for b in runs[1][1])
+    checked = 0
+    for a, b in zip(runs[0][1], runs[1][1]):
+        na, nb = float(a.norm()), float(b.norm())
+        if nb > 1e-6 * top:                      # (gradients that are zero in exact arithmetic -- a shift in front of a BatchNorm -- are rounding noise)
+            assert float((a * b).sum()) / (na * nb) > 0.999 and abs(na - nb) <= 2e-2 * nb
+            checked += 1
+    assert checked > 200
+
+
 def test_resnet_f_train_step():
     pc.check_resnet_train_step(DEV, "resnet_f", (2, 64, 64))
 

@@ -54,6 +54,23 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6t)
+  # Round 6: the trunk's three stride-2 downsample convs on the 1x1 GEMM over gathered pixels (forward with the BatchNorm statistics in the epilogue,
+  # weight gradient, data gradient + scatter) against the direct kernels + statistics pass (DREAM_DS_GEMM=0)
+  echo "== pytest"; timeout 1800 python -m pytest tests -m gpu -q -x --timeout 900 -k "resnet or layouts or pool or data_parallel or graph or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_DS_GEMM=0 line rt16_ds0_$r $R
+    line rt16_ds1_$r $R
+  done
+  DREAM_DS_GEMM=0 line rt128_ds0 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  line rt128_ds1 --arch resnet_h --mode train --batch 128 --steps 3 --warmup 2
+  for r in a b; do
+    DREAM_DS_GEMM=0 line rf32_ds0_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+    line rf32_ds1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  done
+  timeout 300 python tools/layer_profile.py --arch resnet_h --mode train --batch 16 --top 60 2>&1 | grep -v "Warning\|warn\|amdgpu.ids\|imagenet_init" > $O/layer_profile_resnet_h_train16.txt; grep -n "subsample2\|scatter2\|conv2d" $O/layer_profile_resnet_h_train16.txt | head -20 | cut -c1-160
+  ;;
 g6s)
   # Round 6: Winograd-domain weight gradients, step 4: ONE dy load per stage (a lane owns one pixel of the tile's 2 x 2; the other column / row by DPP;
   # row 2 of A dY A^T stored negated, flipped by the reduction kernels) -- build/libwgw_new4.so against build/libhead.so (= the commit before)
