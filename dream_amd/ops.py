@@ -609,11 +609,15 @@ WGRAD_BIAS_FUSION = _os.environ.get("DREAM_WGRAD_BIAS_FUSION", "1") != "0"
 UPS_WGRAD_AS_CONVT = _os.environ.get("DREAM_UPS_WGRAD", "winograd16") == "convT9"
 
 
+WGRAD_WINOGRAD_MIN_PIXELS_64 = int(__import__("os").environ.get("DREAM_WGRAD_WINOGRAD_MIN_PIXELS", "150000"))      # A/B: 4000000 = the rule of rounds 2-5
+
+
 def wgrad_winograd_pays(pixels, cin, cout):
     """Where the Winograd-domain weight gradient beats the direct kernel (profiles/r02_microbench_wgrad_wino_b128.txt:
-    1.2-2.1x on the layers with >= 128 x 64 channel pairs or >= 4 M pixels; it loses on small 64 x 64-channel maps, whose
-    split-K partials and short loops dominate)."""
-    return cin % 64 == 0 and cout % 16 == 0 and cout >= 64 and (cin * cout >= 8192 or pixels >= 4000000)
+    1.2-2.1x on the layers with >= 128 x 64 channel pairs; on 64 x 64-channel layers, whose split-K partials and short loops weigh
+    more, from ~150 k pixels on since the round-6 kernel: 16 x 100 x 100 pixels 0.178 -> 0.103 ms, 128 x 100 x 100 1.4 -> 0.43 ms,
+    gpurun_out r06_wgw_b16 / profiles/r06_ab_convT_wgrad_five_loads.txt; rounds 2-5: from 4 M pixels on)."""
+    return cin % 64 == 0 and cout % 16 == 0 and cout >= 64 and (cin * cout >= 8192 or pixels >= WGRAD_WINOGRAD_MIN_PIXELS_64)
 
 
 def conv3x3_wgrad_winograd(x_nhwc, dy_nhwc, cout, cin, want_bias=True, flags=0):

@@ -54,6 +54,19 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6u)
+  # Round 6: the Winograd-domain weight gradient on 64 x 64-channel layers from 150 k pixels on (was: 4 M) -- DREAM_WGRAD_WINOGRAD_MIN_PIXELS=4000000 = before
+  echo "== pytest"; timeout 1800 python -m pytest tests -m gpu -q -x --timeout 900 -k "wgrad or train or full_size or headline" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  for r in a b c; do
+    DREAM_WGRAD_WINOGRAD_MIN_PIXELS=4000000 line vq_train_old_$r --mode train --steps 5 --warmup 2
+    line vq_train_new_$r --mode train --steps 5 --warmup 2
+  done
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_WGRAD_WINOGRAD_MIN_PIXELS=4000000 line rt16_old_$r $R
+    line rt16_new_$r $R
+  done
+  ;;
 g6t)
   # Round 6: the trunk's three stride-2 downsample convs on the 1x1 GEMM over gathered pixels (forward with the BatchNorm statistics in the epilogue,
   # weight gradient, data gradient + scatter) against the direct kernels + statistics pass (DREAM_DS_GEMM=0)
