@@ -118,6 +118,54 @@ __global__ void __launch_bounds__(256) scatter2_kernel(const f32x4 *ys, f32x4 *x
     }
 }
 
+// The patches a 3x3 stride-2 pad-1 conv reads, one row of 9 C columns per output pixel: col[(b,i,j)][t C + c] = x[b, 2i - 1 + ky, 2j - 1 + kx, c],
+// t = 3 ky + kx, zeros outside the image; Ho = (H - 1) / 2 + 1.  On small maps (ResNet-101's layer4.0.conv2 at 16 frames: 2704 output pixels)
+// the direct kernel cannot fill the chip (36 TFLOP/s); as a GEMM over these rows the conv, its weight gradient and its data gradient run
+// on the 1x1 GEMM kernels.  col2im3s2 is the transpose: dx[b,y,x,:] = sum of the (one, two or four) patch entries that read pixel (y, x),
+// added in a fixed order (ky, then kx).
+__global__ void __launch_bounds__(256) im2col3s2_kernel(const f32x4 *x, f32x4 *col, int B, int H, int W, int C4) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * 9 * C4;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int t = (int)(r % 9);
+        r /= 9;
+        const int ox = (int)(r % Wo);
+        r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const int py = 2 * oy - 1 + t / 3, px = 2 * ox - 1 + t % 3;
+        col[i] = (py >= 0 && py < H && px >= 0 && px < W) ? x[(((size_t)b * H + py) * W + px) * C4 + c] : zero;
+    }
+}
+__global__ void __launch_bounds__(256) col2im3s2_kernel(const f32x4 *col, f32x4 *dx, int B, int H, int W, int C4) {
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int px = (int)(r % W);
+        r /= W;
+        const int py = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = py + 1 - ky;                       // = 2 oy
+            if (ty < 0 || (ty & 1) || (ty >> 1) >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = px + 1 - kx;
+                if (tx < 0 || (tx & 1) || (tx >> 1) >= Wo) continue;
+                acc = acc + col[((((size_t)b * Ho + (ty >> 1)) * Wo + (tx >> 1)) * 9 + 3 * ky + kx) * C4 + c];
+            }
+        }
+        dx[i] = acc;
+    }
+}
+
 // nearest x2 upsample backward: dx[b,y,x,:] = sum of the 2x2 block of dy
 __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const f32x4 *dy, f32x4 *dx, int B, int H, int W, int C4) {
     const int Hs = H / 2, Ws = W / 2;
@@ -647,6 +695,20 @@ extern "C" int dream_scatter2_nhwc_f32(const float *ys, float *x, int B, int H, 
     DREAM_REQUIRE(ys && x && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "scatter2: bad arguments (C=%d must be a multiple of 4)", C);
     const size_t total = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(scatter2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)ys, (f32x4 *)x, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_im2col3s2_nhwc_f32(const float *x, float *col, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(x && col && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "im2col3s2: bad arguments (C=%d must be a multiple of 4)", C);
+    const size_t total = (size_t)B * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * 9 * (C / 4);
+    hipLaunchKernelGGL(im2col3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)x, (f32x4 *)col, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_col2im3s2_nhwc_f32(const float *col, float *dx, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(col && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "col2im3s2: bad arguments (C=%d must be a multiple of 4)", C);
+    const size_t total = (size_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(col2im3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)col, (f32x4 *)dx, B, H, W, C / 4);
     DREAM_LAUNCH_OK();
     return 0;
 }

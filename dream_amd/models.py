@@ -1139,6 +1139,7 @@ class ResnetSimple(nn.Module):
         self.bn_fusion_head = os.environ.get("DREAM_BN_FUSION_HEAD", "1") == "1"
         self.stem_on_gemm = os.environ.get("DREAM_STEM_GEMM", "1") == "1"     # training: the 7x7 stem + its statistics + its weight gradient on the 1x1 GEMM
         self.ds_on_gemm = os.environ.get("DREAM_DS_GEMM", "1") == "1"         # training: the stride-2 downsample convs on the 1x1 GEMM over gathered pixels
+        self.COL3_MAX_PIXELS = int(os.environ.get("DREAM_COL3_MAX_PIXELS", "12000"))   # ... and 3x3 stride-2 convs with at most this many output pixels
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
         # the data-gradient epilogue; "0" = the three-launch kernels of rounds 1-3 (A/B, tests)
@@ -1633,10 +1634,22 @@ class ResnetSimple(nn.Module):
             xs = ops.subsample2(x)
             if ops.conv1x1_applies(xs, cout):
                 sub2, x, stride = (int(x.shape[1]), int(x.shape[2])), xs, 1
+        col3 = None
+        if (self.ds_on_gemm and k == 3 and stride == 2 and pre is None and self.conv1x1_algorithm == "gemm" and int(conv.padding[0]) == 1
+                and int(conv.weight.shape[1]) == int(x.shape[3]) and int(x.shape[3]) % 64 == 0 and cout % 64 == 0
+                and int(x.shape[0]) * ((int(x.shape[1]) - 1) // 2 + 1) * ((int(x.shape[2]) - 1) // 2 + 1) <= self.COL3_MAX_PIXELS):
+            # ... and a 3x3 stride-2 conv with too few output pixels for the direct kernel to fill the chip (layer4.0.conv2 at 16 frames:
+            # 2704; 36 TFLOP/s) runs on the GEMM over its patch rows (ops.im2col3s2: [pixels][9 Cin]), in all three directions as well
+            col3 = (int(x.shape[1]), int(x.shape[2]))
+            x, k, stride = ops.im2col3s2(x), 1, 1
         rec = dict(kind="conv", name=name, conv=conv, bn=bn, relu=relu, x=x, pre=pre, k=k, stride=stride, has_res=residual is not None,
-                   y=None, sub2=sub2)
-        if self._gemm1x1(conv, x) or sub2 is not None:
-            packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
+                   y=None, sub2=sub2, col3=col3)
+        if self._gemm1x1(conv, x) or sub2 is not None or col3 is not None:
+            if col3 is not None:       # GEMM weight [Cout][t Cin + c] = w[co][c][ky][kx]
+                packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(
+                    conv.weight.detach().permute(0, 2, 3, 1).reshape(cout, -1, 1, 1).contiguous(), 0))
+            else:
+                packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
             rec["z"], rec["ab"], rec["mean"], rec["invstd"] = ops.conv1x1_bn(
                 x, packed, rows, bn, self._ctr(x.device), pre_ab=None if pre is None else pre["ab"], shift=bias)
         else:
@@ -1858,8 +1871,11 @@ class ResnetSimple(nn.Module):
                 if rec["has_res"]:
                     block["g_idt"] = gm          # masked block-output gradient == gradient of the identity branch
                 pre = rec["pre"]
-                def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"], pre=pre):
-                    if pre is not None:          # the conv's input was relu(BN(x)), applied by its loader: so does the weight gradient's
+                def leaf(conv=conv, x=rec["x"], dz=dz, cout=cout, cin=cin, k=rec["k"], stride=rec["stride"], pre=pre, col3=rec.get("col3")):
+                    if col3 is not None:         # the conv ran on its patch rows: dW [Cout][t Cin + c] -> [Cout][Cin][3][3]
+                        dw2 = ops.conv1x1_wgrad(x, dz, cout, 9 * cin)
+                        grads[conv.weight] = dw2.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous()
+                    elif pre is not None:        # the conv's input was relu(BN(x)), applied by its loader: so does the weight gradient's
                         if not ops.conv1x1_wgrad_applies(x, dz, cout):
                             y_in = ops.bn_apply_ab(x, pre["ab"], None, True)
                             grads[conv.weight] = ops.conv2d_wgrad(y_in, dz, cout, cin, k, stride)[0]
@@ -1896,6 +1912,11 @@ class ResnetSimple(nn.Module):
                         gmask, dg1, db1 = ops.conv3x3_winograd_bwd_bnmask(dz, u_t, cin, prod["z"], prod["ab"], prod["mean"], prod["invstd"],
                                                                          self._ctr(dz.device))
                         g = ("masked", gmask, dg1, db1)
+                    elif rec.get("col3") is not None:
+                        # the conv ran on its patch rows: the GEMM's data gradient is the gradient of those rows, summed back onto the map
+                        packed_t, rows = self._cached(("g1", name), [conv.weight], lambda: ops.pack_conv1x1_weight(
+                            conv.weight.detach().permute(0, 2, 3, 1).reshape(cout, -1, 1, 1).contiguous(), 1))
+                        g = ops.col2im3s2(ops.conv1x1(dz, packed_t, rows, None, None, None, 0), *rec["col3"])
                     else:
                         g = self._bwd_data(name, conv, dz, cin, rec["k"], rec["stride"], in_hw)
             elif kind == "block_begin":

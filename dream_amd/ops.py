@@ -558,6 +558,26 @@ def scatter2(ys, h, w):
     return x
 
 
+def im2col3s2(x):
+    """The patches of a 3x3 stride-2 pad-1 conv as rows: [B, Ho, Wo, 9 C], column t C + c = tap t = 3 ky + kx of channel c."""
+    x = _f32(x)
+    b, h, w, c = (int(v) for v in x.shape)
+    col = torch.empty((b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, 9 * c), dtype=torch.float32, device=x.device)
+    call("dream_im2col3s2_nhwc_f32", ptr(x), ptr(col), b, h, w, c, stream())
+    return col
+
+
+def col2im3s2(col, h, w):
+    """The transpose of im2col3s2: [B, h, w, C] with every pixel the sum of the patch entries that read it."""
+    col = _f32(col)
+    b, ho, wo, c9 = (int(v) for v in col.shape)
+    if (ho, wo) != ((h - 1) // 2 + 1, (w - 1) // 2 + 1) or c9 % 9:
+        raise RuntimeError("col2im3s2: %dx%dx%d are not the patch rows of a %dx%d map" % (ho, wo, c9, h, w))
+    dx = torch.empty((b, h, w, c9 // 9), dtype=torch.float32, device=col.device)
+    call("dream_col2im3s2_nhwc_f32", ptr(col), ptr(dx), b, h, w, c9 // 9, stream())
+    return dx
+
+
 class wgrad_width:
     """``with ops.wgrad_width(p):`` the weight-gradient launches planned by this thread inside the block split their contraction only
     until ``p`` per cent of the full-width workgroup count exist (csrc/api.hip dream_wgrad_set_width: thread-local) -- for leaves that

@@ -383,6 +383,12 @@ int dream_maxpool2_relu_bwd_nhwc_f32(const float *dy, const float *x, float *dx,
  * network.py:310-335) run on the 1x1 GEMM entry points above in the forward, weight-gradient and data-gradient direction.  C % 4 == 0. */
 int dream_subsample2_nhwc_f32(const float *x, float *y, int B, int H, int W, int C, void *stream);
 int dream_scatter2_nhwc_f32(const float *ys, float *x, int B, int H, int W, int C, void *stream);
+/* Round 6: the patches a 3x3 stride-2 pad-1 convolution reads as rows of 9 C columns (col [B,Ho,Wo,9 C], column t C + c = tap t = 3 ky + kx,
+ * channel c; Ho = (H - 1) / 2 + 1; zeros outside the image) and the transpose (dx [B,H,W,C] = the sum of the patch entries that read each
+ * pixel, fixed order).  ResNet-101's layer4.0.conv2 (/root/reference/dream/models.py:22-32 -> torchvision Bottleneck.conv2, stride 2) has too
+ * few output pixels at 16 frames per GPU for the direct kernel to fill the chip; over these rows it runs on the 1x1 GEMM entry points. */
+int dream_im2col3s2_nhwc_f32(const float *x, float *col, int B, int H, int W, int C, void *stream);
+int dream_col2im3s2_nhwc_f32(const float *col, float *dx, int B, int H, int W, int C, void *stream);
 int dream_upsample2_bwd_nhwc_f32(const float *dy, float *dx, int B, int H, int W, int C, void *stream);
 /* conv3x3 weight+bias gradient: x [B,H,W,Cin] (or half-res with UPSAMPLE2X), dy [B,H,W,Cout] NHWC
  * -> dw_packed [9][CoutPad][Cin] (mode-0 layout, overwritten), dbias [Cout] (overwritten).

@@ -444,6 +444,19 @@ def check_pool_and_layouts(dev):
         full = torch.zeros_like(x)
         full[:, ::2, ::2, :] = x[:, ::2, ::2, :]
         assert torch.equal(ops.scatter2(ys, shape[1], shape[2]).cpu(), full)
+    # the patch rows of a 3x3 stride-2 pad-1 conv and their transpose (round 6: ResNet's layer4.0.conv2 on the 1x1 GEMM)
+    for shape in ((2, 9, 14, 8), (1, 25, 25, 16), (2, 4, 6, 4), (1, 1, 5, 4)):
+        x = torch.randn(*shape)
+        b, h, w_, c = shape
+        unf = F.unfold(x.permute(0, 3, 1, 2), 3, padding=1, stride=2)                  # [B, C * 9, L], channel-major
+        ho, wo = (h - 1) // 2 + 1, (w_ - 1) // 2 + 1
+        ref = unf.reshape(b, c, 9, ho, wo).permute(0, 3, 4, 2, 1).reshape(b, ho, wo, 9 * c)
+        col = ops.im2col3s2(to(dev, x))
+        assert torch.equal(col.cpu(), ref)
+        g = torch.randn(b, ho, wo, 9 * c)
+        back = F.fold(g.reshape(b, ho, wo, 9, c).permute(0, 4, 3, 1, 2).reshape(b, c * 9, ho * wo), (h, w_), 3, padding=1, stride=2)
+        got = ops.col2im3s2(to(dev, g), h, w_).cpu()
+        assert float((got - back.permute(0, 2, 3, 1)).abs().max()) <= 1e-5
     w = torch.randn(40, 24, 3, 3)
     packed, rows, rp, cp = ops.pack_weight(to(dev, w), 0)
     assert rows == 40 and rp % 128 == 0 and cp == 32
