@@ -166,6 +166,36 @@ __global__ void __launch_bounds__(256) col2im3s2_kernel(const f32x4 *col, f32x4 
     }
 }
 
+// ConvTranspose2d(k4, s2, p1) as a GEMM + this gather (round 6, small maps: ResNet-101's first decoder layer, 2048 -> 256 on 13 x 13 maps at 16
+// frames, is 2704 input pixels -- too few tiles for the Winograd kernel to fill the chip): g[b,i,j][(4 ky + kx) C + c] = sum over ci of
+// x[b,i,j,ci] w[ci][c][ky][kx] is a 1x1 GEMM with N = 16 C, and output pixel (Y, X) = (2 i - 1 + ky, 2 j - 1 + kx) collects its (at most
+// four) contributions: z[b,Y,X,c] = bias[c] + the sum over ky, kx (ascending) of the entries with (Y + 1 - ky) and (X + 1 - kx) even.
+__global__ void __launch_bounds__(256) col2im4s2_kernel(const f32x4 *g, const f32x4 *bias, f32x4 *z, int B, int H, int W, int C4) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        size_t r = i / C4;
+        const int X = (int)(r % Wo);
+        r /= Wo;
+        const int Y = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        f32x4 acc = bias ? bias[c] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int ky = ((Y + 1) & 1) + 2 * a, iy = (Y + 1 - ky) >> 1;
+            if (Y + 1 - ky < 0 || iy >= H) continue;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int kx = ((X + 1) & 1) + 2 * e, ix = (X + 1 - kx) >> 1;
+                if (X + 1 - kx < 0 || ix >= W) continue;
+                acc = acc + g[((((size_t)b * H + iy) * W + ix) * 16 + 4 * ky + kx) * C4 + c];
+            }
+        }
+        z[i] = acc;
+    }
+}
+
 // nearest x2 upsample backward: dx[b,y,x,:] = sum of the 2x2 block of dy
 __global__ void __launch_bounds__(256) upsample2_bwd_kernel(const f32x4 *dy, f32x4 *dx, int B, int H, int W, int C4) {
     const int Hs = H / 2, Ws = W / 2;
@@ -709,6 +739,14 @@ extern "C" int dream_col2im3s2_nhwc_f32(const float *col, float *dx, int B, int 
     DREAM_REQUIRE(col && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "col2im3s2: bad arguments (C=%d must be a multiple of 4)", C);
     const size_t total = (size_t)B * H * W * (C / 4);
     hipLaunchKernelGGL(col2im3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)col, (f32x4 *)dx, B, H, W, C / 4);
+    DREAM_LAUNCH_OK();
+    return 0;
+}
+extern "C" int dream_col2im4s2_nhwc_f32(const float *g, const float *bias, float *z, int B, int H, int W, int C, void *stream) {
+    DREAM_REQUIRE(g && z && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "col2im4s2: bad arguments (C=%d must be a multiple of 4)", C);
+    const size_t total = (size_t)B * 2 * H * 2 * W * (C / 4);
+    hipLaunchKernelGGL(col2im4s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)g, (const f32x4 *)bias, (f32x4 *)z,
+                       B, H, W, C / 4);
     DREAM_LAUNCH_OK();
     return 0;
 }

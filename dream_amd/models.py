@@ -1139,6 +1139,7 @@ class ResnetSimple(nn.Module):
         self.bn_fusion_head = os.environ.get("DREAM_BN_FUSION_HEAD", "1") == "1"
         self.stem_on_gemm = os.environ.get("DREAM_STEM_GEMM", "1") == "1"     # training: the 7x7 stem + its statistics + its weight gradient on the 1x1 GEMM
         self.ds_on_gemm = os.environ.get("DREAM_DS_GEMM", "1") == "1"         # training: the stride-2 downsample convs on the 1x1 GEMM over gathered pixels
+        self.CONVT_GEMM_MAX_PIXELS = int(os.environ.get("DREAM_CONVT_GEMM_MAX_PIXELS", "6000"))   # training forward: transposed convs on small maps as GEMM + gather
         self.COL3_MAX_PIXELS = int(os.environ.get("DREAM_COL3_MAX_PIXELS", "12000"))   # ... and 3x3 stride-2 convs with at most this many output pixels
         # training: BatchNorm without its separate passes (round 4) -- statistics finished inside the launch that sums them (the
         # 1x1 convs' own epilogues where possible), BN + ReLU applied by the consuming 1x1 conv's loader, the backward reductions in
@@ -1731,7 +1732,17 @@ class ResnetSimple(nn.Module):
                 name = "%s.%d" % (sname, i)
                 if isinstance(m, nn.ConvTranspose2d):
                     bn = mods[i + 1]
-                    if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
+                    co_t, npx = int(m.weight.shape[1]), int(y.shape[0]) * int(y.shape[1]) * int(y.shape[2])
+                    if (self.ds_on_gemm and self.conv1x1_algorithm == "gemm" and npx <= self.CONVT_GEMM_MAX_PIXELS and co_t % 4 == 0
+                            and tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2) and tuple(m.padding) == (1, 1)
+                            and tuple(m.output_padding) == (0, 0) and int(y.shape[3]) == int(m.weight.shape[0]) and ops.conv1x1_applies(y, 16 * co_t)):
+                        # Round 6: a transposed conv on a small map (the first decoder layer: 2048 -> 256 on 13 x 13 maps, 2704 pixels at 16
+                        # frames -- 50-100 workgroups of the Winograd kernel on 256 CUs) as ONE 1x1 GEMM with N = 16 Cout (the sixteen tap
+                        # contributions of every input pixel) + a gather that sums the <= 4 contributions landing on each output pixel
+                        pk, rows = self._cached(("g0T", name), [m.weight], lambda m=m, co_t=co_t: ops.pack_conv1x1_weight(
+                            m.weight.detach().permute(2, 3, 1, 0).reshape(16 * co_t, -1, 1, 1).contiguous(), 0))
+                        z = ops.col2im4s2(ops.conv1x1(y, pk, rows, None, None, None, 0), co_t, m.bias.detach() if m.bias is not None else None)
+                    elif self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
                         tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
                         u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))
                         z = ops.conv_transpose4x4s2_winograd_tile(tile, y, u4, cout, None, m.bias.detach(), 0)

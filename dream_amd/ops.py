@@ -578,6 +578,17 @@ def col2im3s2(col, h, w):
     return dx
 
 
+def col2im4s2(g, cout, bias=None):
+    """[B,H,W,16 cout] tap contributions of a ConvTranspose2d(k4, s2, p1) (column (4 ky + kx) cout + c) -> its output [B,2H,2W,cout] (+ bias)."""
+    g = _f32(g)
+    b, h, w, n = (int(v) for v in g.shape)
+    if n != 16 * cout:
+        raise RuntimeError("col2im4s2: %d columns are not 16 x %d" % (n, cout))
+    z = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=g.device)
+    call("dream_col2im4s2_nhwc_f32", ptr(g), ptr(None if bias is None else _f32(bias)), ptr(z), b, h, w, cout, stream())
+    return z
+
+
 class wgrad_width:
     """``with ops.wgrad_width(p):`` the weight-gradient launches planned by this thread inside the block split their contraction only
     until ``p`` per cent of the full-width workgroup count exist (csrc/api.hip dream_wgrad_set_width: thread-local) -- for leaves that

@@ -457,6 +457,13 @@ def check_pool_and_layouts(dev):
         back = F.fold(g.reshape(b, ho, wo, 9, c).permute(0, 4, 3, 1, 2).reshape(b, c * 9, ho * wo), (h, w_), 3, padding=1, stride=2)
         got = ops.col2im3s2(to(dev, g), h, w_).cpu()
         assert float((got - back.permute(0, 2, 3, 1)).abs().max()) <= 1e-5
+    # ConvTranspose2d(k4, s2, p1) = per-pixel tap contributions (a 1x1 GEMM) + col2im4s2 (round 6: the decoder's first layer on small maps)
+    for (b, h, w_, cin, cout) in ((2, 5, 7, 6, 8), (1, 13, 13, 4, 4), (1, 1, 1, 3, 4)):
+        x, wt, bias = torch.randn(b, h, w_, cin), torch.randn(cin, cout, 4, 4), torch.randn(cout)
+        g = torch.einsum("bhwi,iokl->bhwklo", x.double(), wt.double()).reshape(b, h, w_, 16 * cout).float()
+        ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+        got = ops.col2im4s2(to(dev, g), cout, to(dev, bias)).cpu()
+        assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
     w = torch.randn(40, 24, 3, 3)
     packed, rows, rp, cp = ops.pack_weight(to(dev, w), 0)
     assert rows == 40 and rp % 128 == 0 and cp == 32

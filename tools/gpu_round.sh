@@ -54,6 +54,21 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6w)
+  # Round 6: the decoder's transposed convs on small maps as ONE 1x1 GEMM (N = 16 Cout) + a gather (training forward): DREAM_CONVT_GEMM_MAX_PIXELS=0
+  # (Winograd kernel) / 4096 (default: the first decoder layer at 16 frames) / 12000 (+ the second)
+  echo "== pytest"; timeout 1800 python -m pytest tests -m gpu -q -x --timeout 900 -k "resnet or layouts or pool or train" > $O/pytest.log 2>&1; echo "rc=$?"; tail -2 $O/pytest.log
+  R="--arch resnet_h --mode train --batch 16 --steps 10 --warmup 4"
+  for r in a b c; do
+    DREAM_CONVT_GEMM_MAX_PIXELS=0 line rt16_t0_$r $R
+    line rt16_t4096_$r $R
+    DREAM_CONVT_GEMM_MAX_PIXELS=12000 line rt16_t12000_$r $R
+  done
+  for r in a b; do
+    DREAM_CONVT_GEMM_MAX_PIXELS=0 line rf32_t0_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+    DREAM_CONVT_GEMM_MAX_PIXELS=6000 line rf32_t6000_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
+  done
+  ;;
 g6v)
   # Round 6: 3x3 stride-2 convs with few output pixels on the 1x1 GEMM over their patch rows (im2col3s2 / col2im3s2): DREAM_COL3_MAX_PIXELS=0 (direct
   # kernels) / 4096 (default: layer4.0.conv2 at 16 frames) / 12000 (+ layer3.0.conv2)
