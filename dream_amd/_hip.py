@@ -160,7 +160,7 @@ _SIGNATURES = {
     "dream_maxpool2_relu_bwd_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "dream_upsample2_bwd_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_subsample2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
-    "dream_col2im4s2_nhwc_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dream_col2im4s2_nhwc_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dream_im2col3s2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_col2im3s2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "dream_scatter2_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),

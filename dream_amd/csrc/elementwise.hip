@@ -169,8 +169,10 @@ __global__ void __launch_bounds__(256) col2im3s2_kernel(const f32x4 *col, f32x4 
 // ConvTranspose2d(k4, s2, p1) as a GEMM + this gather (round 6, small maps: ResNet-101's first decoder layer, 2048 -> 256 on 13 x 13 maps at 16
 // frames, is 2704 input pixels -- too few tiles for the Winograd kernel to fill the chip): g[b,i,j][(4 ky + kx) C + c] = sum over ci of
 // x[b,i,j,ci] w[ci][c][ky][kx] is a 1x1 GEMM with N = 16 C, and output pixel (Y, X) = (2 i - 1 + ky, 2 j - 1 + kx) collects its (at most
-// four) contributions: z[b,Y,X,c] = bias[c] + the sum over ky, kx (ascending) of the entries with (Y + 1 - ky) and (X + 1 - kx) even.
-__global__ void __launch_bounds__(256) col2im4s2_kernel(const f32x4 *g, const f32x4 *bias, f32x4 *z, int B, int H, int W, int C4) {
+// four) contributions: z[b,Y,X,c] = bias[c] + the sum over ky, kx (ascending) of the entries with (Y + 1 - ky) and (X + 1 - kx) even
+// (training: scale == null, shift = the bias); with a scale (evaluation: the folded BatchNorm) z = sum * scale + shift, then the ReLU.
+__global__ void __launch_bounds__(256) col2im4s2_kernel(const f32x4 *g, const f32x4 *scale, const f32x4 *bias, f32x4 *z, int B, int H, int W,
+                                                        int C4, int relu) {
     const int Ho = 2 * H, Wo = 2 * W;
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -180,7 +182,8 @@ __global__ void __launch_bounds__(256) col2im4s2_kernel(const f32x4 *g, const f3
         r /= Wo;
         const int Y = (int)(r % Ho);
         const int b = (int)(r / Ho);
-        f32x4 acc = bias ? bias[c] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        f32x4 acc = (bias && !scale) ? bias[c] : zero;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             const int ky = ((Y + 1) & 1) + 2 * a, iy = (Y + 1 - ky) >> 1;
@@ -191,6 +194,11 @@ __global__ void __launch_bounds__(256) col2im4s2_kernel(const f32x4 *g, const f3
                 if (X + 1 - kx < 0 || ix >= W) continue;
                 acc = acc + g[((((size_t)b * H + iy) * W + ix) * 16 + 4 * ky + kx) * C4 + c];
             }
+        }
+        if (scale) acc = acc * scale[c] + (bias ? bias[c] : zero);
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaxf(acc[e], 0.0f);
         }
         z[i] = acc;
     }
@@ -742,11 +750,13 @@ extern "C" int dream_col2im3s2_nhwc_f32(const float *col, float *dx, int B, int 
     DREAM_LAUNCH_OK();
     return 0;
 }
-extern "C" int dream_col2im4s2_nhwc_f32(const float *g, const float *bias, float *z, int B, int H, int W, int C, void *stream) {
+extern "C" int dream_col2im4s2_nhwc_f32(const float *g, const float *scale, const float *shift, float *z, int B, int H, int W, int C, int flags,
+                                        void *stream) {
     DREAM_REQUIRE(g && z && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "col2im4s2: bad arguments (C=%d must be a multiple of 4)", C);
+    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "col2im4s2: unsupported flags 0x%x", flags);
     const size_t total = (size_t)B * 2 * H * 2 * W * (C / 4);
-    hipLaunchKernelGGL(col2im4s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)g, (const f32x4 *)bias, (f32x4 *)z,
-                       B, H, W, C / 4);
+    hipLaunchKernelGGL(col2im4s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f32x4 *)g, (const f32x4 *)scale,
+                       (const f32x4 *)shift, (f32x4 *)z, B, H, W, C / 4, (flags & DREAM_CONV_RELU) ? 1 : 0);
     DREAM_LAUNCH_OK();
     return 0;
 }

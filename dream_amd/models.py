@@ -1309,8 +1309,24 @@ class ResnetSimple(nn.Module):
             # the 1x1 convs of the bottlenecks: a plain GEMM without LDS (gemm1x1.hip), folded BatchNorm / residual / ReLU fused
             packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
             return ops.conv1x1(x, packed, rows, scale, shift, residual, CONV_RELU if relu else 0)
+        if (self.ds_on_gemm and k == 1 and stride == 2 and self.conv1x1_algorithm == "gemm" and cin == int(x.shape[3]) and cin % 64 == 0):
+            # the stride-2 downsample convs on the GEMM over the pixels they read (as in training: _unit_fused)
+            xs = ops.subsample2(x)
+            if ops.conv1x1_applies(xs, cout):
+                packed, rows = self._cached(("g0", name), [conv.weight], lambda: ops.pack_conv1x1_weight(conv.weight.detach(), 0))
+                return ops.conv1x1(xs, packed, rows, scale, shift, residual, CONV_RELU if relu else 0)
         packed, rows, _ = self._cached(("w", name), [conv.weight], lambda: ops.pack_conv_weight(conv.weight.detach(), 0))
         return ops.conv2d(x, packed, rows, k, stride, scale, shift, residual, CONV_RELU if relu else 0)
+
+    def _convT_gemm(self, name, m, y):
+        """Does this transposed conv run as one 1x1 GEMM (N = 16 Cout) + a gather (small maps: run_forward_train_fused)?  -> packed weight or None."""
+        co_t, npx = int(m.weight.shape[1]), int(y.shape[0]) * int(y.shape[1]) * int(y.shape[2])
+        if not (self.ds_on_gemm and self.conv1x1_algorithm == "gemm" and npx <= self.CONVT_GEMM_MAX_PIXELS and co_t % 4 == 0
+                and tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2) and tuple(m.padding) == (1, 1)
+                and tuple(m.output_padding) == (0, 0) and int(y.shape[3]) == int(m.weight.shape[0]) and ops.conv1x1_applies(y, 16 * co_t)):
+            return None
+        return self._cached(("g0T", name), [m.weight], lambda: ops.pack_conv1x1_weight(
+            m.weight.detach().permute(2, 3, 1, 0).reshape(16 * co_t, -1, 1, 1).contiguous(), 0))
 
     def _gemm1x1(self, conv, x):
         """Stride-1 1x1 convs with channel counts the LDS-free GEMM kernel takes (all of ResNet-101's: multiples of 64)."""
@@ -1399,7 +1415,10 @@ class ResnetSimple(nn.Module):
                 if isinstance(m, nn.ConvTranspose2d):
                     bn = mods[i + 1]
                     scale, shift = self._fold(name, bn, m.bias)
-                    if self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
+                    gT = self._convT_gemm(name, m, y)
+                    if gT is not None:
+                        y = ops.col2im4s2(ops.conv1x1(y, gT[0], gT[1], None, None, None, 0), int(m.weight.shape[1]), shift, scale=scale, flags=CONV_RELU)
+                    elif self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
                         tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
                         u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))
                         y = ops.conv_transpose4x4s2_winograd_tile(tile, y, u4, cout, scale, shift, CONV_RELU)
@@ -1732,16 +1751,13 @@ class ResnetSimple(nn.Module):
                 name = "%s.%d" % (sname, i)
                 if isinstance(m, nn.ConvTranspose2d):
                     bn = mods[i + 1]
-                    co_t, npx = int(m.weight.shape[1]), int(y.shape[0]) * int(y.shape[1]) * int(y.shape[2])
-                    if (self.ds_on_gemm and self.conv1x1_algorithm == "gemm" and npx <= self.CONVT_GEMM_MAX_PIXELS and co_t % 4 == 0
-                            and tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2) and tuple(m.padding) == (1, 1)
-                            and tuple(m.output_padding) == (0, 0) and int(y.shape[3]) == int(m.weight.shape[0]) and ops.conv1x1_applies(y, 16 * co_t)):
+                    co_t = int(m.weight.shape[1])
+                    gT = self._convT_gemm(name, m, y)
+                    if gT is not None:
                         # Round 6: a transposed conv on a small map (the first decoder layer: 2048 -> 256 on 13 x 13 maps, 2704 pixels at 16
                         # frames -- 50-100 workgroups of the Winograd kernel on 256 CUs) as ONE 1x1 GEMM with N = 16 Cout (the sixteen tap
                         # contributions of every input pixel) + a gather that sums the <= 4 contributions landing on each output pixel
-                        pk, rows = self._cached(("g0T", name), [m.weight], lambda m=m, co_t=co_t: ops.pack_conv1x1_weight(
-                            m.weight.detach().permute(2, 3, 1, 0).reshape(16 * co_t, -1, 1, 1).contiguous(), 0))
-                        z = ops.col2im4s2(ops.conv1x1(y, pk, rows, None, None, None, 0), co_t, m.bias.detach() if m.bias is not None else None)
+                        z = ops.col2im4s2(ops.conv1x1(y, gT[0], gT[1], None, None, None, 0), co_t, m.bias.detach() if m.bias is not None else None)
                     elif self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
                         tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
                         u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))

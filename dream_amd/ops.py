@@ -578,14 +578,16 @@ def col2im3s2(col, h, w):
     return dx
 
 
-def col2im4s2(g, cout, bias=None):
-    """[B,H,W,16 cout] tap contributions of a ConvTranspose2d(k4, s2, p1) (column (4 ky + kx) cout + c) -> its output [B,2H,2W,cout] (+ bias)."""
+def col2im4s2(g, cout, bias=None, scale=None, flags=0):
+    """[B,H,W,16 cout] tap contributions of a ConvTranspose2d(k4, s2, p1) (column (4 ky + kx) cout + c) -> its output [B,2H,2W,cout]:
+    bias + sum (scale None), or sum * scale + bias (the folded BatchNorm of the evaluation path); flags: CONV_RELU."""
     g = _f32(g)
     b, h, w, n = (int(v) for v in g.shape)
     if n != 16 * cout:
         raise RuntimeError("col2im4s2: %d columns are not 16 x %d" % (n, cout))
     z = torch.empty((b, 2 * h, 2 * w, cout), dtype=torch.float32, device=g.device)
-    call("dream_col2im4s2_nhwc_f32", ptr(g), ptr(None if bias is None else _f32(bias)), ptr(z), b, h, w, cout, stream())
+    call("dream_col2im4s2_nhwc_f32", ptr(g), ptr(None if scale is None else _f32(scale)), ptr(None if bias is None else _f32(bias)), ptr(z),
+         b, h, w, cout, flags, stream())
     return z
 
 

@@ -391,8 +391,9 @@ int dream_im2col3s2_nhwc_f32(const float *x, float *col, int B, int H, int W, in
 int dream_col2im3s2_nhwc_f32(const float *col, float *dx, int B, int H, int W, int C, void *stream);
 /* Round 6: nn.ConvTranspose2d(k4, s2, p1) on small maps as a 1x1 GEMM + a gather (/root/reference/dream/models.py:37-136, the ResNet decoder's
  * first layer): g [B,H,W,16 C] holds, per input pixel, its sixteen tap contributions (column (4 ky + kx) C + c = dream_conv1x1_nhwc_f32 with
- * the weight matrix [16 C][Cin]); z [B,2H,2W,C] = bias (or null) + the (at most four) contributions that land on each output pixel. */
-int dream_col2im4s2_nhwc_f32(const float *g, const float *bias, float *z, int B, int H, int W, int C, void *stream);
+ * the weight matrix [16 C][Cin]); z [B,2H,2W,C] = shift (the bias, or null) + the (at most four) contributions that land on each output
+ * pixel when scale is null (training), (their sum) * scale + shift with a scale (evaluation: the folded BatchNorm); flags: DREAM_CONV_RELU. */
+int dream_col2im4s2_nhwc_f32(const float *g, const float *scale, const float *shift, float *z, int B, int H, int W, int C, int flags, void *stream);
 int dream_upsample2_bwd_nhwc_f32(const float *dy, float *dx, int B, int H, int W, int C, void *stream);
 /* conv3x3 weight+bias gradient: x [B,H,W,Cin] (or half-res with UPSAMPLE2X), dy [B,H,W,Cout] NHWC
  * -> dw_packed [9][CoutPad][Cin] (mode-0 layout, overwritten), dbias [Cout] (overwritten).

@@ -464,6 +464,10 @@ def check_pool_and_layouts(dev):
         ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=2, padding=1).permute(0, 2, 3, 1)
         got = ops.col2im4s2(to(dev, g), cout, to(dev, bias)).cpu()
         assert float((got.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        sc = torch.rand(cout) + 0.5
+        got = ops.col2im4s2(to(dev, g), cout, to(dev, bias), scale=to(dev, sc), flags=ops.CONV_RELU).cpu()
+        ref2 = ((ref - bias.double()) * sc.double() + bias.double()).clamp_min(0.0)
+        assert float((got.double() - ref2).abs().max()) <= 1e-5 * max(1.0, float(ref2.abs().max()))
     w = torch.randn(40, 24, 3, 3)
     packed, rows, rp, cp = ops.pack_weight(to(dev, w), 0)
     assert rows == 40 and rp % 128 == 0 and cp == 32
