@@ -582,6 +582,7 @@ int gemm1x1_launch(GemmParams p, long M, int K, int N, int x_stride, bool pre, i
     int ks = 1;
     const long per_level = rows == 64 ? 768 : 1280;
     if (g_conv1x1_ksplit > 0) ks = g_conv1x1_ksplit;
+    else if (p.flags & DREAM_CONV_NO_KSPLIT) ks = 1;
     else if (tiles < per_level && K % 128 == 0) ks = 4;
     else if (tiles < 2 * per_level && K % 64 == 0) ks = 2;
     DREAM_REQUIRE(K % (32 * ks) == 0, "conv1x1: K=%d cannot be split %d ways", K, ks);
@@ -633,7 +634,7 @@ extern "C" int dream_conv1x1_nhwc_f32(const float *x, const float *w_packed, con
     DREAM_REQUIRE(x && w_packed && y, "conv1x1: null pointer");
     DREAM_REQUIRE(M > 0 && K > 0 && N > 0 && x_stride >= K, "conv1x1: bad shape M=%ld K=%d N=%d stride=%d", M, K, N, x_stride);
     DREAM_REQUIRE(K % 32 == 0 && N % 4 == 0 && x_stride % 4 == 0, "conv1x1: K %% 32, N %% 4, stride %% 4 (got %d, %d, %d)", K, N, x_stride);
-    DREAM_REQUIRE((flags & ~DREAM_CONV_RELU) == 0, "conv1x1: unsupported flags 0x%x", flags);
+    DREAM_REQUIRE((flags & ~(DREAM_CONV_RELU | DREAM_CONV_NO_KSPLIT)) == 0, "conv1x1: unsupported flags 0x%x", flags);
     DREAM_REQUIRE((size_t)M * (size_t)x_stride * 4 < ((size_t)1 << 31) && (size_t)M * (size_t)N * 4 < ((size_t)1 << 33),
                   "conv1x1: tensor too large for 32-bit offsets");
     GemmParams p = {};

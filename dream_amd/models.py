@@ -1389,10 +1389,19 @@ class ResnetSimple(nn.Module):
             return self.run_forward_f16x3(x)
         # stem: 7x7 s2 conv as im2col (K = 147 -> 160) + 1-tap MFMA conv, BN+ReLU fused; then MaxPool(3,2,1)
         col = ops.im2col_nchw(x, 7, 7, 2, 3, 160)
-        w1 = self._cached(("w", "conv1"), [self.conv1.weight],
-                          lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
         s1, t1 = self._fold("bn1", self.bn1)
-        y = ops.conv2d(col, w1[0], 64, 1, 1, s1, t1, None, CONV_RELU)
+        if self.stem_on_gemm and self.conv1x1_algorithm == "gemm" and ops.conv1x1_applies(col, 64):
+            # Round 6: the im2col rows (K = 160) through the 1x1 GEMM kernel (the 1-tap direct kernel ran them at 69 TFLOP/s; this is a
+            # stream of 0.8 GB in, 0.3 GB out at 32 frames)
+            def build():
+                w2 = self.conv1.weight.detach().reshape(64, 147)
+                return ops.pack_conv1x1_weight(torch.cat([w2, w2.new_zeros((64, 13))], dim=1).reshape(64, 160, 1, 1), 0)
+            packed, rows = self._cached(("g0e", "conv1"), [self.conv1.weight], build)
+            y = ops.conv1x1(col, packed, rows, s1, t1, None, CONV_RELU)
+        else:
+            w1 = self._cached(("w", "conv1"), [self.conv1.weight],
+                              lambda: ops.pack_matrix_weight(self.conv1.weight.detach().reshape(64, 147), 160))
+            y = ops.conv2d(col, w1[0], 64, 1, 1, s1, t1, None, CONV_RELU)
         del col
         y = ops.maxpool3s2(y)
         for li in (1, 2, 3, 4):
@@ -1417,7 +1426,7 @@ class ResnetSimple(nn.Module):
                     scale, shift = self._fold(name, bn, m.bias)
                     gT = self._convT_gemm(name, m, y)
                     if gT is not None:
-                        y = ops.col2im4s2(ops.conv1x1(y, gT[0], gT[1], None, None, None, 0), int(m.weight.shape[1]), shift, scale=scale, flags=CONV_RELU)
+                        y = ops.col2im4s2(ops.conv1x1(y, gT[0], gT[1], None, None, None, ops.CONV_NO_KSPLIT), int(m.weight.shape[1]), shift, scale=scale, flags=CONV_RELU)
                     elif self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
                         tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
                         u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))
@@ -1757,7 +1766,7 @@ class ResnetSimple(nn.Module):
                         # Round 6: a transposed conv on a small map (the first decoder layer: 2048 -> 256 on 13 x 13 maps, 2704 pixels at 16
                         # frames -- 50-100 workgroups of the Winograd kernel on 256 CUs) as ONE 1x1 GEMM with N = 16 Cout (the sixteen tap
                         # contributions of every input pixel) + a gather that sums the <= 4 contributions landing on each output pixel
-                        z = ops.col2im4s2(ops.conv1x1(y, gT[0], gT[1], None, None, None, 0), co_t, m.bias.detach() if m.bias is not None else None)
+                        z = ops.col2im4s2(ops.conv1x1(y, gT[0], gT[1], None, None, None, ops.CONV_NO_KSPLIT), co_t, m.bias.detach() if m.bias is not None else None)
                     elif self.convT_algorithm == "winograd" and ops.convT4x4_winograd_applies(y, int(m.weight.shape[1])):
                         tile = ops.convT4x4_winograd_tile(y, int(m.weight.shape[1]))
                         u4, cout = self._cached(("wu4", name, tile), [m.weight], lambda m=m, tile=tile: ops.pack_convT4x4_winograd_weight_tile(m.weight.detach(), tile))

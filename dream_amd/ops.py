@@ -11,6 +11,7 @@ from ._hip import CONV_RELU, CONV_UPSAMPLE2X, CONV_OUT_NCHW, call, ptr, stream, 
 CONV_ZEROSTUFF2X = 8
 CONV_POOL2 = 16
 CONV_RELUMASK = 32
+CONV_NO_KSPLIT = 128            # conv1x1: no K split over wavefronts (results independent of the row count in the last bit)
 CONV_RES_AFTER_RELU = 64        # the residual is a skip connection: y = relu(conv + shift) + residual
 
 

@@ -45,6 +45,9 @@ extern "C" {
 #define DREAM_CONV_RES_AFTER_RELU 64 /* `residual` is added AFTER the ReLU: y = relu(conv + shift) + residual -- the hourglass skip
                                       connections (dream/models.py:774-799: x = relu(conv(..)) ; x = x + x_0_k_d) folded into the
                                       producing conv's epilogue (inference).  Not with DREAM_CONV_RELUMASK / DREAM_CONV_POOL2. */
+#define DREAM_CONV_NO_KSPLIT 128  /* dream_conv1x1_nhwc_f32 only: never split the contraction over wavefronts.  The split (1 / 2 / 4) is chosen by the
+                                      number of output tiles, i.e. by the ROW count: a caller whose results must not depend on the batch size in the
+                                      last bit (the transposed convs run as GEMM + gather, whose N = 16 Cout always gives enough tiles) fixes it */
 #define DREAM_CONV_ZEROSTUFF2X 8   /* input is [B,H/2,W/2,Cin] placed at the even positions of a zero [B,H,W,Cin]
                                       grid: with mode-1 packed weights this is ConvTranspose2d(k=3,s=2,p=1,
                                       output_padding=1) (dream/models.py:621-686) */

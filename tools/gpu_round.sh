@@ -54,6 +54,19 @@ g6j)
     line rf32_head1_$r --arch resnet_f --mode train --batch 32 --steps 4 --warmup 2
   done
   ;;
+g6y)
+  # Round 6: evaluation stem (im2col rows, K = 160) on the 1x1 GEMM (DREAM_STEM_GEMM=0 = the 1-tap direct kernel); the transposed-conv GEMM without a K split
+  echo "== pytest"; timeout 2400 python -m pytest tests -m gpu -q --timeout 900 > $O/pytest.log 2>&1; echo "rc=$?"; grep -E "passed|failed" $O/pytest.log | tail -1; grep -E "^FAILED|^ERROR" $O/pytest.log | head
+  for r in a b c; do
+    DREAM_STEM_GEMM=0 line rf32_old_$r --arch resnet_f --batch 32
+    line rf32_new_$r --arch resnet_f --batch 32
+  done
+  for r in a b; do
+    DREAM_STEM_GEMM=0 line rh128_old_$r --arch resnet_h --batch 128
+    line rh128_new_$r --arch resnet_h --batch 128
+  done
+  line rt16 --arch resnet_h --mode train --batch 16 --steps 10 --warmup 4
+  ;;
 g6x)
   # Round 6: the evaluation path: stride-2 downsample convs on the GEMM over gathered pixels, the first decoder layer's transposed conv as GEMM + gather
   # (folded BatchNorm + ReLU in the gather) -- DREAM_DS_GEMM=0 = the direct / Winograd kernels
